@@ -1,0 +1,189 @@
+/*
+ * mecano_hip.h -- C-ABI of the MI355X batched rigid-body-dynamics engine.
+ *
+ * This is the drop-in boundary for ONE hot path of ihmcrobotics/mecano (Java):
+ *
+ *   InverseDynamicsCalculator              (RNEA)  algorithms/InverseDynamicsCalculator.java:481-501,567
+ *   ForwardDynamicsCalculator              (ABA)   algorithms/ForwardDynamicsCalculator.java:475-520,556-591
+ *   CompositeRigidBodyMassMatrixCalculator (CRBA)  algorithms/CompositeRigidBodyMassMatrixCalculator.java:344-348
+ *
+ * (paths below are relative to src/main/java/us/ihmc/mecano/ of the reference).
+ *
+ * The reference evaluates one configuration per compute() call, on one CPU
+ * thread, reading q / qd through the MovingReferenceFrame tree.  This library
+ * evaluates B configurations per call on one GPU.  A Java (Panama / JNI), C++
+ * or Python host flattens a MultiBodySystemReadOnly once into mh_model_desc
+ * (recipe: tools/MultiBodySystemFactories.java:401-470,782-868 -- see
+ * INTEGRATION.md), then calls mh_rnea / mh_aba / mh_crba with state matrices
+ * laid out exactly like the DMatrixRMaj column vectors Mecano uses, stacked
+ * along a new leading batch dimension.
+ *
+ * Conventions (all identical to the reference; B is the only new dimension):
+ *   - rigid transform X[12] = { R row-major (9), p (3) } maps coordinates of a
+ *     frame into its parent frame: x_parent = R * x_child + p
+ *     (ReferenceFrame.getTransformToParent()).
+ *   - spatial vectors are ordered angular(3) then linear(3).
+ *   - SixDoF configuration = quaternion (x, y, z, s) then position (x, y, z)
+ *     (multiBodySystem/interfaces/SixDoFJointReadOnly.java:21-26); it is
+ *     normalised on input like Euclid's Quaternion.set does.  SixDoF velocity /
+ *     acceleration / effort = (angular, linear) expressed in the frame after
+ *     the joint (multiBodySystem/SixDoFJoint.java:64-70).
+ *   - gravity is the vector g; the root acceleration is set to -g, expressed in
+ *     the root body-fixed frame (InverseDynamicsCalculator.java:343-348).
+ *   - external wrenches are per body, expressed in (and about the origin of)
+ *     that body's body-fixed (CoM) frame (InverseDynamicsCalculator.java:469-472).
+ *   - the mass matrix is dense row-major nv x nv with both triangles filled and
+ *     zeros for unrelated branches (CompositeRigidBodyMassMatrixCalculator.java:298,841-845).
+ *   - row r of a state matrix belongs to the joint DoF (or configuration entry)
+ *     whose entry in dof_indices (cfg_indices) equals r: the
+ *     JointMatrixIndexProvider contract
+ *     (multiBodySystem/interfaces/JointMatrixIndexProvider.java:71-123).
+ *
+ * No function throws or aborts; every entry point returns an mh_status and
+ * mh_last_error() gives a thread-local message.  The library never falls back
+ * to a CPU implementation: without a usable HIP device every compute call
+ * returns MH_ERR_NO_DEVICE.
+ */
+#ifndef MECANO_HIP_H
+#define MECANO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_ABI_VERSION 1
+
+/* ---- status codes (the Java shim maps them back to Mecano's exception types) ---- */
+typedef enum mh_status
+{
+   MH_OK = 0,
+   MH_ERR_INVALID_ARGUMENT = 1,   /* IllegalArgumentException / NullPointerException        */
+   MH_ERR_BAD_DIMENSION = 2,      /* MatrixDimensionException (ForwardDynamicsCalculator.java:522-533) */
+   MH_ERR_UNSUPPORTED_JOINT = 3,  /* joint kind outside {REVOLUTE, PRISMATIC, SIXDOF, ...}  */
+   MH_ERR_LOOP_CLOSURE = 4,       /* kinematic loops: unsupported, as in ForwardDynamicsCalculator.java:207-211 */
+   MH_ERR_BAD_TOPOLOGY = 5,       /* parent[] is not a forest / index maps are not a permutation */
+   MH_ERR_BAD_AXIS = 6,           /* 1-DoF axis is not a unit vector                          */
+   MH_ERR_NO_DEVICE = 7,          /* no HIP device / kernels not loadable                     */
+   MH_ERR_HIP = 8,                /* a HIP runtime call failed (message has the HIP error)     */
+   MH_ERR_OUT_OF_MEMORY = 9,
+   MH_ERR_NOT_RESERVED = 10,      /* batch larger than mh_reserve()d while allocation is forbidden */
+   MH_ERR_SINGULAR = 11           /* reserved */
+} mh_status;
+
+/* ---- joint kinds ---- */
+typedef enum mh_joint_type
+{
+   MH_JOINT_REVOLUTE = 0,  /* multiBodySystem/RevoluteJoint.java   nq=1 nv=1 */
+   MH_JOINT_PRISMATIC = 1, /* multiBodySystem/PrismaticJoint.java  nq=1 nv=1 */
+   MH_JOINT_SIXDOF = 2,    /* multiBodySystem/SixDoFJoint.java     nq=7 nv=6 */
+   MH_JOINT_FIXED = 3      /* multiBodySystem/FixedJoint.java      nq=0 nv=0 */
+} mh_joint_type;
+
+/* ---- memory layout of batched state matrices ---- */
+typedef enum mh_layout
+{
+   MH_LAYOUT_AOS = 0, /* [B][n]: B stacked DMatrixRMaj column vectors (default) */
+   MH_LAYOUT_SOA = 1  /* [n][B]: one row per DoF, batch contiguous               */
+} mh_layout;
+
+/*
+ * Flat description of a MultiBodySystemReadOnly, joints listed in the order of
+ * input.getJointMatrixIndexProvider().getIndexedJointsInOrder()
+ * (multiBodySystem/interfaces/MultiBodySystemReadOnly.java:57-60,101-104).
+ * Joints in getJointsToIgnore() are simply not listed (their subtree inertia,
+ * if it must be considered, is lumped by the host into the parent's J/mass/com
+ * as InverseDynamicsCalculator.java:832-860 does).
+ */
+typedef struct mh_model_desc
+{
+   int32_t n_joints;
+   int32_t nq; /* rows of a configuration matrix */
+   int32_t nv; /* rows of a velocity / acceleration / effort matrix */
+   const int32_t *parent;      /* [n] index of the parent joint (joint.getPredecessor().getParentJoint()), -1 if the predecessor is the root body */
+   const int32_t *joint_type;  /* [n] mh_joint_type */
+   const double *axis;         /* [3n] joint axis in the joint frame (OneDoFJointReadOnly.getJointAxis()); ignored for SIXDOF/FIXED */
+   const double *X_before;     /* [12n] joint.getFrameBeforeJoint().getTransformToParent(); identity when that frame is the parent frame itself (tools/MecanoFactories.java:81-91) */
+   const double *X_com;        /* [12n] joint.getSuccessor().getBodyFixedFrame().getTransformToParent() (multiBodySystem/RigidBody.java:170-185) */
+   const double *inertia_J;    /* [9n] successor.getInertia().getMomentOfInertia(), row-major, in the body-fixed frame */
+   const double *inertia_mass; /* [n]  successor.getInertia().getMass() */
+   const double *inertia_com;  /* [3n] successor.getInertia().getCenterOfMassOffset() (normally zero) */
+   const int32_t *dof_indices; /* [sum of joint DoFs] getJointDoFIndices(joint), concatenated joint by joint */
+   const int32_t *cfg_indices; /* [sum of joint configuration sizes] getJointConfigurationIndices(joint), concatenated */
+} mh_model_desc;
+
+/* Per-call switches: mirror of the calculators' setters. */
+typedef struct mh_options
+{
+   int32_t consider_coriolis;      /* InverseDynamicsCalculator.setConsiderCoriolisAndCentrifugalForces (java:291-296); RNEA only; default 1 */
+   int32_t consider_accelerations; /* InverseDynamicsCalculator.setConsiderJointAccelerations (java:301-306); RNEA only; default 1 */
+   int32_t layout;                 /* mh_layout of every batched matrix of the call */
+   int32_t reserved0;
+   void *stream;                   /* hipStream_t to launch on; NULL = the device's null stream */
+} mh_options;
+
+typedef struct mh_model *mh_model_t;
+
+/* ---- library / device ---- */
+int32_t mh_abi_version(void);
+const char *mh_last_error(void);           /* thread-local, never NULL */
+mh_status mh_device_count(int32_t *count); /* 0 devices is MH_OK with *count = 0 */
+mh_status mh_set_device(int32_t device);   /* device used by subsequent calls of this thread */
+void mh_options_default(mh_options *opts); /* coriolis=1, accelerations=1, AoS, null stream */
+
+/* ---- model (replaces the calculators' constructors, InverseDynamicsCalculator.java:226-282) ---- */
+mh_status mh_model_create(const mh_model_desc *desc, mh_model_t *model_out);
+void mh_model_destroy(mh_model_t model);
+int32_t mh_model_nq(mh_model_t model);
+int32_t mh_model_nv(mh_model_t model);
+int32_t mh_model_n_joints(mh_model_t model);
+/* name of the kernel variant compute calls will use for this model ("generic", "topo:<hash>") */
+const char *mh_model_kernel_variant(mh_model_t model);
+
+/* Pre-allocate device workspace for batches up to max_batch so that compute calls allocate nothing. */
+mh_status mh_reserve(mh_model_t model, int64_t max_batch);
+
+/*
+ * ---- compute, DEVICE pointers ----
+ * q [B][nq], qd/qdd/tau [B][nv] (or transposed with MH_LAYOUT_SOA), gravity[3] is a HOST pointer,
+ * f_ext is NULL or a device pointer [B][n_joints][6] (AoS) / [n_joints*6][B] (SoA) holding, for the
+ * successor body of each listed joint, the external wrench (moment, force) in its body-fixed frame.
+ * Calls are asynchronous on opts->stream.
+ */
+mh_status mh_rnea_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd,
+                      const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out);
+mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau,
+                     const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out);
+mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out);
+
+mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd,
+                      const double gravity[3], const float *f_ext, const mh_options *opts, float *tau_out);
+mh_status mh_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau,
+                     const double gravity[3], const float *f_ext, const mh_options *opts, float *qdd_out);
+mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_options *opts, float *H_out);
+
+/*
+ * ---- compute, HOST pointers (what a JNI / Panama shim with heap or off-heap arrays calls) ----
+ * Same arguments, all pointers in host memory; the call copies in, launches, copies out and
+ * synchronises before returning.
+ */
+mh_status mh_rnea_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd,
+                           const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out);
+mh_status mh_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau,
+                          const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out);
+mh_status mh_crba_f64_host(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out);
+
+/* ---- measurement helper: HIP-event timing of launches on a stream (bench.py, §8d timing protocol) ---- */
+typedef struct mh_timer *mh_timer_t;
+mh_status mh_timer_create(mh_timer_t *timer_out);
+void mh_timer_destroy(mh_timer_t timer);
+mh_status mh_timer_start(mh_timer_t timer, void *stream);
+mh_status mh_timer_stop(mh_timer_t timer, void *stream);
+mh_status mh_timer_elapsed_ms(mh_timer_t timer, float *ms_out); /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MECANO_HIP_H */

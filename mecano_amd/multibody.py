@@ -1,0 +1,334 @@
+"""Host-side mirror of the part of Mecano's multi-body API the three calculators are built from.
+
+The reference is Java; this container (and the GPU box) has no JVM, so the host side above the
+C-ABI is mirrored here in Python with the reference's names, argument meaning and error
+behaviour, so that the parity tests read like the reference's own tests.  The Java shim a
+maintainer would add on the reference side is in ``java/`` and ``INTEGRATION.md``.
+
+Mirrored types (paths relative to /root/reference/src/main/java/us/ihmc/mecano/):
+
+* ``RigidBody``            multiBodySystem/RigidBody.java:25-264
+* ``RevoluteJoint``        multiBodySystem/RevoluteJoint.java:23-97
+* ``PrismaticJoint``       multiBodySystem/PrismaticJoint.java:20-59
+* ``SixDoFJoint``          multiBodySystem/SixDoFJoint.java:26-122
+* ``FixedJoint``           multiBodySystem/FixedJoint.java
+* ``JointMatrixIndexProvider``  multiBodySystem/interfaces/JointMatrixIndexProvider.java:71-123
+* ``MultiBodySystem``      multiBodySystem/interfaces/MultiBodySystemReadOnly.java:26-335
+
+Only *structure* lives here (topology, frames, inertias, index maps).  Joint state is not
+stored per joint object as in Mecano: it is the batched matrices handed to ``compute``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+REVOLUTE, PRISMATIC, SIXDOF, FIXED = 0, 1, 2, 3
+
+
+def _as_transform(transform) -> Optional[np.ndarray]:
+    """Accepts None, a 4x4, a (R 3x3, p 3) pair or a flat 12-vector; returns flat 12 (R row-major, p)."""
+    if transform is None:
+        return None
+    if isinstance(transform, tuple) and len(transform) == 2:
+        R, p = np.asarray(transform[0], dtype=np.float64), np.asarray(transform[1], dtype=np.float64)
+        return np.concatenate([R.reshape(9), p.reshape(3)])
+    t = np.asarray(transform, dtype=np.float64)
+    if t.shape == (4, 4):
+        return np.concatenate([t[:3, :3].reshape(9), t[:3, 3]])
+    if t.size == 12:
+        return t.reshape(12).copy()
+    raise ValueError("transform must be None, 4x4, (R, p) or 12 values")
+
+
+IDENTITY12 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
+
+
+class RigidBody:
+    """multiBodySystem/RigidBody.java.  ``RigidBody(name)`` creates a root body ("elevator", :79-108);
+    ``RigidBody(name, parentJoint, momentOfInertia, mass, centerOfMassOffset | inertiaPose)`` a moving body whose
+    body-fixed frame is ``inertiaPose`` under the frame after the parent joint (:123-185)."""
+
+    def __init__(self, name: str, parentJoint: "Joint" = None, momentOfInertia=None, mass: float = 0.0,
+                 centerOfMassOffset=None, inertiaPose=None):
+        if name is None:
+            raise ValueError("Name can not be null")  # RigidBody.java:172-173
+        self.name = name
+        self.parentJoint = parentJoint
+        self.childrenJoints: List[Joint] = []
+        if parentJoint is None:
+            self.momentOfInertia = None
+            self.mass = 0.0
+            self.inertiaPose = IDENTITY12.copy()
+            return
+        if inertiaPose is not None:
+            self.inertiaPose = _as_transform(inertiaPose)
+        else:
+            c = np.zeros(3) if centerOfMassOffset is None else np.asarray(centerOfMassOffset, dtype=np.float64)
+            self.inertiaPose = np.concatenate([np.eye(3).reshape(9), c.reshape(3)])
+        J = np.asarray(momentOfInertia, dtype=np.float64)
+        if J.shape == (3,):
+            J = np.diag(J)
+        self.momentOfInertia = J.reshape(3, 3).copy()
+        self.mass = float(mass)
+        # SpatialInertia's own CoM offset inside the body-fixed frame: zero for bodies built this way (RigidBody.java:141-146)
+        self.centerOfMassOffset = np.zeros(3)
+        parentJoint.setSuccessor(self)
+
+    def isRootBody(self) -> bool:
+        return self.parentJoint is None
+
+    def getParentJoint(self):
+        return self.parentJoint
+
+    def getChildrenJoints(self):
+        return self.childrenJoints
+
+    def addChildJoint(self, joint: "Joint"):
+        self.childrenJoints.append(joint)
+
+    def getName(self):
+        return self.name
+
+    def subtreeJointList(self) -> List["Joint"]:
+        """Depth-first pre-order, children in insertion order (iterators/JointIterator.java:130-177)."""
+        out: List[Joint] = []
+        stack = list(reversed(self.childrenJoints))
+        while stack:
+            j = stack.pop()
+            out.append(j)
+            if j.successor is not None:
+                stack.extend(reversed(j.successor.childrenJoints))
+        return out
+
+    def __repr__(self):
+        return f"RigidBody({self.name})"
+
+
+class Joint:
+    """multiBodySystem/Joint.java:12-105.  ``transformToParent`` = pose of the frame before the joint in the
+    frame after the parent joint (``None`` = that frame itself, tools/MecanoFactories.java:81-91)."""
+
+    joint_type = -1
+    degreesOfFreedom = 0
+    configurationMatrixSize = 0
+
+    def __init__(self, name: str, predecessor: RigidBody, transformToParent=None):
+        if name is None:
+            raise ValueError("Name can not be null")
+        self.name = name
+        self.predecessor = predecessor
+        self.successor: Optional[RigidBody] = None
+        self.transformToParent = _as_transform(transformToParent)
+        predecessor.addChildJoint(self)
+
+    def setSuccessor(self, successor: RigidBody):
+        self.successor = successor
+
+    def getPredecessor(self):
+        return self.predecessor
+
+    def getSuccessor(self):
+        return self.successor
+
+    def getName(self):
+        return self.name
+
+    def getDegreesOfFreedom(self) -> int:
+        return self.degreesOfFreedom
+
+    def getConfigurationMatrixSize(self) -> int:
+        return self.configurationMatrixSize
+
+    def subtreeList(self) -> List["Joint"]:
+        out = [self]
+        if self.successor is not None:
+            out.extend(self.successor.subtreeJointList())
+        return out
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.name})"
+
+
+class OneDoFJoint(Joint):
+    degreesOfFreedom = 1
+    configurationMatrixSize = 1
+
+    def __init__(self, name, predecessor, transformToParent, jointAxis):
+        super().__init__(name, predecessor, transformToParent)
+        self.jointAxis = np.asarray(jointAxis, dtype=np.float64).reshape(3).copy()
+
+    def getJointAxis(self):
+        return self.jointAxis
+
+
+class RevoluteJoint(OneDoFJoint):
+    joint_type = REVOLUTE
+
+    def __init__(self, name, predecessor, transformToParent=None, jointAxis=(0.0, 0.0, 1.0)):
+        super().__init__(name, predecessor, transformToParent, jointAxis)
+
+
+class PrismaticJoint(OneDoFJoint):
+    joint_type = PRISMATIC
+
+    def __init__(self, name, predecessor, transformToParent=None, jointAxis=(0.0, 0.0, 1.0)):
+        super().__init__(name, predecessor, transformToParent, jointAxis)
+
+
+class SixDoFJoint(Joint):
+    joint_type = SIXDOF
+    degreesOfFreedom = 6
+    configurationMatrixSize = 7
+
+
+class FixedJoint(Joint):
+    joint_type = FIXED
+    degreesOfFreedom = 0
+    configurationMatrixSize = 0
+
+
+class JointMatrixIndexProvider:
+    """multiBodySystem/interfaces/JointMatrixIndexProvider.java:71-123: running sums in list order."""
+
+    def __init__(self, joints: Sequence[Joint]):
+        self._joints = list(joints)
+        self._dof = {}
+        self._cfg = {}
+        d = c = 0
+        for j in self._joints:
+            self._dof[id(j)] = list(range(d, d + j.getDegreesOfFreedom()))
+            self._cfg[id(j)] = list(range(c, c + j.getConfigurationMatrixSize()))
+            d += j.getDegreesOfFreedom()
+            c += j.getConfigurationMatrixSize()
+        self.numberOfDoFs = d
+        self.configurationSize = c
+
+    @staticmethod
+    def toIndexProvider(joints: Sequence[Joint]) -> "JointMatrixIndexProvider":
+        return JointMatrixIndexProvider(joints)
+
+    def getIndexedJointsInOrder(self) -> List[Joint]:
+        return self._joints
+
+    def getJointDoFIndices(self, joint: Joint) -> List[int]:
+        return self._dof[id(joint)]
+
+    def getJointConfigurationIndices(self, joint: Joint) -> List[int]:
+        return self._cfg[id(joint)]
+
+
+@dataclass
+class ModelDesc:
+    """The flat arrays of ``mh_model_desc`` (include/mecano_hip.h)."""
+
+    n_joints: int
+    nq: int
+    nv: int
+    parent: np.ndarray
+    joint_type: np.ndarray
+    axis: np.ndarray
+    X_before: np.ndarray
+    X_com: np.ndarray
+    inertia_J: np.ndarray
+    inertia_mass: np.ndarray
+    inertia_com: np.ndarray
+    dof_indices: np.ndarray
+    cfg_indices: np.ndarray
+
+    def topology_key(self) -> str:
+        """Stable key of (parents, joint kinds): what a topology-specialised kernel is compiled for."""
+        import hashlib
+        h = hashlib.sha1()
+        h.update(self.parent.astype(np.int32).tobytes())
+        h.update(self.joint_type.astype(np.int32).tobytes())
+        return h.hexdigest()[:12]
+
+
+class MultiBodySystem:
+    """multiBodySystem/interfaces/MultiBodySystemReadOnly.java: root body + joints to consider / ignore + index provider."""
+
+    def __init__(self, rootBody: RigidBody, jointsToIgnore: Iterable[Joint] = (), jointMatrixIndexProvider=None):
+        self.rootBody = rootBody
+        self.allJoints = rootBody.subtreeJointList()
+        ignored = []
+        for j in jointsToIgnore:  # a joint to ignore takes its whole subtree with it (MultiBodySystemReadOnly.java:167-171)
+            for jj in j.subtreeList():
+                if jj not in ignored:
+                    ignored.append(jj)
+        self.jointsToIgnore = ignored
+        ignored_ids = {id(j) for j in ignored}
+        self.jointsToConsider = [j for j in self.allJoints if id(j) not in ignored_ids]
+        self.jointMatrixIndexProvider = jointMatrixIndexProvider or JointMatrixIndexProvider.toIndexProvider(self.jointsToConsider)
+
+    @staticmethod
+    def toMultiBodySystemInput(rootBody: RigidBody, jointsToIgnore: Iterable[Joint] = ()) -> "MultiBodySystem":
+        while not rootBody.isRootBody():  # MultiBodySystemTools.getRootBody
+            rootBody = rootBody.getParentJoint().getPredecessor()
+        return MultiBodySystem(rootBody, jointsToIgnore)
+
+    def getRootBody(self):
+        return self.rootBody
+
+    def getAllJoints(self):
+        return self.allJoints
+
+    def getJointsToConsider(self):
+        return self.jointsToConsider
+
+    def getJointsToIgnore(self):
+        return self.jointsToIgnore
+
+    def getJointMatrixIndexProvider(self):
+        return self.jointMatrixIndexProvider
+
+    def getNumberOfDoFs(self) -> int:
+        return sum(j.getDegreesOfFreedom() for j in self.jointsToConsider)
+
+    def getConfigurationSize(self) -> int:
+        return sum(j.getConfigurationMatrixSize() for j in self.jointsToConsider)
+
+    # ------------------------------------------------------------------ flattening (INTEGRATION.md, Appendix B of SURVEY.md)
+    def toModelDesc(self) -> ModelDesc:
+        """Model-extraction recipe of tools/MultiBodySystemFactories.java:401-470,782-868 applied to this mirror."""
+        provider = self.jointMatrixIndexProvider
+        joints = provider.getIndexedJointsInOrder()
+        index_of = {id(j): i for i, j in enumerate(joints)}
+        n = len(joints)
+        parent = np.full(n, -1, dtype=np.int32)
+        jtype = np.zeros(n, dtype=np.int32)
+        axis = np.zeros((n, 3))
+        Xb = np.tile(IDENTITY12, (n, 1))
+        Xc = np.tile(IDENTITY12, (n, 1))
+        J = np.zeros((n, 9))
+        mass = np.zeros(n)
+        com = np.zeros((n, 3))
+        dof, cfg = [], []
+        for i, j in enumerate(joints):
+            if j.joint_type not in (REVOLUTE, PRISMATIC, SIXDOF, FIXED):
+                raise NotImplementedError(f"unsupported joint kind: {j}")
+            jtype[i] = j.joint_type
+            pj = j.getPredecessor().getParentJoint()
+            if pj is not None:
+                if id(pj) not in index_of:
+                    raise ValueError(f"{j} hangs below an ignored joint")
+                parent[i] = index_of[id(pj)]
+            if j.transformToParent is not None:
+                Xb[i] = j.transformToParent
+            if isinstance(j, OneDoFJoint):
+                axis[i] = j.jointAxis
+            body = j.getSuccessor()
+            if body is None:
+                raise ValueError(f"{j} has no successor")
+            Xc[i] = body.inertiaPose
+            J[i] = body.momentOfInertia.reshape(9)
+            mass[i] = body.mass
+            com[i] = body.centerOfMassOffset
+            dof.extend(provider.getJointDoFIndices(j))
+            cfg.extend(provider.getJointConfigurationIndices(j))
+        nv = (max(dof) + 1) if dof else 0
+        nq = (max(cfg) + 1) if cfg else 0
+        return ModelDesc(n, nq, nv, parent, jtype, axis.reshape(-1), Xb.reshape(-1), Xc.reshape(-1), J.reshape(-1), mass,
+                         com.reshape(-1), np.asarray(dof, dtype=np.int32), np.asarray(cfg, dtype=np.int32))

@@ -1,0 +1,177 @@
+"""Seeded random multi-body systems and states, after the reference's test generators.
+
+Distributions follow tools/MultiBodySystemRandomTools.java and tools/MecanoRandomTools.java of the
+reference (paths relative to /root/reference/src/main/java/us/ihmc/mecano/):
+
+* moment of inertia  J = L L^T, diag(L) ~ U(1e-4, 2), off-diagonal ~ U(-0.5, 0.5)   (MecanoRandomTools.java:623-647 as called at MultiBodySystemRandomTools.java:1367)
+* mass = 0.1 + U(0, 1), CoM offset ~ U(-1, 1)^3                                      (MultiBodySystemRandomTools.java:1365-1370)
+* joint axis: uniform unit vector; joint offset: random rigid transform, none when the predecessor is the root body (:1182,1198,1213,1229)
+* trees: parent of joint i = successor of a uniformly chosen earlier joint          (:1108-1135)
+* states: 1-DoF q, qd, qdd, tau ~ U(-1, 1) scaled; SixDoF: uniform unit quaternion, position / twist / ... ~ U(-1, 1)^3 (:45-125)
+
+The random stream is numpy's PCG64, not java.util.Random: bit-compatibility with the Java
+generators is NOT claimed.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+from .multibody import (FixedJoint, Joint, MultiBodySystem, PrismaticJoint, RevoluteJoint, RigidBody, SixDoFJoint)
+
+
+def nextVector3D(rng, lo=-1.0, hi=1.0):
+    return rng.uniform(lo, hi, 3)
+
+
+def nextUnitVector3D(rng):
+    v = rng.normal(size=3)
+    return v / np.linalg.norm(v)
+
+
+def nextQuaternion(rng):
+    """Uniform unit quaternion (x, y, z, s)."""
+    q = rng.normal(size=4)
+    return q / np.linalg.norm(q)
+
+
+def quaternionToMatrix(q):
+    x, y, z, s = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * s), 2 * (x * z + y * s)],
+                     [2 * (x * y + z * s), 1 - 2 * (x * x + z * z), 2 * (y * z - x * s)],
+                     [2 * (x * z - y * s), 2 * (y * z + x * s), 1 - 2 * (x * x + y * y)]])
+
+
+def nextRigidBodyTransform(rng):
+    return (quaternionToMatrix(nextQuaternion(rng)), nextVector3D(rng))
+
+
+def nextSymmetricPositiveDefiniteMatrix3D(rng, minDiagonal=1.0e-4, maxDiagonal=2.0, minMaxOffDiagonal=0.5):
+    L = np.zeros((3, 3))
+    L[0, 0] = rng.uniform(minDiagonal, maxDiagonal)
+    L[1, 0] = rng.uniform(-minMaxOffDiagonal, minMaxOffDiagonal)
+    L[1, 1] = rng.uniform(minDiagonal, maxDiagonal)
+    L[2, 0] = rng.uniform(-minMaxOffDiagonal, minMaxOffDiagonal)
+    L[2, 1] = rng.uniform(-minMaxOffDiagonal, minMaxOffDiagonal)
+    L[2, 2] = rng.uniform(minDiagonal, maxDiagonal)
+    return L @ L.T
+
+
+def nextRigidBody(rng, name: str, parentJoint: Joint) -> RigidBody:
+    J = nextSymmetricPositiveDefiniteMatrix3D(rng)
+    mass = 0.1 + rng.uniform()
+    com = nextVector3D(rng)
+    return RigidBody(name, parentJoint, J, mass, centerOfMassOffset=com)
+
+
+def _offset(rng, predecessor: RigidBody):
+    return None if predecessor.isRootBody() else nextRigidBodyTransform(rng)
+
+
+def nextRevoluteJoint(rng, name, predecessor, jointAxis=None):
+    axis = nextUnitVector3D(rng) if jointAxis is None else jointAxis
+    return RevoluteJoint(name, predecessor, _offset(rng, predecessor), axis)
+
+
+def nextPrismaticJoint(rng, name, predecessor, jointAxis=None):
+    axis = nextUnitVector3D(rng) if jointAxis is None else jointAxis
+    return PrismaticJoint(name, predecessor, _offset(rng, predecessor), axis)
+
+
+def nextSixDoFJoint(rng, name, predecessor):
+    return SixDoFJoint(name, predecessor, _offset(rng, predecessor))
+
+
+def nextFixedJoint(rng, name, predecessor):
+    return FixedJoint(name, predecessor, _offset(rng, predecessor))
+
+
+_KINDS = {"revolute": nextRevoluteJoint, "prismatic": nextPrismaticJoint, "sixdof": nextSixDoFJoint, "fixed": nextFixedJoint}
+
+
+def _next_joint(rng, kinds: Sequence[str], name, predecessor):
+    return _KINDS[kinds[rng.integers(len(kinds))]](rng, name, predecessor)
+
+
+def nextJointChain(rng, numberOfJoints: int, kinds=("revolute",), rootBody: RigidBody = None, prefix="") -> List[Joint]:
+    """nextRevoluteJointChain / nextPrismaticJointChain / nextOneDoFJointChain / nextJointChain."""
+    predecessor = rootBody or RigidBody(prefix + "rootBody")
+    joints = []
+    for i in range(numberOfJoints):
+        j = _next_joint(rng, kinds, f"{prefix}joint{i}", predecessor)
+        predecessor = nextRigidBody(rng, f"{prefix}body{i}", j)
+        joints.append(j)
+    return joints
+
+
+def nextJointTree(rng, numberOfJoints: int, kinds=("revolute",), rootBody: RigidBody = None, prefix="") -> List[Joint]:
+    """MultiBodySystemRandomTools.nextJointTree (:1108-1135); returns the joints in DFS pre-order like the reference."""
+    root = rootBody or RigidBody(prefix + "rootBody")
+    predecessor = root
+    created = []
+    for i in range(numberOfJoints):
+        j = _next_joint(rng, kinds, f"{prefix}joint{i}", predecessor)
+        nextRigidBody(rng, f"{prefix}body{i}", j)
+        created.append(j)
+        predecessor = created[rng.integers(len(created))].getSuccessor()
+    return root.subtreeJointList()
+
+
+def nextFloatingChain(rng, numberOfJoints: int, kinds=("revolute",), tree=False) -> List[Joint]:
+    """SixDoF root joint (no offset, as InverseDynamicsCalculatorTest.java:129-133) + a random chain or tree below it."""
+    root = RigidBody("rootBody")
+    floating = SixDoFJoint("floatingJoint", root)
+    pelvis = nextRigidBody(rng, "floatingBody", floating)
+    if tree:
+        nextJointTree(rng, numberOfJoints, kinds, rootBody=pelvis)
+    else:
+        nextJointChain(rng, numberOfJoints, kinds, rootBody=pelvis)
+    return root.subtreeJointList()
+
+
+def nextHumanoid(rng) -> MultiBodySystem:
+    """The 30-DoF humanoid of BASELINE.json configs[2..3] / SURVEY.md section 8d: SixDoF pelvis + 24 revolute joints:
+    legs 6 x 2, waist/torso 3, arms 4 x 2, neck 1  =>  nv = 30, nq = 31, 25 moving bodies, depth 8 pelvis->hand.
+    DFS pre-order with children in creation order: left leg, right leg, torso chain, left arm, right arm, neck."""
+    root = RigidBody("elevator")
+    pelvis_joint = SixDoFJoint("pelvis", root)
+    pelvis = nextRigidBody(rng, "pelvisBody", pelvis_joint)
+
+    def chain(prefix, base, count):
+        body = base
+        for k in range(count):
+            j = nextRevoluteJoint(rng, f"{prefix}{k}", body)
+            body = nextRigidBody(rng, f"{prefix}{k}Body", j)
+        return body
+
+    chain("leftLeg", pelvis, 6)
+    chain("rightLeg", pelvis, 6)
+    chest = chain("spine", pelvis, 3)
+    chain("leftArm", chest, 4)
+    chain("rightArm", chest, 4)
+    chain("neck", chest, 1)
+    return MultiBodySystem.toMultiBodySystemInput(root)
+
+
+def nextState(rng, system: MultiBodySystem, batch: int, q_range=np.pi):
+    """Random batched (q, qd, qdd, tau) matrices [B, nq] / [B, nv] honouring the system's index provider."""
+    provider = system.getJointMatrixIndexProvider()
+    nq = max((max(provider.getJointConfigurationIndices(j), default=-1) for j in provider.getIndexedJointsInOrder()), default=-1) + 1
+    nv = max((max(provider.getJointDoFIndices(j), default=-1) for j in provider.getIndexedJointsInOrder()), default=-1) + 1
+    q = np.zeros((batch, nq))
+    qd = rng.uniform(-1, 1, (batch, nv))
+    qdd = rng.uniform(-1, 1, (batch, nv))
+    tau = rng.uniform(-1, 1, (batch, nv))
+    for j in provider.getIndexedJointsInOrder():
+        ci = provider.getJointConfigurationIndices(j)
+        if isinstance(j, SixDoFJoint):
+            quat = rng.normal(size=(batch, 4))
+            quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+            q[:, ci[:4]] = quat
+            q[:, ci[4:]] = rng.uniform(-1, 1, (batch, 3))
+        elif isinstance(j, RevoluteJoint):
+            q[:, ci[0]] = rng.uniform(-q_range, q_range, batch)
+        elif isinstance(j, PrismaticJoint):
+            q[:, ci[0]] = rng.uniform(-1, 1, batch)
+    return q, qd, qdd, tau

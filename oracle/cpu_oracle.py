@@ -1,0 +1,95 @@
+"""ctypes front-end of the C oracle (oracle/mecano_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (mecano_amd) never does.  Parity status of the oracle: see the header of
+mecano_oracle.c ("parity unpinned" against the Java reference; pinned by the reference tests'
+invariants, an independent Featherstone implementation and Lagrangian closed forms).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmecano_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "mecano_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libmecano_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(_LIB_PATH)
+        P = ctypes.c_void_p
+        lib.mo_model_create.restype = P
+        lib.mo_model_create.argtypes = [ctypes.c_int] * 3 + [P] * 10
+        lib.mo_model_destroy.argtypes = [P]
+        lib.mo_rnea.argtypes = [P, ctypes.c_long, P, P, P, P, P, ctypes.c_int, ctypes.c_int, P]
+        lib.mo_aba.argtypes = [P, ctypes.c_long, P, P, P, P, P, P]
+        lib.mo_aba.restype = ctypes.c_int
+        lib.mo_crba.argtypes = [P, ctypes.c_long, P, P]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype=np.float64):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+class OracleModel:
+    """Holds a flattened model (mecano_amd.multibody.ModelDesc); joints must be listed parents-first."""
+
+    def __init__(self, desc):
+        lib = _load()
+        self.desc = desc
+        self._keep = [_c(desc.parent, np.int32), _c(desc.joint_type, np.int32), _c(desc.axis), _c(desc.X_before), _c(desc.X_com),
+                      _c(desc.inertia_J), _c(desc.inertia_mass), _c(desc.inertia_com), _c(desc.dof_indices, np.int32),
+                      _c(desc.cfg_indices, np.int32)]
+        self.nq, self.nv, self.n = desc.nq, desc.nv, desc.n_joints
+        self._h = lib.mo_model_create(desc.n_joints, desc.nq, desc.nv, *[_p(a) for a in self._keep])
+        if not self._h:
+            raise ValueError("oracle: invalid model (joints must be parents-first, <= 512 joints)")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.mo_model_destroy(self._h)
+            self._h = None
+
+    def rnea(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None, consider_coriolis=True, consider_accelerations=True):
+        q, qd, qdd, f_ext = _c(q), _c(qd), _c(qdd), _c(f_ext)
+        B = q.shape[0]
+        g = np.asarray(gravity, dtype=np.float64)
+        tau = np.zeros((B, self.nv))
+        _load().mo_rnea(self._h, B, _p(q), _p(qd), _p(qdd), _p(g), _p(f_ext), int(consider_coriolis), int(consider_accelerations), _p(tau))
+        return tau
+
+    def aba(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None):
+        q, qd, tau, f_ext = _c(q), _c(qd), _c(tau), _c(f_ext)
+        B = q.shape[0]
+        g = np.asarray(gravity, dtype=np.float64)
+        qdd = np.zeros((B, self.nv))
+        rc = _load().mo_aba(self._h, B, _p(q), _p(qd), _p(tau), _p(g), _p(f_ext), _p(qdd))
+        if rc:
+            raise ArithmeticError("oracle ABA: joint-space inertia block not positive definite")
+        return qdd
+
+    def crba(self, q):
+        q = _c(q)
+        B = q.shape[0]
+        H = np.zeros((B, self.nv, self.nv))
+        _load().mo_crba(self._h, B, _p(q), _p(H))
+        return H

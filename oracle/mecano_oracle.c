@@ -1,0 +1,941 @@
+/*
+ * mecano_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A scalar, single-threaded, double-precision restatement of the three Mecano
+ * calculators this repository accelerates, written from the reference's
+ * algorithm (frames, step order, branch conditions) and NOT copied from it:
+ *
+ *   RNEA  algorithms/InverseDynamicsCalculator.java:873-959
+ *   ABA   algorithms/ForwardDynamicsCalculator.java:1085-1310
+ *   CRBA  algorithms/CompositeRigidBodyMassMatrixCalculator.java:588-707,770-798
+ *
+ * (all citations are relative to /root/reference/src/main/java/us/ihmc/mecano/).
+ *
+ * PARITY STATUS: the reference is Java 17 + EJML 0.39 + Euclid 0.21.0; no JVM
+ * exists in the build container or on the GPU box, and the reference's tests
+ * hold no stored golden vectors for this path.  This
+ * oracle is therefore pinned only by (i) the reference tests' own invariants
+ * and closed-form known answers, restated in tests/ (ABA o RNEA = id,
+ * H qdd + bias = RNEA, ballistic free body, sphere wrench, ...), (ii) an
+ * independent textbook Featherstone implementation (oracle/featherstone_np.py)
+ * and (iii) sympy Lagrangian closed forms (tests/golden/).  Against the Java
+ * reference itself:  *** parity unpinned ***.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call into this file.  The product (mecano_amd/csrc) never does.
+ *
+ * Like Mecano, the oracle keeps
+ *   - body accelerations in the body-fixed (CoM) frames for RNEA
+ *     (InverseDynamicsCalculator.java:798,885) and everything of ABA / CRBA in
+ *     the frames after the joints (ForwardDynamicsCalculator.java:175-176);
+ *   - transforms between neighbouring frames composed through the world frame,
+ *     as Euclid's ReferenceFrame.getTransformToDesiredFrame does
+ *     (spatial/SpatialAcceleration.java:266-277);
+ *   - the articulated-body inertia as three 3x3 blocks (angular A, linear L,
+ *     cross C) transformed by "rotate, then translate"
+ *     (algorithms/ArticulatedBodyInertia.java:42-55,359-375);
+ *   - composite rigid-body inertias as (J, m, c) triples with the |m| >= 1e-7
+ *     guard when adding (spatial/interfaces/FixedFrameSpatialInertiaBasics.java:167-176);
+ *   - the fast / general Newton-Euler switch at |c|^2 < 1e-11
+ *     (spatial/interfaces/SpatialInertiaReadOnly.java:56,104-107).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MO_REVOLUTE 0
+#define MO_PRISMATIC 1
+#define MO_SIXDOF 2
+#define MO_FIXED 3
+
+#define MO_MAX_JOINTS 512
+#define COM_OFFSET_ZERO_EPSILON 1.0e-11 /* SpatialInertiaReadOnly.java:56 */
+
+typedef struct
+{
+   double R[9];
+   double p[3];
+} xf_t;
+
+typedef struct
+{
+   int n, nq, nv;
+   int parent[MO_MAX_JOINTS];
+   int type[MO_MAX_JOINTS];
+   int ndof[MO_MAX_JOINTS], ncfg[MO_MAX_JOINTS];
+   int dof_ofs[MO_MAX_JOINTS], cfg_ofs[MO_MAX_JOINTS]; /* offsets into the concatenated index maps */
+   int *dof_idx, *cfg_idx;
+   double axis[MO_MAX_JOINTS][3];
+   xf_t Xb[MO_MAX_JOINTS];   /* beforeJoint -> parent frame           */
+   xf_t Xcom[MO_MAX_JOINTS]; /* body-fixed  -> afterJoint              */
+   double J[MO_MAX_JOINTS][9];
+   double mass[MO_MAX_JOINTS];
+   double com[MO_MAX_JOINTS][3];
+} mo_model;
+
+/* ------------------------------------------------------------------ 3-vector / 3x3 helpers */
+static void v3_cross(const double a[3], const double b[3], double out[3])
+{
+   double x = a[1] * b[2] - a[2] * b[1];
+   double y = a[2] * b[0] - a[0] * b[2];
+   double z = a[0] * b[1] - a[1] * b[0];
+   out[0] = x, out[1] = y, out[2] = z;
+}
+static double v3_dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void m3_mulv(const double M[9], const double v[3], double out[3])
+{
+   double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+   double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+   double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+   out[0] = x, out[1] = y, out[2] = z;
+}
+static void m3_tmulv(const double M[9], const double v[3], double out[3])
+{
+   double x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+   double y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+   double z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+   out[0] = x, out[1] = y, out[2] = z;
+}
+static void m3_mul(const double A[9], const double B[9], double out[9])
+{
+   double t[9];
+   for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+         t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+   memcpy(out, t, sizeof t);
+}
+static void m3_transpose(const double A[9], double out[9])
+{
+   double t[9] = {A[0], A[3], A[6], A[1], A[4], A[7], A[2], A[5], A[8]};
+   memcpy(out, t, sizeof t);
+}
+static void m3_tilde(const double v[3], double out[9])
+{
+   out[0] = 0, out[1] = -v[2], out[2] = v[1];
+   out[3] = v[2], out[4] = 0, out[5] = -v[0];
+   out[6] = -v[1], out[7] = v[0], out[8] = 0;
+}
+/* M <- R M R^T   (tools/MecanoTools.java:1053-1071 for symmetric M; RotationMatrix.transform(Matrix3D) in general) */
+static void m3_conj(const double R[9], double M[9])
+{
+   double Rt[9], t[9];
+   m3_transpose(R, Rt);
+   m3_mul(R, M, t);
+   m3_mul(t, Rt, M);
+}
+
+/* ------------------------------------------------------------------ rigid transforms */
+static void xf_identity(xf_t *X)
+{
+   memset(X, 0, sizeof *X);
+   X->R[0] = X->R[4] = X->R[8] = 1.0;
+}
+static void xf_mul(const xf_t *a, const xf_t *b, xf_t *out) /* out = a o b */
+{
+   xf_t t;
+   m3_mul(a->R, b->R, t.R);
+   m3_mulv(a->R, b->p, t.p);
+   for (int k = 0; k < 3; k++)
+      t.p[k] += a->p[k];
+   *out = t;
+}
+static void xf_inv(const xf_t *a, xf_t *out)
+{
+   xf_t t;
+   m3_transpose(a->R, t.R);
+   m3_mulv(t.R, a->p, t.p);
+   for (int k = 0; k < 3; k++)
+      t.p[k] = -t.p[k];
+   *out = t;
+}
+/* transform taking coordinates in frame A to frame B, composed through the world like Euclid does */
+static void xf_between(const xf_t *W_A, const xf_t *W_B, xf_t *out)
+{
+   xf_t inv;
+   xf_inv(W_B, &inv);
+   xf_mul(&inv, W_A, out);
+}
+/* motion vectors: w' = R w ; v' = R v + p x w'   (spatial/interfaces/FixedFrameSpatialMotionBasics.java:311-321) */
+static void xf_motion(const xf_t *X, const double in[6], double out[6])
+{
+   double w[3], v[3], c[3];
+   m3_mulv(X->R, in, w);
+   m3_mulv(X->R, in + 3, v);
+   v3_cross(X->p, w, c);
+   for (int k = 0; k < 3; k++)
+      out[k] = w[k], out[3 + k] = v[k] + c[k];
+}
+/* force vectors: f' = R f ; n' = R n + p x f'   (spatial/interfaces/FixedFrameSpatialForceBasics.java:249-259) */
+static void xf_force(const xf_t *X, const double in[6], double out[6])
+{
+   double n[3], f[3], c[3];
+   m3_mulv(X->R, in, n);
+   m3_mulv(X->R, in + 3, f);
+   v3_cross(X->p, f, c);
+   for (int k = 0; k < 3; k++)
+      out[k] = n[k] + c[k], out[3 + k] = f[k];
+}
+/* inverse of xf_motion: v'' = R^T (v - p x w) ; w'' = R^T w  (FixedFrameSpatialMotionBasics.java:343-353) */
+static void xf_motion_inv(const xf_t *X, const double in[6], double out[6])
+{
+   double c[3], t[3];
+   v3_cross(X->p, in, c);
+   for (int k = 0; k < 3; k++)
+      t[k] = in[3 + k] - c[k];
+   m3_tmulv(X->R, in, out);
+   m3_tmulv(X->R, t, out + 3);
+}
+
+/* ------------------------------------------------------------------ joint kinematics */
+/* Joint transform afterJoint -> beforeJoint.
+ * revolute : tools/MecanoFactories.java:231-260 (axis-angle; the X/Y/Z shortcuts are the same rotation)
+ * prismatic: multiBodySystem/interfaces/PrismaticJointReadOnly.java:18-22
+ * sixdof   : multiBodySystem/interfaces/FloatingJointReadOnly.java:34-37 (quaternion x,y,z,s then position) */
+static void joint_transform(const mo_model *m, int i, const double *qrow, xf_t *X)
+{
+   xf_identity(X);
+   const int *ci = m->cfg_idx + m->cfg_ofs[i];
+   switch (m->type[i])
+   {
+      case MO_REVOLUTE:
+      {
+         double q = qrow[ci[0]];
+         const double *a = m->axis[i];
+         double nrm = sqrt(v3_dot(a, a));
+         double ux = a[0] / nrm, uy = a[1] / nrm, uz = a[2] / nrm;
+         double c = cos(q), s = sin(q), t = 1.0 - c;
+         X->R[0] = t * ux * ux + c, X->R[1] = t * ux * uy - s * uz, X->R[2] = t * ux * uz + s * uy;
+         X->R[3] = t * ux * uy + s * uz, X->R[4] = t * uy * uy + c, X->R[5] = t * uy * uz - s * ux;
+         X->R[6] = t * ux * uz - s * uy, X->R[7] = t * uy * uz + s * ux, X->R[8] = t * uz * uz + c;
+         break;
+      }
+      case MO_PRISMATIC:
+      {
+         double q = qrow[ci[0]];
+         for (int k = 0; k < 3; k++)
+            X->p[k] = q * m->axis[i][k];
+         break;
+      }
+      case MO_SIXDOF:
+      {
+         double x = qrow[ci[0]], y = qrow[ci[1]], z = qrow[ci[2]], s = qrow[ci[3]];
+         double nrm = sqrt(x * x + y * y + z * z + s * s); /* Euclid Quaternion.set normalises */
+         x /= nrm, y /= nrm, z /= nrm, s /= nrm;
+         X->R[0] = 1 - 2 * (y * y + z * z), X->R[1] = 2 * (x * y - z * s), X->R[2] = 2 * (x * z + y * s);
+         X->R[3] = 2 * (x * y + z * s), X->R[4] = 1 - 2 * (x * x + z * z), X->R[5] = 2 * (y * z - x * s);
+         X->R[6] = 2 * (x * z - y * s), X->R[7] = 2 * (y * z + x * s), X->R[8] = 1 - 2 * (x * x + y * y);
+         X->p[0] = qrow[ci[4]], X->p[1] = qrow[ci[5]], X->p[2] = qrow[ci[6]];
+         break;
+      }
+      default:
+         break;
+   }
+}
+/* Motion subspace S (6 x ndof, column-major by DoF) in afterJoint coordinates:
+ * unit twists (multiBodySystem/interfaces/JointReadOnly.java:201-207); SixDoF identity (tools/MecanoTools.java:964-1000) */
+static void joint_subspace(const mo_model *m, int i, double S[6][6])
+{
+   memset(S, 0, 36 * sizeof(double));
+   switch (m->type[i])
+   {
+      case MO_REVOLUTE:
+         for (int k = 0; k < 3; k++)
+            S[0][k] = m->axis[i][k];
+         break;
+      case MO_PRISMATIC:
+         for (int k = 0; k < 3; k++)
+            S[0][3 + k] = m->axis[i][k];
+         break;
+      case MO_SIXDOF:
+         for (int k = 0; k < 6; k++)
+            S[k][k] = 1.0;
+         break;
+      default:
+         break;
+   }
+}
+/* S * x for the DoFs of joint i, x read through the dof index map (NULL -> zero) */
+static void joint_S_times(const mo_model *m, int i, double S[6][6], const double *xrow, double out[6])
+{
+   memset(out, 0, 6 * sizeof(double));
+   if (!xrow)
+      return;
+   const int *di = m->dof_idx + m->dof_ofs[i];
+   for (int d = 0; d < m->ndof[i]; d++)
+      for (int k = 0; k < 6; k++)
+         out[k] += S[d][k] * xrow[di[d]];
+}
+
+/* ------------------------------------------------------------------ per-configuration kinematics (the frame tree) */
+typedef struct
+{
+   xf_t W_after[MO_MAX_JOINTS]; /* afterJoint_i  -> world */
+   xf_t W_body[MO_MAX_JOINTS];  /* bodyFixed_i   -> world */
+   double tw_after[MO_MAX_JOINTS][6]; /* twist of afterJoint_i w.r.t. world, in afterJoint_i */
+   double tw_body[MO_MAX_JOINTS][6];  /* same body, expressed in bodyFixed_i                  */
+   double vJ[MO_MAX_JOINTS][6];       /* joint twist in afterJoint_i                          */
+   double S[MO_MAX_JOINTS][6][6];
+} mo_kin;
+
+/* rootBody.updateFramesRecursively() + lazy twist propagation (frames/MovingReferenceFrame.java:279-311) */
+static void kinematics(const mo_model *m, const double *qrow, const double *qdrow, mo_kin *k)
+{
+   xf_t W_world;
+   double zero6[6] = {0};
+   xf_identity(&W_world);
+   for (int i = 0; i < m->n; i++)
+   {
+      int p = m->parent[i];
+      const xf_t *W_par = p < 0 ? &W_world : &k->W_after[p];
+      const double *tw_par = p < 0 ? zero6 : k->tw_after[p];
+      xf_t W_before, XJ, T;
+      double tw_before[6], t6[6];
+
+      xf_mul(W_par, &m->Xb[i], &W_before);
+      joint_transform(m, i, qrow, &XJ);
+      xf_mul(&W_before, &XJ, &k->W_after[i]);
+      xf_mul(&k->W_after[i], &m->Xcom[i], &k->W_body[i]);
+
+      joint_subspace(m, i, k->S[i]);
+      joint_S_times(m, i, k->S[i], qdrow, k->vJ[i]); /* OneDoFJoint.java:170-172, SixDoFJoint.java:67-69 */
+
+      xf_between(W_par, &W_before, &T);
+      xf_motion(&T, tw_par, tw_before);
+      xf_between(&W_before, &k->W_after[i], &T);
+      xf_motion(&T, tw_before, t6);
+      for (int c = 0; c < 6; c++)
+         k->tw_after[i][c] = t6[c] + k->vJ[i][c];
+      xf_between(&k->W_after[i], &k->W_body[i], &T);
+      xf_motion(&T, k->tw_after[i], k->tw_body[i]);
+   }
+}
+
+/* ------------------------------------------------------------------ Newton-Euler of one body
+ * spatial/interfaces/SpatialInertiaReadOnly.java:229-296 with tools/MecanoTools.java:571-598,728-752 (CoM at the origin)
+ * or :632-702,785-822 (offset CoM).  acc / tw may be NULL exactly like the Java arguments. */
+static void dynamic_wrench(const double J[9], double mass, const double c[3], const double *acc, const double *tw, double out[6])
+{
+   double n[3] = {0, 0, 0}, f[3] = {0, 0, 0};
+   if (v3_dot(c, c) < COM_OFFSET_ZERO_EPSILON)
+   {
+      if (tw)
+      {
+         double Jw[3];
+         m3_mulv(J, tw, Jw);
+         v3_cross(tw, Jw, n);
+      }
+      if (acc)
+      {
+         double Jwd[3];
+         m3_mulv(J, acc, Jwd);
+         for (int k = 0; k < 3; k++)
+            n[k] += Jwd[k];
+      }
+      if (acc)
+         for (int k = 0; k < 3; k++)
+            f[k] = acc[3 + k];
+      if (tw)
+      {
+         double wxv[3];
+         v3_cross(tw, tw + 3, wxv);
+         for (int k = 0; k < 3; k++)
+            f[k] += wxv[k];
+      }
+      for (int k = 0; k < 3; k++)
+         f[k] *= mass;
+   }
+   else
+   {
+      /* moment: J wd + w x J w + m (c x a + w (v.c) - v (w.c)) */
+      double t[3] = {0, 0, 0};
+      if (acc)
+         v3_cross(c, acc + 3, t);
+      if (tw)
+      {
+         double wc = v3_dot(tw, c), vc = v3_dot(tw + 3, c), Jw[3], wJw[3];
+         for (int k = 0; k < 3; k++)
+            t[k] = mass * (t[k] + tw[k] * vc - tw[3 + k] * wc);
+         m3_mulv(J, tw, Jw);
+         v3_cross(tw, Jw, wJw);
+         for (int k = 0; k < 3; k++)
+            t[k] += wJw[k];
+      }
+      /* (without a twist the reference leaves c x a unscaled by the mass: MecanoTools.java:650-692) */
+      if (acc)
+      {
+         double Jwd[3];
+         m3_mulv(J, acc, Jwd);
+         for (int k = 0; k < 3; k++)
+            n[k] = Jwd[k] + t[k];
+      }
+      else
+         memcpy(n, t, sizeof t);
+      /* force: m (a - c x wd - w x (c x w - v)) */
+      double g[3] = {0, 0, 0};
+      if (acc)
+      {
+         double cxwd[3];
+         v3_cross(c, acc, cxwd);
+         for (int k = 0; k < 3; k++)
+            g[k] = acc[3 + k] - cxwd[k];
+      }
+      if (tw)
+      {
+         double cxw[3], u[3], wxu[3];
+         v3_cross(c, tw, cxw);
+         for (int k = 0; k < 3; k++)
+            u[k] = cxw[k] - tw[3 + k];
+         v3_cross(tw, u, wxu);
+         for (int k = 0; k < 3; k++)
+            g[k] -= wxu[k];
+      }
+      for (int k = 0; k < 3; k++)
+         f[k] = mass * g[k];
+   }
+   for (int k = 0; k < 3; k++)
+      out[k] = n[k], out[3 + k] = f[k];
+}
+
+/* ================================================================== RNEA
+ * InverseDynamicsCalculator.java:873-917 (passOne), :930-959 (passTwo), :961-966 (children) */
+static void rnea_one(const mo_model *m, const double *q, const double *qd, const double *qdd, const double g[3], const double *fext,
+                     int coriolis, int accel, double *tau)
+{
+   static _Thread_local mo_kin K;
+   static _Thread_local double acc[MO_MAX_JOINTS][6], wrench[MO_MAX_JOINTS][6];
+   xf_t W_world, T;
+   double a_root[6] = {0, 0, 0, -g[0], -g[1], -g[2]}; /* :343-348 */
+   double zero6[6] = {0};
+   xf_identity(&W_world);
+   kinematics(m, q, qd, &K);
+
+   for (int i = 0; i < m->n; i++)
+   {
+      int p = m->parent[i];
+      const xf_t *Wp_body = p < 0 ? &W_world : &K.W_body[p];
+      const double *a_par = p < 0 ? a_root : acc[p];
+      const double *tw_par = p < 0 ? zero6 : K.tw_body[p];
+      double a[6];
+      memcpy(a, a_par, sizeof a);
+      if (coriolis)
+      {
+         /* predecessor twist = -(joint twist) re-expressed in the predecessor body frame (JointReadOnly.java:270-281) */
+         double d[6], c1[3], c2[3], c3[3];
+         xf_between(&K.W_after[i], Wp_body, &T);
+         xf_motion(&T, K.vJ[i], d);
+         for (int k = 0; k < 6; k++)
+            d[k] = -d[k];
+         /* non-flipped branch of SpatialAccelerationBasics.java:192-200 */
+         v3_cross(d + 3, tw_par, c1);     /* v_delta x w_body     */
+         v3_cross(d, tw_par + 3, c2);     /* w_delta x v_body     */
+         v3_cross(d, tw_par, c3);         /* w_delta x w_body     */
+         for (int k = 0; k < 3; k++)
+            a[3 + k] += c1[k] + c2[k], a[k] += c3[k];
+      }
+      xf_between(Wp_body, &K.W_body[i], &T);
+      xf_motion(&T, a, acc[i]);
+      if (accel)
+      {
+         double aJ[6], aJb[6];
+         joint_S_times(m, i, K.S[i], qdd, aJ); /* :898-899 */
+         xf_between(&K.W_after[i], &K.W_body[i], &T);
+         xf_motion(&T, aJ, aJb);               /* :907 */
+         for (int k = 0; k < 6; k++)
+            acc[i][k] += aJb[k];
+      }
+   }
+   for (int i = m->n - 1; i >= 0; i--)
+   {
+      double w[6];
+      dynamic_wrench(m->J[i], m->mass[i], m->com[i], acc[i], coriolis ? K.tw_body[i] : NULL, w); /* :935-944 */
+      if (fext)
+         for (int k = 0; k < 6; k++)
+            w[k] -= fext[6 * i + k]; /* :946 */
+      xf_between(&K.W_body[i], &K.W_after[i], &T);
+      xf_force(&T, w, wrench[i]); /* :947 */
+   }
+   /* children first (passTwoRecursive :920-928): descending index visits every child before its parent */
+   for (int i = m->n - 1; i >= 0; i--)
+   {
+      const int *di = m->dof_idx + m->dof_ofs[i];
+      for (int d = 0; d < m->ndof[i]; d++)
+      {
+         double s = 0;
+         for (int k = 0; k < 6; k++)
+            s += K.S[i][d][k] * wrench[i][k]; /* :952-953 */
+         tau[di[d]] = s;
+      }
+      int p = m->parent[i];
+      if (p >= 0)
+      {
+         double w[6];
+         xf_between(&K.W_after[i], &K.W_after[p], &T);
+         xf_force(&T, wrench[i], w); /* :961-966 */
+         for (int k = 0; k < 6; k++)
+            wrench[p][k] += w[k];
+      }
+   }
+}
+
+/* ================================================================== articulated-body inertia as (A, L, C) blocks
+ * 6x6 = [[A, C], [C^T, L]]  (ArticulatedBodyInertia.java:42-55,312-319) */
+typedef struct
+{
+   double A[9], L[9], C[9];
+} abi_t;
+
+/* ArticulatedBodyInertia.java:176-186 : rigid inertia (J, m, c) -> A = J, L = m 1, C = m [c]x */
+static void abi_from_rigid(const double J[9], double mass, const double c[3], abi_t *I)
+{
+   memcpy(I->A, J, 9 * sizeof(double));
+   memset(I->L, 0, sizeof I->L);
+   I->L[0] = I->L[4] = I->L[8] = mass;
+   m3_tilde(c, I->C);
+   for (int k = 0; k < 9; k++)
+      I->C[k] *= mass;
+}
+/* ArticulatedBodyInertia.java:359-375: rotate the three blocks, then translate.
+ * Translation (ArticulatedBodyInertiaAlorigthmTools.java:83-101,150-162), in matrix form with P = [p]x :
+ *   A' = A + P C^T - C P - P L P ,   C' = C + P L ,   L' = L                                           */
+static void abi_apply_transform(const xf_t *X, abi_t *I)
+{
+   double P[9], Ct[9], t1[9], t2[9], t3[9], PL[9];
+   m3_conj(X->R, I->A);
+   m3_conj(X->R, I->L);
+   m3_conj(X->R, I->C);
+   m3_tilde(X->p, P);
+   m3_transpose(I->C, Ct);
+   m3_mul(P, Ct, t1);
+   m3_mul(I->C, P, t2);
+   m3_mul(P, I->L, PL);
+   m3_mul(PL, P, t3);
+   for (int k = 0; k < 9; k++)
+   {
+      I->A[k] += t1[k] - t2[k] - t3[k];
+      I->C[k] += PL[k];
+   }
+}
+static void abi_to_dense(const abi_t *I, double M[36])
+{
+   for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+      {
+         M[6 * r + c] = I->A[3 * r + c];
+         M[6 * r + 3 + c] = I->C[3 * r + c];
+         M[6 * (3 + r) + c] = I->C[3 * c + r];
+         M[6 * (3 + r) + 3 + c] = I->L[3 * r + c];
+      }
+}
+static void abi_sub_dense(abi_t *I, const double M[36]) /* ArticulatedBodyInertia.java:219-241 */
+{
+   for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+      {
+         I->A[3 * r + c] -= M[6 * r + c];
+         I->C[3 * r + c] -= M[6 * r + 3 + c];
+         I->L[3 * r + c] -= M[6 * (3 + r) + 3 + c];
+      }
+}
+static void abi_mulv(const abi_t *I, const double x[6], double out[6])
+{
+   double M[36];
+   abi_to_dense(I, M);
+   for (int r = 0; r < 6; r++)
+   {
+      double s = 0;
+      for (int c = 0; c < 6; c++)
+         s += M[6 * r + c] * x[c];
+      out[r] = s;
+   }
+}
+
+/* rigid inertia (J, m, c) algebra used by CRBA and to bring a body inertia to the afterJoint frame
+ * SpatialInertiaBasics.java:222-239: rotate J and c, then parallel axis J -= m ([p]x[c]x + [c]x[p]x + [p]x[p]x), c += p
+ * (tools/MecanoTools.java:449-547) */
+typedef struct
+{
+   double J[9], m, c[3];
+} rigid_t;
+static void rigid_apply_transform(const xf_t *X, rigid_t *I)
+{
+   double P[9], Cx[9], t1[9], t2[9], t3[9], c2[3];
+   m3_conj(X->R, I->J);
+   m3_mulv(X->R, I->c, c2);
+   m3_tilde(X->p, P);
+   m3_tilde(c2, Cx);
+   m3_mul(P, Cx, t1);
+   m3_mul(Cx, P, t2);
+   m3_mul(P, P, t3);
+   for (int k = 0; k < 9; k++)
+      I->J[k] -= I->m * (t1[k] + t2[k] + t3[k]);
+   for (int k = 0; k < 3; k++)
+      I->c[k] = c2[k] + X->p[k];
+}
+static void rigid_add(rigid_t *I, const rigid_t *o) /* FixedFrameSpatialInertiaBasics.java:167-176 */
+{
+   for (int k = 0; k < 9; k++)
+      I->J[k] += o->J[k];
+   for (int k = 0; k < 3; k++)
+      I->c[k] = I->c[k] * I->m + o->m * o->c[k];
+   I->m += o->m;
+   if (fabs(I->m) >= 1.0e-7)
+      for (int k = 0; k < 3; k++)
+         I->c[k] *= 1.0 / I->m;
+}
+/* momentum = I * twist  (SpatialInertiaReadOnly.java:334-357) */
+static void rigid_mulv(const rigid_t *I, const double x[6], double out[6])
+{
+   if (v3_dot(I->c, I->c) < COM_OFFSET_ZERO_EPSILON)
+   {
+      m3_mulv(I->J, x, out);
+      for (int k = 0; k < 3; k++)
+         out[3 + k] = I->m * x[3 + k];
+   }
+   else
+   {
+      double cxv[3], Jw[3], wxc[3];
+      v3_cross(I->c, x + 3, cxv);
+      m3_mulv(I->J, x, Jw);
+      v3_cross(x, I->c, wxc);
+      for (int k = 0; k < 3; k++)
+      {
+         out[k] = I->m * cxv[k] + Jw[k];
+         out[3 + k] = I->m * (wxc[k] + x[3 + k]);
+      }
+   }
+}
+
+/* symmetric positive definite inverse by Cholesky (EJML LinearSolverFactory_DDRM.symmPosDef, ForwardDynamicsCalculator.java:1040,1195-1196;
+ * for 2..5 DoFs the reference uses a minor-based unrolled inverse, the same matrix up to rounding) */
+static int spd_inverse(int n, const double *D, double *Dinv)
+{
+   double Lc[36] = {0};
+   for (int i = 0; i < n; i++)
+      for (int j = 0; j <= i; j++)
+      {
+         double s = D[i * n + j];
+         for (int k = 0; k < j; k++)
+            s -= Lc[i * n + k] * Lc[j * n + k];
+         if (i == j)
+         {
+            if (s <= 0)
+               return 1;
+            Lc[i * n + i] = sqrt(s);
+         }
+         else
+            Lc[i * n + j] = s / Lc[j * n + j];
+      }
+   for (int c = 0; c < n; c++)
+   {
+      double y[6], x[6];
+      for (int i = 0; i < n; i++)
+      {
+         double s = (i == c) ? 1.0 : 0.0;
+         for (int k = 0; k < i; k++)
+            s -= Lc[i * n + k] * y[k];
+         y[i] = s / Lc[i * n + i];
+      }
+      for (int i = n - 1; i >= 0; i--)
+      {
+         double s = y[i];
+         for (int k = i + 1; k < n; k++)
+            s -= Lc[k * n + i] * x[k];
+         x[i] = s / Lc[i * n + i];
+      }
+      for (int i = 0; i < n; i++)
+         Dinv[i * n + c] = x[i];
+   }
+   return 0;
+}
+
+/* ================================================================== ABA
+ * ForwardDynamicsCalculator.java:1085-1127 (passOne), :1136-1254 (passTwo), :1259-1310 (passThree) */
+static int aba_one(const mo_model *m, const double *q, const double *qd, const double *tau, const double g[3], const double *fext, double *qdd)
+{
+   static _Thread_local mo_kin K;
+   static _Thread_local xf_t Xup[MO_MAX_JOINTS]; /* afterJoint_i -> afterJoint_parent (or root body frame) :1096-1099 */
+   static _Thread_local double pb[MO_MAX_JOINTS][6], cb[MO_MAX_JOINTS][6], pA[MO_MAX_JOINTS][6];
+   static _Thread_local abi_t IA[MO_MAX_JOINTS];
+   static _Thread_local double U[MO_MAX_JOINTS][6][6], Dinv[MO_MAX_JOINTS][36], u[MO_MAX_JOINTS][6], acc[MO_MAX_JOINTS][6];
+   xf_t W_world, T;
+   xf_identity(&W_world);
+   kinematics(m, q, qd, &K);
+
+   /* ---- pass one */
+   for (int i = 0; i < m->n; i++)
+   {
+      int p = m->parent[i];
+      double w[6], c1[3], c2[3], c3[3];
+      xf_between(&K.W_after[i], p < 0 ? &W_world : &K.W_after[p], &Xup[i]);
+      dynamic_wrench(m->J[i], m->mass[i], m->com[i], NULL, K.tw_body[i], w); /* :1110 */
+      if (fext)
+         for (int k = 0; k < 6; k++)
+            w[k] -= fext[6 * i + k];
+      xf_between(&K.W_body[i], &K.W_after[i], &T);
+      xf_force(&T, w, pb[i]); /* :1112 */
+      /* bias acceleration, flipped branch of SpatialAccelerationBasics.java:204-217 with delta = joint twist */
+      v3_cross(K.tw_after[i], K.vJ[i] + 3, c1);     /* w_body x v_J */
+      v3_cross(K.tw_after[i] + 3, K.vJ[i], c2);     /* v_body x w_J */
+      v3_cross(K.tw_after[i], K.vJ[i], c3);         /* w_body x w_J */
+      for (int k = 0; k < 3; k++)
+         cb[i][k] = c3[k], cb[i][3 + k] = c1[k] + c2[k];
+   }
+   /* ---- pass two: leaves to root */
+   for (int i = 0; i < m->n; i++)
+   {
+      rigid_t I;
+      memcpy(I.J, m->J[i], sizeof I.J);
+      I.m = m->mass[i];
+      memcpy(I.c, m->com[i], sizeof I.c);
+      xf_between(&K.W_body[i], &K.W_after[i], &T);
+      rigid_apply_transform(&T, &I); /* spatialInertia.changeFrame(frameAfterJoint) :1149 */
+      abi_from_rigid(I.J, I.m, I.c, &IA[i]);
+      memcpy(pA[i], pb[i], sizeof pA[i]);
+   }
+   for (int i = m->n - 1; i >= 0; i--)
+   {
+      int p = m->parent[i], nd = m->ndof[i];
+      const int *di = m->dof_idx + m->dof_ofs[i];
+      double D[36];
+      /* U = IA S (:1177) ; D = S^T U (:1179) */
+      for (int d = 0; d < nd; d++)
+         abi_mulv(&IA[i], K.S[i][d], U[i][d]);
+      for (int a = 0; a < nd; a++)
+         for (int b = 0; b < nd; b++)
+         {
+            double s = 0;
+            for (int k = 0; k < 6; k++)
+               s += K.S[i][a][k] * U[i][b][k];
+            D[a * nd + b] = s;
+         }
+      if (nd == 1)
+         Dinv[i][0] = 1.0 / D[0]; /* :1183 */
+      else if (nd > 1 && spd_inverse(nd, D, Dinv[i]))
+         return 1;
+      /* u = tau - S^T pA (:1200-1215) */
+      for (int d = 0; d < nd; d++)
+      {
+         double s = 0;
+         for (int k = 0; k < 6; k++)
+            s += K.S[i][d][k] * pA[i][k];
+         u[i][d] = tau[di[d]] - s;
+      }
+      if (p >= 0)
+      {
+         /* Ia = IA - U Dinv U^T (:1220-1226) ; pa = pA + Ia c + U Dinv u (:1229-1234) */
+         double UD[6][6] = {{0}}, M[36], pa[6], Iac[6];
+         abi_t Ia = IA[i];
+         for (int r = 0; r < 6; r++)
+            for (int b = 0; b < nd; b++)
+            {
+               double s = 0;
+               for (int a = 0; a < nd; a++)
+                  s += U[i][a][r] * Dinv[i][a * nd + b];
+               UD[b][r] = s;
+            }
+         for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 6; c++)
+            {
+               double s = 0;
+               for (int b = 0; b < nd; b++)
+                  s += UD[b][r] * U[i][b][c];
+               M[6 * r + c] = s;
+            }
+         abi_sub_dense(&Ia, M);
+         abi_mulv(&Ia, cb[i], Iac);
+         for (int r = 0; r < 6; r++)
+         {
+            double s = pA[i][r] + Iac[r];
+            for (int b = 0; b < nd; b++)
+               s += UD[b][r] * u[i][b];
+            pa[r] = s;
+         }
+         /* hand over to the parent (:1156-1166) */
+         double paP[6];
+         abi_apply_transform(&Xup[i], &Ia);
+         xf_force(&Xup[i], pa, paP);
+         for (int k = 0; k < 9; k++)
+            IA[p].A[k] += Ia.A[k], IA[p].L[k] += Ia.L[k], IA[p].C[k] += Ia.C[k];
+         for (int k = 0; k < 6; k++)
+            pA[p][k] += paP[k];
+      }
+   }
+   /* ---- pass three: root to leaves */
+   double a_root[6] = {0, 0, 0, -g[0], -g[1], -g[2]}; /* :259-264 */
+   for (int i = 0; i < m->n; i++)
+   {
+      int p = m->parent[i], nd = m->ndof[i];
+      const int *di = m->dof_idx + m->dof_ofs[i];
+      double ap[6], r[6], qddj[6];
+      xf_motion_inv(&Xup[i], p < 0 ? a_root : acc[p], ap); /* :1270-1271 */
+      for (int k = 0; k < 6; k++)
+         ap[k] += cb[i][k]; /* :1273 */
+      for (int d = 0; d < nd; d++)
+      {
+         double s = 0;
+         for (int k = 0; k < 6; k++)
+            s += U[i][d][k] * ap[k];
+         r[d] = u[i][d] - s; /* :1280-1281 */
+      }
+      for (int a = 0; a < nd; a++)
+      {
+         double s = 0;
+         for (int b = 0; b < nd; b++)
+            s += Dinv[i][a * nd + b] * r[b];
+         qddj[a] = s; /* :1282 */
+         qdd[di[a]] = s;
+      }
+      memcpy(acc[i], ap, sizeof ap);
+      for (int d = 0; d < nd; d++)
+         for (int k = 0; k < 6; k++)
+            acc[i][k] += K.S[i][d][k] * qddj[d]; /* :1300-1305 */
+   }
+   return 0;
+}
+
+/* ================================================================== CRBA
+ * CompositeRigidBodyMassMatrixCalculator.java:588-707 + ancestor walk :770-798 */
+static void crba_one(const mo_model *m, const double *q, double *H)
+{
+   static _Thread_local mo_kin K;
+   static _Thread_local xf_t Xup[MO_MAX_JOINTS];
+   static _Thread_local rigid_t Ic[MO_MAX_JOINTS];
+   xf_t W_world, T;
+   xf_identity(&W_world);
+   kinematics(m, q, NULL, &K);
+   memset(H, 0, sizeof(double) * (size_t)m->nv * (size_t)m->nv); /* :298 */
+   for (int i = 0; i < m->n; i++)
+   {
+      int p = m->parent[i];
+      if (p >= 0)
+         xf_between(&K.W_after[i], &K.W_after[p], &Xup[i]); /* :592-593 */
+      else
+         xf_identity(&Xup[i]);
+      memcpy(Ic[i].J, m->J[i], sizeof Ic[i].J);
+      Ic[i].m = m->mass[i];
+      memcpy(Ic[i].c, m->com[i], sizeof Ic[i].c);
+      xf_between(&K.W_body[i], &K.W_after[i], &T);
+      rigid_apply_transform(&T, &Ic[i]); /* :646-650 */
+   }
+   for (int i = m->n - 1; i >= 0; i--)
+   {
+      int nd = m->ndof[i];
+      const int *di = m->dof_idx + m->dof_ofs[i];
+      double F[6][6];
+      for (int d = 0; d < nd; d++)
+         rigid_mulv(&Ic[i], K.S[i][d], F[d]); /* :663-667 */
+      for (int a = 0; a < nd; a++)
+         for (int b = 0; b < nd; b++)
+         {
+            double s = 0;
+            for (int k = 0; k < 6; k++)
+               s += K.S[i][a][k] * F[b][k];
+            H[(size_t)di[a] * m->nv + di[b]] = s; /* :700-707 (setSymmetricEntry :841-845) */
+            H[(size_t)di[b] * m->nv + di[a]] = s;
+         }
+      /* climb the ancestors, re-expressing F on the way (:783-792) */
+      int prev = i, anc = m->parent[i];
+      while (anc >= 0)
+      {
+         const int *dj = m->dof_idx + m->dof_ofs[anc];
+         for (int b = 0; b < nd; b++)
+         {
+            double Fn[6];
+            xf_force(&Xup[prev], F[b], Fn);
+            memcpy(F[b], Fn, sizeof Fn);
+            for (int a = 0; a < m->ndof[anc]; a++)
+            {
+               double s = 0;
+               for (int k = 0; k < 6; k++)
+                  s += K.S[anc][a][k] * F[b][k];
+               H[(size_t)dj[a] * m->nv + di[b]] = s;
+               H[(size_t)di[b] * m->nv + dj[a]] = s;
+            }
+         }
+         prev = anc;
+         anc = m->parent[anc];
+      }
+      /* composite inertia to the parent (:651-661) */
+      int p = m->parent[i];
+      if (p >= 0)
+      {
+         rigid_t child = Ic[i];
+         rigid_apply_transform(&Xup[i], &child);
+         rigid_add(&Ic[p], &child);
+      }
+   }
+}
+
+/* ================================================================== public C API (ctypes / bench) */
+static int joint_ndof(int type) { return type == MO_SIXDOF ? 6 : (type == MO_FIXED ? 0 : 1); }
+static int joint_ncfg(int type) { return type == MO_SIXDOF ? 7 : (type == MO_FIXED ? 0 : 1); }
+
+/* Joints must be listed parents-first (Mecano's default DFS pre-order is; IT/JointIterator.java:155-161). */
+void *mo_model_create(int n, int nq, int nv, const int *parent, const int *type, const double *axis, const double *X_before,
+                      const double *X_com, const double *J, const double *mass, const double *com, const int *dof_indices,
+                      const int *cfg_indices)
+{
+   if (n <= 0 || n > MO_MAX_JOINTS)
+      return NULL;
+   mo_model *m = (mo_model *)calloc(1, sizeof *m);
+   m->n = n, m->nq = nq, m->nv = nv;
+   int dofs = 0, cfgs = 0;
+   for (int i = 0; i < n; i++)
+   {
+      if (parent[i] >= i || type[i] < 0 || type[i] > MO_FIXED)
+      {
+         free(m);
+         return NULL;
+      }
+      m->parent[i] = parent[i], m->type[i] = type[i];
+      m->ndof[i] = joint_ndof(type[i]), m->ncfg[i] = joint_ncfg(type[i]);
+      m->dof_ofs[i] = dofs, m->cfg_ofs[i] = cfgs;
+      dofs += m->ndof[i], cfgs += m->ncfg[i];
+      memcpy(m->axis[i], axis + 3 * i, 3 * sizeof(double));
+      memcpy(m->Xb[i].R, X_before + 12 * i, 9 * sizeof(double));
+      memcpy(m->Xb[i].p, X_before + 12 * i + 9, 3 * sizeof(double));
+      memcpy(m->Xcom[i].R, X_com + 12 * i, 9 * sizeof(double));
+      memcpy(m->Xcom[i].p, X_com + 12 * i + 9, 3 * sizeof(double));
+      memcpy(m->J[i], J + 9 * i, 9 * sizeof(double));
+      m->mass[i] = mass[i];
+      memcpy(m->com[i], com + 3 * i, 3 * sizeof(double));
+   }
+   m->dof_idx = (int *)malloc(sizeof(int) * (size_t)(dofs > 0 ? dofs : 1));
+   m->cfg_idx = (int *)malloc(sizeof(int) * (size_t)(cfgs > 0 ? cfgs : 1));
+   memcpy(m->dof_idx, dof_indices, sizeof(int) * (size_t)dofs);
+   memcpy(m->cfg_idx, cfg_indices, sizeof(int) * (size_t)cfgs);
+   return m;
+}
+void mo_model_destroy(void *h)
+{
+   mo_model *m = (mo_model *)h;
+   if (!m)
+      return;
+   free(m->dof_idx);
+   free(m->cfg_idx);
+   free(m);
+}
+/* batched wrappers: AoS [B][n] matrices, fext [B][n_joints][6] or NULL */
+void mo_rnea(void *h, long B, const double *q, const double *qd, const double *qdd, const double *g, const double *fext, int coriolis,
+             int accel, double *tau)
+{
+   const mo_model *m = (const mo_model *)h;
+   for (long b = 0; b < B; b++)
+      rnea_one(m, q + b * m->nq, qd + b * m->nv, qdd ? qdd + b * m->nv : NULL, g, fext ? fext + b * 6 * m->n : NULL, coriolis,
+               accel && qdd, tau + b * m->nv);
+}
+int mo_aba(void *h, long B, const double *q, const double *qd, const double *tau, const double *g, const double *fext, double *qdd)
+{
+   const mo_model *m = (const mo_model *)h;
+   int rc = 0;
+   for (long b = 0; b < B; b++)
+      rc |= aba_one(m, q + b * m->nq, qd + b * m->nv, tau + b * m->nv, g, fext ? fext + b * 6 * m->n : NULL, qdd + b * m->nv);
+   return rc;
+}
+void mo_crba(void *h, long B, const double *q, double *H)
+{
+   const mo_model *m = (const mo_model *)h;
+   for (long b = 0; b < B; b++)
+      crba_one(m, q + b * m->nq, H + (size_t)b * m->nv * m->nv);
+}
