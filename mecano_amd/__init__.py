@@ -1,0 +1,10 @@
+"""mecano_amd -- MI355X-native batched RNEA / ABA / CRBA behind Mecano's calculator API.
+
+Importing this package does not load the HIP library; the first model creation does, and fails loudly
+(ImportError) when mecano_amd/libmecano_hip.so has not been built.  There is no CPU fallback.
+"""
+from .multibody import (FixedJoint, JointMatrixIndexProvider, ModelDesc, MultiBodySystem, PrismaticJoint, RevoluteJoint, RigidBody,
+                        SixDoFJoint)
+
+__all__ = ["FixedJoint", "JointMatrixIndexProvider", "ModelDesc", "MultiBodySystem", "PrismaticJoint", "RevoluteJoint", "RigidBody",
+           "SixDoFJoint"]

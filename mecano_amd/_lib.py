@@ -1,0 +1,89 @@
+"""ctypes binding of the C-ABI (include/mecano_hip.h).  Fails loudly when the library is missing: there is no
+Python or CPU fallback for the compute path."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmecano_hip.so")
+
+MH_OK = 0
+STATUS_NAMES = {0: "MH_OK", 1: "MH_ERR_INVALID_ARGUMENT", 2: "MH_ERR_BAD_DIMENSION", 3: "MH_ERR_UNSUPPORTED_JOINT", 4: "MH_ERR_LOOP_CLOSURE",
+                5: "MH_ERR_BAD_TOPOLOGY", 6: "MH_ERR_BAD_AXIS", 7: "MH_ERR_NO_DEVICE", 8: "MH_ERR_HIP", 9: "MH_ERR_OUT_OF_MEMORY",
+                10: "MH_ERR_NOT_RESERVED", 11: "MH_ERR_SINGULAR"}
+LAYOUT_AOS, LAYOUT_SOA = 0, 1
+
+# every symbol include/mecano_hip.h declares (tests/test_abi.py checks the library exports each one)
+ABI_SYMBOLS = [
+    "mh_abi_version", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
+    "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64",
+    "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_timer_create",
+    "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
+]
+
+
+class MhModelDesc(ctypes.Structure):
+    _fields_ = [("n_joints", ctypes.c_int32), ("nq", ctypes.c_int32), ("nv", ctypes.c_int32),
+                ("parent", ctypes.c_void_p), ("joint_type", ctypes.c_void_p), ("axis", ctypes.c_void_p), ("X_before", ctypes.c_void_p),
+                ("X_com", ctypes.c_void_p), ("inertia_J", ctypes.c_void_p), ("inertia_mass", ctypes.c_void_p),
+                ("inertia_com", ctypes.c_void_p), ("dof_indices", ctypes.c_void_p), ("cfg_indices", ctypes.c_void_p)]
+
+
+class MhOptions(ctypes.Structure):
+    _fields_ = [("consider_coriolis", ctypes.c_int32), ("consider_accelerations", ctypes.c_int32), ("layout", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+
+
+class MecanoHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises ImportError when it has not been built (python -m mecano_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m mecano_amd.build` (hipcc, gfx950). "
+                          "mecano_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    lib.mh_abi_version.restype = I32
+    lib.mh_last_error.restype = ctypes.c_char_p
+    lib.mh_device_count.argtypes = [ctypes.POINTER(I32)]
+    lib.mh_set_device.argtypes = [I32]
+    lib.mh_options_default.argtypes = [ctypes.POINTER(MhOptions)]
+    lib.mh_options_default.restype = None
+    lib.mh_model_create.argtypes = [ctypes.POINTER(MhModelDesc), ctypes.POINTER(P)]
+    lib.mh_model_destroy.argtypes = [P]
+    lib.mh_model_destroy.restype = None
+    for f in ("mh_model_nq", "mh_model_nv", "mh_model_n_joints"):
+        getattr(lib, f).argtypes = [P]
+        getattr(lib, f).restype = I32
+    lib.mh_model_kernel_variant.argtypes = [P]
+    lib.mh_model_kernel_variant.restype = ctypes.c_char_p
+    lib.mh_reserve.argtypes = [P, I64]
+    opt = ctypes.POINTER(MhOptions)
+    for f in ("mh_rnea_f64", "mh_aba_f64", "mh_rnea_f32", "mh_aba_f32", "mh_rnea_f64_host", "mh_aba_f64_host"):
+        getattr(lib, f).argtypes = [P, I64, P, P, P, P, P, opt, P]
+    for f in ("mh_crba_f64", "mh_crba_f32", "mh_crba_f64_host"):
+        getattr(lib, f).argtypes = [P, I64, P, opt, P]
+    lib.mh_timer_create.argtypes = [ctypes.POINTER(P)]
+    lib.mh_timer_destroy.argtypes = [P]
+    lib.mh_timer_destroy.restype = None
+    lib.mh_timer_start.argtypes = [P, P]
+    lib.mh_timer_stop.argtypes = [P, P]
+    lib.mh_timer_elapsed_ms.argtypes = [P, ctypes.POINTER(ctypes.c_float)]
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != MH_OK:
+        raise MecanoHipError(status, load().mh_last_error().decode())

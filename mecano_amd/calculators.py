@@ -1,0 +1,124 @@
+"""Batched drop-ins for Mecano's three calculators, with the reference's method names.
+
+* ``InverseDynamicsCalculator``              algorithms/InverseDynamicsCalculator.java:186-251, 291-306, 318-403, 444-501, 567
+* ``ForwardDynamicsCalculator``              algorithms/ForwardDynamicsCalculator.java:112-196, 234-319, 348-381, 475-520, 556-567
+* ``CompositeRigidBodyMassMatrixCalculator`` algorithms/CompositeRigidBodyMassMatrixCalculator.java:157-233, 286-303, 344-348
+
+Differences a user of the reference must know (all forced by batching, none changes results):
+
+* Mecano's calculators read q and qd from the joints' reference frames, which the caller refreshes with
+  ``rootBody.updateFramesRecursively()``.  Here the state of B configurations is passed explicitly:
+  ``compute(q, qd, qdd)`` with matrices shaped [B, nq] / [B, nv] indexed by the system's
+  JointMatrixIndexProvider.  The engine does its own forward kinematics on the GPU.
+* results are returned as (and kept in) a batched matrix: ``getJointTauMatrix()`` is [B, nv].
+* ``CompositeRigidBodyMassMatrixCalculator`` has no result cache to ``reset()``; ``reset()`` is a no-op kept for
+  source compatibility.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .engine import HipModel
+from .multibody import MultiBodySystem, RigidBody
+
+
+def _as_system(inp) -> MultiBodySystem:
+    if isinstance(inp, MultiBodySystem):
+        return inp
+    if isinstance(inp, RigidBody):  # InverseDynamicsCalculator(RigidBodyReadOnly) :186-199
+        return MultiBodySystem.toMultiBodySystemInput(inp)
+    raise TypeError("expected a MultiBodySystem or a RigidBody")
+
+
+class _Base:
+    def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
+        self.input = _as_system(input)
+        if self.input.getJointsToIgnore() and considerIgnoredSubtreesInertia:
+            raise NotImplementedError("lumping of ignored subtrees (InverseDynamicsCalculator.java:832-860) is not implemented yet; "
+                                      "pass considerIgnoredSubtreesInertia=False")
+        self.model = HipModel(self.input.toModelDesc())
+        self._gravity = np.zeros(3)
+        self._f_ext = None
+        self.layout = _lib.LAYOUT_AOS
+
+    def getInput(self) -> MultiBodySystem:
+        return self.input
+
+    # ---- gravity: InverseDynamicsCalculator.java:318-403 / ForwardDynamicsCalculator.java:234-319
+    def setGravitationalAcceleration(self, *g):
+        """``setGravitationalAcceleration(gz)`` (gravity along z, usually negative), ``(gx, gy, gz)`` or a 3-vector."""
+        if len(g) == 1 and np.ndim(g[0]) == 0:
+            self._gravity = np.array([0.0, 0.0, float(g[0])])
+        elif len(g) == 1:
+            self._gravity = np.asarray(g[0], dtype=np.float64).reshape(3).copy()
+        elif len(g) == 3:
+            self._gravity = np.array([float(g[0]), float(g[1]), float(g[2])])
+        else:
+            raise ValueError("gravity is a scalar (z) or three components")
+
+    def setRootAcceleration(self, linearAcceleration):
+        """Root linear acceleration a0; gravity g is applied as a0 = -g (InverseDynamicsCalculator.java:343-348,424)."""
+        self._gravity = -np.asarray(linearAcceleration, dtype=np.float64).reshape(3)
+
+    # ---- external wrenches: InverseDynamicsCalculator.java:444-472 / ForwardDynamicsCalculator.java:348-381
+    def setExternalWrenches(self, f_ext):
+        """[B, n_joints, 6] (moment, force) per successor body, in its body-fixed frame; joints in index-provider order."""
+        self._f_ext = f_ext
+
+    def setExternalWrenchesToZero(self):
+        self._f_ext = None
+
+
+class InverseDynamicsCalculator(_Base):
+    def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
+        super().__init__(input, considerIgnoredSubtreesInertia)
+        self._coriolis = True
+        self._accel = True
+        self._tau = None
+
+    def setConsiderCoriolisAndCentrifugalForces(self, flag: bool):
+        self._coriolis = bool(flag)
+
+    def setConsiderJointAccelerations(self, flag: bool):
+        self._accel = bool(flag)
+
+    def compute(self, q, qd, qdd):
+        self._tau = self.model.rnea(q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis, self._accel)
+        return self._tau
+
+    def getJointTauMatrix(self):
+        return self._tau
+
+
+class ForwardDynamicsCalculator(_Base):
+    def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
+        super().__init__(input, considerIgnoredSubtreesInertia)
+        self._qdd = None
+
+    def compute(self, q, qd, tau):
+        self._qdd = self.model.aba(q, qd, tau, self._gravity, self._f_ext, self.layout)
+        return self._qdd
+
+    def getJointAccelerationMatrix(self):
+        return self._qdd
+
+
+class CompositeRigidBodyMassMatrixCalculator(_Base):
+    def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
+        super().__init__(input, considerIgnoredSubtreesInertia)
+        self._H = None
+
+    def reset(self):
+        self._H = None
+
+    def compute(self, q):
+        self._H = self.model.crba(q, self.layout)
+        return self._H
+
+    def getMassMatrix(self, q=None):
+        if q is not None:
+            return self.compute(q)
+        return self._H

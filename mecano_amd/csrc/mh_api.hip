@@ -1,0 +1,642 @@
+// mh_api.hip -- host side of the C-ABI declared in include/mecano_hip.h.
+//
+// Model build (once per MultiBodySystemReadOnly): validation, parents-first ordering, canonical joint frames,
+// workspace slot assignment, upload.  Compute calls: argument checks, workspace, kernel launch on the caller's
+// stream.  No CPU implementation of the algorithms exists in this library: without a HIP device the compute
+// entry points return MH_ERR_NO_DEVICE.
+#include "../../include/mecano_hip.h"
+#include "mh_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace
+{
+thread_local char g_err[512] = "";
+
+mh_status fail(mh_status code, const char *fmt, ...)
+{
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(g_err, sizeof g_err, fmt, ap);
+   va_end(ap);
+   return code;
+}
+#define HIP_TRY(expr)                                                                                      \
+   do                                                                                                      \
+   {                                                                                                       \
+      hipError_t e_ = (expr);                                                                              \
+      if (e_ != hipSuccess)                                                                                \
+         return fail(e_ == hipErrorOutOfMemory ? MH_ERR_OUT_OF_MEMORY : MH_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+   } while (0)
+
+// ------------------------------------------------------------------ tiny host 3x3 helpers (double)
+struct M3d
+{
+   double m[9];
+};
+M3d m3_identity() { return M3d{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+M3d m3_mul(const M3d &a, const M3d &b)
+{
+   M3d o;
+   for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+         o.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+   return o;
+}
+M3d m3_T(const M3d &a) { return M3d{{a.m[0], a.m[3], a.m[6], a.m[1], a.m[4], a.m[7], a.m[2], a.m[5], a.m[8]}}; }
+void m3_mulv(const M3d &a, const double v[3], double o[3])
+{
+   double x = a.m[0] * v[0] + a.m[1] * v[1] + a.m[2] * v[2];
+   double y = a.m[3] * v[0] + a.m[4] * v[1] + a.m[5] * v[2];
+   double z = a.m[6] * v[0] + a.m[7] * v[1] + a.m[8] * v[2];
+   o[0] = x, o[1] = y, o[2] = z;
+}
+// rotation Q with Q * ez = k (k unit): columns (x', y', k) of a right-handed orthonormal basis
+M3d frame_with_z(const double k[3])
+{
+   int least = std::fabs(k[0]) <= std::fabs(k[1]) ? (std::fabs(k[0]) <= std::fabs(k[2]) ? 0 : 2) : (std::fabs(k[1]) <= std::fabs(k[2]) ? 1 : 2);
+   double h[3] = {0, 0, 0};
+   h[least] = 1.0;
+   double d = h[0] * k[0] + h[1] * k[1] + h[2] * k[2];
+   double x[3] = {h[0] - d * k[0], h[1] - d * k[1], h[2] - d * k[2]};
+   double n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+   x[0] /= n, x[1] /= n, x[2] /= n;
+   double y[3] = {k[1] * x[2] - k[2] * x[1], k[2] * x[0] - k[0] * x[2], k[0] * x[1] - k[1] * x[0]};
+   return M3d{{x[0], y[0], k[0], x[1], y[1], k[1], x[2], y[2], k[2]}};
+}
+
+int joint_ndof(int t) { return t == MH_JOINT_SIXDOF ? 6 : (t == MH_JOINT_FIXED ? 0 : 1); }
+int joint_ncfg(int t) { return t == MH_JOINT_SIXDOF ? 7 : (t == MH_JOINT_FIXED ? 0 : 1); }
+
+struct Workspace
+{
+   void *ptr = nullptr;
+   size_t bytes = 0;
+};
+} // namespace
+
+struct mh_model
+{
+   int n = 0, nq = 0, nv = 0, n_slots = 0;
+   int device = 0;
+   int cu_count = 256;
+   std::vector<int> meta, dof_map, cfg_map;
+   std::vector<double> consts;
+   int *d_meta = nullptr, *d_dof = nullptr, *d_cfg = nullptr;
+   double *d_consts64 = nullptr;
+   float *d_consts32 = nullptr;
+   Workspace ws;
+   // staging buffers of the *_host entry points
+   Workspace stage;
+   std::string variant = "generic";
+};
+
+namespace
+{
+mh_status ensure_bytes(Workspace &w, size_t bytes)
+{
+   if (w.bytes >= bytes)
+      return MH_OK;
+   if (w.ptr)
+      HIP_TRY(hipFree(w.ptr));
+   w.ptr = nullptr, w.bytes = 0;
+   HIP_TRY(hipMalloc(&w.ptr, bytes));
+   w.bytes = bytes;
+   return MH_OK;
+}
+
+struct Launch
+{
+   int block, grid;
+   long lanes;
+};
+Launch plan_launch(const mh_model *m, int64_t B)
+{
+   Launch L;
+   L.block = 64; // one wave per workgroup: a small batch spreads over as many CUs as it has waves
+   long waves = (B + 63) / 64;
+   long cap = (long)m->cu_count * 8; // 8 waves per CU resident at most for these register budgets
+   L.grid = (int)std::max<long>(1, std::min(waves, cap));
+   L.lanes = (long)L.grid * L.block;
+   return L;
+}
+mh_status ensure_workspace(mh_model *m, int64_t B, size_t elem)
+{
+   Launch L = plan_launch(m, B);
+   return ensure_bytes(m->ws, (size_t)m->n_slots * (size_t)L.lanes * elem);
+}
+
+template <typename T>
+mh::DevModel dev_model(const mh_model *m)
+{
+   mh::DevModel d;
+   d.n = m->n, d.nq = m->nq, d.nv = m->nv, d.n_slots = m->n_slots;
+   d.meta = m->d_meta, d.dof_map = m->d_dof, d.cfg_map = m->d_cfg;
+   d.consts = sizeof(T) == 8 ? (const void *)m->d_consts64 : (const void *)m->d_consts32;
+   return d;
+}
+
+mh_status check_common(mh_model_t model, int64_t B, const mh_options *opts)
+{
+   if (!model)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model is NULL");
+   if (B < 0)
+      return fail(MH_ERR_BAD_DIMENSION, "negative batch size %lld", (long long)B);
+   if (opts && opts->layout != MH_LAYOUT_AOS && opts->layout != MH_LAYOUT_SOA)
+      return fail(MH_ERR_INVALID_ARGUMENT, "unknown layout %d", opts->layout);
+   int cur = 0;
+   if (hipGetDevice(&cur) != hipSuccess)
+      return fail(MH_ERR_NO_DEVICE, "no usable HIP device");
+   if (cur != model->device)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model lives on device %d but the calling thread's device is %d", model->device, cur);
+   return MH_OK;
+}
+
+enum Algo
+{
+   ALGO_RNEA,
+   ALGO_ABA,
+   ALGO_CRBA
+};
+
+template <typename T>
+mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd, const T *in3, const double gravity[3], const T *fext,
+                 const mh_options *opts_in, T *out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   if (B == 0)
+      return MH_OK;
+   st = ensure_workspace(model, B, sizeof(T));
+   if (st != MH_OK)
+      return st;
+   const Launch L = plan_launch(model, B);
+   hipStream_t stream = (hipStream_t)opts.stream;
+
+   mh::Args<T> A;
+   A.m = dev_model<T>(model);
+   A.B = B;
+   A.q = q, A.qd = qd, A.in3 = in3, A.fext = fext, A.out = out;
+   A.ws = (T *)model->ws.ptr;
+   A.ws_stride = L.lanes;
+   const bool soa = opts.layout == MH_LAYOUT_SOA;
+   A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
+   A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
+   A.f_bs = soa ? 1 : (long)model->n * 6, A.f_es = soa ? B : 1;
+   A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
+   A.coriolis = opts.consider_coriolis, A.accel = opts.consider_accelerations;
+   const size_t lds = (size_t)model->n * mh::MC_STRIDE * sizeof(T);
+   if (lds > 160 * 1024)
+      return fail(MH_ERR_BAD_DIMENSION, "model constants (%zu B) exceed the 160 KiB LDS of a gfx950 CU", lds);
+
+   switch (algo)
+   {
+      case ALGO_RNEA:
+         hipLaunchKernelGGL(mh::rnea_kernel<T>, dim3(L.grid), dim3(L.block), lds, stream, A);
+         break;
+      case ALGO_ABA:
+         hipLaunchKernelGGL(mh::aba_kernel<T>, dim3(L.grid), dim3(L.block), lds, stream, A);
+         break;
+      case ALGO_CRBA:
+      {
+         const size_t hbytes = (size_t)B * model->nv * model->nv * sizeof(T);
+         HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
+         A.v_bs = soa ? 1 : (long)model->nv * model->nv;
+         hipLaunchKernelGGL(mh::crba_kernel<T>, dim3(L.grid), dim3(L.block), lds, stream, A);
+         break;
+      }
+   }
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
+
+// host-pointer front end: stage through one device buffer, run, copy back, synchronise
+mh_status launch_host(Algo algo, mh_model_t model, int64_t B, const double *q, const double *qd, const double *in3, const double gravity[3],
+                      const double *fext, const mh_options *opts_in, double *out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   if (B == 0)
+      return MH_OK;
+   const size_t nq = model->nq, nv = model->nv, nj = model->n;
+   const size_t s_q = (size_t)B * nq, s_v = (size_t)B * nv, s_f = fext ? (size_t)B * nj * 6 : 0;
+   const size_t s_out = algo == ALGO_CRBA ? (size_t)B * nv * nv : s_v;
+   const size_t total = (s_q + 2 * s_v + s_f + s_out) * sizeof(double);
+   st = ensure_bytes(model->stage, total);
+   if (st != MH_OK)
+      return st;
+   hipStream_t stream = (hipStream_t)opts.stream;
+   double *d_q = (double *)model->stage.ptr, *d_qd = d_q + s_q, *d_in3 = d_qd + s_v, *d_f = d_in3 + s_v, *d_out = d_f + s_f;
+   HIP_TRY(hipMemcpyAsync(d_q, q, s_q * sizeof(double), hipMemcpyHostToDevice, stream));
+   if (algo != ALGO_CRBA)
+   {
+      HIP_TRY(hipMemcpyAsync(d_qd, qd, s_v * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(d_in3, in3, s_v * sizeof(double), hipMemcpyHostToDevice, stream));
+      if (fext)
+         HIP_TRY(hipMemcpyAsync(d_f, fext, s_f * sizeof(double), hipMemcpyHostToDevice, stream));
+   }
+   st = launch<double>(algo, model, B, d_q, d_qd, d_in3, gravity, fext ? d_f : nullptr, &opts, d_out);
+   if (st != MH_OK)
+      return st;
+   HIP_TRY(hipMemcpyAsync(out, d_out, s_out * sizeof(double), hipMemcpyDeviceToHost, stream));
+   HIP_TRY(hipStreamSynchronize(stream));
+   return MH_OK;
+}
+} // namespace
+
+// =================================================================================================== C-ABI
+extern "C" {
+
+int32_t mh_abi_version(void) { return MH_ABI_VERSION; }
+const char *mh_last_error(void) { return g_err; }
+
+mh_status mh_device_count(int32_t *count)
+{
+   if (!count)
+      return fail(MH_ERR_INVALID_ARGUMENT, "count is NULL");
+   int c = 0;
+   if (hipGetDeviceCount(&c) != hipSuccess)
+      c = 0;
+   *count = c;
+   return MH_OK;
+}
+mh_status mh_set_device(int32_t device)
+{
+   HIP_TRY(hipSetDevice(device));
+   return MH_OK;
+}
+void mh_options_default(mh_options *opts)
+{
+   if (!opts)
+      return;
+   opts->consider_coriolis = 1;
+   opts->consider_accelerations = 1;
+   opts->layout = MH_LAYOUT_AOS;
+   opts->reserved0 = 0;
+   opts->stream = nullptr;
+}
+
+mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
+{
+   if (!d || !model_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "desc / model_out is NULL");
+   *model_out = nullptr;
+   const int n = d->n_joints;
+   if (n <= 0)
+      return fail(MH_ERR_INVALID_ARGUMENT, "n_joints = %d", n);
+   if (!d->parent || !d->joint_type || !d->axis || !d->X_before || !d->X_com || !d->inertia_J || !d->inertia_mass || !d->inertia_com
+       || !d->dof_indices || !d->cfg_indices)
+      return fail(MH_ERR_INVALID_ARGUMENT, "a model array is NULL");
+   if (d->nq < 0 || d->nv < 0)
+      return fail(MH_ERR_BAD_DIMENSION, "nq = %d, nv = %d", d->nq, d->nv);
+
+   // ---- validation of kinds, parents (forest, no loop), index maps (injective, in range)
+   std::vector<int> dofo(n + 1, 0), cfgo(n + 1, 0);
+   for (int i = 0; i < n; i++)
+   {
+      const int t = d->joint_type[i];
+      if (t < MH_JOINT_REVOLUTE || t > MH_JOINT_FIXED)
+         return fail(MH_ERR_UNSUPPORTED_JOINT, "joint %d has unsupported kind %d", i, t);
+      if (d->parent[i] < -1 || d->parent[i] >= n || d->parent[i] == i)
+         return fail(MH_ERR_BAD_TOPOLOGY, "joint %d has parent %d", i, d->parent[i]);
+      dofo[i + 1] = dofo[i] + joint_ndof(t);
+      cfgo[i + 1] = cfgo[i] + joint_ncfg(t);
+   }
+   {
+      std::vector<char> seen_v(d->nv, 0), seen_q(d->nq, 0);
+      for (int k = 0; k < dofo[n]; k++)
+      {
+         const int r = d->dof_indices[k];
+         if (r < 0 || r >= d->nv || seen_v[r])
+            return fail(MH_ERR_BAD_TOPOLOGY, "dof_indices[%d] = %d is out of range or repeated (nv = %d)", k, r, d->nv);
+         seen_v[r] = 1;
+      }
+      for (int k = 0; k < cfgo[n]; k++)
+      {
+         const int r = d->cfg_indices[k];
+         if (r < 0 || r >= d->nq || seen_q[r])
+            return fail(MH_ERR_BAD_TOPOLOGY, "cfg_indices[%d] = %d is out of range or repeated (nq = %d)", k, r, d->nq);
+         seen_q[r] = 1;
+      }
+   }
+   // ---- engine order: depth-first pre-order, children in the caller's order (chains stay contiguous)
+   std::vector<std::vector<int>> children(n);
+   std::vector<int> roots;
+   for (int i = 0; i < n; i++)
+      (d->parent[i] < 0 ? roots : children[d->parent[i]]).push_back(i);
+   std::vector<int> order; // engine index -> caller index
+   order.reserve(n);
+   {
+      std::vector<int> stack(roots.rbegin(), roots.rend());
+      while (!stack.empty())
+      {
+         int i = stack.back();
+         stack.pop_back();
+         order.push_back(i);
+         for (auto it = children[i].rbegin(); it != children[i].rend(); ++it)
+            stack.push_back(*it);
+      }
+   }
+   if ((int)order.size() != n)
+      return fail(MH_ERR_LOOP_CLOSURE, "parent[] contains a cycle: %d of %d joints are reachable from the root", (int)order.size(), n);
+   std::vector<int> engine_of(n);
+   for (int e = 0; e < n; e++)
+      engine_of[order[e]] = e;
+
+   // ---- canonical frames: Q_i maps the canonical after-joint axes of joint i to Mecano's after-joint axes
+   std::vector<M3d> Q(n);
+   for (int e = 0; e < n; e++)
+   {
+      const int i = order[e];
+      const int t = d->joint_type[i];
+      if (t == MH_JOINT_REVOLUTE || t == MH_JOINT_PRISMATIC)
+      {
+         const double *a = d->axis + 3 * i;
+         const double nrm = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+         if (!(std::fabs(nrm - 1.0) <= 1.0e-6))
+            return fail(MH_ERR_BAD_AXIS, "joint %d: axis (%g, %g, %g) is not a unit vector", i, a[0], a[1], a[2]);
+         const double k[3] = {a[0] / nrm, a[1] / nrm, a[2] / nrm};
+         Q[e] = frame_with_z(k);
+      }
+      else
+         Q[e] = m3_identity();
+   }
+
+   mh_model *m = new mh_model();
+   m->n = n, m->nq = d->nq, m->nv = d->nv;
+   m->meta.assign((size_t)n * mh::MI_STRIDE, 0);
+   m->consts.assign((size_t)n * mh::MC_STRIDE, 0.0);
+   m->dof_map.assign(d->dof_indices, d->dof_indices + dofo[n]);
+   m->cfg_map.assign(d->cfg_indices, d->cfg_indices + cfgo[n]);
+   if (m->dof_map.empty())
+      m->dof_map.push_back(0);
+   if (m->cfg_map.empty())
+      m->cfg_map.push_back(0);
+
+   int slots = 0;
+   for (int e = 0; e < n; e++)
+   {
+      const int i = order[e];
+      const int t = d->joint_type[i];
+      const int pe = d->parent[i] < 0 ? -1 : engine_of[d->parent[i]];
+      int *mi = &m->meta[(size_t)e * mh::MI_STRIDE];
+      double *c = &m->consts[(size_t)e * mh::MC_STRIDE];
+      mi[mh::MI_PARENT] = pe;
+      mi[mh::MI_TYPE] = t;
+      mi[mh::MI_DOF] = dofo[i];
+      mi[mh::MI_CFG] = cfgo[i];
+      mi[mh::MI_EXT] = i;
+      int flags = 0;
+      if (pe >= 0 && pe == e - 1)
+         flags |= mh::MF_PARENT_ADJ;
+      bool nonadj_child = false;
+      for (int ch : children[i])
+         if (engine_of[ch] != e + 1)
+            nonadj_child = true;
+      if (nonadj_child)
+         flags |= mh::MF_STORE_VA | mh::MF_HAS_ACC;
+      if (pe >= 0 && pe != e - 1)
+      {
+         // first contributor = highest engine index among the non-adjacent children of the parent
+         int hi = -1;
+         for (int ch : children[d->parent[i]])
+            if (engine_of[ch] != pe + 1)
+               hi = std::max(hi, engine_of[ch]);
+         if (hi == e)
+            flags |= mh::MF_ACC_FIRST;
+      }
+      mi[mh::MI_FLAGS] = flags;
+      mi[mh::MI_SLOT_JP] = slots, slots += (t == MH_JOINT_REVOLUTE ? 2 : 0);
+      mi[mh::MI_SLOT_F] = slots, slots += 8;
+      mi[mh::MI_SLOT_C] = slots, slots += 6;
+      mi[mh::MI_SLOT_VA] = slots, slots += (nonadj_child ? 12 : 0);
+      mi[mh::MI_SLOT_IA] = slots, slots += (nonadj_child ? 21 : 0);
+
+      // X_before' = Qp^T X_before Q : canonical before-joint frame in the parent's canonical after-joint frame
+      const M3d Qp = pe < 0 ? m3_identity() : Q[pe];
+      M3d Rb;
+      std::memcpy(Rb.m, d->X_before + 12 * i, sizeof Rb.m);
+      const M3d Rb2 = m3_mul(m3_mul(m3_T(Qp), Rb), Q[e]);
+      double pb2[3];
+      m3_mulv(m3_T(Qp), d->X_before + 12 * i + 9, pb2);
+      for (int k = 0; k < 9; k++)
+         c[mh::MC_RB + k] = Rb2.m[k];
+      for (int k = 0; k < 3; k++)
+         c[mh::MC_PB + k] = pb2[k];
+      // body-fixed -> canonical after-joint: R' = Q^T Rc, p' = Q^T pc
+      M3d Rc;
+      std::memcpy(Rc.m, d->X_com + 12 * i, sizeof Rc.m);
+      const M3d Rf = m3_mul(m3_T(Q[e]), Rc);
+      double pf[3];
+      m3_mulv(m3_T(Q[e]), d->X_com + 12 * i + 9, pf);
+      for (int k = 0; k < 9; k++)
+         c[mh::MC_RF + k] = Rf.m[k];
+      for (int k = 0; k < 3; k++)
+         c[mh::MC_PF + k] = pf[k];
+      // spatial inertia about the canonical after-joint origin.  J is the rotational inertia about the ORIGIN of the
+      // body-fixed frame with the CoM at c_b there (spatial/interfaces/SpatialInertiaReadOnly.java:394-415).
+      const double mass = d->inertia_mass[i];
+      const double *cb = d->inertia_com + 3 * i;
+      M3d J;
+      std::memcpy(J.m, d->inertia_J + 9 * i, sizeof J.m);
+      const M3d Jr = m3_mul(m3_mul(Rf, J), m3_T(Rf)); // about the body-fixed origin, canonical axes
+      double cr[3];
+      m3_mulv(Rf, cb, cr); // CoM relative to the body-fixed origin, canonical axes
+      // shift the origin from the body-fixed origin (at pf) to the after-joint origin: c' = cr + pf
+      const double h0[3] = {mass * cr[0], mass * cr[1], mass * cr[2]};
+      const double dd = 2.0 * (pf[0] * h0[0] + pf[1] * h0[1] + pf[2] * h0[2]) + mass * (pf[0] * pf[0] + pf[1] * pf[1] + pf[2] * pf[2]);
+      double I[9];
+      for (int r = 0; r < 3; r++)
+         for (int s = 0; s < 3; s++)
+            I[3 * r + s] = Jr.m[3 * r + s] + (r == s ? dd : 0.0) - (pf[r] * h0[s] + h0[r] * pf[s] + mass * pf[r] * pf[s]);
+      c[mh::MC_M] = mass;
+      for (int k = 0; k < 3; k++)
+         c[mh::MC_H + k] = h0[k] + mass * pf[k];
+      c[mh::MC_I + 0] = I[0], c[mh::MC_I + 1] = 0.5 * (I[1] + I[3]), c[mh::MC_I + 2] = 0.5 * (I[2] + I[6]);
+      c[mh::MC_I + 3] = I[4], c[mh::MC_I + 4] = 0.5 * (I[5] + I[7]), c[mh::MC_I + 5] = I[8];
+   }
+   m->n_slots = std::max(slots, 1);
+
+   // ---- device side
+   int dev = 0, ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+   {
+      delete m;
+      return fail(MH_ERR_NO_DEVICE, "no HIP device: the model cannot be uploaded (there is no CPU path)");
+   }
+   hipError_t e = hipGetDevice(&dev);
+   if (e == hipSuccess)
+   {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess)
+         m->cu_count = prop.multiProcessorCount;
+   }
+   m->device = dev;
+   std::vector<float> c32(m->consts.begin(), m->consts.end());
+   auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+      hipError_t r = hipMalloc(dst, bytes);
+      if (r != hipSuccess)
+         return r;
+      return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+   };
+   if (e == hipSuccess)
+      e = up((void **)&m->d_meta, m->meta.data(), m->meta.size() * sizeof(int));
+   if (e == hipSuccess)
+      e = up((void **)&m->d_dof, m->dof_map.data(), m->dof_map.size() * sizeof(int));
+   if (e == hipSuccess)
+      e = up((void **)&m->d_cfg, m->cfg_map.data(), m->cfg_map.size() * sizeof(int));
+   if (e == hipSuccess)
+      e = up((void **)&m->d_consts64, m->consts.data(), m->consts.size() * sizeof(double));
+   if (e == hipSuccess)
+      e = up((void **)&m->d_consts32, c32.data(), c32.size() * sizeof(float));
+   if (e != hipSuccess)
+   {
+      mh_model_destroy(m);
+      return fail(MH_ERR_HIP, "model upload failed: %s", hipGetErrorString(e));
+   }
+   *model_out = m;
+   return MH_OK;
+}
+
+void mh_model_destroy(mh_model_t m)
+{
+   if (!m)
+      return;
+   (void)hipFree(m->d_meta);
+   (void)hipFree(m->d_dof);
+   (void)hipFree(m->d_cfg);
+   (void)hipFree(m->d_consts64);
+   (void)hipFree(m->d_consts32);
+   (void)hipFree(m->ws.ptr);
+   (void)hipFree(m->stage.ptr);
+   delete m;
+}
+int32_t mh_model_nq(mh_model_t m) { return m ? m->nq : -1; }
+int32_t mh_model_nv(mh_model_t m) { return m ? m->nv : -1; }
+int32_t mh_model_n_joints(mh_model_t m) { return m ? m->n : -1; }
+const char *mh_model_kernel_variant(mh_model_t m) { return m ? m->variant.c_str() : ""; }
+
+mh_status mh_reserve(mh_model_t m, int64_t max_batch)
+{
+   mh_status st = check_common(m, max_batch, nullptr);
+   if (st != MH_OK)
+      return st;
+   return ensure_workspace(m, max_batch, sizeof(double));
+}
+
+mh_status mh_rnea_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                      const double *f_ext, const mh_options *opts, double *tau_out)
+{
+   return launch<double>(ALGO_RNEA, model, B, q, qd, qdd, gravity, f_ext, opts, tau_out);
+}
+mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
+                     const double *f_ext, const mh_options *opts, double *qdd_out)
+{
+   return launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+}
+mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
+{
+   return launch<double>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+}
+mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
+                      const float *f_ext, const mh_options *opts, float *tau_out)
+{
+   return launch<float>(ALGO_RNEA, model, B, q, qd, qdd, gravity, f_ext, opts, tau_out);
+}
+mh_status mh_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau, const double gravity[3],
+                     const float *f_ext, const mh_options *opts, float *qdd_out)
+{
+   return launch<float>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+}
+mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_options *opts, float *H_out)
+{
+   return launch<float>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+}
+
+mh_status mh_rnea_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                           const double *f_ext, const mh_options *opts, double *tau_out)
+{
+   return launch_host(ALGO_RNEA, model, B, q, qd, qdd, gravity, f_ext, opts, tau_out);
+}
+mh_status mh_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
+                          const double *f_ext, const mh_options *opts, double *qdd_out)
+{
+   return launch_host(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+}
+mh_status mh_crba_f64_host(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
+{
+   return launch_host(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+}
+
+// ---- HIP-event timer
+struct mh_timer
+{
+   hipEvent_t start, stop;
+};
+mh_status mh_timer_create(mh_timer_t *out)
+{
+   if (!out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "timer_out is NULL");
+   mh_timer *t = new mh_timer();
+   if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess)
+   {
+      delete t;
+      return fail(MH_ERR_NO_DEVICE, "cannot create HIP events");
+   }
+   *out = t;
+   return MH_OK;
+}
+void mh_timer_destroy(mh_timer_t t)
+{
+   if (!t)
+      return;
+   (void)hipEventDestroy(t->start);
+   (void)hipEventDestroy(t->stop);
+   delete t;
+}
+mh_status mh_timer_start(mh_timer_t t, void *stream)
+{
+   if (!t)
+      return fail(MH_ERR_INVALID_ARGUMENT, "timer is NULL");
+   HIP_TRY(hipEventRecord(t->start, (hipStream_t)stream));
+   return MH_OK;
+}
+mh_status mh_timer_stop(mh_timer_t t, void *stream)
+{
+   if (!t)
+      return fail(MH_ERR_INVALID_ARGUMENT, "timer is NULL");
+   HIP_TRY(hipEventRecord(t->stop, (hipStream_t)stream));
+   return MH_OK;
+}
+mh_status mh_timer_elapsed_ms(mh_timer_t t, float *ms)
+{
+   if (!t || !ms)
+      return fail(MH_ERR_INVALID_ARGUMENT, "timer / ms_out is NULL");
+   HIP_TRY(hipEventSynchronize(t->stop));
+   HIP_TRY(hipEventElapsedTime(ms, t->start, t->stop));
+   return MH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,341 @@
+// mh_device.h -- small spatial-algebra building blocks for the gfx950 kernels.
+//
+// Everything here works on plain scalars in registers (lane = one configuration), in the engine's
+// *canonical joint frames*: the frame after every 1-DoF joint is rotated once, on the host, so that the
+// joint axis is +z.  A revolute joint is then Rz(q), a prismatic joint a slide along z, S is a unit
+// basis vector, tau = one component of the joint wrench, U = one column of the articulated inertia.
+// Results (tau, qdd, H) are scalars per DoF and do not depend on that choice of frame.
+//
+// Spatial vectors are (angular, linear) like Mecano's (spatial/interfaces/SpatialVectorReadOnly.java).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MH_DEV __device__ __forceinline__
+
+namespace mh
+{
+template <typename T>
+struct V3
+{
+   T x, y, z;
+};
+template <typename T>
+struct SV
+{ // spatial vector
+   V3<T> a, l;
+};
+template <typename T>
+struct M3
+{ // general 3x3, row-major
+   T xx, xy, xz, yx, yy, yz, zx, zy, zz;
+};
+template <typename T>
+struct S3
+{ // symmetric 3x3
+   T xx, xy, xz, yy, yz, zz;
+};
+template <typename T>
+struct XF
+{ // rigid transform child -> parent: x_p = R x_c + p
+   M3<T> R;
+   V3<T> p;
+};
+// rigid-body inertia about a frame origin: mass, first moment h = m c, rotational inertia I about the origin
+template <typename T>
+struct RI
+{
+   T m;
+   V3<T> h;
+   S3<T> I;
+};
+// articulated-body inertia [[A, C], [C^T, L]]  (algorithms/ArticulatedBodyInertia.java:42-55)
+template <typename T>
+struct ABI
+{
+   S3<T> A, L;
+   M3<T> C;
+};
+
+template <typename T>
+MH_DEV V3<T> v3(T x, T y, T z)
+{
+   return V3<T>{x, y, z};
+}
+template <typename T>
+MH_DEV V3<T> operator+(V3<T> a, V3<T> b)
+{
+   return {a.x + b.x, a.y + b.y, a.z + b.z};
+}
+template <typename T>
+MH_DEV V3<T> operator-(V3<T> a, V3<T> b)
+{
+   return {a.x - b.x, a.y - b.y, a.z - b.z};
+}
+template <typename T>
+MH_DEV V3<T> operator*(T s, V3<T> a)
+{
+   return {s * a.x, s * a.y, s * a.z};
+}
+template <typename T>
+MH_DEV V3<T> cross(V3<T> a, V3<T> b)
+{
+   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename T>
+MH_DEV T dot(V3<T> a, V3<T> b)
+{
+   return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+template <typename T>
+MH_DEV V3<T> mul(const M3<T> &R, V3<T> v)
+{ // R v
+   return {R.xx * v.x + R.xy * v.y + R.xz * v.z, R.yx * v.x + R.yy * v.y + R.yz * v.z, R.zx * v.x + R.zy * v.y + R.zz * v.z};
+}
+template <typename T>
+MH_DEV V3<T> tmul(const M3<T> &R, V3<T> v)
+{ // R^T v
+   return {R.xx * v.x + R.yx * v.y + R.zx * v.z, R.xy * v.x + R.yy * v.y + R.zy * v.z, R.xz * v.x + R.yz * v.y + R.zz * v.z};
+}
+template <typename T>
+MH_DEV V3<T> mul(const S3<T> &A, V3<T> v)
+{
+   return {A.xx * v.x + A.xy * v.y + A.xz * v.z, A.xy * v.x + A.yy * v.y + A.yz * v.z, A.xz * v.x + A.yz * v.y + A.zz * v.z};
+}
+// rotation about z by angle with (c, s):  Rz v  and  Rz^T v
+template <typename T>
+MH_DEV V3<T> rotz(T c, T s, V3<T> v)
+{
+   return {c * v.x - s * v.y, s * v.x + c * v.y, v.z};
+}
+template <typename T>
+MH_DEV V3<T> rotzT(T c, T s, V3<T> v)
+{
+   return {c * v.x + s * v.y, c * v.y - s * v.x, v.z};
+}
+
+// ---- motion vectors parent -> child through X (child -> parent pose):  w' = R^T w ; v' = R^T (v + w x p)
+template <typename T>
+MH_DEV SV<T> motion_to_child(const XF<T> &X, SV<T> m)
+{
+   SV<T> o;
+   o.a = tmul(X.R, m.a);
+   o.l = tmul(X.R, m.l + cross(m.a, X.p));
+   return o;
+}
+// ---- force vectors child -> parent:  f' = R f ; n' = R n + p x f'      (spatial/interfaces/FixedFrameSpatialForceBasics.java:249-259)
+template <typename T>
+MH_DEV SV<T> force_to_parent(const XF<T> &X, SV<T> w)
+{
+   SV<T> o;
+   o.l = mul(X.R, w.l);
+   o.a = mul(X.R, w.a) + cross(X.p, o.l);
+   return o;
+}
+
+// ---- rigid inertia times motion vector: momentum = [I w + h x v ; m v - h x w]
+template <typename T>
+MH_DEV SV<T> mul(const RI<T> &I, SV<T> v)
+{
+   SV<T> o;
+   o.a = mul(I.I, v.a) + cross(I.h, v.l);
+   o.l = I.m * v.l - cross(I.h, v.a);
+   return o;
+}
+// v x* f  (spatial force cross product): [w x n + v x f ; w x f]
+template <typename T>
+MH_DEV SV<T> crf(SV<T> v, SV<T> f)
+{
+   SV<T> o;
+   o.a = cross(v.a, f.a) + cross(v.l, f.l);
+   o.l = cross(v.a, f.l);
+   return o;
+}
+// v x m (spatial motion cross product): [w x mw ; w x mv + v x mw]
+template <typename T>
+MH_DEV SV<T> crm(SV<T> v, SV<T> m)
+{
+   SV<T> o;
+   o.a = cross(v.a, m.a);
+   o.l = cross(v.a, m.l) + cross(v.l, m.a);
+   return o;
+}
+template <typename T>
+MH_DEV SV<T> operator+(SV<T> a, SV<T> b)
+{
+   return {a.a + b.a, a.l + b.l};
+}
+template <typename T>
+MH_DEV SV<T> operator-(SV<T> a, SV<T> b)
+{
+   return {a.a - b.a, a.l - b.l};
+}
+
+// ---- quaternion (x, y, z, s), normalised on input like Euclid's Quaternion.set, to a rotation matrix
+template <typename T>
+MH_DEV M3<T> quat_to_R(T x, T y, T z, T s)
+{
+   T inv = T(1) / sqrt(x * x + y * y + z * z + s * s);
+   x *= inv, y *= inv, z *= inv, s *= inv;
+   M3<T> R;
+   R.xx = T(1) - T(2) * (y * y + z * z), R.xy = T(2) * (x * y - z * s), R.xz = T(2) * (x * z + y * s);
+   R.yx = T(2) * (x * y + z * s), R.yy = T(1) - T(2) * (x * x + z * z), R.yz = T(2) * (y * z - x * s);
+   R.zx = T(2) * (x * z - y * s), R.zy = T(2) * (y * z + x * s), R.zz = T(1) - T(2) * (x * x + y * y);
+   return R;
+}
+
+// ---- R S R^T for symmetric S
+template <typename T>
+MH_DEV S3<T> conj(const M3<T> &R, const S3<T> &S)
+{
+   // T = R S
+   T txx = R.xx * S.xx + R.xy * S.xy + R.xz * S.xz, txy = R.xx * S.xy + R.xy * S.yy + R.xz * S.yz, txz = R.xx * S.xz + R.xy * S.yz + R.xz * S.zz;
+   T tyx = R.yx * S.xx + R.yy * S.xy + R.yz * S.xz, tyy = R.yx * S.xy + R.yy * S.yy + R.yz * S.yz, tyz = R.yx * S.xz + R.yy * S.yz + R.yz * S.zz;
+   T tzx = R.zx * S.xx + R.zy * S.xy + R.zz * S.xz, tzy = R.zx * S.xy + R.zy * S.yy + R.zz * S.yz, tzz = R.zx * S.xz + R.zy * S.yz + R.zz * S.zz;
+   S3<T> o;
+   o.xx = txx * R.xx + txy * R.xy + txz * R.xz;
+   o.xy = txx * R.yx + txy * R.yy + txz * R.yz;
+   o.xz = txx * R.zx + txy * R.zy + txz * R.zz;
+   o.yy = tyx * R.yx + tyy * R.yy + tyz * R.yz;
+   o.yz = tyx * R.zx + tyy * R.zy + tyz * R.zz;
+   o.zz = tzx * R.zx + tzy * R.zy + tzz * R.zz;
+   return o;
+}
+// ---- R M R^T for a general M
+template <typename T>
+MH_DEV M3<T> conj(const M3<T> &R, const M3<T> &M)
+{
+   T txx = R.xx * M.xx + R.xy * M.yx + R.xz * M.zx, txy = R.xx * M.xy + R.xy * M.yy + R.xz * M.zy, txz = R.xx * M.xz + R.xy * M.yz + R.xz * M.zz;
+   T tyx = R.yx * M.xx + R.yy * M.yx + R.yz * M.zx, tyy = R.yx * M.xy + R.yy * M.yy + R.yz * M.zy, tyz = R.yx * M.xz + R.yy * M.yz + R.yz * M.zz;
+   T tzx = R.zx * M.xx + R.zy * M.yx + R.zz * M.zx, tzy = R.zx * M.xy + R.zy * M.yy + R.zz * M.zy, tzz = R.zx * M.xz + R.zy * M.yz + R.zz * M.zz;
+   M3<T> o;
+   o.xx = txx * R.xx + txy * R.xy + txz * R.xz, o.xy = txx * R.yx + txy * R.yy + txz * R.yz, o.xz = txx * R.zx + txy * R.zy + txz * R.zz;
+   o.yx = tyx * R.xx + tyy * R.xy + tyz * R.xz, o.yy = tyx * R.yx + tyy * R.yy + tyz * R.yz, o.yz = tyx * R.zx + tyy * R.zy + tyz * R.zz;
+   o.zx = tzx * R.xx + tzy * R.xy + tzz * R.xz, o.zy = tzx * R.yx + tzy * R.yy + tzz * R.yz, o.zz = tzx * R.zx + tzy * R.zy + tzz * R.zz;
+   return o;
+}
+// ---- Rz(c,s) S Rz^T : planar rotation of a symmetric matrix
+template <typename T>
+MH_DEV S3<T> conj_z(T c, T s, const S3<T> &S)
+{
+   S3<T> o;
+   T cc = c * c, ss = s * s, cs = c * s;
+   o.xx = cc * S.xx - T(2) * cs * S.xy + ss * S.yy;
+   o.yy = ss * S.xx + T(2) * cs * S.xy + cc * S.yy;
+   o.xy = cs * (S.xx - S.yy) + (cc - ss) * S.xy;
+   o.xz = c * S.xz - s * S.yz;
+   o.yz = s * S.xz + c * S.yz;
+   o.zz = S.zz;
+   return o;
+}
+// ---- Rz M Rz^T for a general M
+template <typename T>
+MH_DEV M3<T> conj_z(T c, T s, const M3<T> &M)
+{
+   // rows first: T = Rz M
+   T txx = c * M.xx - s * M.yx, txy = c * M.xy - s * M.yy, txz = c * M.xz - s * M.yz;
+   T tyx = s * M.xx + c * M.yx, tyy = s * M.xy + c * M.yy, tyz = s * M.xz + c * M.yz;
+   M3<T> o;
+   o.xx = c * txx - s * txy, o.xy = s * txx + c * txy, o.xz = txz;
+   o.yx = c * tyx - s * tyy, o.yy = s * tyx + c * tyy, o.yz = tyz;
+   o.zx = c * M.zx - s * M.zy, o.zy = s * M.zx + c * M.zy, o.zz = M.zz;
+   return o;
+}
+
+// ---- translate an articulated inertia by p (frame origin moves so that old origin sits at p in the new frame):
+//      with P = [p]x :  C' = C + P L ;  A' = A + P C^T + (P C'^T)^T ;  L' = L
+//      (algorithms/ArticulatedBodyInertiaAlorigthmTools.java:32-163 in matrix form)
+template <typename T>
+MH_DEV void translate(ABI<T> &I, V3<T> p)
+{
+   const S3<T> &L = I.L;
+   const M3<T> C = I.C;
+   // PL = P L, rows: (P L)_x* = -pz L_y* + py L_z*, (P L)_y* = pz L_x* - px L_z*, (P L)_z* = -py L_x* + px L_y*
+   M3<T> N; // C' = C + P L
+   N.xx = C.xx - p.z * L.xy + p.y * L.xz, N.xy = C.xy - p.z * L.yy + p.y * L.yz, N.xz = C.xz - p.z * L.yz + p.y * L.zz;
+   N.yx = C.yx + p.z * L.xx - p.x * L.xz, N.yy = C.yy + p.z * L.xy - p.x * L.yz, N.yz = C.yz + p.z * L.xz - p.x * L.zz;
+   N.zx = C.zx - p.y * L.xx + p.x * L.xy, N.zy = C.zy - p.y * L.xy + p.x * L.yy, N.zz = C.zz - p.y * L.xz + p.x * L.yz;
+   // M1 = P C^T : (M1)_ij = sum_k P_ik C_jk ;  M2 = P N^T ;  A' = A + M1 + M2^T  (symmetric)
+   // row x of P = (0, -pz, py), row y = (pz, 0, -px), row z = (-py, px, 0)
+   T m1xx = -p.z * C.xy + p.y * C.xz, m1xy = -p.z * C.yy + p.y * C.yz, m1xz = -p.z * C.zy + p.y * C.zz;
+   T m1yy = p.z * C.yx - p.x * C.yz, m1yz = p.z * C.zx - p.x * C.zz;
+   T m1zz = -p.y * C.zx + p.x * C.zy;
+   T m2xx = -p.z * N.xy + p.y * N.xz;
+   T m2yx = p.z * N.xx - p.x * N.xz, m2yy = p.z * N.yx - p.x * N.yz;
+   T m2zx = -p.y * N.xx + p.x * N.xy, m2zy = -p.y * N.yx + p.x * N.yy, m2zz = -p.y * N.zx + p.x * N.zy;
+   I.A.xx += m1xx + m2xx;
+   I.A.xy += m1xy + m2yx;
+   I.A.xz += m1xz + m2zx;
+   I.A.yy += m1yy + m2yy;
+   I.A.yz += m1yz + m2zy;
+   I.A.zz += m1zz + m2zz;
+   I.C = N;
+}
+// ---- slide along z by d (prismatic joint): same as translate(I, {0,0,d})
+template <typename T>
+MH_DEV void translate_z(ABI<T> &I, T d)
+{
+   translate(I, V3<T>{T(0), T(0), d});
+}
+template <typename T>
+MH_DEV void rotate(ABI<T> &I, const M3<T> &R)
+{
+   I.A = conj(R, I.A);
+   I.L = conj(R, I.L);
+   I.C = conj(R, I.C);
+}
+template <typename T>
+MH_DEV void rotate_z(ABI<T> &I, T c, T s)
+{
+   I.A = conj_z(c, s, I.A);
+   I.L = conj_z(c, s, I.L);
+   I.C = conj_z(c, s, I.C);
+}
+// I * (a, l)
+template <typename T>
+MH_DEV SV<T> mul(const ABI<T> &I, SV<T> v)
+{
+   SV<T> o;
+   o.a = mul(I.A, v.a) + mul(I.C, v.l);
+   o.l = tmul(I.C, v.a) + mul(I.L, v.l);
+   return o;
+}
+template <typename T>
+MH_DEV ABI<T> abi_from_rigid(const RI<T> &r)
+{ // algorithms/ArticulatedBodyInertia.java:176-186 : A = I, L = m 1, C = [h]x
+   ABI<T> o;
+   o.A = r.I;
+   o.L = S3<T>{r.m, T(0), T(0), r.m, T(0), r.m};
+   o.C = M3<T>{T(0), -r.h.z, r.h.y, r.h.z, T(0), -r.h.x, -r.h.y, r.h.x, T(0)};
+   return o;
+}
+
+// ---- rigid inertia child -> parent through (R, p):  m' = m ; h' = R h + m p ; I' = R I R^T + shift
+//      shift of the rotational inertia when the origin moves by p (old origin at p in the new frame), with
+//      hR = R h :  I' = I_R + ( 2 (p.hR) + m p.p ) 1 - ( p hR^T + hR p^T + m p p^T )
+//      (parallel axis, tools/MecanoTools.java:449-547 with c = h/m)
+template <typename T>
+MH_DEV void shift_origin(RI<T> &r, V3<T> p)
+{
+   V3<T> h = r.h;
+   T d = T(2) * dot(p, h) + r.m * dot(p, p);
+   r.I.xx += d - (T(2) * p.x * h.x + r.m * p.x * p.x);
+   r.I.yy += d - (T(2) * p.y * h.y + r.m * p.y * p.y);
+   r.I.zz += d - (T(2) * p.z * h.z + r.m * p.z * p.z);
+   r.I.xy -= p.x * h.y + h.x * p.y + r.m * p.x * p.y;
+   r.I.xz -= p.x * h.z + h.x * p.z + r.m * p.x * p.z;
+   r.I.yz -= p.y * h.z + h.y * p.z + r.m * p.y * p.z;
+   r.h = h + r.m * p;
+}
+template <typename T>
+MH_DEV void add(RI<T> &a, const RI<T> &b)
+{
+   a.m += b.m;
+   a.h = a.h + b.h;
+   a.I.xx += b.I.xx, a.I.xy += b.I.xy, a.I.xz += b.I.xz, a.I.yy += b.I.yy, a.I.yz += b.I.yz, a.I.zz += b.I.zz;
+}
+
+// ---- sincos
+MH_DEV void sincos_t(double x, double &s, double &c) { sincos(x, &s, &c); }
+MH_DEV void sincos_t(float x, float &s, float &c) { sincosf(x, &s, &c); }
+
+} // namespace mh

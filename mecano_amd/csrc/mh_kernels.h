@@ -1,0 +1,822 @@
+// mh_kernels.h -- generic (run-time topology) batched RNEA / ABA / CRBA kernels for gfx950.
+//
+// Mapping: one wavefront lane = one configuration (q, qd, qdd | tau); the 64 lanes of a wave stride the batch, so
+// every workspace access and every SoA state access is one contiguous 512-byte (fp64) line per wave-instruction.
+// The kinematic tree (parents, joint kinds, index maps) is wave-uniform and is read through scalar loads; the
+// per-joint constants (pose of the joint in its parent, spatial inertia of the successor) are staged once per
+// workgroup in LDS and read as broadcasts.  Per-lane intermediates that must survive between the outward and
+// the inward sweep of the tree live in a per-lane-strided global workspace (slot-major: ws[slot][lane]).
+//
+// Replaces, per configuration (paths relative to /root/reference/src/main/java/us/ihmc/mecano/):
+//   rnea_kernel  algorithms/InverseDynamicsCalculator.java:873-959 + the frame update it relies on
+//   aba_kernel   algorithms/ForwardDynamicsCalculator.java:1085-1310
+//   crba_kernel  algorithms/CompositeRigidBodyMassMatrixCalculator.java:588-707,770-798
+// in the engine's canonical joint frames (see mh_device.h); outputs are frame-independent.
+#pragma once
+#include "mh_device.h"
+
+namespace mh
+{
+enum : int
+{
+   JT_REVOLUTE = 0,
+   JT_PRISMATIC = 1,
+   JT_SIXDOF = 2,
+   JT_FIXED = 3
+};
+
+// ---- per-joint integer record (wave-uniform, scalar loads)
+enum : int
+{
+   MI_PARENT = 0,   // engine index of the parent joint, -1 = root body
+   MI_TYPE = 1,
+   MI_DOF = 2,      // offset into dof_map
+   MI_CFG = 3,      // offset into cfg_map
+   MI_EXT = 4,      // index of the joint in the caller's mh_model_desc order (f_ext rows)
+   MI_FLAGS = 5,
+   MI_SLOT_JP = 6,  // 2 slots (cos, sin) for revolute joints
+   MI_SLOT_F = 7,   // 8 slots: RNEA wrench (6) | ABA bias wrench -> U (6) + Dinv, u
+   MI_SLOT_VA = 8,  // 12 slots: velocity + acceleration for children that do not directly follow their parent
+   MI_SLOT_C = 9,   // 6 slots: ABA bias acceleration
+   MI_SLOT_IA = 10, // 21 slots: ABA articulated inertia / CRBA composite inertia accumulator
+   MI_STRIDE = 12
+};
+enum : int
+{
+   MF_PARENT_ADJ = 1, // parent == j - 1: hand values over in registers
+   MF_STORE_VA = 2,   // some child c != j + 1 exists: it reloads (v, a) from the workspace
+   MF_ACC_FIRST = 4,  // this body is the first (highest index) non-adjacent child of its parent: store, do not add
+   MF_HAS_ACC = 8     // some child c != j + 1 exists: its inertia contribution arrives through the workspace
+};
+// ---- per-joint real constants (LDS)
+enum : int
+{
+   MC_RB = 0,  // 9: rotation of the canonical before-joint frame in the parent's canonical after-joint frame, row-major
+   MC_PB = 9,  // 3: its position
+   MC_M = 12,  // mass
+   MC_H = 13,  // 3: first moment m c about the canonical after-joint origin
+   MC_I = 16,  // 6: rotational inertia about that origin (xx, xy, xz, yy, yz, zz)
+   MC_RF = 22, // 9: rotation body-fixed -> canonical after-joint (for external wrenches)
+   MC_PF = 31, // 3: position of the body-fixed frame
+   MC_STRIDE = 34
+};
+
+struct DevModel
+{
+   int n, nq, nv, n_slots;
+   const int *meta;    // [n][MI_STRIDE]
+   const int *dof_map; // concatenated getJointDoFIndices
+   const int *cfg_map; // concatenated getJointConfigurationIndices
+   const void *consts; // [n][MC_STRIDE] of T
+};
+
+template <typename T>
+struct Args
+{
+   DevModel m;
+   long B;
+   const T *q, *qd, *in3; // in3 = qdd (RNEA) | tau (ABA)
+   const T *fext;
+   T *out;
+   T *ws;
+   long ws_stride; // lanes in the grid
+   long q_bs, q_es; // batch stride / element stride of configuration matrices
+   long v_bs, v_es; // ... of velocity-sized matrices
+   long f_bs, f_es; // ... of the external wrench array (element = joint * 6 + component)
+   T gx, gy, gz;
+   int coriolis, accel;
+};
+
+template <typename T>
+MH_DEV XF<T> load_xb(const T *c)
+{
+   XF<T> X;
+   X.R = M3<T>{c[MC_RB + 0], c[MC_RB + 1], c[MC_RB + 2], c[MC_RB + 3], c[MC_RB + 4], c[MC_RB + 5], c[MC_RB + 6], c[MC_RB + 7], c[MC_RB + 8]};
+   X.p = V3<T>{c[MC_PB + 0], c[MC_PB + 1], c[MC_PB + 2]};
+   return X;
+}
+template <typename T>
+MH_DEV RI<T> load_inertia(const T *c)
+{
+   RI<T> r;
+   r.m = c[MC_M];
+   r.h = V3<T>{c[MC_H + 0], c[MC_H + 1], c[MC_H + 2]};
+   r.I = S3<T>{c[MC_I + 0], c[MC_I + 1], c[MC_I + 2], c[MC_I + 3], c[MC_I + 4], c[MC_I + 5]};
+   return r;
+}
+
+// joint transform of one lane: only the members of the joint's kind are meaningful
+template <typename T>
+struct JX
+{
+   T c, s;  // revolute: cos q, sin q
+   T d;     // prismatic: q
+   XF<T> X; // sixdof: after-joint -> before-joint
+};
+
+// motion vector from the parent's after-joint frame into this joint's after-joint frame (no joint velocity added)
+template <typename T>
+MH_DEV SV<T> motion_down(int type, const JX<T> &jx, const XF<T> &Xb, SV<T> m)
+{
+   SV<T> b = motion_to_child(Xb, m);
+   if (type == JT_REVOLUTE)
+      return SV<T>{rotzT(jx.c, jx.s, b.a), rotzT(jx.c, jx.s, b.l)};
+   if (type == JT_PRISMATIC)
+      return SV<T>{b.a, V3<T>{b.l.x + b.a.y * jx.d, b.l.y - b.a.x * jx.d, b.l.z}};
+   if (type == JT_SIXDOF)
+      return motion_to_child(jx.X, b);
+   return b;
+}
+// force vector from this joint's after-joint frame up into the parent's after-joint frame
+template <typename T>
+MH_DEV SV<T> force_up(int type, const JX<T> &jx, const XF<T> &Xb, SV<T> w)
+{
+   SV<T> b;
+   if (type == JT_REVOLUTE)
+      b = SV<T>{rotz(jx.c, jx.s, w.a), rotz(jx.c, jx.s, w.l)};
+   else if (type == JT_PRISMATIC)
+      b = SV<T>{V3<T>{w.a.x - jx.d * w.l.y, w.a.y + jx.d * w.l.x, w.a.z}, w.l};
+   else if (type == JT_SIXDOF)
+      b = force_to_parent(jx.X, w);
+   else
+      b = w;
+   return force_to_parent(Xb, b);
+}
+template <typename T>
+MH_DEV void abi_up(int type, const JX<T> &jx, const XF<T> &Xb, ABI<T> &I)
+{
+   if (type == JT_REVOLUTE)
+      rotate_z(I, jx.c, jx.s);
+   else if (type == JT_PRISMATIC)
+      translate_z(I, jx.d);
+   else if (type == JT_SIXDOF)
+   {
+      rotate(I, jx.X.R);
+      translate(I, jx.X.p);
+   }
+   rotate(I, Xb.R);
+   translate(I, Xb.p);
+}
+template <typename T>
+MH_DEV void rigid_up(int type, const JX<T> &jx, const XF<T> &Xb, RI<T> &r)
+{
+   if (type == JT_REVOLUTE)
+   {
+      r.h = rotz(jx.c, jx.s, r.h);
+      r.I = conj_z(jx.c, jx.s, r.I);
+   }
+   else if (type == JT_PRISMATIC)
+      shift_origin(r, V3<T>{T(0), T(0), jx.d});
+   else if (type == JT_SIXDOF)
+   {
+      r.h = mul(jx.X.R, r.h);
+      r.I = conj(jx.X.R, r.I);
+      shift_origin(r, jx.X.p);
+   }
+   r.h = mul(Xb.R, r.h);
+   r.I = conj(Xb.R, r.I);
+   shift_origin(r, Xb.p);
+}
+
+#define MH_WS(slot) ws[(long)(slot)*ws_stride]
+
+// joint transform from the inputs (first visit of a body in a kernel); stores (cos, sin) of revolute joints
+template <typename T>
+MH_DEV JX<T> joint_from_q(int type, const int *cfg_map, int cfg_ofs, const T *qrow, long q_es, T *ws, long ws_stride, int slot_jp, bool store)
+{
+   JX<T> jx;
+   jx.c = T(1), jx.s = T(0), jx.d = T(0);
+   if (type == JT_REVOLUTE)
+   {
+      T qv = qrow[cfg_map[cfg_ofs] * q_es];
+      sincos_t(qv, jx.s, jx.c);
+      if (store)
+      {
+         MH_WS(slot_jp) = jx.c;
+         MH_WS(slot_jp + 1) = jx.s;
+      }
+   }
+   else if (type == JT_PRISMATIC)
+      jx.d = qrow[cfg_map[cfg_ofs] * q_es];
+   else if (type == JT_SIXDOF)
+   {
+      const int *ci = cfg_map + cfg_ofs;
+      jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
+      jx.X.p = V3<T>{qrow[ci[4] * q_es], qrow[ci[5] * q_es], qrow[ci[6] * q_es]};
+   }
+   return jx;
+}
+// joint transform on a later visit: revolute (cos, sin) come back from the workspace, the rest is re-read from q
+template <typename T>
+MH_DEV JX<T> joint_again(int type, const int *cfg_map, int cfg_ofs, const T *qrow, long q_es, const T *ws, long ws_stride, int slot_jp)
+{
+   JX<T> jx;
+   jx.c = T(1), jx.s = T(0), jx.d = T(0);
+   if (type == JT_REVOLUTE)
+   {
+      jx.c = MH_WS(slot_jp);
+      jx.s = MH_WS(slot_jp + 1);
+   }
+   else if (type == JT_PRISMATIC)
+      jx.d = qrow[cfg_map[cfg_ofs] * q_es];
+   else if (type == JT_SIXDOF)
+   {
+      const int *ci = cfg_map + cfg_ofs;
+      jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
+      jx.X.p = V3<T>{qrow[ci[4] * q_es], qrow[ci[5] * q_es], qrow[ci[6] * q_es]};
+   }
+   return jx;
+}
+
+template <typename T>
+MH_DEV void ws_store6(T *ws, long ws_stride, int slot, SV<T> v)
+{
+   MH_WS(slot + 0) = v.a.x, MH_WS(slot + 1) = v.a.y, MH_WS(slot + 2) = v.a.z;
+   MH_WS(slot + 3) = v.l.x, MH_WS(slot + 4) = v.l.y, MH_WS(slot + 5) = v.l.z;
+}
+template <typename T>
+MH_DEV SV<T> ws_load6(const T *ws, long ws_stride, int slot)
+{
+   SV<T> v;
+   v.a = V3<T>{MH_WS(slot + 0), MH_WS(slot + 1), MH_WS(slot + 2)};
+   v.l = V3<T>{MH_WS(slot + 3), MH_WS(slot + 4), MH_WS(slot + 5)};
+   return v;
+}
+template <typename T>
+MH_DEV void ws_add6(T *ws, long ws_stride, int slot, SV<T> v)
+{
+   MH_WS(slot + 0) += v.a.x, MH_WS(slot + 1) += v.a.y, MH_WS(slot + 2) += v.a.z;
+   MH_WS(slot + 3) += v.l.x, MH_WS(slot + 4) += v.l.y, MH_WS(slot + 5) += v.l.z;
+}
+
+// velocity of the joint in its own (canonical) after-joint frame, and the matching slice of another DoF-sized vector
+template <typename T>
+MH_DEV SV<T> joint_vec(int type, const int *dof_map, int dof_ofs, const T *row, long es, bool enabled)
+{
+   SV<T> o{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
+   if (!enabled)
+      return o;
+   if (type == JT_REVOLUTE)
+      o.a.z = row[dof_map[dof_ofs] * es];
+   else if (type == JT_PRISMATIC)
+      o.l.z = row[dof_map[dof_ofs] * es];
+   else if (type == JT_SIXDOF)
+   {
+      const int *di = dof_map + dof_ofs;
+      o.a = V3<T>{row[di[0] * es], row[di[1] * es], row[di[2] * es]};
+      o.l = V3<T>{row[di[3] * es], row[di[4] * es], row[di[5] * es]};
+   }
+   return o;
+}
+// external wrench of the body (body-fixed frame) brought to the canonical after-joint frame
+template <typename T>
+MH_DEV SV<T> load_fext(const T *c, const T *frow, long f_es, int ext)
+{
+   XF<T> X;
+   X.R = M3<T>{c[MC_RF + 0], c[MC_RF + 1], c[MC_RF + 2], c[MC_RF + 3], c[MC_RF + 4], c[MC_RF + 5], c[MC_RF + 6], c[MC_RF + 7], c[MC_RF + 8]};
+   X.p = V3<T>{c[MC_PF + 0], c[MC_PF + 1], c[MC_PF + 2]};
+   SV<T> w;
+   const long e = (long)ext * 6;
+   w.a = V3<T>{frow[(e + 0) * f_es], frow[(e + 1) * f_es], frow[(e + 2) * f_es]};
+   w.l = V3<T>{frow[(e + 3) * f_es], frow[(e + 4) * f_es], frow[(e + 5) * f_es]};
+   return force_to_parent(X, w);
+}
+
+template <typename T>
+MH_DEV void stage_consts(const DevModel &m, T *lds)
+{
+   const T *g = (const T *)m.consts;
+   for (int i = threadIdx.x; i < m.n * MC_STRIDE; i += blockDim.x)
+      lds[i] = g[i];
+   __syncthreads();
+}
+
+// ============================================================================================ RNEA
+template <typename T>
+__global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   T *C = (T *)lds_raw;
+   stage_consts<T>(A.m, C);
+   const DevModel &m = A.m;
+   const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   const long ws_stride = A.ws_stride;
+   T *ws = A.ws + lane;
+   const V3<T> Z{T(0), T(0), T(0)};
+
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *qdrow = A.qd + cfg * A.v_bs;
+      const T *qddrow = A.in3 + cfg * A.v_bs;
+      const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
+      T *trow = A.out + cfg * A.v_bs;
+
+      // ---- outward sweep: velocities, accelerations, Newton-Euler wrench of every body
+      SV<T> v_prev{Z, Z}, a_prev{Z, Z};
+      for (int j = 0; j < m.n; j++)
+      {
+         const int *mi = m.meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const T *c = C + j * MC_STRIDE;
+         SV<T> vp, ap;
+         if (parent < 0)
+         {
+            vp = SV<T>{Z, Z};
+            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // InverseDynamicsCalculator.java:343-348
+         }
+         else if (flags & MF_PARENT_ADJ)
+         {
+            vp = v_prev, ap = a_prev;
+         }
+         else
+         {
+            const int sp = m.meta[parent * MI_STRIDE + MI_SLOT_VA];
+            vp = ws_load6(ws, ws_stride, sp);
+            ap = ws_load6(ws, ws_stride, sp + 6);
+         }
+         const XF<T> Xb = load_xb(c);
+         const JX<T> jx = joint_from_q<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> vJ = joint_vec<T>(type, m.dof_map, mi[MI_DOF], qdrow, A.v_es, A.coriolis != 0);
+         const SV<T> aJ = joint_vec<T>(type, m.dof_map, mi[MI_DOF], qddrow, A.v_es, A.accel != 0);
+         SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         SV<T> a = motion_down(type, jx, Xb, ap) + aJ + crm(v, vJ);
+         if (!A.coriolis)
+            v = SV<T>{Z, Z};
+         const RI<T> I = load_inertia(c);
+         SV<T> f = mul(I, a) + crf(v, mul(I, v));
+         if (frow)
+            f = f - load_fext(c, frow, A.f_es, mi[MI_EXT]);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_F], f);
+         if (flags & MF_STORE_VA)
+         {
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA] + 6, a);
+         }
+         v_prev = v, a_prev = a;
+      }
+      // ---- inward sweep: joint efforts, wrenches handed to the parents
+      SV<T> carry{Z, Z};
+      bool have_carry = false;
+      for (int j = m.n - 1; j >= 0; j--)
+      {
+         const int *mi = m.meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const T *c = C + j * MC_STRIDE;
+         SV<T> f = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         if (have_carry)
+            f = f + carry;
+         const int *di = m.dof_map + mi[MI_DOF];
+         if (type == JT_REVOLUTE)
+            trow[di[0] * A.v_es] = f.a.z;
+         else if (type == JT_PRISMATIC)
+            trow[di[0] * A.v_es] = f.l.z;
+         else if (type == JT_SIXDOF)
+         {
+            trow[di[0] * A.v_es] = f.a.x, trow[di[1] * A.v_es] = f.a.y, trow[di[2] * A.v_es] = f.a.z;
+            trow[di[3] * A.v_es] = f.l.x, trow[di[4] * A.v_es] = f.l.y, trow[di[5] * A.v_es] = f.l.z;
+         }
+         have_carry = false;
+         if (parent >= 0)
+         {
+            const XF<T> Xb = load_xb(c);
+            const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+            const SV<T> fp = force_up(type, jx, Xb, f);
+            if (flags & MF_PARENT_ADJ)
+            {
+               carry = fp;
+               have_carry = true;
+            }
+            else
+               ws_add6(ws, ws_stride, m.meta[parent * MI_STRIDE + MI_SLOT_F], fp);
+         }
+      }
+   }
+}
+
+// ============================================================================================ ABA
+template <typename T>
+MH_DEV void ws_store_abi(T *ws, long ws_stride, int s, const ABI<T> &I)
+{
+   MH_WS(s + 0) = I.A.xx, MH_WS(s + 1) = I.A.xy, MH_WS(s + 2) = I.A.xz, MH_WS(s + 3) = I.A.yy, MH_WS(s + 4) = I.A.yz, MH_WS(s + 5) = I.A.zz;
+   MH_WS(s + 6) = I.L.xx, MH_WS(s + 7) = I.L.xy, MH_WS(s + 8) = I.L.xz, MH_WS(s + 9) = I.L.yy, MH_WS(s + 10) = I.L.yz, MH_WS(s + 11) = I.L.zz;
+   MH_WS(s + 12) = I.C.xx, MH_WS(s + 13) = I.C.xy, MH_WS(s + 14) = I.C.xz, MH_WS(s + 15) = I.C.yx, MH_WS(s + 16) = I.C.yy, MH_WS(s + 17) = I.C.yz;
+   MH_WS(s + 18) = I.C.zx, MH_WS(s + 19) = I.C.zy, MH_WS(s + 20) = I.C.zz;
+}
+template <typename T>
+MH_DEV ABI<T> ws_load_abi(const T *ws, long ws_stride, int s)
+{
+   ABI<T> I;
+   I.A = S3<T>{MH_WS(s + 0), MH_WS(s + 1), MH_WS(s + 2), MH_WS(s + 3), MH_WS(s + 4), MH_WS(s + 5)};
+   I.L = S3<T>{MH_WS(s + 6), MH_WS(s + 7), MH_WS(s + 8), MH_WS(s + 9), MH_WS(s + 10), MH_WS(s + 11)};
+   I.C = M3<T>{MH_WS(s + 12), MH_WS(s + 13), MH_WS(s + 14), MH_WS(s + 15), MH_WS(s + 16), MH_WS(s + 17), MH_WS(s + 18), MH_WS(s + 19), MH_WS(s + 20)};
+   return I;
+}
+template <typename T>
+MH_DEV void add(ABI<T> &a, const ABI<T> &b)
+{
+   a.A.xx += b.A.xx, a.A.xy += b.A.xy, a.A.xz += b.A.xz, a.A.yy += b.A.yy, a.A.yz += b.A.yz, a.A.zz += b.A.zz;
+   a.L.xx += b.L.xx, a.L.xy += b.L.xy, a.L.xz += b.L.xz, a.L.yy += b.L.yy, a.L.yz += b.L.yz, a.L.zz += b.L.zz;
+   a.C.xx += b.C.xx, a.C.xy += b.C.xy, a.C.xz += b.C.xz, a.C.yx += b.C.yx, a.C.yy += b.C.yy, a.C.yz += b.C.yz;
+   a.C.zx += b.C.zx, a.C.zy += b.C.zy, a.C.zz += b.C.zz;
+}
+// Ia = IA - U U^T / D for a 1-DoF joint whose U = (ua, ul)
+template <typename T>
+MH_DEV void rank1_down(ABI<T> &I, V3<T> ua, V3<T> ul, T dinv)
+{
+   V3<T> sa = dinv * ua, sl = dinv * ul;
+   I.A.xx -= sa.x * ua.x, I.A.xy -= sa.x * ua.y, I.A.xz -= sa.x * ua.z, I.A.yy -= sa.y * ua.y, I.A.yz -= sa.y * ua.z, I.A.zz -= sa.z * ua.z;
+   I.L.xx -= sl.x * ul.x, I.L.xy -= sl.x * ul.y, I.L.xz -= sl.x * ul.z, I.L.yy -= sl.y * ul.y, I.L.yz -= sl.y * ul.z, I.L.zz -= sl.z * ul.z;
+   I.C.xx -= sa.x * ul.x, I.C.xy -= sa.x * ul.y, I.C.xz -= sa.x * ul.z;
+   I.C.yx -= sa.y * ul.x, I.C.yy -= sa.y * ul.y, I.C.yz -= sa.y * ul.z;
+   I.C.zx -= sa.z * ul.x, I.C.zy -= sa.z * ul.y, I.C.zz -= sa.z * ul.z;
+}
+// solve IA x = b for a symmetric positive definite 6x6 (floating joint: ForwardDynamicsCalculator.java:1195-1196 uses a
+// Cholesky inverse); LDL^T without square roots, fully unrolled so that M stays in registers
+template <typename T>
+MH_DEV SV<T> spd6_solve(const ABI<T> &I, SV<T> b)
+{
+   T M[6][6];
+   M[0][0] = I.A.xx, M[0][1] = I.A.xy, M[0][2] = I.A.xz, M[1][1] = I.A.yy, M[1][2] = I.A.yz, M[2][2] = I.A.zz;
+   M[0][3] = I.C.xx, M[0][4] = I.C.xy, M[0][5] = I.C.xz, M[1][3] = I.C.yx, M[1][4] = I.C.yy, M[1][5] = I.C.yz;
+   M[2][3] = I.C.zx, M[2][4] = I.C.zy, M[2][5] = I.C.zz;
+   M[3][3] = I.L.xx, M[3][4] = I.L.xy, M[3][5] = I.L.xz, M[4][4] = I.L.yy, M[4][5] = I.L.yz, M[5][5] = I.L.zz;
+   T x[6] = {b.a.x, b.a.y, b.a.z, b.l.x, b.l.y, b.l.z};
+   T dinv[6];
+   // upper-triangular LDL^T in place: M[i][j] (i<j) becomes L_ji
+#pragma unroll
+   for (int k = 0; k < 6; k++)
+   {
+      dinv[k] = T(1) / M[k][k];
+      T l[6];
+#pragma unroll
+      for (int j = k + 1; j < 6; j++)
+      {
+         l[j] = M[k][j] * dinv[k];
+#pragma unroll
+         for (int i = k + 1; i <= j; i++)
+            M[i][j] -= M[k][i] * l[j]; // row k still holds the unscaled entries here
+         x[j] -= l[j] * x[k];          // forward substitution fused
+      }
+#pragma unroll
+      for (int j = k + 1; j < 6; j++)
+         M[k][j] = l[j];
+   }
+#pragma unroll
+   for (int k = 0; k < 6; k++)
+      x[k] *= dinv[k];
+#pragma unroll
+   for (int k = 5; k >= 0; k--)
+   {
+#pragma unroll
+      for (int j = k + 1; j < 6; j++)
+         x[k] -= M[k][j] * x[j];
+   }
+   return SV<T>{V3<T>{x[0], x[1], x[2]}, V3<T>{x[3], x[4], x[5]}};
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   T *C = (T *)lds_raw;
+   stage_consts<T>(A.m, C);
+   const DevModel &m = A.m;
+   const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   const long ws_stride = A.ws_stride;
+   T *ws = A.ws + lane;
+   const V3<T> Z{T(0), T(0), T(0)};
+
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *qdrow = A.qd + cfg * A.v_bs;
+      const T *taurow = A.in3 + cfg * A.v_bs;
+      const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
+      T *orow = A.out + cfg * A.v_bs;
+
+      // ---- pass one (ForwardDynamicsCalculator.java:1085-1127): velocities, bias wrench p, bias acceleration c
+      SV<T> v_prev{Z, Z};
+      for (int j = 0; j < m.n; j++)
+      {
+         const int *mi = m.meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const T *c = C + j * MC_STRIDE;
+         SV<T> vp;
+         if (parent < 0)
+            vp = SV<T>{Z, Z};
+         else if (flags & MF_PARENT_ADJ)
+            vp = v_prev;
+         else
+            vp = ws_load6(ws, ws_stride, m.meta[parent * MI_STRIDE + MI_SLOT_VA]);
+         const XF<T> Xb = load_xb(c);
+         const JX<T> jx = joint_from_q<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> vJ = joint_vec<T>(type, m.dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+         const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         const RI<T> I = load_inertia(c);
+         SV<T> p = crf(v, mul(I, v));
+         if (frow)
+            p = p - load_fext(c, frow, A.f_es, mi[MI_EXT]);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_F], p);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_C], crm(v, vJ));
+         if (flags & MF_STORE_VA)
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
+         v_prev = v;
+      }
+      // ---- pass two (:1136-1254): articulated inertias and bias wrenches, leaves to root
+      ABI<T> Icarry;
+      SV<T> pcarry{Z, Z};
+      bool have_carry = false;
+      for (int j = m.n - 1; j >= 0; j--)
+      {
+         const int *mi = m.meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const T *c = C + j * MC_STRIDE;
+         ABI<T> IA = abi_from_rigid(load_inertia(c));
+         SV<T> pA = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         if (have_carry)
+         {
+            add(IA, Icarry);
+            pA = pA + pcarry;
+         }
+         if (flags & MF_HAS_ACC)
+            add(IA, ws_load_abi(ws, ws_stride, mi[MI_SLOT_IA]));
+         have_carry = false;
+         const int sf = mi[MI_SLOT_F];
+         const int *di = m.dof_map + mi[MI_DOF];
+         ABI<T> Ia = IA;
+         SV<T> pa = pA;
+         if (type == JT_REVOLUTE || type == JT_PRISMATIC)
+         {
+            V3<T> ua, ul;
+            T D, pz;
+            if (type == JT_REVOLUTE)
+            {
+               ua = V3<T>{IA.A.xz, IA.A.yz, IA.A.zz}, ul = V3<T>{IA.C.zx, IA.C.zy, IA.C.zz};
+               D = IA.A.zz, pz = pA.a.z;
+            }
+            else
+            {
+               ua = V3<T>{IA.C.xz, IA.C.yz, IA.C.zz}, ul = V3<T>{IA.L.xz, IA.L.yz, IA.L.zz};
+               D = IA.L.zz, pz = pA.l.z;
+            }
+            const T dinv = T(1) / D;                          // :1183
+            const T u = taurow[di[0] * A.v_es] - pz;          // :1200-1215
+            ws_store6(ws, ws_stride, sf, SV<T>{ua, ul});
+            MH_WS(sf + 6) = dinv;
+            MH_WS(sf + 7) = u;
+            if (parent >= 0)
+            {
+               rank1_down(Ia, ua, ul, dinv);                   // :1220-1226
+               const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+               const T ud = u * dinv;
+               pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
+            }
+         }
+         else if (type == JT_SIXDOF)
+         {
+            // S = 1_6: U = IA, D = IA.  Pass three needs only x = IA^-1 u; for the parent Ia = 0 and pa = pA + u = tau.
+            const SV<T> tau{V3<T>{taurow[di[0] * A.v_es], taurow[di[1] * A.v_es], taurow[di[2] * A.v_es]},
+                            V3<T>{taurow[di[3] * A.v_es], taurow[di[4] * A.v_es], taurow[di[5] * A.v_es]}};
+            const SV<T> x = spd6_solve(IA, tau - pA);
+            ws_store6(ws, ws_stride, sf, x);
+            if (parent >= 0)
+            {
+               Ia.A = S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)};
+               Ia.L = Ia.A;
+               Ia.C = M3<T>{T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+               pa = tau;
+            }
+         }
+         else if (parent >= 0)
+         { // fixed joint: the whole articulated body is handed over unchanged (c = 0)
+            pa = pA;
+         }
+         if (parent >= 0)
+         {
+            const XF<T> Xb = load_xb(c);
+            const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+            abi_up(type, jx, Xb, Ia);                            // :1156-1166
+            const SV<T> pp = force_up(type, jx, Xb, pa);
+            if (flags & MF_PARENT_ADJ)
+            {
+               Icarry = Ia, pcarry = pp, have_carry = true;
+            }
+            else
+            {
+               const int *pmi = m.meta + parent * MI_STRIDE;
+               if (flags & MF_ACC_FIRST)
+                  ws_store_abi(ws, ws_stride, pmi[MI_SLOT_IA], Ia);
+               else
+               {
+                  ABI<T> acc = ws_load_abi(ws, ws_stride, pmi[MI_SLOT_IA]);
+                  add(acc, Ia);
+                  ws_store_abi(ws, ws_stride, pmi[MI_SLOT_IA], acc);
+               }
+               ws_add6(ws, ws_stride, pmi[MI_SLOT_F], pp);
+            }
+         }
+      }
+      // ---- pass three (:1259-1310): joint accelerations, root to leaves
+      SV<T> a_prev{Z, Z};
+      for (int j = 0; j < m.n; j++)
+      {
+         const int *mi = m.meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const T *c = C + j * MC_STRIDE;
+         SV<T> ap;
+         if (parent < 0)
+            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :259-264
+         else if (flags & MF_PARENT_ADJ)
+            ap = a_prev;
+         else
+            ap = ws_load6(ws, ws_stride, m.meta[parent * MI_STRIDE + MI_SLOT_VA]);
+         const XF<T> Xb = load_xb(c);
+         const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         SV<T> a = motion_down(type, jx, Xb, ap) + ws_load6(ws, ws_stride, mi[MI_SLOT_C]); // :1270-1273
+         const int sf = mi[MI_SLOT_F];
+         const int *di = m.dof_map + mi[MI_DOF];
+         if (type == JT_REVOLUTE || type == JT_PRISMATIC)
+         {
+            const SV<T> U = ws_load6(ws, ws_stride, sf);
+            const T dinv = MH_WS(sf + 6), u = MH_WS(sf + 7);
+            const T qdd = dinv * (u - (dot(U.a, a.a) + dot(U.l, a.l))); // :1280-1282
+            orow[di[0] * A.v_es] = qdd;
+            if (type == JT_REVOLUTE)
+               a.a.z += qdd;
+            else
+               a.l.z += qdd;
+         }
+         else if (type == JT_SIXDOF)
+         {
+            const SV<T> x = ws_load6(ws, ws_stride, sf);
+            const SV<T> qdd = x - a;
+            orow[di[0] * A.v_es] = qdd.a.x, orow[di[1] * A.v_es] = qdd.a.y, orow[di[2] * A.v_es] = qdd.a.z;
+            orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
+            a = x;
+         }
+         if (flags & MF_STORE_VA)
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], a);
+         a_prev = a;
+      }
+   }
+}
+
+// ============================================================================================ CRBA
+template <typename T>
+MH_DEV void ws_store_ri(T *ws, long ws_stride, int s, const RI<T> &r)
+{
+   MH_WS(s + 0) = r.m, MH_WS(s + 1) = r.h.x, MH_WS(s + 2) = r.h.y, MH_WS(s + 3) = r.h.z;
+   MH_WS(s + 4) = r.I.xx, MH_WS(s + 5) = r.I.xy, MH_WS(s + 6) = r.I.xz, MH_WS(s + 7) = r.I.yy, MH_WS(s + 8) = r.I.yz, MH_WS(s + 9) = r.I.zz;
+}
+template <typename T>
+MH_DEV RI<T> ws_load_ri(const T *ws, long ws_stride, int s)
+{
+   RI<T> r;
+   r.m = MH_WS(s + 0);
+   r.h = V3<T>{MH_WS(s + 1), MH_WS(s + 2), MH_WS(s + 3)};
+   r.I = S3<T>{MH_WS(s + 4), MH_WS(s + 5), MH_WS(s + 6), MH_WS(s + 7), MH_WS(s + 8), MH_WS(s + 9)};
+   return r;
+}
+// unit motion vector of DoF k of a joint of the given kind, canonical frame
+template <typename T>
+MH_DEV SV<T> unit_twist(int type, int k)
+{
+   SV<T> s{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
+   if (type == JT_REVOLUTE)
+      s.a.z = T(1);
+   else if (type == JT_PRISMATIC)
+      s.l.z = T(1);
+   else
+   {
+      s.a.x = k == 0 ? T(1) : T(0), s.a.y = k == 1 ? T(1) : T(0), s.a.z = k == 2 ? T(1) : T(0);
+      s.l.x = k == 3 ? T(1) : T(0), s.l.y = k == 4 ? T(1) : T(0), s.l.z = k == 5 ? T(1) : T(0);
+   }
+   return s;
+}
+template <typename T>
+MH_DEV T comp(SV<T> w, int k)
+{
+   return k == 0 ? w.a.x : k == 1 ? w.a.y : k == 2 ? w.a.z : k == 3 ? w.l.x : k == 4 ? w.l.y : w.l.z;
+}
+
+// H is [B][nv][nv] row-major (h_bs = nv*nv, element (r,c) at r*nv + c) and must be zero-filled before the launch:
+// the kernel writes only the entries of related joints (CompositeRigidBodyMassMatrixCalculator.java:298,841-845).
+template <typename T>
+__global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   T *C = (T *)lds_raw;
+   stage_consts<T>(A.m, C);
+   const DevModel &m = A.m;
+   const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   const long ws_stride = A.ws_stride;
+   T *ws = A.ws + lane;
+   const int nv = m.nv;
+
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      const T *qrow = A.q + cfg * A.q_bs;
+      T *H = A.out + cfg * A.v_bs; // v_bs / v_es carry the per-configuration / per-entry strides of H here
+      const long h_es = A.v_es;
+      for (int j = 0; j < m.n; j++)
+      {
+         const int *mi = m.meta + j * MI_STRIDE;
+         (void)joint_from_q<T>(mi[MI_TYPE], m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+      }
+      RI<T> rcarry;
+      bool have_carry = false;
+      for (int j = m.n - 1; j >= 0; j--)
+      {
+         const int *mi = m.meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const T *c = C + j * MC_STRIDE;
+         RI<T> Ic = load_inertia(c);
+         if (have_carry)
+            add(Ic, rcarry);
+         if (flags & MF_HAS_ACC)
+            add(Ic, ws_load_ri(ws, ws_stride, mi[MI_SLOT_IA]));
+         have_carry = false;
+         const int nd = type == JT_SIXDOF ? 6 : (type == JT_FIXED ? 0 : 1);
+         const int *dj = m.dof_map + mi[MI_DOF];
+         const XF<T> Xb = load_xb(c);
+         const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         for (int k = 0; k < nd; k++)
+         {
+            SV<T> F = mul(Ic, unit_twist<T>(type, k)); // :663-667
+            const int col = dj[k];
+            // diagonal block (:700-707)
+            if (type == JT_REVOLUTE)
+               H[((long)col * nv + col) * h_es] = F.a.z;
+            else if (type == JT_PRISMATIC)
+               H[((long)col * nv + col) * h_es] = F.l.z;
+            else
+               for (int r = 0; r < 6; r++)
+                  H[((long)dj[r] * nv + col) * h_es] = comp(F, r);
+            // ancestors (:783-792)
+            int prev = j, anc = parent;
+            XF<T> Xp = Xb;
+            JX<T> jp = jx;
+            int tp = type;
+            while (anc >= 0)
+            {
+               F = force_up(tp, jp, Xp, F);
+               const int *ma = m.meta + anc * MI_STRIDE;
+               const int ta = ma[MI_TYPE];
+               const int *da = m.dof_map + ma[MI_DOF];
+               if (ta == JT_REVOLUTE)
+               {
+                  H[((long)da[0] * nv + col) * h_es] = F.a.z;
+                  H[((long)col * nv + da[0]) * h_es] = F.a.z;
+               }
+               else if (ta == JT_PRISMATIC)
+               {
+                  H[((long)da[0] * nv + col) * h_es] = F.l.z;
+                  H[((long)col * nv + da[0]) * h_es] = F.l.z;
+               }
+               else if (ta == JT_SIXDOF)
+                  for (int r = 0; r < 6; r++)
+                  {
+                     const T hv = comp(F, r);
+                     H[((long)da[r] * nv + col) * h_es] = hv;
+                     H[((long)col * nv + da[r]) * h_es] = hv;
+                  }
+               prev = anc;
+               anc = ma[MI_PARENT];
+               if (anc >= 0)
+               {
+                  Xp = load_xb(C + prev * MC_STRIDE);
+                  jp = joint_again<T>(ta, m.cfg_map, ma[MI_CFG], qrow, A.q_es, ws, ws_stride, ma[MI_SLOT_JP]);
+                  tp = ta;
+               }
+            }
+         }
+         if (parent >= 0)
+         {
+            rigid_up(type, jx, Xb, Ic); // :651-661
+            if (flags & MF_PARENT_ADJ)
+            {
+               rcarry = Ic, have_carry = true;
+            }
+            else
+            {
+               const int sp = m.meta[parent * MI_STRIDE + MI_SLOT_IA];
+               if (flags & MF_ACC_FIRST)
+                  ws_store_ri(ws, ws_stride, sp, Ic);
+               else
+               {
+                  RI<T> acc = ws_load_ri(ws, ws_stride, sp);
+                  add(acc, Ic);
+                  ws_store_ri(ws, ws_stride, sp, acc);
+               }
+            }
+         }
+      }
+   }
+}
+
+#undef MH_WS
+} // namespace mh

@@ -1,0 +1,168 @@
+"""Thin object wrapper over the C-ABI: a device-resident model plus batched rnea / aba / crba calls.
+
+Device inputs are torch tensors on a HIP device (torch is used for device memory and streams only); numpy
+inputs go through the host-pointer entry points.  Every compute goes through libmecano_hip.so: nothing here
+computes dynamics in Python.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .multibody import ModelDesc
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class HipModel:
+    """mh_model_t: the flattened MultiBodySystemReadOnly, uploaded once (replaces the calculators' constructors)."""
+
+    def __init__(self, desc: ModelDesc):
+        lib = _lib.load()
+        self.desc = desc
+        self._arrays = dict(
+            parent=_np(desc.parent, np.int32), joint_type=_np(desc.joint_type, np.int32), axis=_np(desc.axis, np.float64),
+            X_before=_np(desc.X_before, np.float64), X_com=_np(desc.X_com, np.float64), inertia_J=_np(desc.inertia_J, np.float64),
+            inertia_mass=_np(desc.inertia_mass, np.float64), inertia_com=_np(desc.inertia_com, np.float64),
+            dof_indices=_np(desc.dof_indices, np.int32), cfg_indices=_np(desc.cfg_indices, np.int32))
+        d = _lib.MhModelDesc()
+        d.n_joints, d.nq, d.nv = int(desc.n_joints), int(desc.nq), int(desc.nv)
+        for k, a in self._arrays.items():
+            setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
+        handle = ctypes.c_void_p()
+        _lib.check(lib.mh_model_create(ctypes.byref(d), ctypes.byref(handle)))
+        self._h = handle
+        self.nq, self.nv, self.n_joints = desc.nq, desc.nv, desc.n_joints
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().mh_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def kernel_variant(self) -> str:
+        return _lib.load().mh_model_kernel_variant(self._h).decode()
+
+    def reserve(self, max_batch: int):
+        _lib.check(_lib.load().mh_reserve(self._h, int(max_batch)))
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _options(layout, consider_coriolis=True, consider_accelerations=True, stream=None):
+        o = _lib.MhOptions()
+        o.consider_coriolis = int(bool(consider_coriolis))
+        o.consider_accelerations = int(bool(consider_accelerations))
+        o.layout = int(layout)
+        o.reserved0 = 0
+        o.stream = stream
+        return o
+
+    @staticmethod
+    def _is_torch(x):
+        return type(x).__module__.startswith("torch")
+
+    def _batch(self, x, n, layout):
+        if x.ndim != 2:
+            raise _lib.MecanoHipError(2, f"expected a 2-D state matrix, got shape {tuple(x.shape)}")
+        rows, B = (x.shape[1], x.shape[0]) if layout == _lib.LAYOUT_AOS else (x.shape[0], x.shape[1])
+        if rows != n:
+            # the MatrixDimensionException of ForwardDynamicsCalculator.java:522-533
+            raise _lib.MecanoHipError(2, f"state matrix has {rows} rows per configuration, the system needs {n}")
+        return B
+
+    def _run(self, kind, q, qd, x3, gravity, f_ext, layout, consider_coriolis, consider_accelerations):
+        lib = _lib.load()
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        if self._is_torch(q):
+            import torch
+            dt = q.dtype
+            if dt not in (torch.float64, torch.float32):
+                raise TypeError("state tensors must be float64 or float32")
+            tensors = [q] if kind == "crba" else [q, qd, x3]
+            if f_ext is not None:
+                tensors.append(f_ext)
+            for t in tensors:
+                if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                    raise ValueError("device tensors must be contiguous, on the HIP device and of one dtype")
+            B = self._batch(q, self.nq, layout)
+            if kind != "crba":
+                if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
+                    raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+            stream = torch.cuda.current_stream(q.device).cuda_stream
+            opts = self._options(layout, consider_coriolis, consider_accelerations, stream)
+            sfx = "f64" if dt == torch.float64 else "f32"
+            if kind == "crba":
+                shape = (B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B)
+                out = torch.empty(shape, dtype=dt, device=q.device)
+                _lib.check(getattr(lib, f"mh_crba_{sfx}")(self._h, B, q.data_ptr(), ctypes.byref(opts), out.data_ptr()))
+            else:
+                out = torch.empty_like(qd)
+                fp = f_ext.data_ptr() if f_ext is not None else None
+                _lib.check(getattr(lib, f"mh_{kind}_{sfx}")(self._h, B, q.data_ptr(), qd.data_ptr(), x3.data_ptr(), g, fp, ctypes.byref(opts),
+                                                            out.data_ptr()))
+            return out
+        # numpy: host-pointer entry points (fp64)
+        q = _np(q, np.float64)
+        B = self._batch(q, self.nq, layout)
+        opts = self._options(layout, consider_coriolis, consider_accelerations, None)
+        if kind == "crba":
+            out = np.empty((B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B))
+            _lib.check(lib.mh_crba_f64_host(self._h, B, q.ctypes.data, ctypes.byref(opts), out.ctypes.data))
+            return out
+        qd, x3 = _np(qd, np.float64), _np(x3, np.float64)
+        if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        f = None if f_ext is None else _np(f_ext, np.float64)
+        out = np.empty_like(qd)
+        _lib.check(getattr(lib, f"mh_{kind}_f64_host")(self._h, B, q.ctypes.data, qd.ctypes.data, x3.ctypes.data, g,
+                                                       None if f is None else f.ctypes.data, ctypes.byref(opts), out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------ the three hot-path calls
+    def rnea(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS, consider_coriolis=True,
+             consider_accelerations=True):
+        return self._run("rnea", q, qd, qdd, gravity, f_ext, layout, consider_coriolis, consider_accelerations)
+
+    def aba(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS):
+        return self._run("aba", q, qd, tau, gravity, f_ext, layout, True, True)
+
+    def crba(self, q, layout=_lib.LAYOUT_AOS):
+        return self._run("crba", q, None, None, (0.0, 0.0, 0.0), None, layout, True, True)
+
+
+class HipTimer:
+    """HIP events recorded on the stream the kernels are launched on (bench.py, SURVEY.md section 8d timing protocol)."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().mh_timer_create(ctypes.byref(self._h)))
+
+    def start(self, stream=None):
+        _lib.check(_lib.load().mh_timer_start(self._h, stream))
+
+    def stop(self, stream=None):
+        _lib.check(_lib.load().mh_timer_stop(self._h, stream))
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float()
+        _lib.check(_lib.load().mh_timer_elapsed_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().mh_timer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
