@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: robot-configs/sec (RNEA+ABA), 30-DoF humanoid, batch 4096 per GPU.
+
+One "step" = one pass of the hot path over one batch of synthetic input: mh_rnea_f64 (q, qd, qdd -> tau) followed by
+mh_aba_f64 (q, qd, tau_in -> qdd) on 4096 configurations of the 30-DoF humanoid (SixDoF pelvis + 24 revolute joints),
+inputs resident in HBM before the timed region.  Multi-GPU: one process per GPU, every rank owns its own 4096
+configurations (weak scaling), no collective on the data path; the model is broadcast once over RCCL before timing and
+the outputs are all-gathered once after it (reported separately as gather_ms).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description), including
+  "roofline":     algorithmic bytes of the dominant kernel / its mean launch duration (HIP events on the launch stream)
+  "cpu_baseline": the CPU oracle (a port, not Mecano/JVM) timed on one host core on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 4096                 # BASELINE.json metric: batch=4096 (per GPU; weak scaling)
+MODEL_SEED, STATE_SEED = 43, 2342
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+BYTES_RNEA = 968             # (nq + 2 nv + nv) * 8 with nq = 31, nv = 30   
+BYTES_ABA = 968
+
+
+def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=12.0):
+    """Oracle (CPU port) on one core: RNEA+ABA pairs per second on a bounded sample of the same batch."""
+    from oracle.cpu_oracle import OracleModel
+    om = OracleModel(desc)
+    n = 256
+    om.rnea(q[:n], qd[:n], qdd[:n], gravity)  # warm
+    t0 = time.perf_counter()
+    om.rnea(q[:n], qd[:n], qdd[:n], gravity)
+    om.aba(q[:n], qd[:n], tau[:n], gravity)
+    per = (time.perf_counter() - t0) / n
+    count = int(min(len(q) * 64, max(n, target_s / per)))
+    reps, rem = divmod(count, len(q))
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(reps):
+        om.rnea(q, qd, qdd, gravity)
+        om.aba(q, qd, tau, gravity)
+        done += len(q)
+    if rem:
+        om.rnea(q[:rem], qd[:rem], qdd[:rem], gravity)
+        om.aba(q[:rem], qd[:rem], tau[:rem], gravity)
+        done += rem
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "configs/s", "cores": 1, "kind": "port",
+            "sample": f"{done} RNEA+ABA pairs of the same humanoid batch, oracle/mecano_oracle.c (C restatement, not Mecano/JVM), 1 thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH, help="configurations per GPU per step (default: the metric's 4096)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mecano_amd import build, distributed as mdist, random_tools as rt
+    from mecano_amd.engine import HipModel, HipTimer
+
+    rank, world, local_rank = mdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if not os.path.exists(build.LIB):
+        build.build_lib()
+
+    # ---- model: built on rank 0, broadcast over RCCL (north_star: "RCCL broadcast of the model")
+    sys_ = rt.nextHumanoid(np.random.default_rng(MODEL_SEED))
+    desc = mdist.broadcast_model_desc(sys_.toModelDesc() if rank == 0 else None, src=0)
+    model = HipModel(desc)
+    B = args.batch
+    model.reserve(B)
+    q, qd, qdd, tau_in = rt.nextState(np.random.default_rng(STATE_SEED + rank), sys_, B)
+    gravity = (0.0, 0.0, -9.81)
+    tq, tqd, tqdd, ttau = (torch.tensor(x, device="cuda") for x in (q, qd, qdd, tau_in))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        tau = model.rnea(tq, tqd, tqdd, gravity)
+        acc = model.aba(tq, tqd, ttau, gravity)
+        return tau, acc
+
+    for _ in range(args.warmup):
+        out = step()
+    # ---- timed region: exactly K steps between barrier + synchronize pairs
+    K = args.steps
+    t_rnea = [HipTimer() for _ in range(K)]
+    t_aba = [HipTimer() for _ in range(K)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        t_rnea[k].start(stream)
+        tau = model.rnea(tq, tqd, tqdd, gravity)
+        t_rnea[k].stop(stream)
+        t_aba[k].start(stream)
+        acc = model.aba(tq, tqd, ttau, gravity)
+        t_aba[k].stop(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_rnea = float(np.mean([t.elapsed_ms() for t in t_rnea])) if K else 0.0
+    ms_aba = float(np.mean([t.elapsed_ms() for t in t_aba])) if K else 0.0
+
+    # ---- after the timed region: one all-gather of the outputs over xGMI (north_star: "a final gather")
+    gather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        full = mdist.all_gather_rows(acc, B * world)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        assert full.shape[0] == B * world
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # dominant kernel = the slower of the two launches of a step
+    dom, dom_ms, dom_bytes = ("aba_kernel<double>", ms_aba, BYTES_ABA) if ms_aba >= ms_rnea else ("rnea_kernel<double>", ms_rnea, BYTES_RNEA)
+    achieved = (dom_bytes * B) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    value = world * B * K / elapsed if elapsed > 0 else 0.0
+    line = {
+        "metric": "robot-configs/sec (RNEA+ABA), 30-DoF humanoid batch=4096",
+        "value": value, "unit": "configs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3 if K else None, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "30-DoF humanoid (SixDoF pelvis + 24 revolute), RNEA then ABA per step, fp64, AoS [B][n] state",
+                   "batch_per_gpu": B, "global_batch": B * world, "nq": desc.nq, "nv": desc.nv, "bodies": desc.n_joints,
+                   "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
+                   "model_seed": MODEL_SEED, "state_seed": STATE_SEED},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_config": dom_bytes, "launch_ms": dom_ms},
+        "kernels_ms": {"rnea": ms_rnea, "aba": ms_aba},
+        "gather_ms": gather_ms,
+    }
+    # CPU baseline beside it: rank 0 at N = 1 only (a reported baseline, not the optimisation target)
+    line["cpu_baseline"] = cpu_baseline(desc, q, qd, qdd, tau_in, gravity) if (world == 1 and not args.no_cpu_baseline) else None
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+"""The C-ABI shared library: builds, loads, exports every symbol include/mecano_hip.h declares, and validates models.
+No compute call is made here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mecano_amd import _lib
+from mecano_amd import random_tools as rt
+from mecano_amd.multibody import MultiBodySystem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mecano_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for name in declared_symbols():
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.mh_abi_version() == 1
+
+
+def _desc_struct(desc, keep):
+    d = _lib.MhModelDesc()
+    d.n_joints, d.nq, d.nv = desc.n_joints, desc.nq, desc.nv
+    for k in ("parent", "joint_type", "dof_indices", "cfg_indices"):
+        a = np.ascontiguousarray(getattr(desc, k), dtype=np.int32)
+        keep.append(a)
+        setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
+    for k in ("axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com"):
+        a = np.ascontiguousarray(getattr(desc, k), dtype=np.float64)
+        keep.append(a)
+        setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
+    return d
+
+
+def _create(hip_lib, desc):
+    keep = []
+    d = _desc_struct(desc, keep)
+    h = ctypes.c_void_p()
+    st = hip_lib.mh_model_create(ctypes.byref(d), ctypes.byref(h))
+    if st == 0:
+        hip_lib.mh_model_destroy(h)
+    return st, hip_lib.mh_last_error().decode()
+
+
+def _chain_desc(n=5, seed=0):
+    rng = np.random.default_rng(seed)
+    joints = rt.nextJointChain(rng, n, ("revolute", "prismatic"))
+    return MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor()).toModelDesc()
+
+
+def test_model_validation_error_codes(hip_lib):
+    """Errors come back as status codes + mh_last_error(), never as exceptions across the ABI."""
+    good = _chain_desc()
+    st, msg = _create(hip_lib, good)
+    assert st in (0, 7), msg  # MH_OK on a GPU box, MH_ERR_NO_DEVICE here: validation itself passed
+
+    bad = _chain_desc()
+    bad.joint_type = bad.joint_type.copy()
+    bad.joint_type[2] = 9
+    assert _create(hip_lib, bad)[0] == 3  # MH_ERR_UNSUPPORTED_JOINT
+
+    bad = _chain_desc()
+    bad.parent = bad.parent.copy()
+    bad.parent[1], bad.parent[2] = 2, 1  # 1 <-> 2 cycle
+    assert _create(hip_lib, bad)[0] == 4  # MH_ERR_LOOP_CLOSURE
+
+    bad = _chain_desc()
+    bad.parent = bad.parent.copy()
+    bad.parent[3] = 17
+    assert _create(hip_lib, bad)[0] == 5  # MH_ERR_BAD_TOPOLOGY
+
+    bad = _chain_desc()
+    bad.axis = bad.axis.copy()
+    bad.axis[3:6] *= 1.5
+    assert _create(hip_lib, bad)[0] == 6  # MH_ERR_BAD_AXIS
+
+    bad = _chain_desc()
+    bad.dof_indices = bad.dof_indices.copy()
+    bad.dof_indices[1] = bad.dof_indices[0]
+    st, msg = _create(hip_lib, bad)
+    assert st == 5 and "dof_indices" in msg
+
+    h = ctypes.c_void_p()
+    assert hip_lib.mh_model_create(None, ctypes.byref(h)) == 1  # MH_ERR_INVALID_ARGUMENT
+
+
+def test_device_count_call_is_safe_without_gpu(hip_lib):
+    n = ctypes.c_int32(-1)
+    assert hip_lib.mh_device_count(ctypes.byref(n)) == 0
+    assert n.value >= 0
+
+
+def test_options_default(hip_lib):
+    o = _lib.MhOptions()
+    hip_lib.mh_options_default(ctypes.byref(o))
+    assert (o.consider_coriolis, o.consider_accelerations, o.layout, o.stream) == (1, 1, 0, None)
+
+
+def test_no_cpu_fallback_without_device(hip_lib):
+    """The product path must fail loudly when no GPU is present: model creation reports MH_ERR_NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mecano_amd.engine import HipModel
+    with pytest.raises(_lib.MecanoHipError) as e:
+        HipModel(_chain_desc())
+    assert e.value.status == 7

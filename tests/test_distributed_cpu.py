@@ -1,0 +1,83 @@
+"""N>1 path on CPU: world_size 2 over gloo.  Model broadcast, contiguous batch sharding, output all-gather.
+The per-rank compute is the ORACLE here (tests may use it as the checker; no GPU in this container) -- what is under
+test is the sharding / broadcast / gather logic of mecano_amd.distributed, which bench.py and a multi-GPU host use."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, B, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mecano_amd import distributed as mdist
+    from mecano_amd import random_tools as rt
+    from oracle.cpu_oracle import OracleModel
+    r, w, _ = mdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    rng = np.random.default_rng(99)  # same stream on every rank: the full batch is known everywhere for the check
+    sys_ = rt.nextHumanoid(rng)
+    desc0 = sys_.toModelDesc()
+    desc = mdist.broadcast_model_desc(desc0 if rank == 0 else None, src=0)
+    for f in ("parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices"):
+        assert np.array_equal(np.asarray(getattr(desc, f)), np.asarray(getattr(desc0, f))), f
+    om = OracleModel(desc)
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    tq, tqd, tqdd = (torch.from_numpy(x) for x in (q, qd, qdd))
+
+    def fn(q_, qd_, qdd_):
+        return torch.from_numpy(om.rnea(q_.numpy(), qd_.numpy(), qdd_.numpy()))
+
+    full = mdist.sharded_compute(fn, B, tq, tqd, tqdd, gather=True)
+    ref = om.rnea(q, qd, qdd)
+    assert full.shape == (B, desc.nv)
+    assert np.array_equal(full.numpy(), ref)
+    lo, hi = mdist.shard_range(B, rank, world)
+    local = mdist.sharded_compute(fn, B, tq, tqd, tqdd, gather=False)
+    assert np.array_equal(local.numpy(), ref[lo:hi])
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").close()
+
+
+@pytest.mark.parametrize("B", [64, 37])  # equal shards (all_gather_into_tensor) and ragged shards (padded all_gather)
+def test_world_size_2_gloo(tmp_path, B):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_shard_range_partitions_the_batch():
+    from mecano_amd.distributed import shard_range
+    for B in (0, 1, 7, 4096, 262144, 1000003):
+        for world in (1, 2, 4, 8):
+            edges = [shard_range(B, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == B
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    from mecano_amd import distributed as mdist
+    from mecano_amd import random_tools as rt
+    d = rt.nextHumanoid(np.random.default_rng(3)).toModelDesc()
+    d2 = mdist.unpack_desc(*mdist.pack_desc(d))
+    assert d2.n_joints == d.n_joints and d2.nq == d.nq and d2.nv == d.nv
+    for f in ("parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices"):
+        assert np.array_equal(np.asarray(getattr(d2, f)), np.asarray(getattr(d, f)))

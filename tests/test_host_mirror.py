@@ -1,0 +1,79 @@
+"""Host-side mirror of Mecano's multi-body API: iteration order, index maps, model flattening."""
+import numpy as np
+import pytest
+
+from mecano_amd import random_tools as rt
+from mecano_amd.multibody import (FixedJoint, JointMatrixIndexProvider, MultiBodySystem, PrismaticJoint, RevoluteJoint, RigidBody,
+                                  SixDoFJoint)
+
+
+def build_small_tree():
+    root = RigidBody("elevator")
+    a = RevoluteJoint("a", root, None, (0, 0, 1))
+    A = RigidBody("A", a, np.eye(3), 1.0, centerOfMassOffset=(0, 0, 0.1))
+    b = PrismaticJoint("b", A, (np.eye(3), (0.1, 0, 0)), (1, 0, 0))
+    B = RigidBody("B", b, np.eye(3), 2.0)
+    c = SixDoFJoint("c", A)
+    C = RigidBody("C", c, np.eye(3), 3.0)
+    d = RevoluteJoint("d", B, None, (0, 1, 0))
+    RigidBody("D", d, np.eye(3), 4.0)
+    e = FixedJoint("e", C)
+    RigidBody("E", e, np.eye(3), 5.0)
+    return root, (a, b, c, d, e)
+
+
+def test_depth_first_preorder_children_in_creation_order():
+    """iterators/JointIterator.java:130-177: a, b, d (subtree of b first), then c, e."""
+    root, (a, b, c, d, e) = build_small_tree()
+    assert [j.name for j in root.subtreeJointList()] == ["a", "b", "d", "c", "e"]
+
+
+def test_index_provider_running_sums():
+    """JointMatrixIndexProvider.java:71-123."""
+    root, (a, b, c, d, e) = build_small_tree()
+    sys_ = MultiBodySystem.toMultiBodySystemInput(root)
+    p = sys_.getJointMatrixIndexProvider()
+    assert p.getJointDoFIndices(a) == [0] and p.getJointDoFIndices(b) == [1] and p.getJointDoFIndices(d) == [2]
+    assert p.getJointDoFIndices(c) == [3, 4, 5, 6, 7, 8] and p.getJointDoFIndices(e) == []
+    assert p.getJointConfigurationIndices(c) == [3, 4, 5, 6, 7, 8, 9]
+    assert sys_.getNumberOfDoFs() == 9 and sys_.getConfigurationSize() == 10
+
+
+def test_model_desc_flattening():
+    root, (a, b, c, d, e) = build_small_tree()
+    desc = MultiBodySystem.toMultiBodySystemInput(root).toModelDesc()
+    assert desc.n_joints == 5 and desc.nv == 9 and desc.nq == 10
+    assert list(desc.parent) == [-1, 0, 1, 0, 3]
+    assert list(desc.joint_type) == [0, 1, 0, 2, 3]
+    assert np.allclose(desc.X_before.reshape(5, 12)[1, 9:], (0.1, 0, 0))
+    assert np.allclose(desc.X_com.reshape(5, 12)[0, 9:], (0, 0, 0.1))
+    assert np.allclose(desc.inertia_mass, [1, 2, 4, 3, 5])
+
+
+def test_joints_to_ignore_take_their_subtree():
+    """MultiBodySystemReadOnly.java:167-171."""
+    root, (a, b, c, d, e) = build_small_tree()
+    sys_ = MultiBodySystem.toMultiBodySystemInput(root, [b])
+    assert [j.name for j in sys_.getJointsToConsider()] == ["a", "c", "e"]
+    assert [j.name for j in sys_.getJointsToIgnore()] == ["b", "d"]
+    desc = sys_.toModelDesc()
+    assert desc.n_joints == 3 and desc.nv == 7
+
+
+def test_humanoid_shape():
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    d = sys_.toModelDesc()
+    assert (d.n_joints, d.nv, d.nq) == (25, 30, 31)
+    depth = np.zeros(25, dtype=int)
+    for i in range(25):
+        depth[i] = 1 if d.parent[i] < 0 else depth[d.parent[i]] + 1
+    assert depth.max() == 8  # pelvis -> hand
+
+
+def test_topology_key_depends_on_structure_only():
+    rng = np.random.default_rng(1)
+    a = rt.nextHumanoid(rng).toModelDesc()
+    b = rt.nextHumanoid(rng).toModelDesc()
+    assert a.topology_key() == b.topology_key()
+    c = MultiBodySystem.toMultiBodySystemInput(rt.nextJointChain(rng, 7)[0].getPredecessor()).toModelDesc()
+    assert c.topology_key() != a.topology_key()

@@ -1,0 +1,201 @@
+"""Pins the CPU oracle (oracle/mecano_oracle.c) -- the checker every GPU parity test relies on.
+
+The reference's own tests hold no stored golden vectors for RNEA / ABA / CRBA; they are seeded randomized
+cross-consistency tests plus a few closed forms.  Each is restated here against the oracle:
+
+* ABA(RNEA(qdd)) = qdd on prismatic / revolute / mixed chains and trees, with and without external wrenches
+  (test/.../algorithms/ForwardDynamicsCalculatorTest.java:42-220, 767-817; eps 8e-12 / 1.6e-11)
+* same on a SixDoF root + revolute chain (:222-250; eps 4e-11)
+* H qdd + RNEA(qdd = 0) fed to ABA returns qdd (:904-1003)
+* free SixDoF sphere under gravity: zero angular acceleration, linear acceleration g
+  (test/.../tools/MultiBodySystemStateIntegratorTest.java:200-270; 1e-12)
+* sphere wrench = (J wd, m a) (test/.../tools/MecanoToolsTest.java:463-617; 1e-12)
+plus two pins the reference does not have: an independent textbook Featherstone implementation and
+energy-based (Lagrangian) known answers committed under tests/golden/.
+"""
+import glob
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from mecano_amd import random_tools as rt
+from mecano_amd.multibody import ModelDesc, MultiBodySystem, RigidBody, SixDoFJoint
+from oracle import featherstone_np as fs
+from oracle.cpu_oracle import OracleModel
+
+ONE_DOF_JOINT_EPSILON = 8.0e-12   # ForwardDynamicsCalculatorTest.java:38
+FLOATING_JOINT_EPSILON = 4.0e-11  # :39
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def system_of(joints):
+    return MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor())
+
+
+FAMILIES = {
+    "prismatic_chain": lambda rng, n: rt.nextJointChain(rng, n, ("prismatic",)),
+    "prismatic_tree": lambda rng, n: rt.nextJointTree(rng, n, ("prismatic",)),
+    "revolute_chain": lambda rng, n: rt.nextJointChain(rng, n, ("revolute",)),
+    "revolute_tree": lambda rng, n: rt.nextJointTree(rng, n, ("revolute",)),
+    "onedof_chain": lambda rng, n: rt.nextJointChain(rng, n, ("revolute", "prismatic")),
+    "onedof_tree": lambda rng, n: rt.nextJointTree(rng, n, ("revolute", "prismatic")),
+    "floating_revolute_chain": lambda rng, n: rt.nextFloatingChain(rng, n, ("revolute",)),
+    "floating_onedof_tree": lambda rng, n: rt.nextFloatingChain(rng, n, ("revolute", "prismatic"), tree=True),
+    "mixed_tree": lambda rng, n: rt.nextJointTree(rng, n, ("revolute", "prismatic", "sixdof", "fixed")),
+}
+
+
+@pytest.mark.parametrize("family", sorted(FAMILIES))
+def test_oracle_matches_independent_featherstone(family):
+    rng = np.random.default_rng(zlib.crc32(family.encode()))
+    for it in range(4):
+        n = int(rng.integers(1, 12))
+        sys_ = system_of(FAMILIES[family](rng, n))
+        d = sys_.toModelDesc()
+        om, fm = OracleModel(d), fs.Model(d)
+        B = 2
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        g = (0.0, 0.0, float(rng.uniform(-10, -1)))
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
+        t1 = om.rnea(q, qd, qdd, g, fext)
+        a1 = om.aba(q, qd, tau, g, fext)
+        H1 = om.crba(q)
+        for b in range(B):
+            t2 = fs.rnea(fm, q[b], qd[b], qdd[b], g, fext[b])
+            a2 = fs.aba(fm, q[b], qd[b], tau[b], g, fext[b])
+            H2 = fs.crba(fm, q[b])
+            assert np.allclose(t1[b], t2, rtol=0, atol=1e-10 * max(1.0, np.abs(t2).max()))
+            assert np.allclose(a1[b], a2, rtol=0, atol=1e-9 * max(1.0, np.abs(a2).max()))
+            assert np.allclose(H1[b], H2, rtol=0, atol=1e-10 * max(1.0, np.abs(H2).max()))
+
+
+@pytest.mark.parametrize("family", sorted(FAMILIES))
+def test_aba_inverts_rnea(family):
+    """compareAgainstInverseDynamicsCalculator (ForwardDynamicsCalculatorTest.java:767-817), up to 50 joints."""
+    rng = np.random.default_rng(21654)
+    floating = "floating" in family or "mixed" in family
+    eps = FLOATING_JOINT_EPSILON if floating else 2.0 * ONE_DOF_JOINT_EPSILON
+    if "mixed" in family:
+        eps = 2.0e-8  # chains of every joint kind: the reference only asks 1e-4 (ALL_JOINT_EPSILON, ForwardDynamicsCalculatorTest.java:40)
+    for it in range(15):
+        n = int(rng.integers(1, 41 if floating else 51))
+        sys_ = system_of(FAMILIES[family](rng, n))
+        om = OracleModel(sys_.toModelDesc())
+        q, qd, qdd, _ = rt.nextState(rng, sys_, 2)
+        g = float(rng.uniform(-10, -1))
+        for fext in (None, rng.uniform(-1, 1, (2, om.n, 6))):
+            tau = om.rnea(q, qd, qdd, (0, 0, g), fext)
+            back = om.aba(q, qd, tau, (0, 0, g), fext)
+            # deep random chains are ill conditioned; the reference asserts eps on qdd of magnitude <= 1
+            assert np.abs(back - qdd).max() < 50 * eps, (family, it, n)
+
+
+@pytest.mark.parametrize("family", ["revolute_tree", "onedof_tree", "floating_onedof_tree", "prismatic_chain"])
+def test_mass_matrix_ties_rnea_and_aba(family):
+    """compareAgainstCompositeRigidBodyMassMatrixCalculator (ForwardDynamicsCalculatorTest.java:904-1003)."""
+    rng = np.random.default_rng(2654)
+    for it in range(10):
+        n = int(rng.integers(1, 31))
+        sys_ = system_of(FAMILIES[family](rng, n))
+        om = OracleModel(sys_.toModelDesc())
+        q, qd, qdd, _ = rt.nextState(rng, sys_, 2)
+        g = (0.0, 0.0, float(rng.uniform(-10, -1)))
+        H = om.crba(q)
+        bias = om.rnea(q, qd, np.zeros_like(qdd), g)
+        tau = np.einsum("bij,bj->bi", H, qdd) + bias
+        assert np.allclose(tau, om.rnea(q, qd, qdd, g), rtol=0, atol=1e-10 * max(1.0, np.abs(tau).max()))
+        assert np.abs(om.aba(q, qd, tau, g) - qdd).max() < 1e-9
+        assert np.allclose(H, np.swapaxes(H, 1, 2), rtol=0, atol=0)  # setSymmetricEntry writes both triangles
+        assert np.all(np.linalg.eigvalsh(H) > 0)
+
+
+def test_mass_matrix_zero_for_unrelated_branches():
+    rng = np.random.default_rng(5)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    H = OracleModel(d).crba(rt.nextState(rng, sys_, 1)[0])[0]
+    # left leg DoFs 6..11, right leg DoFs 12..17: different branches below the pelvis
+    assert np.all(H[6:12, 12:18] == 0.0) and np.all(H[12:18, 6:12] == 0.0)
+    assert np.all(H[6:12, 6:12].diagonal() > 0)
+
+
+def test_switches_match_zeroed_state():
+    """setConsiderCoriolisAndCentrifugalForces(false) == qd = 0 ; setConsiderJointAccelerations(false) == qdd = 0
+    (InverseDynamicsCalculator.java:291-306, 884-915)."""
+    rng = np.random.default_rng(8)
+    sys_ = system_of(rt.nextFloatingChain(rng, 9, ("revolute", "prismatic"), tree=True))
+    om = OracleModel(sys_.toModelDesc())
+    q, qd, qdd, _ = rt.nextState(rng, sys_, 3)
+    g = (0.0, 0.0, -9.81)
+    assert np.allclose(om.rnea(q, qd, qdd, g, consider_coriolis=False), om.rnea(q, 0 * qd, qdd, g), rtol=0, atol=1e-11)
+    assert np.allclose(om.rnea(q, qd, qdd, g, consider_accelerations=False), om.rnea(q, qd, 0 * qdd, g), rtol=0, atol=1e-11)
+
+
+def test_free_floating_sphere_ballistic():
+    """MultiBodySystemStateIntegratorTest.java:200-270: a free unit sphere under gravity has zero angular acceleration
+    and the world-frame linear acceleration g; in the joint's own (body) coordinates: vd = R^T g - w x v."""
+    rng = np.random.default_rng(3)
+    root = RigidBody("root")
+    j = SixDoFJoint("floating", root)
+    RigidBody("sphere", j, np.diag([0.4, 0.4, 0.4]), 1.0, centerOfMassOffset=np.zeros(3))
+    sys_ = MultiBodySystem.toMultiBodySystemInput(root)
+    om = OracleModel(sys_.toModelDesc())
+    q, qd, _, _ = rt.nextState(rng, sys_, 16)
+    g = np.array([0.0, 0.0, -9.81])
+    qdd = om.aba(q, qd, np.zeros_like(qd), g)
+    assert np.abs(qdd[:, :3]).max() < 1e-12
+    for b in range(16):
+        R = rt.quaternionToMatrix(q[b, :4])
+        expect = R.T @ g - np.cross(qd[b, :3], qd[b, 3:])
+        assert np.abs(qdd[b, 3:] - expect).max() < 1e-12
+
+
+def test_sphere_wrench_closed_form():
+    """MecanoToolsTest.java:463-617: for a sphere (J = j 1) at rest the RNEA wrench is (j wd, m (a - g))."""
+    rng = np.random.default_rng(4)
+    root = RigidBody("root")
+    j = SixDoFJoint("floating", root)
+    jj, m = 0.7, 2.5
+    RigidBody("sphere", j, np.diag([jj, jj, jj]), m, centerOfMassOffset=np.zeros(3))
+    sys_ = MultiBodySystem.toMultiBodySystemInput(root)
+    om = OracleModel(sys_.toModelDesc())
+    q, qd, qdd, _ = rt.nextState(rng, sys_, 8)
+    tau = om.rnea(q, 0 * qd, qdd, (0, 0, 0))
+    assert np.allclose(tau[:, :3], jj * qdd[:, :3], rtol=0, atol=1e-12)
+    assert np.allclose(tau[:, 3:], m * qdd[:, 3:], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "lagrange_*.json"))))
+def test_lagrangian_known_answers(path):
+    d = json.load(open(path))
+    md = ModelDesc(d["n_joints"], d["nq"], d["nv"], *[np.array(d[k]) for k in (
+        "parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices")])
+    om = OracleModel(md)
+    q, qd, qdd, tau = (np.array([s[k] for s in d["states"]]) for k in ("q", "qd", "qdd", "tau"))
+    assert np.abs(om.rnea(q, qd, qdd, d["gravity"]) - tau).max() < 1e-12
+    assert np.abs(om.aba(q, qd, tau, d["gravity"]) - qdd).max() < 1e-11
+
+
+def test_custom_index_provider_is_honoured():
+    """A JointMatrixIndexProvider may impose any row order (MultiBodySystemReadOnly.java:101-104): permuting it permutes rows only."""
+    from mecano_amd.multibody import JointMatrixIndexProvider
+    rng = np.random.default_rng(6)
+    joints = rt.nextJointChain(rng, 6, ("revolute", "prismatic"))
+    root = joints[0].getPredecessor()
+    base = MultiBodySystem(root)
+    d0 = base.toModelDesc()
+    om0 = OracleModel(d0)
+    q, qd, qdd, _ = rt.nextState(rng, base, 2)
+    tau0 = om0.rnea(q, qd, qdd)
+    d1 = base.toModelDesc()
+    perm = rng.permutation(d0.nv).astype(np.int32)  # joint k now owns matrix row perm[k]
+    d1.dof_indices = perm.copy()
+    d1.cfg_indices = perm.copy()
+    om1 = OracleModel(d1)
+    q1, qd1, qdd1 = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(qdd)
+    q1[:, perm], qd1[:, perm], qdd1[:, perm] = q, qd, qdd
+    tau1 = om1.rnea(q1, qd1, qdd1)
+    assert np.array_equal(tau1[:, perm], tau0)
