@@ -177,10 +177,10 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    mh_status st = check_common(model, B, &opts);
    if (st != MH_OK)
       return st;
+   if (B == 0)
+      return MH_OK; // an empty batch has nothing to read or write: NULL pointers are fine
    if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
-   if (B == 0)
-      return MH_OK;
    st = ensure_workspace(model, B, sizeof(T));
    if (st != MH_OK)
       return st;
@@ -236,10 +236,10 @@ mh_status launch_host(Algo algo, mh_model_t model, int64_t B, const double *q, c
    mh_status st = check_common(model, B, &opts);
    if (st != MH_OK)
       return st;
-   if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
-      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    if (B == 0)
       return MH_OK;
+   if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    const size_t nq = model->nq, nv = model->nv, nj = model->n;
    const size_t s_q = (size_t)B * nq, s_v = (size_t)B * nv, s_f = fext ? (size_t)B * nj * 6 : 0;
    const size_t s_out = algo == ALGO_CRBA ? (size_t)B * nv * nv : s_v;
