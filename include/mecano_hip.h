@@ -142,6 +142,14 @@ int32_t mh_model_n_joints(mh_model_t model);
 /* name of the kernel variant compute calls will use for this model ("generic", "topo:<hash>") */
 const char *mh_model_kernel_variant(mh_model_t model);
 
+/*
+ * Host-only: validates the description and returns the key of its topology (tree shape + joint kinds, in the engine's
+ * parents-first order) together with that order's parent / kind arrays.  A topology-specialised code object
+ * libmecano_hip_topo_<key>.so placed next to libmecano_hip.so is picked up by mh_model_create (mecano_amd/build.py builds them).
+ * key_out holds 16 hex digits + NUL; parents_out / types_out have n_joints entries (either may be NULL).
+ */
+mh_status mh_topology_key(const mh_model_desc *desc, char key_out[17], int32_t *parents_out, int32_t *types_out);
+
 /* Pre-allocate device workspace for batches up to max_batch so that compute calls allocate nothing. */
 mh_status mh_reserve(mh_model_t model, int64_t max_batch);
 

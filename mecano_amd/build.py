@@ -1,16 +1,32 @@
-"""Builds the HIP shared library in-tree: mecano_amd/libmecano_hip.so (gfx950 only)."""
+"""Builds the HIP shared libraries in-tree (gfx950 only):
+
+* mecano_amd/libmecano_hip.so                  the C-ABI + the generic (run-time topology) kernels
+* mecano_amd/libmecano_hip_topo_<key>.so       one topology-specialised code object per registered kinematic-tree shape;
+                                               libmecano_hip.so picks it up at mh_model_create when the key matches.
+
+`python -m mecano_amd.build` builds everything; `build_spec(desc)` builds the code object of any other model
+(hipcc is needed at that moment; it takes about half a minute per topology).
+"""
 from __future__ import annotations
 
+import ctypes
 import os
 import shutil
 import subprocess
 
+import numpy as np
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libmecano_hip.so")
-SOURCES = [os.path.join(HERE, "csrc", "mh_api.hip")]
-HEADERS = [os.path.join(HERE, "csrc", "mh_kernels.h"), os.path.join(HERE, "csrc", "mh_device.h"),
-           os.path.join(ROOT, "include", "mecano_hip.h")]
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = [os.path.join(CSRC, "mh_api.hip")]
+HEADERS = [os.path.join(CSRC, "mh_kernels.h"), os.path.join(CSRC, "mh_device.h"), os.path.join(ROOT, "include", "mecano_hip.h")]
+SPEC_SOURCE = os.path.join(CSRC, "mh_spec.hip")
+SPEC_HEADERS = HEADERS + [os.path.join(CSRC, "mh_spec_kernels.h")]
+# -fno-signed-zeros -ffinite-math-only: lets the compiler drop the multiplications by the structural zeros of the canonical
+# joint frames (S = e_z); no reassociation is enabled, products and sums keep their written order.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only"]
 
 
 def hipcc() -> str:
@@ -20,23 +36,84 @@ def hipcc() -> str:
     return exe
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def _stale(target, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, SOURCES + HEADERS)
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
-           "-o", LIB] + SOURCES
+    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-o", LIB] + SOURCES + ["-ldl"]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
     return LIB
 
 
+def topology_of(desc):
+    """(key, parents, kinds) of a ModelDesc in the engine's parents-first order, from the library's own host-side planner."""
+    from . import _lib
+    build_lib()
+    lib = _lib.load()
+    keep = []
+    d = _lib.MhModelDesc()
+    d.n_joints, d.nq, d.nv = int(desc.n_joints), int(desc.nq), int(desc.nv)
+    for k, dt in (("parent", np.int32), ("joint_type", np.int32), ("dof_indices", np.int32), ("cfg_indices", np.int32), ("axis", np.float64),
+                  ("X_before", np.float64), ("X_com", np.float64), ("inertia_J", np.float64), ("inertia_mass", np.float64),
+                  ("inertia_com", np.float64)):
+        a = np.ascontiguousarray(getattr(desc, k), dtype=dt)
+        keep.append(a)
+        setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
+    key = ctypes.create_string_buffer(17)
+    parents = np.zeros(desc.n_joints, dtype=np.int32)
+    kinds = np.zeros(desc.n_joints, dtype=np.int32)
+    _lib.check(lib.mh_topology_key(ctypes.byref(d), key, parents.ctypes.data, kinds.ctypes.data))
+    return key.value.decode(), parents, kinds
+
+
+def spec_path(key: str) -> str:
+    return os.path.join(HERE, f"libmecano_hip_topo_{key}.so")
+
+
+def build_spec(desc, force: bool = False, verbose: bool = False) -> str:
+    """Builds the topology-specialised code object of a model (any ModelDesc).  Returns its path."""
+    key, parents, kinds = topology_of(desc)
+    out = spec_path(key)
+    if not force and not _stale(out, [SPEC_SOURCE] + SPEC_HEADERS):
+        return out
+    cmd = [hipcc()] + FLAGS + [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
+                               "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-o", out, SPEC_SOURCE]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return out
+
+
+def registered_models():
+    """Topologies that get a specialised code object at build time: the shapes BASELINE.json's configs name."""
+    from . import random_tools as rt
+    from .multibody import MultiBodySystem
+    rng = np.random.default_rng(0)
+    humanoid = rt.nextHumanoid(rng).toModelDesc()                                                     # configs[2], configs[3], the metric
+    arm7 = MultiBodySystem.toMultiBodySystemInput(rt.nextJointChain(rng, 7)[0].getPredecessor()).toModelDesc()  # configs[0], configs[1]
+    return {"humanoid30": humanoid, "arm7": arm7}
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    out = [build_lib(force, verbose)]
+    for name, desc in registered_models().items():
+        out.append(build_spec(desc, force, verbose))
+    return out
+
+
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    import sys
+    for p in build_all(force="--force" in sys.argv, verbose="-v" in sys.argv):
+        print(p)

@@ -7,13 +7,21 @@
 #include "../../include/mecano_hip.h"
 #include "mh_kernels.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+
+// Per-joint constants of the generic kernels: staged in LDS (1) or read through scalar loads (0).
+#ifndef MH_GENERIC_LDS_CONSTS
+#define MH_GENERIC_LDS_CONSTS 0
+#endif
 
 namespace
 {
@@ -81,9 +89,27 @@ struct Workspace
 };
 } // namespace
 
+// entry points of a topology-specialised code object (mh_spec.hip), resolved with dlsym
+struct SpecLib
+{
+   void *handle = nullptr;
+   int (*launch)(int algo, int flags, const void *args, int grid, void *stream) = nullptr;
+   long (*lds_bytes)(int algo, int flags, int nq, int nv) = nullptr;
+   int (*aba_slots)(void) = nullptr;
+   int (*supports)(int algo, int flags) = nullptr;
+};
+enum : int
+{
+   SPEC_IO_LDS = 1,
+   SPEC_IDENT = 2,
+   SPEC_ST_LDS = 4
+};
+
 struct mh_model
 {
    int n = 0, nq = 0, nv = 0, n_slots = 0;
+   SpecLib spec;
+   std::string topo_key;
    int device = 0;
    int cu_count = 256;
    std::vector<int> meta, dof_map, cfg_map;
@@ -95,6 +121,10 @@ struct mh_model
    // staging buffers of the *_host entry points
    Workspace stage;
    std::string variant = "generic";
+   int use_spec = 1;        // MH_DISABLE_SPEC=1 in the environment forces the generic kernels (A/B measurements)
+   int lds_wave_factor = 1; // ABA hand-over in LDS while waves <= cu_count * factor (MH_ABA_LDS_FACTOR)
+   int ident_maps = 0;      // the engine-order index maps are the identity
+   int force_io = -1, force_st = -1; // MH_SPEC_IO / MH_SPEC_ST = 0 | 1 override the heuristics (measurements)
 };
 
 namespace
@@ -199,24 +229,62 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    A.f_bs = soa ? 1 : (long)model->n * 6, A.f_es = soa ? B : 1;
    A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
    A.coriolis = opts.consider_coriolis, A.accel = opts.consider_accelerations;
-   const size_t lds = (size_t)model->n * mh::MC_STRIDE * sizeof(T);
+   const size_t lds = MH_GENERIC_LDS_CONSTS ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
    if (lds > 160 * 1024)
       return fail(MH_ERR_BAD_DIMENSION, "model constants (%zu B) exceed the 160 KiB LDS of a gfx950 CU", lds);
 
+   if (model->spec.launch && algo != ALGO_CRBA && model->use_spec && sizeof(T) == 8)
+   {
+      // Topology-specialised code object (fp64).  State rows are staged in LDS when the layout is AoS and they fit; ABA's
+      // inward -> outward hand-over lives in LDS while the batch is small enough that one wave per CU is all the device
+      // would get anyway, otherwise in the global workspace.
+      const int a = algo == ALGO_RNEA ? 0 : 1;
+      const long waves = (B + 63) / 64;
+      const long LDS_MAX = 160 * 1024;
+      int flags = model->ident_maps ? SPEC_IDENT : 0;
+      bool io = !soa && model->spec.supports(a, SPEC_IO_LDS) && model->spec.lds_bytes(a, SPEC_IO_LDS, model->nq, model->nv) <= LDS_MAX;
+      if (model->force_io >= 0)
+         io = io && model->force_io;
+      if (io)
+         flags |= SPEC_IO_LDS;
+      if (algo == ALGO_ABA)
+      {
+         bool st = model->spec.lds_bytes(a, flags | SPEC_ST_LDS, model->nq, model->nv) <= LDS_MAX && waves <= (long)model->cu_count * model->lds_wave_factor;
+         if (model->force_st >= 0)
+            st = model->force_st && model->spec.lds_bytes(a, flags | SPEC_ST_LDS, model->nq, model->nv) <= LDS_MAX;
+         if (st)
+            flags |= SPEC_ST_LDS;
+      }
+      const long lds = model->spec.lds_bytes(a, flags, model->nq, model->nv);
+      const long per_cu = lds > 0 ? std::max<long>(1, std::min<long>(8, LDS_MAX / lds)) : 8;
+      const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * per_cu));
+      if (algo == ALGO_ABA && !(flags & SPEC_ST_LDS))
+      {
+         mh_status s2 = ensure_bytes(model->ws, (size_t)std::max(model->n_slots, model->spec.aba_slots()) * (size_t)grid * 64 * sizeof(T));
+         if (s2 != MH_OK)
+            return s2;
+         A.ws = (T *)model->ws.ptr;
+         A.ws_stride = (long)grid * 64;
+      }
+      const int rc = model->spec.launch(a, flags, &A, grid, (void *)stream);
+      if (rc != 0)
+         return fail(MH_ERR_HIP, "specialised kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+      return MH_OK;
+   }
    switch (algo)
    {
       case ALGO_RNEA:
-         hipLaunchKernelGGL(mh::rnea_kernel<T>, dim3(L.grid), dim3(L.block), lds, stream, A);
+         hipLaunchKernelGGL((mh::rnea_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
          break;
       case ALGO_ABA:
-         hipLaunchKernelGGL(mh::aba_kernel<T>, dim3(L.grid), dim3(L.block), lds, stream, A);
+         hipLaunchKernelGGL((mh::aba_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
          break;
       case ALGO_CRBA:
       {
          const size_t hbytes = (size_t)B * model->nv * model->nv * sizeof(T);
          HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
          A.v_bs = soa ? 1 : (long)model->nv * model->nv;
-         hipLaunchKernelGGL(mh::crba_kernel<T>, dim3(L.grid), dim3(L.block), lds, stream, A);
+         hipLaunchKernelGGL((mh::crba_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
          break;
       }
    }
@@ -266,6 +334,142 @@ mh_status launch_host(Algo algo, mh_model_t model, int64_t B, const double *q, c
 }
 } // namespace
 
+
+namespace
+{
+// Host-only part of model creation: validation and the engine's joint order (depth-first, parents first).
+struct Plan
+{
+   std::vector<int> order;     // engine index -> caller index
+   std::vector<int> engine_of; // caller index -> engine index
+   std::vector<int> dofo, cfgo; // per caller joint: offsets into the concatenated index maps
+   std::vector<std::vector<int>> children; // by caller index
+   std::vector<int> eparent, etype;        // engine order
+   std::string key;
+};
+
+mh_status plan_model(const mh_model_desc *d, Plan &P)
+{
+   if (!d)
+      return fail(MH_ERR_INVALID_ARGUMENT, "desc is NULL");
+   const int n = d->n_joints;
+   if (n <= 0)
+      return fail(MH_ERR_INVALID_ARGUMENT, "n_joints = %d", n);
+   if (!d->parent || !d->joint_type || !d->axis || !d->X_before || !d->X_com || !d->inertia_J || !d->inertia_mass || !d->inertia_com
+       || !d->dof_indices || !d->cfg_indices)
+      return fail(MH_ERR_INVALID_ARGUMENT, "a model array is NULL");
+   if (d->nq < 0 || d->nv < 0)
+      return fail(MH_ERR_BAD_DIMENSION, "nq = %d, nv = %d", d->nq, d->nv);
+   P.dofo.assign(n + 1, 0), P.cfgo.assign(n + 1, 0);
+   for (int i = 0; i < n; i++)
+   {
+      const int t = d->joint_type[i];
+      if (t < MH_JOINT_REVOLUTE || t > MH_JOINT_FIXED)
+         return fail(MH_ERR_UNSUPPORTED_JOINT, "joint %d has unsupported kind %d", i, t);
+      if (d->parent[i] < -1 || d->parent[i] >= n || d->parent[i] == i)
+         return fail(MH_ERR_BAD_TOPOLOGY, "joint %d has parent %d", i, d->parent[i]);
+      P.dofo[i + 1] = P.dofo[i] + joint_ndof(t);
+      P.cfgo[i + 1] = P.cfgo[i] + joint_ncfg(t);
+   }
+   {
+      std::vector<char> seen_v(d->nv, 0), seen_q(d->nq, 0);
+      for (int k = 0; k < P.dofo[n]; k++)
+      {
+         const int r = d->dof_indices[k];
+         if (r < 0 || r >= d->nv || seen_v[r])
+            return fail(MH_ERR_BAD_TOPOLOGY, "dof_indices[%d] = %d is out of range or repeated (nv = %d)", k, r, d->nv);
+         seen_v[r] = 1;
+      }
+      for (int k = 0; k < P.cfgo[n]; k++)
+      {
+         const int r = d->cfg_indices[k];
+         if (r < 0 || r >= d->nq || seen_q[r])
+            return fail(MH_ERR_BAD_TOPOLOGY, "cfg_indices[%d] = %d is out of range or repeated (nq = %d)", k, r, d->nq);
+         seen_q[r] = 1;
+      }
+   }
+   // engine order: depth-first pre-order, children in the caller's order (chains stay contiguous)
+   P.children.assign(n, {});
+   std::vector<int> roots;
+   for (int i = 0; i < n; i++)
+      (d->parent[i] < 0 ? roots : P.children[d->parent[i]]).push_back(i);
+   P.order.clear();
+   P.order.reserve(n);
+   {
+      std::vector<int> stack(roots.rbegin(), roots.rend());
+      while (!stack.empty())
+      {
+         int i = stack.back();
+         stack.pop_back();
+         P.order.push_back(i);
+         for (auto it = P.children[i].rbegin(); it != P.children[i].rend(); ++it)
+            stack.push_back(*it);
+      }
+   }
+   if ((int)P.order.size() != n)
+      return fail(MH_ERR_LOOP_CLOSURE, "parent[] contains a cycle: %d of %d joints are reachable from the root", (int)P.order.size(), n);
+   P.engine_of.assign(n, 0);
+   for (int e = 0; e < n; e++)
+      P.engine_of[P.order[e]] = e;
+   P.eparent.assign(n, -1), P.etype.assign(n, 0);
+   unsigned long long h = 1469598103934665603ull; // FNV-1a over (n, parents, kinds) in engine order
+   auto mix = [&](int v) {
+      for (int b = 0; b < 4; b++)
+      {
+         h ^= (unsigned long long)((v >> (8 * b)) & 0xff);
+         h *= 1099511628211ull;
+      }
+   };
+   mix(n);
+   for (int e = 0; e < n; e++)
+   {
+      const int i = P.order[e];
+      P.eparent[e] = d->parent[i] < 0 ? -1 : P.engine_of[d->parent[i]];
+      P.etype[e] = d->joint_type[i];
+      mix(P.eparent[e]);
+      mix(P.etype[e]);
+   }
+   char buf[32];
+   snprintf(buf, sizeof buf, "%016llx", h);
+   P.key = buf;
+   return MH_OK;
+}
+
+// Looks for libmecano_hip_topo_<key>.so next to this library and checks it was built for exactly this tree.
+void try_load_spec(mh_model *m, const Plan &P)
+{
+   Dl_info info;
+   if (!dladdr((const void *)&try_load_spec, &info) || !info.dli_fname)
+      return;
+   std::string dir(info.dli_fname);
+   const size_t slash = dir.find_last_of('/');
+   dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+   const std::string path = dir + "/libmecano_hip_topo_" + P.key + ".so";
+   void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+   if (!h)
+      return;
+   auto f_n = (int (*)(void))dlsym(h, "mh_spec_n");
+   auto f_p = (const int *(*)(void))dlsym(h, "mh_spec_parents");
+   auto f_t = (const int *(*)(void))dlsym(h, "mh_spec_types");
+   SpecLib s;
+   s.handle = h;
+   s.launch = (decltype(s.launch))dlsym(h, "mh_spec_launch");
+   s.lds_bytes = (decltype(s.lds_bytes))dlsym(h, "mh_spec_lds_bytes");
+   s.aba_slots = (decltype(s.aba_slots))dlsym(h, "mh_spec_aba_slots");
+   s.supports = (decltype(s.supports))dlsym(h, "mh_spec_supports");
+   bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
+   for (int e = 0; ok && e < m->n; e++)
+      ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];
+   if (!ok)
+   {
+      dlclose(h);
+      return;
+   }
+   m->spec = s;
+   m->variant = "topo:" + P.key;
+}
+} // namespace
+
 // =================================================================================================== C-ABI
 extern "C" {
 
@@ -303,67 +507,13 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    if (!d || !model_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "desc / model_out is NULL");
    *model_out = nullptr;
+   Plan P;
+   mh_status pst = plan_model(d, P);
+   if (pst != MH_OK)
+      return pst;
    const int n = d->n_joints;
-   if (n <= 0)
-      return fail(MH_ERR_INVALID_ARGUMENT, "n_joints = %d", n);
-   if (!d->parent || !d->joint_type || !d->axis || !d->X_before || !d->X_com || !d->inertia_J || !d->inertia_mass || !d->inertia_com
-       || !d->dof_indices || !d->cfg_indices)
-      return fail(MH_ERR_INVALID_ARGUMENT, "a model array is NULL");
-   if (d->nq < 0 || d->nv < 0)
-      return fail(MH_ERR_BAD_DIMENSION, "nq = %d, nv = %d", d->nq, d->nv);
-
-   // ---- validation of kinds, parents (forest, no loop), index maps (injective, in range)
-   std::vector<int> dofo(n + 1, 0), cfgo(n + 1, 0);
-   for (int i = 0; i < n; i++)
-   {
-      const int t = d->joint_type[i];
-      if (t < MH_JOINT_REVOLUTE || t > MH_JOINT_FIXED)
-         return fail(MH_ERR_UNSUPPORTED_JOINT, "joint %d has unsupported kind %d", i, t);
-      if (d->parent[i] < -1 || d->parent[i] >= n || d->parent[i] == i)
-         return fail(MH_ERR_BAD_TOPOLOGY, "joint %d has parent %d", i, d->parent[i]);
-      dofo[i + 1] = dofo[i] + joint_ndof(t);
-      cfgo[i + 1] = cfgo[i] + joint_ncfg(t);
-   }
-   {
-      std::vector<char> seen_v(d->nv, 0), seen_q(d->nq, 0);
-      for (int k = 0; k < dofo[n]; k++)
-      {
-         const int r = d->dof_indices[k];
-         if (r < 0 || r >= d->nv || seen_v[r])
-            return fail(MH_ERR_BAD_TOPOLOGY, "dof_indices[%d] = %d is out of range or repeated (nv = %d)", k, r, d->nv);
-         seen_v[r] = 1;
-      }
-      for (int k = 0; k < cfgo[n]; k++)
-      {
-         const int r = d->cfg_indices[k];
-         if (r < 0 || r >= d->nq || seen_q[r])
-            return fail(MH_ERR_BAD_TOPOLOGY, "cfg_indices[%d] = %d is out of range or repeated (nq = %d)", k, r, d->nq);
-         seen_q[r] = 1;
-      }
-   }
-   // ---- engine order: depth-first pre-order, children in the caller's order (chains stay contiguous)
-   std::vector<std::vector<int>> children(n);
-   std::vector<int> roots;
-   for (int i = 0; i < n; i++)
-      (d->parent[i] < 0 ? roots : children[d->parent[i]]).push_back(i);
-   std::vector<int> order; // engine index -> caller index
-   order.reserve(n);
-   {
-      std::vector<int> stack(roots.rbegin(), roots.rend());
-      while (!stack.empty())
-      {
-         int i = stack.back();
-         stack.pop_back();
-         order.push_back(i);
-         for (auto it = children[i].rbegin(); it != children[i].rend(); ++it)
-            stack.push_back(*it);
-      }
-   }
-   if ((int)order.size() != n)
-      return fail(MH_ERR_LOOP_CLOSURE, "parent[] contains a cycle: %d of %d joints are reachable from the root", (int)order.size(), n);
-   std::vector<int> engine_of(n);
-   for (int e = 0; e < n; e++)
-      engine_of[order[e]] = e;
+   const std::vector<int> &order = P.order, &engine_of = P.engine_of, &dofo = P.dofo, &cfgo = P.cfgo;
+   const std::vector<std::vector<int>> &children = P.children;
 
    // ---- canonical frames: Q_i maps the canonical after-joint axes of joint i to Mecano's after-joint axes
    std::vector<M3d> Q(n);
@@ -388,8 +538,23 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    m->n = n, m->nq = d->nq, m->nv = d->nv;
    m->meta.assign((size_t)n * mh::MI_STRIDE, 0);
    m->consts.assign((size_t)n * mh::MC_STRIDE, 0.0);
-   m->dof_map.assign(d->dof_indices, d->dof_indices + dofo[n]);
-   m->cfg_map.assign(d->cfg_indices, d->cfg_indices + cfgo[n]);
+   // index maps re-concatenated in ENGINE order: the offset of a joint in them is then a function of the topology alone
+   std::vector<int> edofo(n + 1, 0), ecfgo(n + 1, 0);
+   for (int e = 0; e < n; e++)
+   {
+      const int i = order[e];
+      edofo[e + 1] = edofo[e] + (dofo[i + 1] - dofo[i]);
+      ecfgo[e + 1] = ecfgo[e] + (cfgo[i + 1] - cfgo[i]);
+      for (int k = dofo[i]; k < dofo[i + 1]; k++)
+         m->dof_map.push_back(d->dof_indices[k]);
+      for (int k = cfgo[i]; k < cfgo[i + 1]; k++)
+         m->cfg_map.push_back(d->cfg_indices[k]);
+   }
+   m->ident_maps = (edofo[n] == d->nv && ecfgo[n] == d->nq);
+   for (int k = 0; m->ident_maps && k < edofo[n]; k++)
+      m->ident_maps = m->dof_map[k] == k;
+   for (int k = 0; m->ident_maps && k < ecfgo[n]; k++)
+      m->ident_maps = m->cfg_map[k] == k;
    if (m->dof_map.empty())
       m->dof_map.push_back(0);
    if (m->cfg_map.empty())
@@ -405,8 +570,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       double *c = &m->consts[(size_t)e * mh::MC_STRIDE];
       mi[mh::MI_PARENT] = pe;
       mi[mh::MI_TYPE] = t;
-      mi[mh::MI_DOF] = dofo[i];
-      mi[mh::MI_CFG] = cfgo[i];
+      mi[mh::MI_DOF] = edofo[e];
+      mi[mh::MI_CFG] = ecfgo[e];
       mi[mh::MI_EXT] = i;
       int flags = 0;
       if (pe >= 0 && pe == e - 1)
@@ -494,6 +659,7 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
          m->cu_count = prop.multiProcessorCount;
    }
    m->device = dev;
+   m->topo_key = P.key;
    std::vector<float> c32(m->consts.begin(), m->consts.end());
    auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
       hipError_t r = hipMalloc(dst, bytes);
@@ -516,6 +682,17 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       mh_model_destroy(m);
       return fail(MH_ERR_HIP, "model upload failed: %s", hipGetErrorString(e));
    }
+   if (const char *e = getenv("MH_DISABLE_SPEC"))
+      m->use_spec = atoi(e) ? 0 : 1;
+   if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
+      m->lds_wave_factor = atoi(e);
+   if (const char *e = getenv("MH_SPEC_IO"))
+      m->force_io = atoi(e);
+   if (const char *e = getenv("MH_SPEC_ST"))
+      m->force_st = atoi(e);
+   try_load_spec(m, P);
+   if (!m->use_spec)
+      m->variant = "generic";
    *model_out = m;
    return MH_OK;
 }
@@ -531,7 +708,26 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
    (void)hipFree(m->stage.ptr);
+   if (m->spec.handle)
+      dlclose(m->spec.handle);
    delete m;
+}
+mh_status mh_topology_key(const mh_model_desc *desc, char key_out[17], int32_t *parents_out, int32_t *types_out)
+{
+   Plan P;
+   mh_status st = plan_model(desc, P);
+   if (st != MH_OK)
+      return st;
+   if (key_out)
+      snprintf(key_out, 17, "%s", P.key.c_str());
+   for (int e = 0; e < desc->n_joints; e++)
+   {
+      if (parents_out)
+         parents_out[e] = P.eparent[e];
+      if (types_out)
+         types_out[e] = P.etype[e];
+   }
+   return MH_OK;
 }
 int32_t mh_model_nq(mh_model_t m) { return m ? m->nq : -1; }
 int32_t mh_model_nv(mh_model_t m) { return m ? m->nv : -1; }

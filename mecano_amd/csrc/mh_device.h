@@ -334,8 +334,63 @@ MH_DEV void add(RI<T> &a, const RI<T> &b)
    a.I.xx += b.I.xx, a.I.xy += b.I.xy, a.I.xz += b.I.xz, a.I.yy += b.I.yy, a.I.yz += b.I.yz, a.I.zz += b.I.zz;
 }
 
-// ---- sincos
-MH_DEV void sincos_t(double x, double &s, double &c) { sincos(x, &s, &c); }
+// ---- wave-uniform read-only data (model constants, index maps): read through the constant address space so that the
+//      compiler emits scalar loads (s_load) into SGPRs instead of 64 identical vector loads
+template <typename T>
+MH_DEV T ldc(const T *p)
+{
+   typedef const T __attribute__((address_space(4))) * cptr;
+   return *(cptr)(unsigned long long)p;
+}
+typedef const int __attribute__((address_space(4))) *ciptr;
+MH_DEV ciptr as_const(const int *p) { return (ciptr)(unsigned long long)p; }
+// accessor of one joint's constants: LDS copy (broadcast ds_read) or scalar loads from global memory
+template <typename T, bool LDS>
+struct CRef
+{
+   const T *p;
+   MH_DEV T operator[](int k) const
+   {
+      if constexpr (LDS)
+         return p[k];
+      else
+         return ldc(p + k);
+   }
+};
+
+// ---- sincos.  fp64: Cody-Waite reduction by pi/2 (exact products through FMA) + the classic minimax kernels on
+//      [-pi/4, pi/4]; about 30 instructions instead of the ~120 of the library routine with its Payne-Hanek path.
+//      Error <= ~2 ulp for |x| < 2^19; larger arguments take the library path (out of line).
+__device__ __attribute__((noinline)) void sincos_slow(double x, double *s, double *c) { sincos(x, s, c); }
+MH_DEV void sincos_t(double x, double &s, double &c)
+{
+   if (__builtin_expect(!(fabs(x) < 524288.0), 0))
+   {
+      sincos_slow(x, &s, &c);
+      return;
+   }
+   const double k = rint(x * 6.36619772367581382433e-01);
+   double r = fma(-k, 1.57079632679489655800e+00, x);
+   r = fma(-k, 6.12323399573676603587e-17, r);
+   r = fma(-k, -1.49738490485916983084e-33, r); // third term: only matters for |k| ~ 2^19
+   const double z = r * r;
+   double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+   ps = fma(z, ps, 2.75573137070700676789e-06);
+   ps = fma(z, ps, -1.98412698298579493134e-04);
+   ps = fma(z, ps, 8.33333333332248946124e-03);
+   ps = fma(z, ps, -1.66666666666666324348e-01);
+   const double sr = fma(z * r, ps, r);
+   double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+   pc = fma(z, pc, -2.75573143513906633035e-07);
+   pc = fma(z, pc, 2.48015872894767294178e-05);
+   pc = fma(z, pc, -1.38888888888741095749e-03);
+   pc = fma(z, pc, 4.16666666666666019037e-02);
+   const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+   const int n = (int)k;
+   const double s1 = (n & 1) ? cr : sr, c1 = (n & 1) ? sr : cr;
+   s = (n & 2) ? -s1 : s1;
+   c = ((n + 1) & 2) ? -c1 : c1;
+}
 MH_DEV void sincos_t(float x, float &s, float &c) { sincosf(x, &s, &c); }
 
 } // namespace mh

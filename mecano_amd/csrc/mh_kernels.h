@@ -87,16 +87,16 @@ struct Args
    int coriolis, accel;
 };
 
-template <typename T>
-MH_DEV XF<T> load_xb(const T *c)
+template <typename T, class CR>
+MH_DEV XF<T> load_xb(const CR &c)
 {
    XF<T> X;
    X.R = M3<T>{c[MC_RB + 0], c[MC_RB + 1], c[MC_RB + 2], c[MC_RB + 3], c[MC_RB + 4], c[MC_RB + 5], c[MC_RB + 6], c[MC_RB + 7], c[MC_RB + 8]};
    X.p = V3<T>{c[MC_PB + 0], c[MC_PB + 1], c[MC_PB + 2]};
    return X;
 }
-template <typename T>
-MH_DEV RI<T> load_inertia(const T *c)
+template <typename T, class CR>
+MH_DEV RI<T> load_inertia(const CR &c)
 {
    RI<T> r;
    r.m = c[MC_M];
@@ -182,7 +182,7 @@ MH_DEV void rigid_up(int type, const JX<T> &jx, const XF<T> &Xb, RI<T> &r)
 
 // joint transform from the inputs (first visit of a body in a kernel); stores (cos, sin) of revolute joints
 template <typename T>
-MH_DEV JX<T> joint_from_q(int type, const int *cfg_map, int cfg_ofs, const T *qrow, long q_es, T *ws, long ws_stride, int slot_jp, bool store)
+MH_DEV JX<T> joint_from_q(int type, ciptr cfg_map, int cfg_ofs, const T *qrow, long q_es, T *ws, long ws_stride, int slot_jp, bool store)
 {
    JX<T> jx;
    jx.c = T(1), jx.s = T(0), jx.d = T(0);
@@ -200,7 +200,7 @@ MH_DEV JX<T> joint_from_q(int type, const int *cfg_map, int cfg_ofs, const T *qr
       jx.d = qrow[cfg_map[cfg_ofs] * q_es];
    else if (type == JT_SIXDOF)
    {
-      const int *ci = cfg_map + cfg_ofs;
+      ciptr ci = cfg_map + cfg_ofs;
       jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
       jx.X.p = V3<T>{qrow[ci[4] * q_es], qrow[ci[5] * q_es], qrow[ci[6] * q_es]};
    }
@@ -208,7 +208,7 @@ MH_DEV JX<T> joint_from_q(int type, const int *cfg_map, int cfg_ofs, const T *qr
 }
 // joint transform on a later visit: revolute (cos, sin) come back from the workspace, the rest is re-read from q
 template <typename T>
-MH_DEV JX<T> joint_again(int type, const int *cfg_map, int cfg_ofs, const T *qrow, long q_es, const T *ws, long ws_stride, int slot_jp)
+MH_DEV JX<T> joint_again(int type, ciptr cfg_map, int cfg_ofs, const T *qrow, long q_es, const T *ws, long ws_stride, int slot_jp)
 {
    JX<T> jx;
    jx.c = T(1), jx.s = T(0), jx.d = T(0);
@@ -221,7 +221,7 @@ MH_DEV JX<T> joint_again(int type, const int *cfg_map, int cfg_ofs, const T *qro
       jx.d = qrow[cfg_map[cfg_ofs] * q_es];
    else if (type == JT_SIXDOF)
    {
-      const int *ci = cfg_map + cfg_ofs;
+      ciptr ci = cfg_map + cfg_ofs;
       jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
       jx.X.p = V3<T>{qrow[ci[4] * q_es], qrow[ci[5] * q_es], qrow[ci[6] * q_es]};
    }
@@ -251,7 +251,7 @@ MH_DEV void ws_add6(T *ws, long ws_stride, int slot, SV<T> v)
 
 // velocity of the joint in its own (canonical) after-joint frame, and the matching slice of another DoF-sized vector
 template <typename T>
-MH_DEV SV<T> joint_vec(int type, const int *dof_map, int dof_ofs, const T *row, long es, bool enabled)
+MH_DEV SV<T> joint_vec(int type, ciptr dof_map, int dof_ofs, const T *row, long es, bool enabled)
 {
    SV<T> o{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
    if (!enabled)
@@ -262,15 +262,15 @@ MH_DEV SV<T> joint_vec(int type, const int *dof_map, int dof_ofs, const T *row, 
       o.l.z = row[dof_map[dof_ofs] * es];
    else if (type == JT_SIXDOF)
    {
-      const int *di = dof_map + dof_ofs;
+      ciptr di = dof_map + dof_ofs;
       o.a = V3<T>{row[di[0] * es], row[di[1] * es], row[di[2] * es]};
       o.l = V3<T>{row[di[3] * es], row[di[4] * es], row[di[5] * es]};
    }
    return o;
 }
 // external wrench of the body (body-fixed frame) brought to the canonical after-joint frame
-template <typename T>
-MH_DEV SV<T> load_fext(const T *c, const T *frow, long f_es, int ext)
+template <typename T, class CR>
+MH_DEV SV<T> load_fext(const CR &c, const T *frow, long f_es, int ext)
 {
    XF<T> X;
    X.R = M3<T>{c[MC_RF + 0], c[MC_RF + 1], c[MC_RF + 2], c[MC_RF + 3], c[MC_RF + 4], c[MC_RF + 5], c[MC_RF + 6], c[MC_RF + 7], c[MC_RF + 8]};
@@ -292,13 +292,19 @@ MH_DEV void stage_consts(const DevModel &m, T *lds)
 }
 
 // ============================================================================================ RNEA
-template <typename T>
+template <typename T, bool LDSC>
 __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
-   T *C = (T *)lds_raw;
-   stage_consts<T>(A.m, C);
    const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   if constexpr (LDSC)
+   {
+      T *C = (T *)lds_raw;
+      stage_consts<T>(m, C);
+      CB = C;
+   }
+   const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
    const long ws_stride = A.ws_stride;
@@ -317,9 +323,9 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
       SV<T> v_prev{Z, Z}, a_prev{Z, Z};
       for (int j = 0; j < m.n; j++)
       {
-         const int *mi = m.meta + j * MI_STRIDE;
+         ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
-         const T *c = C + j * MC_STRIDE;
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          SV<T> vp, ap;
          if (parent < 0)
          {
@@ -332,22 +338,22 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
          }
          else
          {
-            const int sp = m.meta[parent * MI_STRIDE + MI_SLOT_VA];
+            const int sp = meta[parent * MI_STRIDE + MI_SLOT_VA];
             vp = ws_load6(ws, ws_stride, sp);
             ap = ws_load6(ws, ws_stride, sp + 6);
          }
-         const XF<T> Xb = load_xb(c);
-         const JX<T> jx = joint_from_q<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
-         const SV<T> vJ = joint_vec<T>(type, m.dof_map, mi[MI_DOF], qdrow, A.v_es, A.coriolis != 0);
-         const SV<T> aJ = joint_vec<T>(type, m.dof_map, mi[MI_DOF], qddrow, A.v_es, A.accel != 0);
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, A.coriolis != 0);
+         const SV<T> aJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qddrow, A.v_es, A.accel != 0);
          SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
          SV<T> a = motion_down(type, jx, Xb, ap) + aJ + crm(v, vJ);
          if (!A.coriolis)
             v = SV<T>{Z, Z};
-         const RI<T> I = load_inertia(c);
+         const RI<T> I = load_inertia<T>(c);
          SV<T> f = mul(I, a) + crf(v, mul(I, v));
          if (frow)
-            f = f - load_fext(c, frow, A.f_es, mi[MI_EXT]);
+            f = f - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
          ws_store6(ws, ws_stride, mi[MI_SLOT_F], f);
          if (flags & MF_STORE_VA)
          {
@@ -361,13 +367,13 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
       bool have_carry = false;
       for (int j = m.n - 1; j >= 0; j--)
       {
-         const int *mi = m.meta + j * MI_STRIDE;
+         ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
-         const T *c = C + j * MC_STRIDE;
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          SV<T> f = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
          if (have_carry)
             f = f + carry;
-         const int *di = m.dof_map + mi[MI_DOF];
+         ciptr di = dof_map + mi[MI_DOF];
          if (type == JT_REVOLUTE)
             trow[di[0] * A.v_es] = f.a.z;
          else if (type == JT_PRISMATIC)
@@ -380,8 +386,8 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
          have_carry = false;
          if (parent >= 0)
          {
-            const XF<T> Xb = load_xb(c);
-            const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+            const XF<T> Xb = load_xb<T>(c);
+            const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
             const SV<T> fp = force_up(type, jx, Xb, f);
             if (flags & MF_PARENT_ADJ)
             {
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
                have_carry = true;
             }
             else
-               ws_add6(ws, ws_stride, m.meta[parent * MI_STRIDE + MI_SLOT_F], fp);
+               ws_add6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_F], fp);
          }
       }
    }
@@ -476,13 +482,19 @@ MH_DEV SV<T> spd6_solve(const ABI<T> &I, SV<T> b)
    return SV<T>{V3<T>{x[0], x[1], x[2]}, V3<T>{x[3], x[4], x[5]}};
 }
 
-template <typename T>
+template <typename T, bool LDSC>
 __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
-   T *C = (T *)lds_raw;
-   stage_consts<T>(A.m, C);
    const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   if constexpr (LDSC)
+   {
+      T *C = (T *)lds_raw;
+      stage_consts<T>(m, C);
+      CB = C;
+   }
+   const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
    const long ws_stride = A.ws_stride;
@@ -501,24 +513,24 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       SV<T> v_prev{Z, Z};
       for (int j = 0; j < m.n; j++)
       {
-         const int *mi = m.meta + j * MI_STRIDE;
+         ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
-         const T *c = C + j * MC_STRIDE;
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          SV<T> vp;
          if (parent < 0)
             vp = SV<T>{Z, Z};
          else if (flags & MF_PARENT_ADJ)
             vp = v_prev;
          else
-            vp = ws_load6(ws, ws_stride, m.meta[parent * MI_STRIDE + MI_SLOT_VA]);
-         const XF<T> Xb = load_xb(c);
-         const JX<T> jx = joint_from_q<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
-         const SV<T> vJ = joint_vec<T>(type, m.dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+            vp = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
          const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
-         const RI<T> I = load_inertia(c);
+         const RI<T> I = load_inertia<T>(c);
          SV<T> p = crf(v, mul(I, v));
          if (frow)
-            p = p - load_fext(c, frow, A.f_es, mi[MI_EXT]);
+            p = p - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
          ws_store6(ws, ws_stride, mi[MI_SLOT_F], p);
          ws_store6(ws, ws_stride, mi[MI_SLOT_C], crm(v, vJ));
          if (flags & MF_STORE_VA)
@@ -531,10 +543,10 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       bool have_carry = false;
       for (int j = m.n - 1; j >= 0; j--)
       {
-         const int *mi = m.meta + j * MI_STRIDE;
+         ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
-         const T *c = C + j * MC_STRIDE;
-         ABI<T> IA = abi_from_rigid(load_inertia(c));
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         ABI<T> IA = abi_from_rigid(load_inertia<T>(c));
          SV<T> pA = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
          if (have_carry)
          {
@@ -545,7 +557,7 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
             add(IA, ws_load_abi(ws, ws_stride, mi[MI_SLOT_IA]));
          have_carry = false;
          const int sf = mi[MI_SLOT_F];
-         const int *di = m.dof_map + mi[MI_DOF];
+         ciptr di = dof_map + mi[MI_DOF];
          ABI<T> Ia = IA;
          SV<T> pa = pA;
          if (type == JT_REVOLUTE || type == JT_PRISMATIC)
@@ -596,8 +608,8 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          }
          if (parent >= 0)
          {
-            const XF<T> Xb = load_xb(c);
-            const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+            const XF<T> Xb = load_xb<T>(c);
+            const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
             abi_up(type, jx, Xb, Ia);                            // :1156-1166
             const SV<T> pp = force_up(type, jx, Xb, pa);
             if (flags & MF_PARENT_ADJ)
@@ -606,7 +618,7 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
             }
             else
             {
-               const int *pmi = m.meta + parent * MI_STRIDE;
+               ciptr pmi = meta + parent * MI_STRIDE;
                if (flags & MF_ACC_FIRST)
                   ws_store_abi(ws, ws_stride, pmi[MI_SLOT_IA], Ia);
                else
@@ -623,21 +635,21 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       SV<T> a_prev{Z, Z};
       for (int j = 0; j < m.n; j++)
       {
-         const int *mi = m.meta + j * MI_STRIDE;
+         ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
-         const T *c = C + j * MC_STRIDE;
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          SV<T> ap;
          if (parent < 0)
             ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :259-264
          else if (flags & MF_PARENT_ADJ)
             ap = a_prev;
          else
-            ap = ws_load6(ws, ws_stride, m.meta[parent * MI_STRIDE + MI_SLOT_VA]);
-         const XF<T> Xb = load_xb(c);
-         const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+            ap = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
          SV<T> a = motion_down(type, jx, Xb, ap) + ws_load6(ws, ws_stride, mi[MI_SLOT_C]); // :1270-1273
          const int sf = mi[MI_SLOT_F];
-         const int *di = m.dof_map + mi[MI_DOF];
+         ciptr di = dof_map + mi[MI_DOF];
          if (type == JT_REVOLUTE || type == JT_PRISMATIC)
          {
             const SV<T> U = ws_load6(ws, ws_stride, sf);
@@ -704,13 +716,19 @@ MH_DEV T comp(SV<T> w, int k)
 
 // H is [B][nv][nv] row-major (h_bs = nv*nv, element (r,c) at r*nv + c) and must be zero-filled before the launch:
 // the kernel writes only the entries of related joints (CompositeRigidBodyMassMatrixCalculator.java:298,841-845).
-template <typename T>
+template <typename T, bool LDSC>
 __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
-   T *C = (T *)lds_raw;
-   stage_consts<T>(A.m, C);
    const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   if constexpr (LDSC)
+   {
+      T *C = (T *)lds_raw;
+      stage_consts<T>(m, C);
+      CB = C;
+   }
+   const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
    const long ws_stride = A.ws_stride;
@@ -724,26 +742,26 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
       const long h_es = A.v_es;
       for (int j = 0; j < m.n; j++)
       {
-         const int *mi = m.meta + j * MI_STRIDE;
-         (void)joint_from_q<T>(mi[MI_TYPE], m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         ciptr mi = meta + j * MI_STRIDE;
+         (void)joint_from_q<T>(mi[MI_TYPE], cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
       }
       RI<T> rcarry;
       bool have_carry = false;
       for (int j = m.n - 1; j >= 0; j--)
       {
-         const int *mi = m.meta + j * MI_STRIDE;
+         ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
-         const T *c = C + j * MC_STRIDE;
-         RI<T> Ic = load_inertia(c);
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         RI<T> Ic = load_inertia<T>(c);
          if (have_carry)
             add(Ic, rcarry);
          if (flags & MF_HAS_ACC)
             add(Ic, ws_load_ri(ws, ws_stride, mi[MI_SLOT_IA]));
          have_carry = false;
          const int nd = type == JT_SIXDOF ? 6 : (type == JT_FIXED ? 0 : 1);
-         const int *dj = m.dof_map + mi[MI_DOF];
-         const XF<T> Xb = load_xb(c);
-         const JX<T> jx = joint_again<T>(type, m.cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         ciptr dj = dof_map + mi[MI_DOF];
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
          for (int k = 0; k < nd; k++)
          {
             SV<T> F = mul(Ic, unit_twist<T>(type, k)); // :663-667
@@ -764,9 +782,9 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
             while (anc >= 0)
             {
                F = force_up(tp, jp, Xp, F);
-               const int *ma = m.meta + anc * MI_STRIDE;
+               ciptr ma = meta + anc * MI_STRIDE;
                const int ta = ma[MI_TYPE];
-               const int *da = m.dof_map + ma[MI_DOF];
+               ciptr da = dof_map + ma[MI_DOF];
                if (ta == JT_REVOLUTE)
                {
                   H[((long)da[0] * nv + col) * h_es] = F.a.z;
@@ -788,8 +806,8 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
                anc = ma[MI_PARENT];
                if (anc >= 0)
                {
-                  Xp = load_xb(C + prev * MC_STRIDE);
-                  jp = joint_again<T>(ta, m.cfg_map, ma[MI_CFG], qrow, A.q_es, ws, ws_stride, ma[MI_SLOT_JP]);
+                  Xp = load_xb<T>(CRef<T, LDSC>{CB + prev * MC_STRIDE});
+                  jp = joint_again<T>(ta, cfg_map, ma[MI_CFG], qrow, A.q_es, ws, ws_stride, ma[MI_SLOT_JP]);
                   tp = ta;
                }
             }
@@ -803,7 +821,7 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
             }
             else
             {
-               const int sp = m.meta[parent * MI_STRIDE + MI_SLOT_IA];
+               const int sp = meta[parent * MI_STRIDE + MI_SLOT_IA];
                if (flags & MF_ACC_FIRST)
                   ws_store_ri(ws, ws_stride, sp, Ic);
                else

@@ -1,0 +1,111 @@
+// mh_spec.hip -- one topology-specialised code object.  Compiled once per kinematic-tree shape by mecano_amd/build.py:
+//
+//   hipcc --offload-arch=gfx950 -DMH_TOPO_N=25 "-DMH_TOPO_PARENTS=-1,0,1,..." "-DMH_TOPO_TYPES=2,0,0,..." \
+//         -shared -o libmecano_hip_topo_<key>.so mh_spec.hip
+//
+// libmecano_hip.so dlopen()s it from its own directory when a model with this topology is created
+// (mh_model_create) and routes mh_rnea_f64 / mh_aba_f64 to it; every other model and dtype runs on the generic kernels.
+#include "mh_spec_kernels.h"
+
+#ifndef MH_TOPO_N
+#error "MH_TOPO_N / MH_TOPO_PARENTS / MH_TOPO_TYPES must be defined"
+#endif
+
+namespace
+{
+struct TP
+{
+   static constexpr int N = MH_TOPO_N;
+   static constexpr int parent[N] = {MH_TOPO_PARENTS};
+   static constexpr int type[N] = {MH_TOPO_TYPES};
+};
+constexpr int kParents[TP::N] = {MH_TOPO_PARENTS};
+constexpr int kTypes[TP::N] = {MH_TOPO_TYPES};
+using TR = mh::Tree<TP>;
+
+enum : int
+{
+   F_IO_LDS = 1, // state rows staged in LDS (AoS layout only)
+   F_IDENT = 2,  // identity index maps
+   F_ST_LDS = 4  // ABA hand-over store in LDS
+};
+
+long lds_bytes(int algo, int flags, int nq, int nv)
+{
+   long b = 0;
+   if (flags & F_IO_LDS)
+      b += (long)(nq + 2 * nv) * 64 * sizeof(double);
+   if (algo == 1 && (flags & F_ST_LDS))
+      b += (long)TR::aba_slot(TP::N) * 64 * sizeof(double);
+   return b;
+}
+
+template <int ALGO, bool IO, bool ID, bool ST>
+hipError_t go(const mh::Args<double> &A, int grid, size_t lds, hipStream_t stream)
+{
+   auto kern = &mh::spec_kernel<TP, double, ALGO, IO, ID, ST>;
+   static size_t attr_bytes = 0; // per instantiation
+   if (lds > 64 * 1024 && lds > attr_bytes)
+   {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess)
+         return e;
+      attr_bytes = lds;
+   }
+   hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, A);
+   return hipGetLastError();
+}
+template <int ALGO, bool IO, bool ID>
+hipError_t go_st(int flags, const mh::Args<double> &A, int grid, size_t lds, hipStream_t s)
+{
+   if constexpr (ALGO == 1)
+   {
+      if (flags & F_ST_LDS)
+         return go<ALGO, IO, ID, true>(A, grid, lds, s);
+   }
+   return go<ALGO, IO, ID, false>(A, grid, lds, s);
+}
+template <int ALGO>
+hipError_t go_flags(int flags, const mh::Args<double> &A, int grid, size_t lds, hipStream_t s)
+{
+   const bool io = flags & F_IO_LDS, id = flags & F_IDENT;
+   if constexpr (ALGO == 0)
+   {
+      if (io && id)
+         return go_st<ALGO, true, true>(flags, A, grid, lds, s);
+      if (io)
+         return go_st<ALGO, true, false>(flags, A, grid, lds, s);
+   }
+   else if (io)
+      return hipErrorNotSupported; // ABA with LDS-staged rows is not built: see mh_spec_supports()
+   if (id)
+      return go_st<ALGO, false, true>(flags, A, grid, lds, s);
+   return go_st<ALGO, false, false>(flags, A, grid, lds, s);
+}
+} // namespace
+
+extern "C" {
+int mh_spec_n(void) { return TP::N; }
+const int *mh_spec_parents(void) { return kParents; }
+const int *mh_spec_types(void) { return kTypes; }
+int mh_spec_nq(void) { return TR::cfg_ofs(TP::N); }
+int mh_spec_nv(void) { return TR::dof_ofs(TP::N); }
+int mh_spec_aba_slots(void) { return TR::aba_slot(TP::N); }
+// which (algo, flag) combinations this code object was built with.  ABA + F_IO_LDS is left out: that variant (512 VGPRs,
+// ~650 spills) returned wrong velocity-dependent terms on gfx950 / ROCm 7.2 although the same staging code is exact in the
+// RNEA kernel, and it was not faster than direct loads at any batch size; see DESIGN.md, open issues.
+int mh_spec_supports(int algo, int flags) { return (algo == 0) || (algo == 1 && !(flags & F_IO_LDS)); }
+// dynamic LDS one workgroup (one wave) needs for (algo, flags) with the model's matrix sizes
+long mh_spec_lds_bytes(int algo, int flags, int nq, int nv) { return lds_bytes(algo, flags, nq, nv); }
+// algo: 0 = RNEA, 1 = ABA; fp64 only.  args points to mh::Args<double>.
+int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream)
+{
+   const mh::Args<double> &A = *(const mh::Args<double> *)args;
+   const size_t lds = (size_t)lds_bytes(algo, flags, A.m.nq, A.m.nv);
+   if (algo == 0)
+      return (int)go_flags<0>(flags, A, grid, lds, (hipStream_t)stream);
+   if (algo == 1)
+      return (int)go_flags<1>(flags, A, grid, lds, (hipStream_t)stream);
+   return (int)hipErrorNotSupported;
+}
+}

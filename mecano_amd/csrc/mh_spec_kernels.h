@@ -1,0 +1,568 @@
+// mh_spec_kernels.h -- topology-specialised RNEA / ABA kernels for gfx950.
+//
+// Same arithmetic and same lane = configuration mapping as the generic kernels (mh_kernels.h), but the kinematic tree
+// (parents and joint kinds, in engine order) is a compile-time constant TP.  The tree walk is then a compile-time
+// recursion: every loop over bodies is unrolled, every joint-kind branch is resolved, the per-joint constants sit at
+// fixed addresses (wave-uniform scalar loads straight into SGPR operands), and the intermediates of the depth-first
+// walk live in registers instead of the per-lane global workspace.
+//
+// Memory plan of one wave (= one workgroup of 64 lanes = 64 configurations):
+//   * IO_LDS: the wave's 64 rows of q, qd and qdd|tau (contiguous in the AoS [B][n] matrices Mecano's layout implies) are
+//     copied once, coalesced, into LDS; each lane then reads its own row from LDS (immediate offsets when the index maps
+//     are the identity).  Results are written in place over the qdd|tau rows and copied out coalesced.
+//   * ABA's hand-over between the inward and the outward sweep (U/D (6), u/D, cos, sin per revolute body) goes through a
+//     per-lane store: LDS (slot-major, 64 lanes per slot) for small batches, the global workspace for large ones.
+//
+// One code object is built per topology (mecano_amd/build.py: hipcc -DMH_TOPO_...); model parameters (poses, inertias,
+// index maps) stay run-time data, so every robot with the same tree shape and joint kinds shares it.
+#pragma once
+#include "mh_kernels.h"
+
+// keeps the instruction scheduler from interleaving the steps of different bodies (which inflates live ranges until
+// the 512-VGPR budget spills): nothing may be moved across this point
+#define MH_BODY_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+namespace mh
+{
+// TP must provide: static constexpr int N; static constexpr int parent[N]; static constexpr int type[N];
+template <class TP>
+struct Tree
+{
+   static constexpr int N = TP::N;
+   static constexpr int ndof(int j) { return TP::type[j] == JT_SIXDOF ? 6 : (TP::type[j] == JT_FIXED ? 0 : 1); }
+   static constexpr int ncfg(int j) { return TP::type[j] == JT_SIXDOF ? 7 : (TP::type[j] == JT_FIXED ? 0 : 1); }
+   static constexpr int dof_ofs(int j)
+   { // offset of joint j in the engine-order index maps
+      int s = 0;
+      for (int i = 0; i < j; i++)
+         s += ndof(i);
+      return s;
+   }
+   static constexpr int cfg_ofs(int j)
+   {
+      int s = 0;
+      for (int i = 0; i < j; i++)
+         s += ncfg(i);
+      return s;
+   }
+   // ABA hand-over slots: revolute 9 (U/D, u/D, cos, sin), prismatic 7, sixdof 6 (IA^-1 u), fixed 0
+   static constexpr int aba_slots_of(int j)
+   {
+      return TP::type[j] == JT_REVOLUTE ? 9 : (TP::type[j] == JT_PRISMATIC ? 7 : (TP::type[j] == JT_SIXDOF ? 6 : 0));
+   }
+   static constexpr int aba_slot(int j)
+   {
+      int s = 0;
+      for (int i = 0; i < j; i++)
+         s += aba_slots_of(i);
+      return s;
+   }
+   static constexpr int n_children(int j)
+   {
+      int c = 0;
+      for (int i = 0; i < N; i++)
+         c += TP::parent[i] == j ? 1 : 0;
+      return c;
+   }
+   static constexpr int child(int j, int k)
+   { // k-th child of j (j = -1: k-th root) in index order
+      int c = 0;
+      for (int i = 0; i < N; i++)
+         if (TP::parent[i] == j)
+         {
+            if (c == k)
+               return i;
+            c++;
+         }
+      return -1;
+   }
+};
+
+template <typename T>
+using lds_ptr = T __attribute__((address_space(3))) *;
+
+// Per-lane store for values that must survive from ABA's inward sweep to its outward sweep: slot-major, lane-minor.
+// LDS flavour: the slot stride is the compile-time constant 64, every access is "ds_write/read_b64 base offset:imm".
+// Global flavour: ws[slot * stride + lane] with a wave-uniform base (scalar address arithmetic).
+template <typename T, bool LDS>
+struct LaneStore
+{
+   lds_ptr<T> lbase; // lds + lane-in-wave
+   T *gbase;         // wave-uniform workspace pointer
+   long stride, lane;
+   MH_DEV void put(int slot, T v) const
+   {
+      if constexpr (LDS)
+         lbase[slot * 64] = v;
+      else
+         gbase[(long)slot * stride + lane] = v;
+   }
+   MH_DEV T get(int slot) const
+   {
+      if constexpr (LDS)
+         return lbase[slot * 64];
+      else
+         return gbase[(long)slot * stride + lane];
+   }
+};
+
+// Everything one lane needs to walk the tree.  IO_LDS: state rows staged in LDS.  IDENT: the index maps are the identity
+// (Mecano's default JointMatrixIndexProvider over joints in depth-first order), so every row index is a compile-time constant.
+template <typename T, bool IO_LDS, bool IDENT, bool ST_LDS>
+struct Ctx
+{
+   const T *C; // per-joint constants [N][MC_STRIDE], global memory, wave-uniform addresses -> scalar loads
+   ciptr dof_map, cfg_map, meta;
+   const T *qrow, *qdrow, *in3row, *frow;
+   T *orow;
+   long q_es, v_es, f_es;
+   lds_ptr<T> lq, lqd, lx, lo; // this lane's rows in LDS (IO_LDS); lo = output row (may alias lx)
+   V3<T> a0l;              // linear part of the root acceleration (-g)
+   int coriolis, accel;
+   LaneStore<T, ST_LDS> st;
+
+   MH_DEV int ci(int k) const { return IDENT ? k : cfg_map[k]; }
+   MH_DEV int di(int k) const { return IDENT ? k : dof_map[k]; }
+   MH_DEV T q(int k) const
+   {
+      if constexpr (IO_LDS)
+         return lq[ci(k)];
+      else
+         return qrow[ci(k) * q_es];
+   }
+   MH_DEV T qd(int k) const
+   {
+      if constexpr (IO_LDS)
+         return lqd[di(k)];
+      else
+         return qdrow[di(k) * v_es];
+   }
+   MH_DEV T in3(int k) const
+   {
+      if constexpr (IO_LDS)
+         return lx[di(k)];
+      else
+         return in3row[di(k) * v_es];
+   }
+   MH_DEV void out(int k, T v) const
+   {
+      if constexpr (IO_LDS)
+         lo[di(k)] = v;
+      else
+         orow[di(k) * v_es] = v;
+   }
+};
+
+template <int TYPE, int CO, class CX, typename T>
+MH_DEV JX<T> spec_joint(const CX &cx)
+{
+   JX<T> jx;
+   jx.c = T(1), jx.s = T(0), jx.d = T(0);
+   if constexpr (TYPE == JT_REVOLUTE)
+      sincos_t(cx.q(CO), jx.s, jx.c);
+   else if constexpr (TYPE == JT_PRISMATIC)
+      jx.d = cx.q(CO);
+   else if constexpr (TYPE == JT_SIXDOF)
+   {
+      jx.X.R = quat_to_R(cx.q(CO + 0), cx.q(CO + 1), cx.q(CO + 2), cx.q(CO + 3));
+      jx.X.p = V3<T>{cx.q(CO + 4), cx.q(CO + 5), cx.q(CO + 6)};
+   }
+   return jx;
+}
+// slice of qd (WHICH = 0) or of qdd|tau (WHICH = 1) belonging to the joint, as a spatial vector in its canonical frame
+template <int TYPE, int DO, int WHICH, class CX, typename T>
+MH_DEV SV<T> spec_vec(const CX &cx, bool enabled)
+{
+   SV<T> o{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
+   if (!enabled)
+      return o;
+   auto rd = [&](int k) { return WHICH == 0 ? cx.qd(k) : cx.in3(k); };
+   if constexpr (TYPE == JT_REVOLUTE)
+      o.a.z = rd(DO);
+   else if constexpr (TYPE == JT_PRISMATIC)
+      o.l.z = rd(DO);
+   else if constexpr (TYPE == JT_SIXDOF)
+   {
+      o.a = V3<T>{rd(DO + 0), rd(DO + 1), rd(DO + 2)};
+      o.l = V3<T>{rd(DO + 3), rd(DO + 4), rd(DO + 5)};
+   }
+   return o;
+}
+template <int TYPE, int DO, class CX, typename T>
+MH_DEV void spec_write(const CX &cx, SV<T> w)
+{
+   if constexpr (TYPE == JT_REVOLUTE)
+      cx.out(DO, w.a.z);
+   else if constexpr (TYPE == JT_PRISMATIC)
+      cx.out(DO, w.l.z);
+   else if constexpr (TYPE == JT_SIXDOF)
+   {
+      cx.out(DO + 0, w.a.x), cx.out(DO + 1, w.a.y), cx.out(DO + 2, w.a.z);
+      cx.out(DO + 3, w.l.x), cx.out(DO + 4, w.l.y), cx.out(DO + 5, w.l.z);
+   }
+}
+
+// ============================================================================================ RNEA
+// Returns the wrench the subtree rooted at joint J exerts on its parent, expressed in the parent's frame
+// (InverseDynamicsCalculator.java:873-966 as one depth-first recursion).
+template <class TP, int J, typename T, class CX>
+struct RneaSub
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx, const SV<T> &v, const SV<T> &a, SV<T> &f)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         f = f + RneaSub<TP, Tree<TP>::child(J, K), T, CX>::run(cx, v, a);
+         children<K + 1>(cx, v, a, f);
+      }
+   }
+   static MH_DEV SV<T> run(const CX &cx, const SV<T> &vp, const SV<T> &ap)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      const XF<T> Xb = load_xb<T>(c);
+      const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+      const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
+      const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
+      const V3<T> Z{T(0), T(0), T(0)};
+      SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
+      const SV<T> a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
+      if (!cx.coriolis)
+         v = SV<T>{Z, Z};
+      const RI<T> I = load_inertia<T>(c);
+      SV<T> f = mul(I, a) + crf(v, mul(I, v));
+      if (cx.frow)
+         f = f - load_fext<T>(c, cx.frow, cx.f_es, cx.meta[J * MI_STRIDE + MI_EXT]);
+      MH_BODY_FENCE();
+      children<0>(cx, v, a, f);
+      MH_BODY_FENCE();
+      spec_write<TYPE, DO, CX, T>(cx, f);
+      const SV<T> up = force_up(TYPE, jx, Xb, f);
+      MH_BODY_FENCE();
+      return up;
+   }
+};
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void rnea_roots(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      const V3<T> Z{T(0), T(0), T(0)};
+      (void)RneaSub<TP, Tree<TP>::child(-1, K), T, CX>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
+      rnea_roots<TP, T, CX, K + 1>(cx);
+   }
+}
+
+// ============================================================================================ ABA
+template <typename T>
+struct AbaUp
+{ // what a subtree hands to its parent: articulated inertia and bias wrench, in the parent's frame
+   ABI<T> I;
+   SV<T> p;
+};
+template <typename T>
+MH_DEV AbaUp<T> aba_up_zero()
+{
+   AbaUp<T> z;
+   z.I.A = S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)};
+   z.I.L = z.I.A;
+   z.I.C = M3<T>{T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+   z.p = SV<T>{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
+   return z;
+}
+
+template <class TP, int J, typename T, class CX>
+struct AbaIn
+{ // inward sweep (ForwardDynamicsCalculator.java:1085-1254) as a depth-first recursion.  Only (v, cos, sin, qd) of a body
+  // stay live while its subtree is walked; everything that depends on the inertia is formed after the children returned.
+   template <int K>
+   static MH_DEV void children(const CX &cx, const SV<T> &v, AbaUp<T> &acc)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         const AbaUp<T> c = AbaIn<TP, Tree<TP>::child(J, K), T, CX>::run(cx, v);
+         if constexpr (K == 0)
+            acc = c;
+         else
+         {
+            add(acc.I, c.I);
+            acc.p = acc.p + c.p;
+         }
+         children<K + 1>(cx, v, acc);
+      }
+   }
+   static MH_DEV AbaUp<T> run(const CX &cx, const SV<T> &vp)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr bool HAS_PARENT = TP::parent[J] >= 0;
+      constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
+      constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J), S0 = Tree<TP>::aba_slot(J);
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+      const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+      SV<T> v;
+      {
+         const XF<T> Xb = load_xb<T>(c);
+         v = motion_down(TYPE, jx, Xb, vp) + vJ;
+      }
+      AbaUp<T> up = aba_up_zero<T>();
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+         children<0>(cx, v, up);
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+      {
+         // The body velocity is formed again after the subtree returned instead of being kept alive across it.  (Keeping it
+         // alive is what the code above asks for, but in the two most register-starved variants of the 25-body kernel hipcc
+         // 7.2 handed back a clobbered v after the children -- velocity-dependent terms off by a few percent, chains
+         // unaffected; re-forming it from the still-live parent velocity is exact and removes 6 long live ranges.)
+         SV<T> vJ2 = vJ;
+         asm volatile("" : "+v"(vJ2.a.x), "+v"(vJ2.a.y), "+v"(vJ2.a.z), "+v"(vJ2.l.x), "+v"(vJ2.l.y), "+v"(vJ2.l.z));
+         v = motion_down(TYPE, jx, load_xb<T>(c), vp) + vJ2;
+      }
+      const RI<T> I = load_inertia<T>(c);
+      ABI<T> IA = abi_from_rigid(I);
+      SV<T> pA = crf(v, mul(I, v));
+      if (cx.frow)
+         pA = pA - load_fext<T>(c, cx.frow, cx.f_es, cx.meta[J * MI_STRIDE + MI_EXT]);
+      if constexpr (!LEAF)
+      {
+         add(IA, up.I);
+         pA = pA + up.p;
+      }
+      AbaUp<T> out = aba_up_zero<T>();
+      if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+      {
+         V3<T> ua, ul;
+         T D, pz;
+         if constexpr (TYPE == JT_REVOLUTE)
+         {
+            ua = V3<T>{IA.A.xz, IA.A.yz, IA.A.zz}, ul = V3<T>{IA.C.zx, IA.C.zy, IA.C.zz};
+            D = IA.A.zz, pz = pA.a.z;
+         }
+         else
+         {
+            ua = V3<T>{IA.C.xz, IA.C.yz, IA.C.zz}, ul = V3<T>{IA.L.xz, IA.L.yz, IA.L.zz};
+            D = IA.L.zz, pz = pA.l.z;
+         }
+         const T dinv = T(1) / D;
+         const T ud = (cx.in3(DO) - pz) * dinv;
+         const V3<T> sa = dinv * ua, sl = dinv * ul;
+         cx.st.put(S0 + 0, sa.x), cx.st.put(S0 + 1, sa.y), cx.st.put(S0 + 2, sa.z);
+         cx.st.put(S0 + 3, sl.x), cx.st.put(S0 + 4, sl.y), cx.st.put(S0 + 5, sl.z);
+         cx.st.put(S0 + 6, ud);
+         if constexpr (TYPE == JT_REVOLUTE)
+         {
+            cx.st.put(S0 + 7, jx.c);
+            cx.st.put(S0 + 8, jx.s);
+         }
+         if constexpr (HAS_PARENT)
+         {
+            rank1_down(IA, ua, ul, dinv);
+            const SV<T> pa = pA + mul(IA, crm(v, vJ)) + SV<T>{ud * ua, ud * ul};
+            const XF<T> Xb = load_xb<T>(c);
+            abi_up(TYPE, jx, Xb, IA);
+            out.I = IA;
+            out.p = force_up(TYPE, jx, Xb, pa);
+         }
+      }
+      else if constexpr (TYPE == JT_SIXDOF)
+      {
+         const SV<T> tau = spec_vec<TYPE, DO, 1, CX, T>(cx, true);
+         const SV<T> x = spd6_solve(IA, tau - pA);
+         cx.st.put(S0 + 0, x.a.x), cx.st.put(S0 + 1, x.a.y), cx.st.put(S0 + 2, x.a.z);
+         cx.st.put(S0 + 3, x.l.x), cx.st.put(S0 + 4, x.l.y), cx.st.put(S0 + 5, x.l.z);
+         if constexpr (HAS_PARENT)
+            out.p = force_up(TYPE, jx, load_xb<T>(c), tau); // Ia = 0, pa = tau
+      }
+      else if constexpr (HAS_PARENT)
+      { // fixed joint
+         const XF<T> Xb = load_xb<T>(c);
+         abi_up(TYPE, jx, Xb, IA);
+         out.I = IA;
+         out.p = force_up(TYPE, jx, Xb, pA);
+      }
+      MH_BODY_FENCE();
+      return out;
+   }
+};
+template <class TP, int J, typename T, class CX>
+struct AbaOut
+{ // outward sweep (ForwardDynamicsCalculator.java:1259-1310)
+   template <int K>
+   static MH_DEV void children(const CX &cx, const SV<T> &v, const SV<T> &a)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         AbaOut<TP, Tree<TP>::child(J, K), T, CX>::run(cx, v, a);
+         children<K + 1>(cx, v, a);
+      }
+   }
+   static MH_DEV void run(const CX &cx, const SV<T> &vp, const SV<T> &ap)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
+      constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J), S0 = Tree<TP>::aba_slot(J);
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      const XF<T> Xb = load_xb<T>(c);
+      JX<T> jx;
+      if constexpr (TYPE == JT_REVOLUTE)
+      {
+         jx.c = cx.st.get(S0 + 7), jx.s = cx.st.get(S0 + 8), jx.d = T(0);
+      }
+      else
+         jx = spec_joint<TYPE, CO, CX, T>(cx);
+      const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+      const SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
+      SV<T> a = motion_down(TYPE, jx, Xb, ap) + crm(v, vJ);
+      if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+      {
+         const V3<T> sa{cx.st.get(S0 + 0), cx.st.get(S0 + 1), cx.st.get(S0 + 2)}, sl{cx.st.get(S0 + 3), cx.st.get(S0 + 4), cx.st.get(S0 + 5)};
+         const T qdd = cx.st.get(S0 + 6) - (dot(sa, a.a) + dot(sl, a.l));
+         cx.out(DO, qdd);
+         if constexpr (TYPE == JT_REVOLUTE)
+            a.a.z += qdd;
+         else
+            a.l.z += qdd;
+      }
+      else if constexpr (TYPE == JT_SIXDOF)
+      {
+         const SV<T> x{V3<T>{cx.st.get(S0 + 0), cx.st.get(S0 + 1), cx.st.get(S0 + 2)}, V3<T>{cx.st.get(S0 + 3), cx.st.get(S0 + 4), cx.st.get(S0 + 5)}};
+         spec_write<TYPE, DO, CX, T>(cx, x - a);
+         a = x;
+      }
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+         children<0>(cx, v, a);
+   }
+};
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void aba_roots_in(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      const V3<T> Z{T(0), T(0), T(0)};
+      (void)AbaIn<TP, Tree<TP>::child(-1, K), T, CX>::run(cx, SV<T>{Z, Z});
+      aba_roots_in<TP, T, CX, K + 1>(cx);
+   }
+}
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void aba_roots_out(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      const V3<T> Z{T(0), T(0), T(0)};
+      AbaOut<TP, Tree<TP>::child(-1, K), T, CX>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
+      aba_roots_out<TP, T, CX, K + 1>(cx);
+   }
+}
+
+// ============================================================================================ kernels
+// coalesced copy of n contiguous elements global -> LDS by one wave; loads are issued 8 deep before the first LDS write
+template <typename T>
+MH_DEV void wave_copy_in(lds_ptr<T> dst, const T *src, int n)
+{
+   for (int base = threadIdx.x; base < n; base += 64 * 8)
+   {
+      T r[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+      {
+         const int i = base + 64 * u;
+         r[u] = i < n ? src[i] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+      {
+         const int i = base + 64 * u;
+         if (i < n)
+            dst[i] = r[u];
+      }
+   }
+}
+template <typename T>
+MH_DEV void wave_copy_out(T *dst, lds_ptr<T> src, int n)
+{
+   for (int i = threadIdx.x; i < n; i += 64)
+      dst[i] = src[i];
+}
+
+template <typename T, class CX>
+MH_DEV void fill_ctx(CX &cx, const Args<T> &A, long cfg)
+{
+   // The model pointers are laundered once per configuration: otherwise loop-invariant code motion lifts all N * 34
+   // constant loads out of the grid-stride loop, which overflows the 102 SGPRs and turns every use into a v_readlane.
+   const void *pc = A.m.consts;
+   const int *pd = A.m.dof_map, *pq = A.m.cfg_map, *pm = A.m.meta;
+   asm volatile("" : "+s"(pc), "+s"(pd), "+s"(pq), "+s"(pm));
+   cx.C = (const T *)pc;
+   cx.dof_map = as_const(pd), cx.cfg_map = as_const(pq), cx.meta = as_const(pm);
+   cx.qrow = A.q + cfg * A.q_bs;
+   cx.qdrow = A.qd + cfg * A.v_bs;
+   cx.in3row = A.in3 + cfg * A.v_bs;
+   cx.frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
+   cx.orow = A.out + cfg * A.v_bs;
+   cx.q_es = A.q_es, cx.v_es = A.v_es, cx.f_es = A.f_es;
+   cx.a0l = V3<T>{-A.gx, -A.gy, -A.gz};
+   cx.coriolis = A.coriolis, cx.accel = A.accel;
+}
+
+// ALGO: 0 = RNEA, 1 = ABA.  One wave per workgroup.
+template <class TP, typename T, int ALGO, bool IO_LDS, bool IDENT, bool ST_LDS>
+__global__ void __launch_bounds__(64) spec_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   using CX = Ctx<T, IO_LDS, IDENT, ST_LDS>;
+   const int nq = A.m.nq, nv = A.m.nv;
+   const lds_ptr<T> lds = (lds_ptr<T>)lds_raw;
+   // LDS map: [64][nq] q | [64][nv] qd | [64][nv] qdd or tau, overwritten by the result | hand-over slots [slot][64]
+   const lds_ptr<T> lq = lds, lqd = lq + (IO_LDS ? 64 * nq : 0), lx = lqd + (IO_LDS ? 64 * nv : 0), lst = lx + (IO_LDS ? 64 * nv : 0);
+   const long wave = blockIdx.x, nwaves = gridDim.x;
+   for (long cfg0 = wave * 64; cfg0 < A.B; cfg0 += nwaves * 64)
+   {
+      const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+      if constexpr (IO_LDS)
+      {
+         wave_copy_in<T>(lq, A.q + cfg0 * nq, rows * nq);
+         wave_copy_in<T>(lqd, A.qd + cfg0 * nv, rows * nv);
+         wave_copy_in<T>(lx, A.in3 + cfg0 * nv, rows * nv);
+         __syncthreads();
+      }
+      if ((int)threadIdx.x < rows)
+      {
+         CX cx;
+         fill_ctx<T>(cx, A, cfg0 + threadIdx.x);
+         cx.lq = lq + threadIdx.x * nq, cx.lqd = lqd + threadIdx.x * nv, cx.lx = lx + threadIdx.x * nv;
+         cx.lo = cx.lx;
+         cx.st.lbase = lst + threadIdx.x;
+         cx.st.gbase = A.ws;
+         cx.st.stride = A.ws_stride, cx.st.lane = wave * 64 + threadIdx.x;
+         asm volatile("" : "+v"(cx.st.lane)); // per configuration: keeps the N * 9 slot addresses from being hoisted out of the loop
+         if constexpr (ALGO == 0)
+            rnea_roots<TP, T, CX>(cx);
+         else
+         {
+            aba_roots_in<TP, T, CX>(cx);
+            // The hand-over store must really be memory, and the outward sweep must recompute the body velocities from
+            // re-read inputs: if the compiler recognises values (or addresses) of the inward sweep it keeps them alive across
+            // the turn-around -- 6 N velocities, N * 9 slot addresses -- and spills kilobytes per lane to scratch.
+            asm volatile("" ::: "memory");
+            asm volatile("" : "+v"(cx.qrow), "+v"(cx.qdrow), "+v"(cx.lq), "+v"(cx.lqd), "+v"(cx.st.lbase), "+v"(cx.st.lane));
+            aba_roots_out<TP, T, CX>(cx);
+         }
+      }
+      if constexpr (IO_LDS)
+      {
+         __syncthreads();
+         wave_copy_out<T>(A.out + cfg0 * nv, lx, rows * nv);
+         __syncthreads();
+      }
+   }
+}
+
+} // namespace mh
