@@ -124,6 +124,7 @@ struct mh_model
    int use_spec = 1;        // MH_DISABLE_SPEC=1 in the environment forces the generic kernels (A/B measurements)
    int lds_wave_factor = 1; // ABA hand-over in LDS while waves <= cu_count * factor (MH_ABA_LDS_FACTOR)
    int ident_maps = 0;      // the engine-order index maps are the identity
+   int dense_maps = 0;      // nq / nv equal the joints' totals (no unused matrix rows): rows can be staged as dense blocks
    int force_io = -1, force_st = -1; // MH_SPEC_IO / MH_SPEC_ST = 0 | 1 override the heuristics (measurements)
 };
 
@@ -242,7 +243,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       const long waves = (B + 63) / 64;
       const long LDS_MAX = 160 * 1024;
       int flags = model->ident_maps ? SPEC_IDENT : 0;
-      bool io = !soa && model->spec.supports(a, SPEC_IO_LDS) && model->spec.lds_bytes(a, SPEC_IO_LDS, model->nq, model->nv) <= LDS_MAX;
+      bool io = !soa && model->dense_maps && model->spec.supports(a, SPEC_IO_LDS) && model->spec.lds_bytes(a, SPEC_IO_LDS, model->nq, model->nv) <= LDS_MAX;
       if (model->force_io >= 0)
          io = io && model->force_io;
       if (io)
@@ -252,6 +253,8 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
          bool st = model->spec.lds_bytes(a, flags | SPEC_ST_LDS, model->nq, model->nv) <= LDS_MAX && waves <= (long)model->cu_count * model->lds_wave_factor;
          if (model->force_st >= 0)
             st = model->force_st && model->spec.lds_bytes(a, flags | SPEC_ST_LDS, model->nq, model->nv) <= LDS_MAX;
+         if (st && !model->spec.supports(a, flags | SPEC_ST_LDS))
+            flags &= ~SPEC_IO_LDS; // small batch: keep the hand-over in LDS, read the state rows directly
          if (st)
             flags |= SPEC_ST_LDS;
       }
@@ -550,7 +553,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       for (int k = cfgo[i]; k < cfgo[i + 1]; k++)
          m->cfg_map.push_back(d->cfg_indices[k]);
    }
-   m->ident_maps = (edofo[n] == d->nv && ecfgo[n] == d->nq);
+   m->dense_maps = (edofo[n] == d->nv && ecfgo[n] == d->nq);
+   m->ident_maps = m->dense_maps;
    for (int k = 0; m->ident_maps && k < edofo[n]; k++)
       m->ident_maps = m->dof_map[k] == k;
    for (int k = 0; m->ident_maps && k < ecfgo[n]; k++)

@@ -45,6 +45,8 @@ struct Tree
          s += ncfg(i);
       return s;
    }
+   static constexpr int total_dofs() { return dof_ofs(N); }
+   static constexpr int total_cfgs() { return cfg_ofs(N); }
    // ABA hand-over slots: revolute 9 (U/D, u/D, cos, sin), prismatic 7, sixdof 6 (IA^-1 u), fixed 0
    static constexpr int aba_slots_of(int j)
    {
@@ -64,17 +66,42 @@ struct Tree
          c += TP::parent[i] == j ? 1 : 0;
       return c;
    }
-   static constexpr int child(int j, int k)
-   { // k-th child of j (j = -1: k-th root) in index order
-      int c = 0;
-      for (int i = 0; i < N; i++)
+   static constexpr int height(int j)
+   { // longest chain of joints below j (a leaf has height 0); children have larger indices than their parent
+      int h = 0;
+      for (int i = N - 1; i > j; i--)
          if (TP::parent[i] == j)
          {
-            if (c == k)
-               return i;
-            c++;
+            const int hc = 1 + height(i);
+            h = hc > h ? hc : h;
          }
-      return -1;
+      return h;
+   }
+   // k-th child of j (j = -1: k-th root), TALLEST SUBTREE FIRST (ties: lower index first).  The walk descends into the
+   // deepest subtree while no partial sum of the siblings is alive yet; the shallower siblings are walked with the
+   // accumulated contribution (27 scalars for ABA) held in registers.  This is what keeps the 25-body ABA under 512 VGPRs.
+   static constexpr int child(int j, int k)
+   {
+      int taken[N] = {};
+      int pick = -1;
+      for (int round = 0; round <= k; round++)
+      {
+         pick = -1;
+         int best = -1;
+         for (int i = 0; i < N; i++)
+            if (TP::parent[i] == j && !taken[i])
+            {
+               const int h = height(i);
+               if (h > best)
+               {
+                  best = h;
+                  pick = i;
+               }
+            }
+         if (pick >= 0)
+            taken[pick] = 1;
+      }
+      return pick;
    }
 };
 
@@ -240,7 +267,11 @@ struct RneaSub
       children<0>(cx, v, a, f);
       MH_BODY_FENCE();
       spec_write<TYPE, DO, CX, T>(cx, f);
-      const SV<T> up = force_up(TYPE, jx, Xb, f);
+      // the joint pose is read again rather than kept in 24 SGPRs per tree level across the subtree (which overflows the
+      // SGPR file and turns every use into a v_readlane); the pointer is laundered so that the reload is not merged away
+      const T *c2p = cx.C + J * MC_STRIDE;
+      asm volatile("" : "+s"(c2p));
+      const SV<T> up = force_up(TYPE, jx, load_xb<T>(CRef<T, false>{c2p}), f);
       MH_BODY_FENCE();
       return up;
    }
@@ -463,27 +494,32 @@ MH_DEV void aba_roots_out(const CX &cx)
 }
 
 // ============================================================================================ kernels
-// coalesced copy of n contiguous elements global -> LDS by one wave; loads are issued 8 deep before the first LDS write
-template <typename T>
-MH_DEV void wave_copy_in(lds_ptr<T> dst, const T *src, int n)
+// Coalesced copy of the wave's rows of q, qd and qdd|tau (contiguous blocks of the AoS matrices) into LDS.  ALL loads are
+// issued before the first LDS write, so the whole staging costs one memory round trip (about a microsecond) instead of one
+// per chunk; 64 * (NQ + 2 NV) elements = NQ + 2 NV loads per lane held in registers for that moment.
+template <typename T, int NQ, int NV>
+MH_DEV void wave_stage_in(lds_ptr<T> lq, lds_ptr<T> lqd, lds_ptr<T> lx, const T *q, const T *qd, const T *x, int rows)
 {
-   for (int base = threadIdx.x; base < n; base += 64 * 8)
-   {
-      T r[8];
+   T rq[NQ], rd[NV], rx[NV];
+   const int nq = rows * NQ, nv = rows * NV, t = threadIdx.x;
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-      {
-         const int i = base + 64 * u;
-         r[u] = i < n ? src[i] : T(0);
-      }
+   for (int u = 0; u < NQ; u++)
+      rq[u] = t + 64 * u < nq ? q[t + 64 * u] : T(0);
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-      {
-         const int i = base + 64 * u;
-         if (i < n)
-            dst[i] = r[u];
-      }
-   }
+   for (int u = 0; u < NV; u++)
+      rd[u] = t + 64 * u < nv ? qd[t + 64 * u] : T(0);
+#pragma unroll
+   for (int u = 0; u < NV; u++)
+      rx[u] = t + 64 * u < nv ? x[t + 64 * u] : T(0);
+#pragma unroll
+   for (int u = 0; u < NQ; u++)
+      lq[t + 64 * u] = rq[u];
+#pragma unroll
+   for (int u = 0; u < NV; u++)
+      lqd[t + 64 * u] = rd[u];
+#pragma unroll
+   for (int u = 0; u < NV; u++)
+      lx[t + 64 * u] = rx[u];
 }
 template <typename T>
 MH_DEV void wave_copy_out(T *dst, lds_ptr<T> src, int n)
@@ -512,6 +548,19 @@ MH_DEV void fill_ctx(CX &cx, const Args<T> &A, long cfg)
    cx.coriolis = A.coriolis, cx.accel = A.accel;
 }
 
+// Touches every 64-byte line of the model constants and index maps with one scalar load each, all in flight together, so
+// that the per-body s_load batches of the walk hit the scalar cache instead of each paying a miss on the way (with one wave
+// per CU nobody else warms it).  Results are discarded.
+MH_DEV void warm_scalar_cache(const void *p, int bytes)
+{
+   typedef const int __attribute__((address_space(4))) * cip;
+   cip a = (cip)(unsigned long long)p;
+   int acc = 0;
+   for (int ofs = 0; ofs < bytes; ofs += 64)
+      acc += a[ofs / 4];
+   asm volatile("" ::"s"(acc));
+}
+
 // ALGO: 0 = RNEA, 1 = ABA.  One wave per workgroup.
 template <class TP, typename T, int ALGO, bool IO_LDS, bool IDENT, bool ST_LDS>
 __global__ void __launch_bounds__(64) spec_kernel(Args<T> A)
@@ -523,14 +572,18 @@ __global__ void __launch_bounds__(64) spec_kernel(Args<T> A)
    // LDS map: [64][nq] q | [64][nv] qd | [64][nv] qdd or tau, overwritten by the result | hand-over slots [slot][64]
    const lds_ptr<T> lq = lds, lqd = lq + (IO_LDS ? 64 * nq : 0), lx = lqd + (IO_LDS ? 64 * nv : 0), lst = lx + (IO_LDS ? 64 * nv : 0);
    const long wave = blockIdx.x, nwaves = gridDim.x;
+   warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   if constexpr (!IDENT)
+   {
+      warm_scalar_cache(A.m.dof_map, nv * 4);
+      warm_scalar_cache(A.m.cfg_map, nq * 4);
+   }
    for (long cfg0 = wave * 64; cfg0 < A.B; cfg0 += nwaves * 64)
    {
       const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
       if constexpr (IO_LDS)
       {
-         wave_copy_in<T>(lq, A.q + cfg0 * nq, rows * nq);
-         wave_copy_in<T>(lqd, A.qd + cfg0 * nv, rows * nv);
-         wave_copy_in<T>(lx, A.in3 + cfg0 * nv, rows * nv);
+         wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs()>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
          __syncthreads();
       }
       if ((int)threadIdx.x < rows)

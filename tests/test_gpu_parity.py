@@ -338,6 +338,41 @@ def test_calculators_read_like_the_reference(torch_cuda):
         assert (forwardDynamicsCalculator.compute(q, qd, tau) - qdd_expected).abs().max().item() < 100 * 8.0e-12
 
 
+@pytest.mark.parametrize("B", [1, 64, 100, 4096, 16448, 40000])
+def test_every_specialised_variant(torch_cuda, B):
+    """The topology-specialised code object has several memory plans (state rows staged in LDS or read directly; ABA hand-over
+    in LDS or in the global workspace).  Each one that the dispatcher may pick is forced in turn through the MH_SPEC_IO / MH_SPEC_ST
+    overrides and checked against the oracle, together with the generic kernels (MH_DISABLE_SPEC), on the humanoid and the arm."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(77 + B)
+    arm = system_of(rt.nextJointChain(rng, 7, ("revolute",)))
+    for sys_ in (rt.nextHumanoid(rng), arm):
+        d = sys_.toModelDesc()
+        om = OracleModel(d)
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        g = (0.3, -0.2, -9.81)
+        idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 300)), [B - 1]]))
+        t_ref, a_ref = om.rnea(q[idx], qd[idx], qdd[idx], g), om.aba(q[idx], qd[idx], tau[idx], g)
+        seen = set()
+        try:
+            for env in ({"MH_DISABLE_SPEC": "1"}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "0"}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "1"},
+                        {"MH_SPEC_IO": "1", "MH_SPEC_ST": "0"}, {"MH_SPEC_IO": "1", "MH_SPEC_ST": "1"}, {}):
+                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST"):
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                hm = HipModel(d)
+                seen.add(hm.kernel_variant)
+                close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), g).cpu().numpy()[idx], t_ref)
+                close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g).cpu().numpy()[idx], a_ref)
+        finally:
+            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST"):
+                os.environ.pop(k, None)
+        assert "generic" in seen and any(v.startswith("topo:") for v in seen), seen
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
