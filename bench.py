@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric: robot-configs/sec (RNEA+ABA), 30-DoF humanoid, batch 4096 per GPU.
 
-One "step" = one pass of the hot path over one batch of synthetic input: mh_rnea_f64 (q, qd, qdd -> tau) followed by
-mh_aba_f64 (q, qd, tau_in -> qdd) on 4096 configurations of the 30-DoF humanoid (SixDoF pelvis + 24 revolute joints),
-inputs resident in HBM before the timed region.  Multi-GPU: one process per GPU, every rank owns its own 4096
+One "step" = one pass of the hot path over one batch of synthetic input: RNEA (q, qd, qdd -> tau) and ABA (q, qd, tau_in -> qdd)
+of the same 4096 configurations of the 30-DoF humanoid (SixDoF pelvis + 24 revolute joints) through mh_rnea_aba_f64 -- one fused
+launch at this batch size (--separate: mh_rnea_f64 then mh_aba_f64) -- with inputs resident in HBM before the timed region.  Multi-GPU: one process per GPU, every rank owns its own 4096
 configurations (weak scaling), no collective on the data path; the model is broadcast once over RCCL before timing and
 the outputs are all-gathered once after it (reported separately as gather_ms).
 
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="configurations per GPU per step (default: the metric's 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate", action="store_true", help="two calls per step (mh_rnea_f64, mh_aba_f64) instead of mh_rnea_aba_f64")
     args = ap.parse_args()
 
     import torch
@@ -93,28 +94,33 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        tau = model.rnea(tq, tqd, tqdd, gravity)
-        acc = model.aba(tq, tqd, ttau, gravity)
-        return tau, acc
+        if args.separate:
+            return model.rnea(tq, tqd, tqdd, gravity), model.aba(tq, tqd, ttau, gravity)
+        return model.rnea_aba(tq, tqd, tqdd, ttau, gravity)
 
     for _ in range(args.warmup):
-        out = step()
-    # ---- timed region: exactly K steps between barrier + synchronize pairs
+        tau, acc = step()
+    # ---- timed region: exactly K steps between barrier + synchronize pairs; HIP events on the launch stream around every launch
     K = args.steps
-    t_rnea = [HipTimer() for _ in range(K)]
-    t_aba = [HipTimer() for _ in range(K)]
+    t_a = [HipTimer() for _ in range(K)]
+    t_b = [HipTimer() for _ in range(K)] if args.separate else []
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(K):
-        t_rnea[k].start(stream)
-        tau = model.rnea(tq, tqd, tqdd, gravity)
-        t_rnea[k].stop(stream)
-        t_aba[k].start(stream)
-        acc = model.aba(tq, tqd, ttau, gravity)
-        t_aba[k].stop(stream)
+        if args.separate:
+            t_a[k].start(stream)
+            tau = model.rnea(tq, tqd, tqdd, gravity)
+            t_a[k].stop(stream)
+            t_b[k].start(stream)
+            acc = model.aba(tq, tqd, ttau, gravity)
+            t_b[k].stop(stream)
+        else:
+            t_a[k].start(stream)
+            tau, acc = model.rnea_aba(tq, tqd, tqdd, ttau, gravity)
+            t_a[k].stop(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -124,8 +130,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_rnea = float(np.mean([t.elapsed_ms() for t in t_rnea])) if K else 0.0
-    ms_aba = float(np.mean([t.elapsed_ms() for t in t_aba])) if K else 0.0
+    ms_a = float(np.mean([t.elapsed_ms() for t in t_a])) if K else 0.0
+    ms_b = float(np.mean([t.elapsed_ms() for t in t_b])) if t_b else 0.0
 
     # ---- after the timed region: one all-gather of the outputs over xGMI (north_star: "a final gather")
     gather_ms = None
@@ -142,8 +148,13 @@ def main():
             dist.destroy_process_group()
         return
 
-    # dominant kernel = the slower of the two launches of a step
-    dom, dom_ms, dom_bytes = ("aba_kernel<double>", ms_aba, BYTES_ABA) if ms_aba >= ms_rnea else ("rnea_kernel<double>", ms_rnea, BYTES_RNEA)
+    fused_launch = (not args.separate) and model.kernel_variant.startswith("topo:") and 2 * ((B + 63) // 64) <= 256
+    if args.separate:  # dominant kernel = the slower of the two launches of a step
+        dom, dom_ms, dom_bytes = ("aba", ms_b, BYTES_ABA) if ms_b >= ms_a else ("rnea", ms_a, BYTES_RNEA)
+        kernels_ms = {"rnea": ms_a, "aba": ms_b}
+    else:              # one launch (fused at this batch size) computing both: 968 + 968 algorithmic bytes per configuration
+        dom, dom_ms, dom_bytes = ("rnea+aba fused" if fused_launch else "rnea+aba (two launches)", ms_a, BYTES_RNEA + BYTES_ABA)
+        kernels_ms = {"rnea_aba": ms_a}
     achieved = (dom_bytes * B) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     value = world * B * K / elapsed if elapsed > 0 else 0.0
     line = {
@@ -151,14 +162,15 @@ def main():
         "value": value, "unit": "configs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3 if K else None, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "30-DoF humanoid (SixDoF pelvis + 24 revolute), RNEA then ABA per step, fp64, AoS [B][n] state",
+        "config": {"workload": "30-DoF humanoid (SixDoF pelvis + 24 revolute), RNEA and ABA of every configuration per step, fp64, AoS [B][n] state",
+                   "entry_point": "mh_rnea_f64 + mh_aba_f64" if args.separate else "mh_rnea_aba_f64",
                    "batch_per_gpu": B, "global_batch": B * world, "nq": desc.nq, "nv": desc.nv, "bodies": desc.n_joints,
                    "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
                    "model_seed": MODEL_SEED, "state_seed": STATE_SEED},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "bytes_per_config": dom_bytes, "launch_ms": dom_ms},
-        "kernels_ms": {"rnea": ms_rnea, "aba": ms_aba},
+        "kernels_ms": kernels_ms,
         "gather_ms": gather_ms,
     }
     # CPU baseline beside it: rank 0 at N = 1 only (a reported baseline, not the optimisation target)

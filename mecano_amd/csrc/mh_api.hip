@@ -97,6 +97,8 @@ struct SpecLib
    long (*lds_bytes)(int algo, int flags, int nq, int nv) = nullptr;
    int (*aba_slots)(void) = nullptr;
    int (*supports)(int algo, int flags) = nullptr;
+   int (*launch_fused)(int flags, const void *args, int waves, void *stream) = nullptr;
+   long (*fused_lds_bytes)(int nq, int nv) = nullptr;
 };
 enum : int
 {
@@ -121,6 +123,7 @@ struct mh_model
    // staging buffers of the *_host entry points
    Workspace stage;
    std::string variant = "generic";
+   int use_fused = 1;       // MH_DISABLE_FUSED=1: mh_rnea_aba_f64 always issues two launches
    int use_spec = 1;        // MH_DISABLE_SPEC=1 in the environment forces the generic kernels (A/B measurements)
    int lds_wave_factor = 1; // ABA hand-over in LDS while waves <= cu_count * factor (MH_ABA_LDS_FACTOR)
    int ident_maps = 0;      // the engine-order index maps are the identity
@@ -222,6 +225,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    A.m = dev_model<T>(model);
    A.B = B;
    A.q = q, A.qd = qd, A.in3 = in3, A.fext = fext, A.out = out;
+   A.in3b = nullptr, A.outb = nullptr;
    A.ws = (T *)model->ws.ptr;
    A.ws_stride = L.lanes;
    const bool soa = opts.layout == MH_LAYOUT_SOA;
@@ -460,6 +464,8 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.lds_bytes = (decltype(s.lds_bytes))dlsym(h, "mh_spec_lds_bytes");
    s.aba_slots = (decltype(s.aba_slots))dlsym(h, "mh_spec_aba_slots");
    s.supports = (decltype(s.supports))dlsym(h, "mh_spec_supports");
+   s.launch_fused = (decltype(s.launch_fused))dlsym(h, "mh_spec_launch_fused");
+   s.fused_lds_bytes = (decltype(s.fused_lds_bytes))dlsym(h, "mh_spec_fused_lds_bytes");
    bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
    for (int e = 0; ok && e < m->n; e++)
       ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];
@@ -688,6 +694,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    }
    if (const char *e = getenv("MH_DISABLE_SPEC"))
       m->use_spec = atoi(e) ? 0 : 1;
+   if (const char *e = getenv("MH_DISABLE_FUSED"))
+      m->use_fused = atoi(e) ? 0 : 1;
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
       m->lds_wave_factor = atoi(e);
    if (const char *e = getenv("MH_SPEC_IO"))
@@ -759,6 +767,46 @@ mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double 
 mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
 {
    return launch<double>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+}
+mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
+                          const double gravity[3], const double *f_ext, const mh_options *opts_in, double *tau_out, double *qdd_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (B == 0)
+      return MH_OK;
+   if (!q || !qd || !qdd || !tau || !gravity || !tau_out || !qdd_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   const long waves = (B + 63) / 64;
+   const bool fusable = model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
+                        && opts.consider_coriolis && opts.consider_accelerations && 2 * waves <= (long)model->cu_count
+                        && model->spec.fused_lds_bytes(model->nq, model->nv) <= 160 * 1024;
+   if (!fusable)
+   {
+      st = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
+      if (st != MH_OK)
+         return st;
+      return mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &opts, qdd_out);
+   }
+   mh::Args<double> A;
+   A.m = dev_model<double>(model);
+   A.B = B;
+   A.q = q, A.qd = qd, A.in3 = qdd, A.fext = f_ext, A.out = tau_out;
+   A.in3b = tau, A.outb = qdd_out;
+   A.ws = nullptr, A.ws_stride = 0;
+   A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
+   A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
+   A.coriolis = 1, A.accel = 1;
+   const int rc = model->spec.launch_fused(model->ident_maps ? SPEC_IDENT : 0, &A, (int)waves, opts.stream);
+   if (rc != 0)
+      return fail(MH_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+   return MH_OK;
 }
 mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
                       const float *f_ext, const mh_options *opts, float *tau_out)

@@ -85,6 +85,9 @@ struct Args
    long f_bs, f_es; // ... of the external wrench array (element = joint * 6 + component)
    T gx, gy, gz;
    int coriolis, accel;
+   // second job of a fused RNEA+ABA launch (specialised kernels only): tau in, qdd out
+   const T *in3b;
+   T *outb;
 };
 
 template <typename T, class CR>

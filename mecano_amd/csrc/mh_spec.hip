@@ -7,6 +7,8 @@
 // (mh_model_create) and routes mh_rnea_f64 / mh_aba_f64 to it; every other model and dtype runs on the generic kernels.
 #include "mh_spec_kernels.h"
 
+#include <algorithm>
+
 #ifndef MH_TOPO_N
 #error "MH_TOPO_N / MH_TOPO_PARENTS / MH_TOPO_TYPES must be defined"
 #endif
@@ -79,6 +81,23 @@ hipError_t go_flags(int flags, const mh::Args<double> &A, int grid, size_t lds, 
 }
 } // namespace
 
+template <bool ID>
+hipError_t go_fused(const mh::Args<double> &A, int waves, hipStream_t stream)
+{
+   auto kern = &mh::spec_fused_kernel<TP, double, ID>;
+   const size_t lds = (size_t)std::max(lds_bytes(0, F_IO_LDS, A.m.nq, A.m.nv), lds_bytes(1, F_ST_LDS, A.m.nq, A.m.nv));
+   static size_t attr_bytes = 0;
+   if (lds > 64 * 1024 && lds > attr_bytes)
+   {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess)
+         return e;
+      attr_bytes = lds;
+   }
+   hipLaunchKernelGGL(kern, dim3(2 * waves), dim3(64), lds, stream, A);
+   return hipGetLastError();
+}
+
 extern "C" {
 int mh_spec_n(void) { return TP::N; }
 const int *mh_spec_parents(void) { return kParents; }
@@ -98,6 +117,13 @@ int mh_spec_supports(int algo, int flags)
 }
 // dynamic LDS one workgroup (one wave) needs for (algo, flags) with the model's matrix sizes
 long mh_spec_lds_bytes(int algo, int flags, int nq, int nv) { return lds_bytes(algo, flags, nq, nv); }
+// fused RNEA + ABA (small batches): `waves` workgroups per job, 2 * waves in the grid; needs dense index maps (rows staged as blocks)
+long mh_spec_fused_lds_bytes(int nq, int nv) { return std::max(lds_bytes(0, F_IO_LDS, nq, nv), lds_bytes(1, F_ST_LDS, nq, nv)); }
+int mh_spec_launch_fused(int flags, const void *args, int waves, void *stream)
+{
+   const mh::Args<double> &A = *(const mh::Args<double> *)args;
+   return (int)((flags & F_IDENT) ? go_fused<true>(A, waves, (hipStream_t)stream) : go_fused<false>(A, waves, (hipStream_t)stream));
+}
 // algo: 0 = RNEA, 1 = ABA; fp64 only.  args points to mh::Args<double>.
 int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream)
 {

@@ -561,17 +561,14 @@ MH_DEV void warm_scalar_cache(const void *p, int bytes)
    asm volatile("" ::"s"(acc));
 }
 
-// ALGO: 0 = RNEA, 1 = ABA.  One wave per workgroup.
+// One wave's share of a batch.  ALGO: 0 = RNEA, 1 = ABA.
 template <class TP, typename T, int ALGO, bool IO_LDS, bool IDENT, bool ST_LDS>
-__global__ void __launch_bounds__(64) spec_kernel(Args<T> A)
+MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
 {
-   extern __shared__ double lds_raw[];
    using CX = Ctx<T, IO_LDS, IDENT, ST_LDS>;
    const int nq = A.m.nq, nv = A.m.nv;
-   const lds_ptr<T> lds = (lds_ptr<T>)lds_raw;
    // LDS map: [64][nq] q | [64][nv] qd | [64][nv] qdd or tau, overwritten by the result | hand-over slots [slot][64]
    const lds_ptr<T> lq = lds, lqd = lq + (IO_LDS ? 64 * nq : 0), lx = lqd + (IO_LDS ? 64 * nv : 0), lst = lx + (IO_LDS ? 64 * nv : 0);
-   const long wave = blockIdx.x, nwaves = gridDim.x;
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
    if constexpr (!IDENT)
    {
@@ -615,6 +612,33 @@ __global__ void __launch_bounds__(64) spec_kernel(Args<T> A)
          wave_copy_out<T>(A.out + cfg0 * nv, lx, rows * nv);
          __syncthreads();
       }
+   }
+}
+
+// One wave per workgroup.
+template <class TP, typename T, int ALGO, bool IO_LDS, bool IDENT, bool ST_LDS>
+__global__ void __launch_bounds__(64) spec_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   spec_wave<TP, T, ALGO, IO_LDS, IDENT, ST_LDS>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
+}
+
+// Fused RNEA + ABA for small batches: the first half of the grid computes tau = RNEA(q, qd, qdd), the second half
+// qdd = ABA(q, qd, tau_in) on the same configurations.  The two jobs are independent, so a batch that cannot fill the
+// device on its own (4096 configurations = 64 waves for 256 CUs) runs both side by side in ONE launch.
+// RNEA rows are staged in LDS; ABA reads its rows directly and keeps its hand-over store in LDS.
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(64) spec_fused_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   const long half = gridDim.x / 2;
+   if ((long)blockIdx.x < half)
+      spec_wave<TP, T, 0, true, IDENT, false>(A, blockIdx.x, half, (lds_ptr<T>)lds_raw);
+   else
+   {
+      Args<T> A2 = A;
+      A2.in3 = A.in3b, A2.out = A.outb;
+      spec_wave<TP, T, 1, false, IDENT, true>(A2, blockIdx.x - half, half, (lds_ptr<T>)lds_raw);
    }
 }
 

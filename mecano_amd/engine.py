@@ -137,6 +137,24 @@ class HipModel:
     def aba(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS):
         return self._run("aba", q, qd, tau, gravity, f_ext, layout, True, True)
 
+    def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None):
+        """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call (device tensors, fp64, AoS)."""
+        import torch
+        lib = _lib.load()
+        for t in (q, qd, qdd, tau) + ((f_ext,) if f_ext is not None else ()):
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("rnea_aba needs contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
+        if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau)):
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        tau_out, qdd_out = torch.empty_like(qd), torch.empty_like(qd)
+        _lib.check(lib.mh_rnea_aba_f64(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), tau.data_ptr(), g,
+                                       f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts), tau_out.data_ptr(),
+                                       qdd_out.data_ptr()))
+        return tau_out, qdd_out
+
     def crba(self, q, layout=_lib.LAYOUT_AOS):
         return self._run("crba", q, None, None, (0.0, 0.0, 0.0), None, layout, True, True)
 

@@ -373,6 +373,29 @@ def test_every_specialised_variant(torch_cuda, B):
         assert "generic" in seen and any(v.startswith("topo:") for v in seen), seen
 
 
+@pytest.mark.parametrize("B", [1, 100, 4096, 8192, 9000, 50000])
+def test_fused_rnea_aba_equals_separate_calls(torch_cuda, B):
+    """mh_rnea_aba_f64: one launch for small batches, two for large ones, generic kernels for other models; always the results of
+    mh_rnea_f64 + mh_aba_f64 (bitwise for the same kernel variant, checked against the oracle as well)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(5 + B)
+    for sys_ in (rt.nextHumanoid(rng), system_of(rt.nextJointTree(rng, 9, ("revolute", "prismatic")))):
+        d = sys_.toModelDesc()
+        hm, om = HipModel(d), OracleModel(d)
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        g = (0.0, 0.0, -9.81)
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
+        for f in (None, fext):
+            t, a = hm.rnea_aba(dev(torch, q), dev(torch, qd), dev(torch, qdd), dev(torch, tau), g, dev(torch, f))
+            idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 200)), [B - 1]]))
+            fi = None if f is None else f[idx]
+            close(t.cpu().numpy()[idx], om.rnea(q[idx], qd[idx], qdd[idx], g, fi))
+            close(a.cpu().numpy()[idx], om.aba(q[idx], qd[idx], tau[idx], g, fi))
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
