@@ -58,6 +58,16 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=12.0):
             "sample": f"{done} RNEA+ABA pairs of the same humanoid batch, oracle/mecano_oracle.c (C restatement, not Mecano/JVM), 1 thread, {dt:.1f} s"}
 
 
+def measured_traffic(fused_launch, B):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
+    separate passes, same command); only quoted for the configuration they were collected on, else null."""
+    path = os.path.join(ROOT, "profiles", "r01_fused_b4096_hbm_pmc.json")
+    if not (fused_launch and B == BATCH and os.path.exists(path)):
+        return None
+    pmc = json.load(open(path))
+    return (pmc["FETCH_SIZE_KB_per_launch_mean"] + pmc["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +178,7 @@ def main():
                    "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
                    "model_seed": MODEL_SEED, "state_seed": STATE_SEED},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(fused_launch, B),
                      "bytes_per_config": dom_bytes, "launch_ms": dom_ms},
         "kernels_ms": kernels_ms,
         "gather_ms": gather_ms,
