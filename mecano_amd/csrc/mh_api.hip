@@ -99,6 +99,9 @@ struct SpecLib
    int (*supports)(int algo, int flags) = nullptr;
    int (*launch_fused)(int flags, const void *args, int waves, void *stream) = nullptr;
    long (*fused_lds_bytes)(int nq, int nv) = nullptr;
+   int (*split_usable)(void) = nullptr;
+   long (*split_lds_bytes)(int algo) = nullptr;
+   int (*launch_split)(int algo, int flags, const void *args, int groups, void *stream) = nullptr;
 };
 enum : int
 {
@@ -123,6 +126,7 @@ struct mh_model
    // staging buffers of the *_host entry points
    Workspace stage;
    std::string variant = "generic";
+   int use_split = -1;      // MH_SPEC_SPLIT = 0 | 1: never / whenever possible use the tree-split kernels (default: small batches)
    int use_fused = 1;       // MH_DISABLE_FUSED=1: mh_rnea_aba_f64 always issues two launches
    int use_spec = 1;        // MH_DISABLE_SPEC=1 in the environment forces the generic kernels (A/B measurements)
    int lds_wave_factor = 1; // ABA hand-over in LDS while waves <= cu_count * factor (MH_ABA_LDS_FACTOR)
@@ -192,6 +196,21 @@ mh_status check_common(mh_model_t model, int64_t B, const mh_options *opts)
    return MH_OK;
 }
 
+// tree-split kernels: 4 waves per 64 configurations; worth it while the batch cannot give every SIMD a wave of its own otherwise
+bool split_ok(const mh_model *m, int algo, int64_t B, bool soa)
+{
+   (void)soa; // the tree-split kernels read their rows with strides: both layouts work
+   if (!m->spec.launch_split || !m->spec.split_usable || !m->spec.split_usable() || !m->use_spec || m->use_split == 0)
+      return false;
+   if (m->spec.split_lds_bytes(algo) > 160 * 1024)
+      return false;
+   if (m->use_split == 1 || algo == 1)
+      return true; // ABA: the split form also needs fewer registers and measured faster at every batch size
+   const long groups = (B + 63) / 64;
+   const long waves = groups * 4 * (algo == 2 ? 2 : 1);
+   return waves <= (long)m->cu_count * 4; // RNEA / fused: while the batch cannot give every SIMD a wave of its own
+}
+
 enum Algo
 {
    ALGO_RNEA,
@@ -238,6 +257,14 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    if (lds > 160 * 1024)
       return fail(MH_ERR_BAD_DIMENSION, "model constants (%zu B) exceed the 160 KiB LDS of a gfx950 CU", lds);
 
+   if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
+   {
+      const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
+      const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, model->ident_maps ? SPEC_IDENT : 0, &A, (int)groups, (void *)stream);
+      if (rc != 0)
+         return fail(MH_ERR_HIP, "tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+      return MH_OK;
+   }
    if (model->spec.launch && algo != ALGO_CRBA && model->use_spec && sizeof(T) == 8)
    {
       // Topology-specialised code object (fp64).  State rows are staged in LDS when the layout is AoS and they fit; ABA's
@@ -466,6 +493,9 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.supports = (decltype(s.supports))dlsym(h, "mh_spec_supports");
    s.launch_fused = (decltype(s.launch_fused))dlsym(h, "mh_spec_launch_fused");
    s.fused_lds_bytes = (decltype(s.fused_lds_bytes))dlsym(h, "mh_spec_fused_lds_bytes");
+   s.split_usable = (decltype(s.split_usable))dlsym(h, "mh_spec_split_usable");
+   s.split_lds_bytes = (decltype(s.split_lds_bytes))dlsym(h, "mh_spec_split_lds_bytes");
+   s.launch_split = (decltype(s.launch_split))dlsym(h, "mh_spec_launch_split");
    bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
    for (int e = 0; ok && e < m->n; e++)
       ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];
@@ -694,6 +724,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    }
    if (const char *e = getenv("MH_DISABLE_SPEC"))
       m->use_spec = atoi(e) ? 0 : 1;
+   if (const char *e = getenv("MH_SPEC_SPLIT"))
+      m->use_split = atoi(e);
    if (const char *e = getenv("MH_DISABLE_FUSED"))
       m->use_fused = atoi(e) ? 0 : 1;
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
@@ -803,6 +835,13 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
    A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
    A.coriolis = 1, A.accel = 1;
+   if (split_ok(model, 2, B, false))
+   {
+      const int rc2 = model->spec.launch_split(2, model->ident_maps ? SPEC_IDENT : 0, &A, (int)waves, opts.stream);
+      if (rc2 != 0)
+         return fail(MH_ERR_HIP, "fused tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc2));
+      return MH_OK;
+   }
    const int rc = model->spec.launch_fused(model->ident_maps ? SPEC_IDENT : 0, &A, (int)waves, opts.stream);
    if (rc != 0)
       return fail(MH_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));

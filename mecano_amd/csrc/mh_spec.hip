@@ -98,7 +98,72 @@ hipError_t go_fused(const mh::Args<double> &A, int waves, hipStream_t stream)
    return hipGetLastError();
 }
 
+using SPL = mh::Split<TP>;
+long split_lds_bytes(int algo)
+{
+   return (long)(SPL::n_limbs() * (algo == 0 ? 6 : 27) + (algo == 1 ? SPL::TRUNK_SLOTS : 0)) * 64 * sizeof(double);
+}
+template <bool ID>
+hipError_t go_fused_split(const mh::Args<double> &A, int groups, hipStream_t stream)
+{
+   if constexpr (SPL::usable())
+   {
+      auto kern = &mh::spec_fused_split_kernel<TP, double, ID>;
+      const size_t lds = (size_t)std::max(split_lds_bytes(0), split_lds_bytes(1));
+      static size_t attr_bytes = 0;
+      if (lds > 64 * 1024 && lds > attr_bytes)
+      {
+         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess)
+            return e;
+         attr_bytes = lds;
+      }
+      hipLaunchKernelGGL(kern, dim3(2 * groups), dim3(256), lds, stream, A);
+      return hipGetLastError();
+   }
+   else
+      return hipErrorNotSupported;
+}
+template <int ALGO, bool ID>
+hipError_t go_split(const mh::Args<double> &A, int groups, hipStream_t stream)
+{
+   if constexpr (SPL::usable())
+   {
+      auto kern = &mh::spec_split_kernel<TP, double, ALGO, ID>;
+      const size_t lds = (size_t)split_lds_bytes(ALGO);
+      static size_t attr_bytes = 0;
+      if (lds > 64 * 1024 && lds > attr_bytes)
+      {
+         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess)
+            return e;
+         attr_bytes = lds;
+      }
+      hipLaunchKernelGGL(kern, dim3(groups), dim3(256), lds, stream, A);
+      return hipGetLastError();
+   }
+   else
+      return hipErrorNotSupported;
+}
+
 extern "C" {
+// tree-split kernels (4 waves per 64 configurations): available when the tree has a trunk with at least two limbs
+int mh_spec_split_usable(void) { return SPL::usable() ? 1 : 0; }
+long mh_spec_split_lds_bytes(int algo) { return algo == 2 ? std::max(split_lds_bytes(0), split_lds_bytes(1)) : split_lds_bytes(algo); }
+// algo: 0 = RNEA, 1 = ABA, 2 = fused RNEA+ABA (2 * groups workgroups); groups = ceil(B / 64) or fewer (grid-stride)
+int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void *stream)
+{
+   const mh::Args<double> &A = *(const mh::Args<double> *)args;
+   const bool id = flags & F_IDENT;
+   hipStream_t s = (hipStream_t)stream;
+   if (algo == 2)
+      return (int)(id ? go_fused_split<true>(A, groups, s) : go_fused_split<false>(A, groups, s));
+   if (algo == 0)
+      return (int)(id ? go_split<0, true>(A, groups, s) : go_split<0, false>(A, groups, s));
+   if (algo == 1)
+      return (int)(id ? go_split<1, true>(A, groups, s) : go_split<1, false>(A, groups, s));
+   return (int)hipErrorNotSupported;
+}
 int mh_spec_n(void) { return TP::N; }
 const int *mh_spec_parents(void) { return kParents; }
 const int *mh_spec_types(void) { return kTypes; }

@@ -105,37 +105,186 @@ struct Tree
    }
 };
 
+// Compile-time partition of the tree for the tree-split kernels: 4 waves of a workgroup walk the SAME 64 configurations.
+//   trunk = every body with two or more child subtrees, and all its ancestors  (humanoid: pelvis, spine 1-3)
+//   limbs = the chains hanging off the trunk with at least MIN_LIMB bodies       (legs, arms); shorter ones stay with the trunk
+// Every wave walks the trunk (redundantly: it would idle otherwise); each limb is walked by one wave only (greedy balance).
+template <class TP, int WAVES = 4, int MIN_LIMB = 2>
+struct Split
+{
+   using TR = Tree<TP>;
+   static constexpr int N = TP::N;
+   struct Plan
+   {
+      bool trunk[N] = {};
+      bool limb_root[N] = {};
+      int limb_of[N] = {};    // limb index of a limb body
+      int root_of[N] = {};    // body index of limb k's root
+      int size_of[N] = {};    // bodies in limb k
+      int owner[N] = {};      // wave that walks limb k
+      int trunk_slot[N + 1] = {};
+      int reg_slot[N] = {};
+      int n_limbs = 0, reg_slots = 0;
+      bool usable = false;
+   };
+   static constexpr Plan make()
+   {
+      Plan P;
+      int nchild[N] = {}, size[N] = {};
+      bool branch[N] = {};
+      for (int j = 0; j < N; j++)
+         if (TP::parent[j] >= 0)
+            nchild[TP::parent[j]]++;
+      for (int j = N - 1; j >= 0; j--)
+      { // children have larger indices than their parent (engine order)
+         size[j] += 1;
+         branch[j] = branch[j] || nchild[j] >= 2;
+         if (TP::parent[j] >= 0)
+         {
+            size[TP::parent[j]] += size[j];
+            branch[TP::parent[j]] = branch[TP::parent[j]] || branch[j];
+         }
+      }
+      for (int j = 0; j < N; j++)
+      {
+         const int p = TP::parent[j];
+         if (branch[j])
+            P.trunk[j] = true;
+         else if (p < 0)
+            P.trunk[j] = false;
+         else if (branch[p])
+            P.trunk[j] = size[j] < MIN_LIMB; // a chain hanging off the trunk: a limb if long enough
+         else
+            P.trunk[j] = P.trunk[p];         // further down a chain: same side as the body above
+      }
+      for (int j = 0; j < N; j++)
+      {
+         const int p = TP::parent[j];
+         P.limb_root[j] = !P.trunk[j] && (p < 0 || P.trunk[p]);
+         if (P.limb_root[j])
+         {
+            P.root_of[P.n_limbs] = j;
+            P.size_of[P.n_limbs] = size[j];
+            P.limb_of[j] = P.n_limbs++;
+         }
+         else if (!P.trunk[j])
+            P.limb_of[j] = P.limb_of[p];
+      }
+      // greedy balance: limbs in decreasing size go to the least loaded wave
+      int load[WAVES] = {};
+      bool done[N] = {};
+      for (int round = 0; round < P.n_limbs; round++)
+      {
+         int best = -1, bs = -1;
+         for (int i = 0; i < P.n_limbs; i++)
+            if (!done[i] && P.size_of[i] > bs)
+            {
+               bs = P.size_of[i];
+               best = i;
+            }
+         int w = 0;
+         for (int i = 1; i < WAVES; i++)
+            if (load[i] < load[w])
+               w = i;
+         P.owner[best] = w;
+         load[w] += bs;
+         done[best] = true;
+      }
+      // ABA hand-over placement: trunk bodies in LDS (all waves write the same values), limb bodies in the owner's registers
+      int regs[WAVES] = {};
+      for (int j = 0; j < N; j++)
+      {
+         P.trunk_slot[j + 1] = P.trunk_slot[j] + (P.trunk[j] ? TR::aba_slots_of(j) : 0);
+         if (!P.trunk[j])
+         {
+            const int w = P.owner[P.limb_of[j]];
+            P.reg_slot[j] = regs[w];
+            regs[w] += TR::aba_slots_of(j);
+         }
+      }
+      for (int w = 0; w < WAVES; w++)
+         P.reg_slots = regs[w] > P.reg_slots ? regs[w] : P.reg_slots;
+      P.usable = P.n_limbs >= 2;
+      for (int j = 0; j < N; j++)
+         if (TP::parent[j] < 0 && !P.trunk[j])
+            P.usable = false; // every root must be a trunk body
+      return P;
+   }
+   static constexpr Plan P = make();
+   static constexpr bool is_trunk(int j) { return P.trunk[j]; }
+   static constexpr int n_limbs() { return P.n_limbs; }
+   static constexpr int limb_root(int k) { return P.root_of[k]; }
+   static constexpr int limb_index(int root) { return P.limb_of[root]; }
+   static constexpr int owner(int k) { return P.owner[k]; }
+   static constexpr bool usable() { return P.usable; }
+   static constexpr int trunk_slot(int j) { return P.trunk_slot[j]; }
+   static constexpr int TRUNK_SLOTS = P.trunk_slot[N];
+   static constexpr int reg_slot(int j) { return P.reg_slot[j]; }
+   static constexpr int reg_slots() { return P.reg_slots; }
+};
+
 template <typename T>
 using lds_ptr = T __attribute__((address_space(3))) *;
 
-// Per-lane store for values that must survive from ABA's inward sweep to its outward sweep: slot-major, lane-minor.
-// LDS flavour: the slot stride is the compile-time constant 64, every access is "ds_write/read_b64 base offset:imm".
-// Global flavour: ws[slot * stride + lane] with a wave-uniform base (scalar address arithmetic).
-template <typename T, bool LDS>
+// Per-lane store for values that must survive from ABA's inward sweep to its outward sweep.  Where slot k of body J lives is
+// a compile-time decision of the store policy SP:
+//   LDS       LDS, slot-major, 64 lanes per slot: "ds_write/read_b64 base offset:imm", no per-slot address register
+//   GLOBAL    global workspace ws[slot * stride + lane], wave-uniform base (scalar address arithmetic)
+//   REG       a register array of the lane (tree-split kernels: the limb bodies of the wave that owns them)
+enum : int
+{
+   ST_LDS_KIND = 0,
+   ST_GLOBAL_KIND = 1,
+   ST_REG_KIND = 2
+};
+template <class TP, int KIND>
+struct WholeStore
+{ // one wave walks the whole tree: everything in LDS or everything in the global workspace
+   static constexpr int REG_SLOTS = 0;
+   static constexpr int kind(int) { return KIND; }
+   static constexpr int index(int j) { return Tree<TP>::aba_slot(j); }
+};
+template <class TP>
+struct SplitStore
+{
+   static constexpr int REG_SLOTS = Split<TP>::reg_slots();
+   static constexpr int kind(int j) { return Split<TP>::is_trunk(j) ? ST_LDS_KIND : ST_REG_KIND; }
+   static constexpr int index(int j) { return Split<TP>::is_trunk(j) ? Split<TP>::trunk_slot(j) : Split<TP>::reg_slot(j); }
+};
+template <typename T, class SP>
 struct LaneStore
 {
    lds_ptr<T> lbase; // lds + lane-in-wave
    T *gbase;         // wave-uniform workspace pointer
    long stride, lane;
-   MH_DEV void put(int slot, T v) const
+   mutable T regs[SP::REG_SLOTS > 0 ? SP::REG_SLOTS : 1];
+   template <int J, int K>
+   MH_DEV void put(T v) const
    {
-      if constexpr (LDS)
+      constexpr int kind = SP::kind(J), slot = SP::index(J) + K;
+      if constexpr (kind == ST_LDS_KIND)
          lbase[slot * 64] = v;
-      else
+      else if constexpr (kind == ST_GLOBAL_KIND)
          gbase[(long)slot * stride + lane] = v;
-   }
-   MH_DEV T get(int slot) const
-   {
-      if constexpr (LDS)
-         return lbase[slot * 64];
       else
+         regs[slot] = v;
+   }
+   template <int J, int K>
+   MH_DEV T get() const
+   {
+      constexpr int kind = SP::kind(J), slot = SP::index(J) + K;
+      if constexpr (kind == ST_LDS_KIND)
+         return lbase[slot * 64];
+      else if constexpr (kind == ST_GLOBAL_KIND)
          return gbase[(long)slot * stride + lane];
+      else
+         return regs[slot];
    }
 };
 
 // Everything one lane needs to walk the tree.  IO_LDS: state rows staged in LDS.  IDENT: the index maps are the identity
 // (Mecano's default JointMatrixIndexProvider over joints in depth-first order), so every row index is a compile-time constant.
-template <typename T, bool IO_LDS, bool IDENT, bool ST_LDS>
+template <typename T, bool IO_LDS, bool IDENT, class SP>
 struct Ctx
 {
    const T *C; // per-joint constants [N][MC_STRIDE], global memory, wave-uniform addresses -> scalar loads
@@ -146,7 +295,9 @@ struct Ctx
    lds_ptr<T> lq, lqd, lx, lo; // this lane's rows in LDS (IO_LDS); lo = output row (may alias lx)
    V3<T> a0l;              // linear part of the root acceleration (-g)
    int coriolis, accel;
-   LaneStore<T, ST_LDS> st;
+   LaneStore<T, SP> st;
+   int wave;                     // tree-split kernels: which wave of the workgroup this is
+   lds_ptr<T> xbase;             // tree-split kernels: limb -> trunk exchange area in LDS (+ lane)
 
    MH_DEV int ci(int k) const { return IDENT ? k : cfg_map[k]; }
    MH_DEV int di(int k) const { return IDENT ? k : dof_map[k]; }
@@ -232,7 +383,33 @@ MH_DEV void spec_write(const CX &cx, SV<T> w)
 // ============================================================================================ RNEA
 // Returns the wrench the subtree rooted at joint J exerts on its parent, expressed in the parent's frame
 // (InverseDynamicsCalculator.java:873-966 as one depth-first recursion).
-template <class TP, int J, typename T, class CX>
+// limb -> trunk exchange area of the tree-split kernels: XW scalars per limb, slot-major, 64 lanes per slot
+template <int LIMB, int XW, int I, class CX, typename T>
+MH_DEV void x_put(const CX &cx, T v)
+{
+   cx.xbase[(LIMB * XW + I) * 64] = v;
+}
+template <int LIMB, int XW, int I, class CX, typename T>
+MH_DEV T x_get(const CX &cx)
+{
+   return cx.xbase[(LIMB * XW + I) * 64];
+}
+template <int LIMB, int XW, int I0, class CX, typename T>
+MH_DEV void x_put6(const CX &cx, const SV<T> &w)
+{
+   x_put<LIMB, XW, I0 + 0, CX, T>(cx, w.a.x), x_put<LIMB, XW, I0 + 1, CX, T>(cx, w.a.y), x_put<LIMB, XW, I0 + 2, CX, T>(cx, w.a.z);
+   x_put<LIMB, XW, I0 + 3, CX, T>(cx, w.l.x), x_put<LIMB, XW, I0 + 4, CX, T>(cx, w.l.y), x_put<LIMB, XW, I0 + 5, CX, T>(cx, w.l.z);
+}
+template <int LIMB, int XW, int I0, class CX, typename T>
+MH_DEV SV<T> x_get6(const CX &cx)
+{
+   return SV<T>{V3<T>{x_get<LIMB, XW, I0 + 0, CX, T>(cx), x_get<LIMB, XW, I0 + 1, CX, T>(cx), x_get<LIMB, XW, I0 + 2, CX, T>(cx)},
+                V3<T>{x_get<LIMB, XW, I0 + 3, CX, T>(cx), x_get<LIMB, XW, I0 + 4, CX, T>(cx), x_get<LIMB, XW, I0 + 5, CX, T>(cx)}};
+}
+
+// MODE 0: the recursion walks the whole subtree.  MODE 1 (tree-split kernels, trunk pass): children that are limb roots are
+// not walked; what their limb hands up is read from the exchange area, where the wave that owns the limb left it.
+template <class TP, int J, typename T, class CX, int MODE = 0>
 struct RneaSub
 {
    template <int K>
@@ -240,7 +417,11 @@ struct RneaSub
    {
       if constexpr (K < Tree<TP>::n_children(J))
       {
-         f = f + RneaSub<TP, Tree<TP>::child(J, K), T, CX>::run(cx, v, a);
+         constexpr int C = Tree<TP>::child(J, K);
+         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+            f = f + x_get6<Split<TP>::limb_index(C), 6, 0, CX, T>(cx);
+         else
+            f = f + RneaSub<TP, C, T, CX, MODE>::run(cx, v, a);
          children<K + 1>(cx, v, a, f);
       }
    }
@@ -276,15 +457,54 @@ struct RneaSub
       return up;
    }
 };
-template <class TP, typename T, class CX, int K = 0>
+template <class TP, typename T, class CX, int MODE = 0, int K = 0>
 MH_DEV void rnea_roots(const CX &cx)
 {
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       const V3<T> Z{T(0), T(0), T(0)};
-      (void)RneaSub<TP, Tree<TP>::child(-1, K), T, CX>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
-      rnea_roots<TP, T, CX, K + 1>(cx);
+      (void)RneaSub<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
+      rnea_roots<TP, T, CX, MODE, K + 1>(cx);
    }
+}
+// velocity and acceleration of trunk body J, walked down from the root (tree-split kernels: every wave needs them for its limbs)
+template <class TP, int J, typename T, class CX>
+MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
+{
+   constexpr int TYPE = TP::type[J];
+   constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
+   const V3<T> Z{T(0), T(0), T(0)};
+   SV<T> vp{Z, Z}, ap{Z, cx.a0l};
+   if constexpr (TP::parent[J] >= 0)
+      trunk_va<TP, TP::parent[J], T, CX>(cx, vp, ap);
+   MH_BODY_FENCE();
+   const CRef<T, false> c{cx.C + J * MC_STRIDE};
+   const XF<T> Xb = load_xb<T>(c);
+   const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+   const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
+   const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
+   v = motion_down(TYPE, jx, Xb, vp) + vJ;
+   a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
+   if (!cx.coriolis)
+      v = SV<T>{Z, Z};
+   MH_BODY_FENCE();
+}
+// velocity only (ABA)
+template <class TP, int J, typename T, class CX>
+MH_DEV SV<T> trunk_v(const CX &cx)
+{
+   constexpr int TYPE = TP::type[J];
+   constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
+   const V3<T> Z{T(0), T(0), T(0)};
+   SV<T> vp{Z, Z};
+   if constexpr (TP::parent[J] >= 0)
+      vp = trunk_v<TP, TP::parent[J], T, CX>(cx);
+   MH_BODY_FENCE();
+   const CRef<T, false> c{cx.C + J * MC_STRIDE};
+   const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+   const SV<T> v = motion_down(TYPE, jx, load_xb<T>(c), vp) + spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+   MH_BODY_FENCE();
+   return v;
 }
 
 // ============================================================================================ ABA
@@ -305,7 +525,36 @@ MH_DEV AbaUp<T> aba_up_zero()
    return z;
 }
 
-template <class TP, int J, typename T, class CX>
+template <int LIMB, class CX, typename T>
+MH_DEV void x_put_up(const CX &cx, const AbaUp<T> &u)
+{
+   constexpr int XW = 27;
+   x_put<LIMB, XW, 0, CX, T>(cx, u.I.A.xx), x_put<LIMB, XW, 1, CX, T>(cx, u.I.A.xy), x_put<LIMB, XW, 2, CX, T>(cx, u.I.A.xz);
+   x_put<LIMB, XW, 3, CX, T>(cx, u.I.A.yy), x_put<LIMB, XW, 4, CX, T>(cx, u.I.A.yz), x_put<LIMB, XW, 5, CX, T>(cx, u.I.A.zz);
+   x_put<LIMB, XW, 6, CX, T>(cx, u.I.L.xx), x_put<LIMB, XW, 7, CX, T>(cx, u.I.L.xy), x_put<LIMB, XW, 8, CX, T>(cx, u.I.L.xz);
+   x_put<LIMB, XW, 9, CX, T>(cx, u.I.L.yy), x_put<LIMB, XW, 10, CX, T>(cx, u.I.L.yz), x_put<LIMB, XW, 11, CX, T>(cx, u.I.L.zz);
+   x_put<LIMB, XW, 12, CX, T>(cx, u.I.C.xx), x_put<LIMB, XW, 13, CX, T>(cx, u.I.C.xy), x_put<LIMB, XW, 14, CX, T>(cx, u.I.C.xz);
+   x_put<LIMB, XW, 15, CX, T>(cx, u.I.C.yx), x_put<LIMB, XW, 16, CX, T>(cx, u.I.C.yy), x_put<LIMB, XW, 17, CX, T>(cx, u.I.C.yz);
+   x_put<LIMB, XW, 18, CX, T>(cx, u.I.C.zx), x_put<LIMB, XW, 19, CX, T>(cx, u.I.C.zy), x_put<LIMB, XW, 20, CX, T>(cx, u.I.C.zz);
+   x_put6<LIMB, XW, 21, CX, T>(cx, u.p);
+}
+template <int LIMB, class CX, typename T>
+MH_DEV AbaUp<T> x_get_up(const CX &cx)
+{
+   constexpr int XW = 27;
+   AbaUp<T> u;
+   u.I.A = S3<T>{x_get<LIMB, XW, 0, CX, T>(cx), x_get<LIMB, XW, 1, CX, T>(cx), x_get<LIMB, XW, 2, CX, T>(cx),
+                 x_get<LIMB, XW, 3, CX, T>(cx), x_get<LIMB, XW, 4, CX, T>(cx), x_get<LIMB, XW, 5, CX, T>(cx)};
+   u.I.L = S3<T>{x_get<LIMB, XW, 6, CX, T>(cx), x_get<LIMB, XW, 7, CX, T>(cx), x_get<LIMB, XW, 8, CX, T>(cx),
+                 x_get<LIMB, XW, 9, CX, T>(cx), x_get<LIMB, XW, 10, CX, T>(cx), x_get<LIMB, XW, 11, CX, T>(cx)};
+   u.I.C = M3<T>{x_get<LIMB, XW, 12, CX, T>(cx), x_get<LIMB, XW, 13, CX, T>(cx), x_get<LIMB, XW, 14, CX, T>(cx),
+                 x_get<LIMB, XW, 15, CX, T>(cx), x_get<LIMB, XW, 16, CX, T>(cx), x_get<LIMB, XW, 17, CX, T>(cx),
+                 x_get<LIMB, XW, 18, CX, T>(cx), x_get<LIMB, XW, 19, CX, T>(cx), x_get<LIMB, XW, 20, CX, T>(cx)};
+   u.p = x_get6<LIMB, XW, 21, CX, T>(cx);
+   return u;
+}
+
+template <class TP, int J, typename T, class CX, int MODE = 0>
 struct AbaIn
 { // inward sweep (ForwardDynamicsCalculator.java:1085-1254) as a depth-first recursion.  Only (v, cos, sin, qd) of a body
   // stay live while its subtree is walked; everything that depends on the inertia is formed after the children returned.
@@ -314,7 +563,12 @@ struct AbaIn
    {
       if constexpr (K < Tree<TP>::n_children(J))
       {
-         const AbaUp<T> c = AbaIn<TP, Tree<TP>::child(J, K), T, CX>::run(cx, v);
+         constexpr int C = Tree<TP>::child(J, K);
+         AbaUp<T> c;
+         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+            c = x_get_up<Split<TP>::limb_index(C), CX, T>(cx);
+         else
+            c = AbaIn<TP, C, T, CX, MODE>::run(cx, v);
          if constexpr (K == 0)
             acc = c;
          else
@@ -383,13 +637,13 @@ struct AbaIn
          const T dinv = T(1) / D;
          const T ud = (cx.in3(DO) - pz) * dinv;
          const V3<T> sa = dinv * ua, sl = dinv * ul;
-         cx.st.put(S0 + 0, sa.x), cx.st.put(S0 + 1, sa.y), cx.st.put(S0 + 2, sa.z);
-         cx.st.put(S0 + 3, sl.x), cx.st.put(S0 + 4, sl.y), cx.st.put(S0 + 5, sl.z);
-         cx.st.put(S0 + 6, ud);
+         cx.st.template put<J, 0>(sa.x), cx.st.template put<J, 1>(sa.y), cx.st.template put<J, 2>(sa.z);
+         cx.st.template put<J, 3>(sl.x), cx.st.template put<J, 4>(sl.y), cx.st.template put<J, 5>(sl.z);
+         cx.st.template put<J, 6>(ud);
          if constexpr (TYPE == JT_REVOLUTE)
          {
-            cx.st.put(S0 + 7, jx.c);
-            cx.st.put(S0 + 8, jx.s);
+            cx.st.template put<J, 7>(jx.c);
+            cx.st.template put<J, 8>(jx.s);
          }
          if constexpr (HAS_PARENT)
          {
@@ -405,8 +659,8 @@ struct AbaIn
       {
          const SV<T> tau = spec_vec<TYPE, DO, 1, CX, T>(cx, true);
          const SV<T> x = spd6_solve(IA, tau - pA);
-         cx.st.put(S0 + 0, x.a.x), cx.st.put(S0 + 1, x.a.y), cx.st.put(S0 + 2, x.a.z);
-         cx.st.put(S0 + 3, x.l.x), cx.st.put(S0 + 4, x.l.y), cx.st.put(S0 + 5, x.l.z);
+         cx.st.template put<J, 0>(x.a.x), cx.st.template put<J, 1>(x.a.y), cx.st.template put<J, 2>(x.a.z);
+         cx.st.template put<J, 3>(x.l.x), cx.st.template put<J, 4>(x.l.y), cx.st.template put<J, 5>(x.l.z);
          if constexpr (HAS_PARENT)
             out.p = force_up(TYPE, jx, load_xb<T>(c), tau); // Ia = 0, pa = tau
       }
@@ -421,15 +675,23 @@ struct AbaIn
       return out;
    }
 };
-template <class TP, int J, typename T, class CX>
+template <class TP, int J, typename T, class CX, int MODE = 0>
 struct AbaOut
-{ // outward sweep (ForwardDynamicsCalculator.java:1259-1310)
+{ // outward sweep (ForwardDynamicsCalculator.java:1259-1310).  MODE 1: a limb hanging off this trunk body is continued only by the
+  // wave that owns it (wave-uniform branch); the trunk itself is walked by every wave, its outputs written by wave 0.
    template <int K>
    static MH_DEV void children(const CX &cx, const SV<T> &v, const SV<T> &a)
    {
       if constexpr (K < Tree<TP>::n_children(J))
       {
-         AbaOut<TP, Tree<TP>::child(J, K), T, CX>::run(cx, v, a);
+         constexpr int C = Tree<TP>::child(J, K);
+         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+         {
+            if (cx.wave == Split<TP>::owner(Split<TP>::limb_index(C)))
+               AbaOut<TP, C, T, CX, 0>::run(cx, v, a);
+         }
+         else
+            AbaOut<TP, C, T, CX, MODE>::run(cx, v, a);
          children<K + 1>(cx, v, a);
       }
    }
@@ -444,7 +706,7 @@ struct AbaOut
       JX<T> jx;
       if constexpr (TYPE == JT_REVOLUTE)
       {
-         jx.c = cx.st.get(S0 + 7), jx.s = cx.st.get(S0 + 8), jx.d = T(0);
+         jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>(), jx.d = T(0);
       }
       else
          jx = spec_joint<TYPE, CO, CX, T>(cx);
@@ -453,9 +715,10 @@ struct AbaOut
       SV<T> a = motion_down(TYPE, jx, Xb, ap) + crm(v, vJ);
       if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
       {
-         const V3<T> sa{cx.st.get(S0 + 0), cx.st.get(S0 + 1), cx.st.get(S0 + 2)}, sl{cx.st.get(S0 + 3), cx.st.get(S0 + 4), cx.st.get(S0 + 5)};
-         const T qdd = cx.st.get(S0 + 6) - (dot(sa, a.a) + dot(sl, a.l));
-         cx.out(DO, qdd);
+         const V3<T> sa{cx.st.template get<J, 0>(), cx.st.template get<J, 1>(), cx.st.template get<J, 2>()}, sl{cx.st.template get<J, 3>(), cx.st.template get<J, 4>(), cx.st.template get<J, 5>()};
+         const T qdd = cx.st.template get<J, 6>() - (dot(sa, a.a) + dot(sl, a.l));
+         if (MODE == 0 || cx.wave == 0)
+            cx.out(DO, qdd);
          if constexpr (TYPE == JT_REVOLUTE)
             a.a.z += qdd;
          else
@@ -463,8 +726,9 @@ struct AbaOut
       }
       else if constexpr (TYPE == JT_SIXDOF)
       {
-         const SV<T> x{V3<T>{cx.st.get(S0 + 0), cx.st.get(S0 + 1), cx.st.get(S0 + 2)}, V3<T>{cx.st.get(S0 + 3), cx.st.get(S0 + 4), cx.st.get(S0 + 5)}};
-         spec_write<TYPE, DO, CX, T>(cx, x - a);
+         const SV<T> x{V3<T>{cx.st.template get<J, 0>(), cx.st.template get<J, 1>(), cx.st.template get<J, 2>()}, V3<T>{cx.st.template get<J, 3>(), cx.st.template get<J, 4>(), cx.st.template get<J, 5>()}};
+         if (MODE == 0 || cx.wave == 0)
+            spec_write<TYPE, DO, CX, T>(cx, x - a);
          a = x;
       }
       MH_BODY_FENCE();
@@ -472,24 +736,24 @@ struct AbaOut
          children<0>(cx, v, a);
    }
 };
-template <class TP, typename T, class CX, int K = 0>
+template <class TP, typename T, class CX, int MODE = 0, int K = 0>
 MH_DEV void aba_roots_in(const CX &cx)
 {
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       const V3<T> Z{T(0), T(0), T(0)};
-      (void)AbaIn<TP, Tree<TP>::child(-1, K), T, CX>::run(cx, SV<T>{Z, Z});
-      aba_roots_in<TP, T, CX, K + 1>(cx);
+      (void)AbaIn<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx, SV<T>{Z, Z});
+      aba_roots_in<TP, T, CX, MODE, K + 1>(cx);
    }
 }
-template <class TP, typename T, class CX, int K = 0>
+template <class TP, typename T, class CX, int MODE = 0, int K = 0>
 MH_DEV void aba_roots_out(const CX &cx)
 {
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       const V3<T> Z{T(0), T(0), T(0)};
-      AbaOut<TP, Tree<TP>::child(-1, K), T, CX>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
-      aba_roots_out<TP, T, CX, K + 1>(cx);
+      AbaOut<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
+      aba_roots_out<TP, T, CX, MODE, K + 1>(cx);
    }
 }
 
@@ -565,7 +829,7 @@ MH_DEV void warm_scalar_cache(const void *p, int bytes)
 template <class TP, typename T, int ALGO, bool IO_LDS, bool IDENT, bool ST_LDS>
 MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
 {
-   using CX = Ctx<T, IO_LDS, IDENT, ST_LDS>;
+   using CX = Ctx<T, IO_LDS, IDENT, WholeStore<TP, ST_LDS ? ST_LDS_KIND : ST_GLOBAL_KIND>>;
    const int nq = A.m.nq, nv = A.m.nv;
    // LDS map: [64][nq] q | [64][nv] qd | [64][nv] qdd or tau, overwritten by the result | hand-over slots [slot][64]
    const lds_ptr<T> lq = lds, lqd = lq + (IO_LDS ? 64 * nq : 0), lx = lqd + (IO_LDS ? 64 * nv : 0), lst = lx + (IO_LDS ? 64 * nv : 0);
@@ -589,6 +853,7 @@ MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
          fill_ctx<T>(cx, A, cfg0 + threadIdx.x);
          cx.lq = lq + threadIdx.x * nq, cx.lqd = lqd + threadIdx.x * nv, cx.lx = lx + threadIdx.x * nv;
          cx.lo = cx.lx;
+         cx.wave = 0, cx.xbase = lst;
          cx.st.lbase = lst + threadIdx.x;
          cx.st.gbase = A.ws;
          cx.st.stride = A.ws_stride, cx.st.lane = wave * 64 + threadIdx.x;
@@ -640,6 +905,119 @@ __global__ void __launch_bounds__(64) spec_fused_kernel(Args<T> A)
       A2.in3 = A.in3b, A2.out = A.outb;
       spec_wave<TP, T, 1, false, IDENT, true>(A2, blockIdx.x - half, half, (lds_ptr<T>)lds_raw);
    }
+}
+
+// ============================================================================================ tree-split kernels
+// Four waves of a 256-thread workgroup walk the SAME 64 configurations (lane = threadIdx.x & 63): every wave walks the trunk,
+// each limb (leg, arm, ...) is walked by the one wave that owns it, and what a limb hands to the trunk crosses waves through a
+// small LDS exchange area behind one workgroup barrier.  The serial chain a wave executes shrinks from N bodies to
+// (trunk + its longest limb); the batch occupies 4x as many SIMDs.  Built for small batches, where latency is everything.
+template <class TP, int K, typename T, class CX>
+MH_DEV void split_rnea_limbs(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if (cx.wave == S::owner(K))
+      {
+         constexpr int R = S::limb_root(K);
+         const V3<T> Z{T(0), T(0), T(0)};
+         SV<T> vp{Z, Z}, ap{Z, cx.a0l};
+         if constexpr (TP::parent[R] >= 0)
+            trunk_va<TP, TP::parent[R], T, CX>(cx, vp, ap);
+         x_put6<K, 6, 0, CX, T>(cx, RneaSub<TP, R, T, CX, 0>::run(cx, vp, ap));
+      }
+      split_rnea_limbs<TP, K + 1, T, CX>(cx);
+   }
+}
+template <class TP, int K, typename T, class CX>
+MH_DEV void split_aba_limbs(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if (cx.wave == S::owner(K))
+      {
+         constexpr int R = S::limb_root(K);
+         const V3<T> Z{T(0), T(0), T(0)};
+         SV<T> vp{Z, Z};
+         if constexpr (TP::parent[R] >= 0)
+            vp = trunk_v<TP, TP::parent[R], T, CX>(cx);
+         x_put_up<K, CX, T>(cx, AbaIn<TP, R, T, CX, 0>::run(cx, vp));
+      }
+      split_aba_limbs<TP, K + 1, T, CX>(cx);
+   }
+}
+
+// One workgroup's share of a batch.  ALGO: 0 = RNEA, 1 = ABA.  State rows are read directly from global memory.
+template <class TP, typename T, int ALGO, bool IDENT>
+MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> lds)
+{
+   using S = Split<TP>;
+   using CX = Ctx<T, false, IDENT, SplitStore<TP>>;
+   constexpr int XW = ALGO == 0 ? 6 : 27;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   // LDS map: exchange [n_limbs * XW][64] | trunk hand-over slots [TRUNK_SLOTS][64] (ABA)
+   const lds_ptr<T> lxc = lds, lst = lds + S::n_limbs() * XW * 64;
+   warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   for (long cfg0 = group * 64; cfg0 < A.B; cfg0 += ngroups * 64)
+   {
+      const bool active = cfg0 + lane < A.B;
+      CX cx;
+      fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+      cx.lq = lds, cx.lqd = lds, cx.lx = lds, cx.lo = lds; // unused: rows are read from global memory
+      cx.wave = wave;
+      cx.xbase = lxc + lane;
+      cx.st.lbase = lst + lane;
+      cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+      if (active)
+      {
+         if constexpr (ALGO == 0)
+            split_rnea_limbs<TP, 0, T, CX>(cx);
+         else
+            split_aba_limbs<TP, 0, T, CX>(cx);
+      }
+      __syncthreads(); // every limb's hand-up is in the exchange area
+      if (active)
+      {
+         if constexpr (ALGO == 0)
+         {
+            if (wave == 0)
+               rnea_roots<TP, T, CX, 1>(cx);
+         }
+         else
+         {
+            aba_roots_in<TP, T, CX, 1>(cx);
+            asm volatile("" ::: "memory");
+            asm volatile("" : "+v"(cx.qrow), "+v"(cx.qdrow), "+v"(cx.st.lbase));
+            aba_roots_out<TP, T, CX, 1>(cx);
+         }
+      }
+      __syncthreads(); // the exchange area is reused by the next batch slice
+   }
+}
+
+// Fused RNEA + ABA, tree-split: workgroups [0, G) compute tau = RNEA(q, qd, qdd), workgroups [G, 2G) qdd = ABA(q, qd, tau_in).
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(256) spec_fused_split_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   const long half = gridDim.x / 2;
+   if ((long)blockIdx.x < half)
+      split_group<TP, T, 0, IDENT>(A, blockIdx.x, half, (lds_ptr<T>)lds_raw);
+   else
+   {
+      Args<T> A2 = A;
+      A2.in3 = A.in3b, A2.out = A.outb;
+      split_group<TP, T, 1, IDENT>(A2, blockIdx.x - half, half, (lds_ptr<T>)lds_raw);
+   }
+}
+template <class TP, typename T, int ALGO, bool IDENT>
+__global__ void __launch_bounds__(256) spec_split_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   split_group<TP, T, ALGO, IDENT>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
 }
 
 } // namespace mh

@@ -209,12 +209,14 @@ def test_layouts_soa_equals_aos(torch_cuda):
     fext = dev(torch, rng.uniform(-1, 1, (B, 25, 6)))
     g = (0.2, 0.1, -9.81)
     T = lambda x: x.t().contiguous()
+    # same arithmetic per configuration; kernels may differ between layouts (rows staged in LDS or read with strides), so the
+    # comparison is to rounding, not bitwise
     a = hm.rnea(q, qd, qdd, g, fext)
     b = hm.rnea(T(q), T(qd), T(qdd), g, T(fext.reshape(B, -1)), layout=_lib.LAYOUT_SOA)
-    assert torch.equal(a, b.t())
+    close(b.t().cpu().numpy(), a.cpu().numpy(), 1e-12)
     a = hm.aba(q, qd, tau, g, fext)
     b = hm.aba(T(q), T(qd), T(tau), g, T(fext.reshape(B, -1)), layout=_lib.LAYOUT_SOA)
-    assert torch.equal(a, b.t())
+    close(b.t().cpu().numpy(), a.cpu().numpy(), 1e-11)
     a = hm.crba(q)
     b = hm.crba(T(q), layout=_lib.LAYOUT_SOA)
     assert torch.equal(a.reshape(B, -1), b.t())
@@ -358,17 +360,21 @@ def test_every_specialised_variant(torch_cuda, B):
         t_ref, a_ref = om.rnea(q[idx], qd[idx], qdd[idx], g), om.aba(q[idx], qd[idx], tau[idx], g)
         seen = set()
         try:
-            for env in ({"MH_DISABLE_SPEC": "1"}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "0"}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "1"},
-                        {"MH_SPEC_IO": "1", "MH_SPEC_ST": "0"}, {"MH_SPEC_IO": "1", "MH_SPEC_ST": "1"}, {}):
-                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST"):
+            off = {"MH_SPEC_SPLIT": "0"}
+            for env in ({"MH_DISABLE_SPEC": "1"}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "1", **off},
+                        {"MH_SPEC_IO": "1", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "1", "MH_SPEC_ST": "1", **off}, {"MH_SPEC_SPLIT": "1"}, {}):
+                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT"):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 hm = HipModel(d)
                 seen.add(hm.kernel_variant)
                 close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), g).cpu().numpy()[idx], t_ref)
                 close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g).cpu().numpy()[idx], a_ref)
+                t2, a2 = hm.rnea_aba(dev(torch, q), dev(torch, qd), dev(torch, qdd), dev(torch, tau), g)
+                close(t2.cpu().numpy()[idx], t_ref)
+                close(a2.cpu().numpy()[idx], a_ref)
         finally:
-            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST"):
+            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT"):
                 os.environ.pop(k, None)
         assert "generic" in seen and any(v.startswith("topo:") for v in seen), seen
 
