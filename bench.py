@@ -61,7 +61,7 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=12.0):
 def measured_traffic(fused_launch, B):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
     separate passes, same command); only quoted for the configuration they were collected on, else null."""
-    path = os.path.join(ROOT, "profiles", "r01_fused_b4096_hbm_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_fused_split_b4096_hbm_pmc.json")
     if not (fused_launch and B == BATCH and os.path.exists(path)):
         return None
     pmc = json.load(open(path))

@@ -100,7 +100,7 @@ struct SpecLib
    int (*launch_fused)(int flags, const void *args, int waves, void *stream) = nullptr;
    long (*fused_lds_bytes)(int nq, int nv) = nullptr;
    int (*split_usable)(void) = nullptr;
-   long (*split_lds_bytes)(int algo) = nullptr;
+   long (*split_lds_bytes)(int algo, int flags, int nq, int nv) = nullptr;
    int (*launch_split)(int algo, int flags, const void *args, int groups, void *stream) = nullptr;
 };
 enum : int
@@ -197,12 +197,19 @@ mh_status check_common(mh_model_t model, int64_t B, const mh_options *opts)
 }
 
 // tree-split kernels: 4 waves per 64 configurations; worth it while the batch cannot give every SIMD a wave of its own otherwise
+// flags for the tree-split kernels: identity maps; rows staged in LDS when the layout is AoS, the maps are dense and it fits
+int split_flags(const mh_model *m, int algo, bool soa)
+{
+   int flags = m->ident_maps ? SPEC_IDENT : 0;
+   if (!soa && m->dense_maps && m->force_io != 0 && m->spec.split_lds_bytes(algo, SPEC_IO_LDS, m->nq, m->nv) <= 160 * 1024)
+      flags |= SPEC_IO_LDS;
+   return flags;
+}
 bool split_ok(const mh_model *m, int algo, int64_t B, bool soa)
 {
-   (void)soa; // the tree-split kernels read their rows with strides: both layouts work
    if (!m->spec.launch_split || !m->spec.split_usable || !m->spec.split_usable() || !m->use_spec || m->use_split == 0)
       return false;
-   if (m->spec.split_lds_bytes(algo) > 160 * 1024)
+   if (m->spec.split_lds_bytes(algo, split_flags(m, algo, soa), m->nq, m->nv) > 160 * 1024)
       return false;
    if (m->use_split == 1 || algo == 1)
       return true; // ABA: the split form also needs fewer registers and measured faster at every batch size
@@ -260,7 +267,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
    {
       const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
-      const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, model->ident_maps ? SPEC_IDENT : 0, &A, (int)groups, (void *)stream);
+      const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa), &A, (int)groups, (void *)stream);
       if (rc != 0)
          return fail(MH_ERR_HIP, "tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
       return MH_OK;
@@ -837,7 +844,7 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    A.coriolis = 1, A.accel = 1;
    if (split_ok(model, 2, B, false))
    {
-      const int rc2 = model->spec.launch_split(2, model->ident_maps ? SPEC_IDENT : 0, &A, (int)waves, opts.stream);
+      const int rc2 = model->spec.launch_split(2, split_flags(model, 2, false), &A, (int)waves, opts.stream);
       if (rc2 != 0)
          return fail(MH_ERR_HIP, "fused tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc2));
       return MH_OK;

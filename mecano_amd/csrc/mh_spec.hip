@@ -99,70 +99,82 @@ hipError_t go_fused(const mh::Args<double> &A, int waves, hipStream_t stream)
 }
 
 using SPL = mh::Split<TP>;
-long split_lds_bytes(int algo)
+long split_lds_bytes(int algo, int flags, int nq, int nv)
 {
-   return (long)(SPL::n_limbs() * (algo == 0 ? 6 : 27) + (algo == 1 ? SPL::TRUNK_SLOTS : 0)) * 64 * sizeof(double);
+   if (algo == 2)
+      return std::max(split_lds_bytes(0, flags, nq, nv), split_lds_bytes(1, flags, nq, nv));
+   long b = (long)(SPL::n_limbs() * (algo == 0 ? 6 : 27) + (algo == 1 ? SPL::TRUNK_SLOTS : 0)) * 64 * sizeof(double);
+   if (flags & F_IO_LDS)
+      b += (long)(nq + 2 * nv) * 64 * sizeof(double);
+   return b;
 }
-template <bool ID>
+template <class K>
+hipError_t launch_lds(K kern, const mh::Args<double> &A, int grid, size_t lds, size_t &attr_bytes, hipStream_t stream)
+{
+   if (lds > 64 * 1024 && lds > attr_bytes)
+   {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess)
+         return e;
+      attr_bytes = lds;
+   }
+   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, A);
+   return hipGetLastError();
+}
+template <bool ID, bool IO>
 hipError_t go_fused_split(const mh::Args<double> &A, int groups, hipStream_t stream)
 {
    if constexpr (SPL::usable())
    {
-      auto kern = &mh::spec_fused_split_kernel<TP, double, ID>;
-      const size_t lds = (size_t)std::max(split_lds_bytes(0), split_lds_bytes(1));
       static size_t attr_bytes = 0;
-      if (lds > 64 * 1024 && lds > attr_bytes)
-      {
-         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-         if (e != hipSuccess)
-            return e;
-         attr_bytes = lds;
-      }
-      hipLaunchKernelGGL(kern, dim3(2 * groups), dim3(256), lds, stream, A);
-      return hipGetLastError();
+      return launch_lds(&mh::spec_fused_split_kernel<TP, double, ID, IO>, A, 2 * groups,
+                        (size_t)split_lds_bytes(2, IO ? F_IO_LDS : 0, A.m.nq, A.m.nv), attr_bytes, stream);
    }
    else
       return hipErrorNotSupported;
 }
-template <int ALGO, bool ID>
+template <int ALGO, bool ID, bool IO>
 hipError_t go_split(const mh::Args<double> &A, int groups, hipStream_t stream)
 {
    if constexpr (SPL::usable())
    {
-      auto kern = &mh::spec_split_kernel<TP, double, ALGO, ID>;
-      const size_t lds = (size_t)split_lds_bytes(ALGO);
       static size_t attr_bytes = 0;
-      if (lds > 64 * 1024 && lds > attr_bytes)
-      {
-         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-         if (e != hipSuccess)
-            return e;
-         attr_bytes = lds;
-      }
-      hipLaunchKernelGGL(kern, dim3(groups), dim3(256), lds, stream, A);
-      return hipGetLastError();
+      return launch_lds(&mh::spec_split_kernel<TP, double, ALGO, ID, IO>, A, groups,
+                        (size_t)split_lds_bytes(ALGO, IO ? F_IO_LDS : 0, A.m.nq, A.m.nv), attr_bytes, stream);
    }
    else
       return hipErrorNotSupported;
+}
+template <bool ID, bool IO>
+hipError_t go_split_algo(int algo, const mh::Args<double> &A, int groups, hipStream_t s)
+{
+   if (algo == 2)
+      return go_fused_split<ID, IO>(A, groups, s);
+   if (algo == 0)
+      return go_split<0, ID, IO>(A, groups, s);
+   if (algo == 1)
+      return go_split<1, ID, IO>(A, groups, s);
+   return hipErrorNotSupported;
 }
 
 extern "C" {
 // tree-split kernels (4 waves per 64 configurations): available when the tree has a trunk with at least two limbs
 int mh_spec_split_usable(void) { return SPL::usable() ? 1 : 0; }
-long mh_spec_split_lds_bytes(int algo) { return algo == 2 ? std::max(split_lds_bytes(0), split_lds_bytes(1)) : split_lds_bytes(algo); }
-// algo: 0 = RNEA, 1 = ABA, 2 = fused RNEA+ABA (2 * groups workgroups); groups = ceil(B / 64) or fewer (grid-stride)
+long mh_spec_split_lds_bytes(int algo, int flags, int nq, int nv) { return split_lds_bytes(algo, flags, nq, nv); }
+// algo: 0 = RNEA, 1 = ABA, 2 = fused RNEA+ABA (2 * groups workgroups); groups = ceil(B / 64) or fewer (grid-stride).
+// flags: F_IDENT, F_IO_LDS (AoS rows staged in LDS; needs dense index maps)
 int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void *stream)
 {
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
-   const bool id = flags & F_IDENT;
+   const bool id = flags & F_IDENT, io = flags & F_IO_LDS;
    hipStream_t s = (hipStream_t)stream;
-   if (algo == 2)
-      return (int)(id ? go_fused_split<true>(A, groups, s) : go_fused_split<false>(A, groups, s));
-   if (algo == 0)
-      return (int)(id ? go_split<0, true>(A, groups, s) : go_split<0, false>(A, groups, s));
-   if (algo == 1)
-      return (int)(id ? go_split<1, true>(A, groups, s) : go_split<1, false>(A, groups, s));
-   return (int)hipErrorNotSupported;
+   if (id && io)
+      return (int)go_split_algo<true, true>(algo, A, groups, s);
+   if (id)
+      return (int)go_split_algo<true, false>(algo, A, groups, s);
+   if (io)
+      return (int)go_split_algo<false, true>(algo, A, groups, s);
+   return (int)go_split_algo<false, false>(algo, A, groups, s);
 }
 int mh_spec_n(void) { return TP::N; }
 const int *mh_spec_parents(void) { return kParents; }

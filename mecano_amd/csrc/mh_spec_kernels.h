@@ -761,34 +761,38 @@ MH_DEV void aba_roots_out(const CX &cx)
 // Coalesced copy of the wave's rows of q, qd and qdd|tau (contiguous blocks of the AoS matrices) into LDS.  ALL loads are
 // issued before the first LDS write, so the whole staging costs one memory round trip (about a microsecond) instead of one
 // per chunk; 64 * (NQ + 2 NV) elements = NQ + 2 NV loads per lane held in registers for that moment.
-template <typename T, int NQ, int NV>
+template <typename T, int NQ, int NV, int NT = 64>
 MH_DEV void wave_stage_in(lds_ptr<T> lq, lds_ptr<T> lqd, lds_ptr<T> lx, const T *q, const T *qd, const T *x, int rows)
-{
-   T rq[NQ], rd[NV], rx[NV];
+{ // NT = threads of the workgroup taking part (64: one wave; 256: the four waves of a tree-split group)
+   constexpr int UQ = (64 * NQ + NT - 1) / NT, UV = (64 * NV + NT - 1) / NT;
+   T rq[UQ], rd[UV], rx[UV];
    const int nq = rows * NQ, nv = rows * NV, t = threadIdx.x;
 #pragma unroll
-   for (int u = 0; u < NQ; u++)
-      rq[u] = t + 64 * u < nq ? q[t + 64 * u] : T(0);
+   for (int u = 0; u < UQ; u++)
+      rq[u] = t + NT * u < nq ? q[t + NT * u] : T(0);
 #pragma unroll
-   for (int u = 0; u < NV; u++)
-      rd[u] = t + 64 * u < nv ? qd[t + 64 * u] : T(0);
+   for (int u = 0; u < UV; u++)
+      rd[u] = t + NT * u < nv ? qd[t + NT * u] : T(0);
 #pragma unroll
-   for (int u = 0; u < NV; u++)
-      rx[u] = t + 64 * u < nv ? x[t + 64 * u] : T(0);
+   for (int u = 0; u < UV; u++)
+      rx[u] = t + NT * u < nv ? x[t + NT * u] : T(0);
 #pragma unroll
-   for (int u = 0; u < NQ; u++)
-      lq[t + 64 * u] = rq[u];
+   for (int u = 0; u < UQ; u++)
+      if (t + NT * u < 64 * NQ)
+         lq[t + NT * u] = rq[u];
 #pragma unroll
-   for (int u = 0; u < NV; u++)
-      lqd[t + 64 * u] = rd[u];
+   for (int u = 0; u < UV; u++)
+      if (t + NT * u < 64 * NV)
+         lqd[t + NT * u] = rd[u];
 #pragma unroll
-   for (int u = 0; u < NV; u++)
-      lx[t + 64 * u] = rx[u];
+   for (int u = 0; u < UV; u++)
+      if (t + NT * u < 64 * NV)
+         lx[t + NT * u] = rx[u];
 }
-template <typename T>
+template <typename T, int NT = 64>
 MH_DEV void wave_copy_out(T *dst, lds_ptr<T> src, int n)
 {
-   for (int i = threadIdx.x; i < n; i += 64)
+   for (int i = threadIdx.x; i < n; i += NT)
       dst[i] = src[i];
 }
 
@@ -949,24 +953,33 @@ MH_DEV void split_aba_limbs(const CX &cx)
    }
 }
 
-// One workgroup's share of a batch.  ALGO: 0 = RNEA, 1 = ABA.  State rows are read directly from global memory.
-template <class TP, typename T, int ALGO, bool IDENT>
+// One workgroup's share of a batch.  ALGO: 0 = RNEA, 1 = ABA.  IO_LDS: the 64 rows of q, qd, qdd|tau are staged once in LDS
+// by all 256 threads (the four waves share them) and the results leave through LDS as one coalesced copy.
+template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS>
 MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> lds)
 {
    using S = Split<TP>;
-   using CX = Ctx<T, false, IDENT, SplitStore<TP>>;
+   using CX = Ctx<T, IO_LDS, IDENT, SplitStore<TP>>;
    constexpr int XW = ALGO == 0 ? 6 : 27;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
-   // LDS map: exchange [n_limbs * XW][64] | trunk hand-over slots [TRUNK_SLOTS][64] (ABA)
-   const lds_ptr<T> lxc = lds, lst = lds + S::n_limbs() * XW * 64;
+   const int nq = A.m.nq, nv = A.m.nv;
+   // LDS map: exchange [n_limbs * XW][64] | trunk hand-over slots [TRUNK_SLOTS][64] (ABA) | [64][nq] q | [64][nv] qd | [64][nv] qdd|tau -> result
+   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * XW * 64, lq = lst + (ALGO == 1 ? S::TRUNK_SLOTS * 64 : 0), lqd = lq + 64 * nq,
+                    lx = lqd + 64 * nv;
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
    for (long cfg0 = group * 64; cfg0 < A.B; cfg0 += ngroups * 64)
    {
-      const bool active = cfg0 + lane < A.B;
+      const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+      const bool active = lane < rows;
+      if constexpr (IO_LDS)
+      {
+         wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
+         __syncthreads();
+      }
       CX cx;
       fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
-      cx.lq = lds, cx.lqd = lds, cx.lx = lds, cx.lo = lds; // unused: rows are read from global memory
+      cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = cx.lx;
       cx.wave = wave;
       cx.xbase = lxc + lane;
       cx.st.lbase = lst + lane;
@@ -990,34 +1003,39 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
          {
             aba_roots_in<TP, T, CX, 1>(cx);
             asm volatile("" ::: "memory");
-            asm volatile("" : "+v"(cx.qrow), "+v"(cx.qdrow), "+v"(cx.st.lbase));
+            asm volatile("" : "+v"(cx.qrow), "+v"(cx.qdrow), "+v"(cx.lq), "+v"(cx.lqd), "+v"(cx.st.lbase));
             aba_roots_out<TP, T, CX, 1>(cx);
          }
       }
-      __syncthreads(); // the exchange area is reused by the next batch slice
+      __syncthreads(); // results complete; the exchange area is free for the next batch slice
+      if constexpr (IO_LDS)
+      {
+         wave_copy_out<T, 256>(A.out + cfg0 * nv, lx, rows * nv);
+         __syncthreads();
+      }
    }
 }
 
 // Fused RNEA + ABA, tree-split: workgroups [0, G) compute tau = RNEA(q, qd, qdd), workgroups [G, 2G) qdd = ABA(q, qd, tau_in).
-template <class TP, typename T, bool IDENT>
+template <class TP, typename T, bool IDENT, bool IO_LDS>
 __global__ void __launch_bounds__(256) spec_fused_split_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
    const long half = gridDim.x / 2;
    if ((long)blockIdx.x < half)
-      split_group<TP, T, 0, IDENT>(A, blockIdx.x, half, (lds_ptr<T>)lds_raw);
+      split_group<TP, T, 0, IDENT, IO_LDS>(A, blockIdx.x, half, (lds_ptr<T>)lds_raw);
    else
    {
       Args<T> A2 = A;
       A2.in3 = A.in3b, A2.out = A.outb;
-      split_group<TP, T, 1, IDENT>(A2, blockIdx.x - half, half, (lds_ptr<T>)lds_raw);
+      split_group<TP, T, 1, IDENT, IO_LDS>(A2, blockIdx.x - half, half, (lds_ptr<T>)lds_raw);
    }
 }
-template <class TP, typename T, int ALGO, bool IDENT>
+template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS>
 __global__ void __launch_bounds__(256) spec_split_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
-   split_group<TP, T, ALGO, IDENT>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
+   split_group<TP, T, ALGO, IDENT, IO_LDS>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
 }
 
 } // namespace mh
