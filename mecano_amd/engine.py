@@ -155,6 +155,33 @@ class HipModel:
                                        qdd_out.data_ptr()))
         return tau_out, qdd_out
 
+    def bind_rnea_aba(self, q, qd, qdd, tau, tau_out, qdd_out, gravity=(0.0, 0.0, -9.81), f_ext=None):
+        """Returns a zero-argument callable that issues mh_rnea_aba_f64 on the given (caller-owned, device-resident) buffers.
+        All argument marshalling is done once here: a steady-state caller (a simulation loop, bench.py) pays one C call per step."""
+        import torch
+        lib = _lib.load()
+        tensors = (q, qd, qdd, tau, tau_out, qdd_out) + ((f_ext,) if f_ext is not None else ())
+        for t in tensors:
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("bind_rnea_aba needs contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
+        if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau, tau_out, qdd_out)):
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        args = (self._h, ctypes.c_int64(B), ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(qd.data_ptr()), ctypes.c_void_p(qdd.data_ptr()),
+                ctypes.c_void_p(tau.data_ptr()), g, ctypes.c_void_p(f_ext.data_ptr()) if f_ext is not None else None, ctypes.byref(opts),
+                ctypes.c_void_p(tau_out.data_ptr()), ctypes.c_void_p(qdd_out.data_ptr()))
+        fn = lib.mh_rnea_aba_f64
+        keep = (tensors, g, opts)
+
+        def call(_fn=fn, _args=args, _keep=keep):
+            st = _fn(*_args)
+            if st:
+                _lib.check(st)
+
+        return call
+
     def crba(self, q, layout=_lib.LAYOUT_AOS):
         return self._run("crba", q, None, None, (0.0, 0.0, 0.0), None, layout, True, True)
 
