@@ -107,9 +107,9 @@ struct Tree
 
 // Compile-time partition of the tree for the tree-split kernels: 4 waves of a workgroup walk the SAME 64 configurations.
 //   trunk = every body with two or more child subtrees, and all its ancestors  (humanoid: pelvis, spine 1-3)
-//   limbs = the chains hanging off the trunk with at least MIN_LIMB bodies       (legs, arms); shorter ones stay with the trunk
+//   limbs = the chains hanging off the trunk with at least MIN_LIMB bodies       (legs, arms, neck)
 // Every wave walks the trunk (redundantly: it would idle otherwise); each limb is walked by one wave only (greedy balance).
-template <class TP, int WAVES = 4, int MIN_LIMB = 2>
+template <class TP, int WAVES = 4, int MIN_LIMB = 1>
 struct Split
 {
    using TR = Tree<TP>;
