@@ -201,6 +201,16 @@ int mh_spec_launch_fused(int flags, const void *args, int waves, void *stream)
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    return (int)((flags & F_IDENT) ? go_fused<true>(A, waves, (hipStream_t)stream) : go_fused<false>(A, waves, (hipStream_t)stream));
 }
+// CRBA (fp64): H must have been zero-filled; grid = waves
+int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
+{
+   const mh::Args<double> &A = *(const mh::Args<double> *)args;
+   if (flags & F_IDENT)
+      hipLaunchKernelGGL((mh::spec_crba_kernel<TP, double, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   else
+      hipLaunchKernelGGL((mh::spec_crba_kernel<TP, double, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   return (int)hipGetLastError();
+}
 // algo: 0 = RNEA, 1 = ABA; fp64 only.  args points to mh::Args<double>.
 int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream)
 {

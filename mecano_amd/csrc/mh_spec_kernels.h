@@ -66,6 +66,20 @@ struct Tree
          c += TP::parent[i] == j ? 1 : 0;
       return c;
    }
+   static constexpr int depth(int j)
+   { // number of ancestors (a root has depth 0)
+      int d = 0;
+      for (int p = TP::parent[j]; p >= 0; p = TP::parent[p])
+         d++;
+      return d;
+   }
+   static constexpr int ancestor_at_depth(int j, int d)
+   {
+      int a = j;
+      for (int k = depth(j); k > d; k--)
+         a = TP::parent[a];
+      return a;
+   }
    static constexpr int height(int j)
    { // longest chain of joints below j (a leaf has height 0); children have larger indices than their parent
       int h = 0;
@@ -296,6 +310,7 @@ struct Ctx
    V3<T> a0l;              // linear part of the root acceleration (-g)
    int coriolis, accel;
    LaneStore<T, SP> st;
+   int nv;                       // CRBA: rows of H
    int wave;                     // tree-split kernels: which wave of the workgroup this is
    lds_ptr<T> xbase;             // tree-split kernels: limb -> trunk exchange area in LDS (+ lane)
 
@@ -757,6 +772,130 @@ MH_DEV void aba_roots_out(const CX &cx)
    }
 }
 
+// ============================================================================================ CRBA
+// Composite-rigid-body mass matrix as one depth-first recursion (CompositeRigidBodyMassMatrixCalculator.java:588-707, 770-798).
+// The joint transforms of the ancestors travel down the recursion in a compile-time-sized path (registers), so that the force
+// vectors F = Ic S of a body can climb to the root without recomputing or reloading anything but the constant poses.
+template <typename T, int D>
+struct CrbaPath
+{
+   JX<T> jx[D > 0 ? D : 1]; // index = depth of the ancestor
+};
+template <int R, int C, class CX, typename T>
+MH_DEV void h_put(const CX &cx, T v)
+{ // H[dof R][dof C] and its mirror image (setSymmetricEntry, :841-845)
+   const long r = cx.di(R), c = cx.di(C);
+   cx.orow[(r * cx.nv + c) * cx.v_es] = v;
+   if constexpr (R != C)
+      cx.orow[(c * cx.nv + r) * cx.v_es] = v;
+}
+template <class TP, int J, typename T, class CX, int D>
+struct CrbaSub
+{
+   using TR = Tree<TP>;
+   template <int K>
+   static MH_DEV void children(const CX &cx, const CrbaPath<T, D + 1> &path, RI<T> &acc)
+   {
+      if constexpr (K < TR::n_children(J))
+      {
+         const RI<T> r = CrbaSub<TP, TR::child(J, K), T, CX, D + 1>::run(cx, path);
+         if constexpr (K == 0)
+            acc = r;
+         else
+            add(acc, r);
+         children<K + 1>(cx, path, acc);
+      }
+   }
+   // rows of ancestor A (at depth DA < D) against column COL of joint J; F arrives expressed in A's frame
+   template <int A, int COL>
+   static MH_DEV void write_ancestor(const CX &cx, const SV<T> &F)
+   {
+      constexpr int TA = TP::type[A], DA = TR::dof_ofs(A);
+      if constexpr (TA == JT_REVOLUTE)
+         h_put<DA, COL, CX, T>(cx, F.a.z);
+      else if constexpr (TA == JT_PRISMATIC)
+         h_put<DA, COL, CX, T>(cx, F.l.z);
+      else if constexpr (TA == JT_SIXDOF)
+      {
+         h_put<DA + 0, COL, CX, T>(cx, F.a.x), h_put<DA + 1, COL, CX, T>(cx, F.a.y), h_put<DA + 2, COL, CX, T>(cx, F.a.z);
+         h_put<DA + 3, COL, CX, T>(cx, F.l.x), h_put<DA + 4, COL, CX, T>(cx, F.l.y), h_put<DA + 5, COL, CX, T>(cx, F.l.z);
+      }
+   }
+   // climb from the body at depth DC (frame of F) to its parent, write the parent's rows, continue to the root
+   template <int DC, int COL>
+   static MH_DEV void climb(const CX &cx, const CrbaPath<T, D + 1> &path, SV<T> F)
+   {
+      if constexpr (DC > 0)
+      {
+         constexpr int CUR = TR::ancestor_at_depth(J, DC), PAR = TR::ancestor_at_depth(J, DC - 1);
+         const CRef<T, false> c{cx.C + CUR * MC_STRIDE};
+         F = force_up(TP::type[CUR], path.jx[DC], load_xb<T>(c), F);
+         write_ancestor<PAR, COL>(cx, F);
+         climb<DC - 1, COL>(cx, path, F);
+      }
+   }
+   template <int K>
+   static MH_DEV void columns(const CX &cx, const CrbaPath<T, D + 1> &path, const RI<T> &Ic)
+   {
+      constexpr int TYPE = TP::type[J], ND = TR::ndof(J), DO = TR::dof_ofs(J);
+      if constexpr (K < ND)
+      {
+         const SV<T> F = mul(Ic, unit_twist<T>(TYPE, K)); // :663-667
+         // diagonal block: rows K..ND-1 of column K (the mirror image is written by h_put)
+         if constexpr (TYPE == JT_REVOLUTE)
+            h_put<DO, DO, CX, T>(cx, F.a.z);
+         else if constexpr (TYPE == JT_PRISMATIC)
+            h_put<DO, DO, CX, T>(cx, F.l.z);
+         else
+         {
+            if constexpr (K <= 0) h_put<DO + 0, DO + K, CX, T>(cx, F.a.x);
+            if constexpr (K <= 1) h_put<DO + 1, DO + K, CX, T>(cx, F.a.y);
+            if constexpr (K <= 2) h_put<DO + 2, DO + K, CX, T>(cx, F.a.z);
+            if constexpr (K <= 3) h_put<DO + 3, DO + K, CX, T>(cx, F.l.x);
+            if constexpr (K <= 4) h_put<DO + 4, DO + K, CX, T>(cx, F.l.y);
+            if constexpr (K <= 5) h_put<DO + 5, DO + K, CX, T>(cx, F.l.z);
+         }
+         climb<D, DO + K>(cx, path, F); // :783-792
+         columns<K + 1>(cx, path, Ic);
+      }
+   }
+   static MH_DEV RI<T> run(const CX &cx, const CrbaPath<T, D> &up)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J], CO = TR::cfg_ofs(J);
+      constexpr bool LEAF = TR::n_children(J) == 0;
+      CrbaPath<T, D + 1> path;
+#pragma unroll
+      for (int d = 0; d < D; d++)
+         path.jx[d] = up.jx[d];
+      path.jx[D] = spec_joint<TYPE, CO, CX, T>(cx);
+      RI<T> acc;
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+         children<0>(cx, path, acc);
+      MH_BODY_FENCE();
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      RI<T> Ic = load_inertia<T>(c);
+      if constexpr (!LEAF)
+         add(Ic, acc);
+      columns<0>(cx, path, Ic);
+      if constexpr (TP::parent[J] >= 0)
+         rigid_up(TYPE, path.jx[D], load_xb<T>(c), Ic); // :651-661
+      MH_BODY_FENCE();
+      return Ic;
+   }
+};
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void crba_roots(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      CrbaPath<T, 0> empty;
+      (void)CrbaSub<TP, Tree<TP>::child(-1, K), T, CX, 0>::run(cx, empty);
+      crba_roots<TP, T, CX, K + 1>(cx);
+   }
+}
+
 // ============================================================================================ kernels
 // Coalesced copy of the wave's rows of q, qd and qdd|tau (contiguous blocks of the AoS matrices) into LDS.  ALL loads are
 // issued before the first LDS write, so the whole staging costs one memory round trip (about a microsecond) instead of one
@@ -1036,6 +1175,23 @@ __global__ void __launch_bounds__(256) spec_split_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
    split_group<TP, T, ALGO, IDENT, IO_LDS>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
+}
+
+// CRBA: H [B][nv][nv] (or [nv*nv][B]) must be zero-filled by the caller; only entries of related joints are written.
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(64) spec_crba_kernel(Args<T> A)
+{
+   using CX = Ctx<T, false, IDENT, WholeStore<TP, ST_GLOBAL_KIND>>;
+   const long lane = (long)blockIdx.x * 64 + threadIdx.x, nlanes = (long)gridDim.x * 64;
+   warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      CX cx;
+      fill_ctx<T>(cx, A, cfg);
+      cx.nv = A.m.nv;
+      cx.wave = 0;
+      crba_roots<TP, T, CX>(cx);
+   }
 }
 
 } // namespace mh
