@@ -41,7 +41,7 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=12.0):
     om.rnea(q[:n], qd[:n], qdd[:n], gravity)
     om.aba(q[:n], qd[:n], tau[:n], gravity)
     per = (time.perf_counter() - t0) / n
-    count = int(min(len(q) * 64, max(n, target_s / per)))
+    count = int(min(len(q) * 1024, max(n, target_s / per)))
     reps, rem = divmod(count, len(q))
     t0 = time.perf_counter()
     done = 0
