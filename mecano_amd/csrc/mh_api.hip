@@ -100,6 +100,7 @@ struct SpecLib
    int (*launch_fused)(int flags, const void *args, int waves, void *stream) = nullptr;
    long (*fused_lds_bytes)(int nq, int nv) = nullptr;
    int (*launch_crba)(int flags, const void *args, int grid, void *stream) = nullptr;
+   int (*crba_packed)(int flags) = nullptr;
    int (*split_usable)(void) = nullptr;
    long (*split_lds_bytes)(int algo, int flags, int nq, int nv) = nullptr;
    int (*launch_split)(int algo, int flags, const void *args, int groups, void *stream) = nullptr;
@@ -324,15 +325,20 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       case ALGO_CRBA:
       {
          const size_t hbytes = (size_t)B * model->nv * model->nv * sizeof(T);
-         HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
          A.v_bs = soa ? 1 : (long)model->nv * model->nv;
-         if (model->spec.launch_crba && model->use_spec && sizeof(T) == 8)
+         if (model->spec.launch_crba && model->spec.crba_packed && model->use_spec && sizeof(T) == 8)
          {
-            const int rc = model->spec.launch_crba(model->ident_maps ? SPEC_IDENT : 0, &A, L.grid, (void *)stream);
+            const int sflags = (model->ident_maps && model->dense_maps) ? SPEC_IDENT : 0;
+            const bool packed = model->spec.crba_packed(sflags) != 0;
+            if (!packed)
+               HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream)); // direct-store kernel writes related entries only
+            const int grid = packed ? (int)std::min<long>((B + 63) / 64, (long)model->cu_count) : L.grid;
+            const int rc = model->spec.launch_crba(sflags, &A, grid, (void *)stream);
             if (rc != 0)
                return fail(MH_ERR_HIP, "specialised CRBA launch failed: %s", hipGetErrorString((hipError_t)rc));
             return MH_OK;
          }
+         HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
          hipLaunchKernelGGL((mh::crba_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
          break;
       }
@@ -509,6 +515,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.launch_fused = (decltype(s.launch_fused))dlsym(h, "mh_spec_launch_fused");
    s.fused_lds_bytes = (decltype(s.fused_lds_bytes))dlsym(h, "mh_spec_fused_lds_bytes");
    s.launch_crba = (decltype(s.launch_crba))dlsym(h, "mh_spec_launch_crba");
+   s.crba_packed = (decltype(s.crba_packed))dlsym(h, "mh_spec_crba_packed");
    s.split_usable = (decltype(s.split_usable))dlsym(h, "mh_spec_split_usable");
    s.split_lds_bytes = (decltype(s.split_lds_bytes))dlsym(h, "mh_spec_split_lds_bytes");
    s.launch_split = (decltype(s.launch_split))dlsym(h, "mh_spec_launch_split");

@@ -201,11 +201,27 @@ int mh_spec_launch_fused(int flags, const void *args, int waves, void *stream)
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    return (int)((flags & F_IDENT) ? go_fused<true>(A, waves, (hipStream_t)stream) : go_fused<false>(A, waves, (hipStream_t)stream));
 }
-// CRBA (fp64): H must have been zero-filled; grid = waves
+// CRBA (fp64).  Returns in *needs_zero_fill whether the caller must zero H first (direct-store kernel) or not (packed kernel).
+long mh_spec_crba_lds_bytes(void) { return (long)mh::HMap<TP>::T.n_slots * 64 * sizeof(double); }
+int mh_spec_crba_packed(int flags) { return (flags & F_IDENT) && mh_spec_crba_lds_bytes() <= 160 * 1024 ? 1 : 0; }
 int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
 {
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
-   if (flags & F_IDENT)
+   if (mh_spec_crba_packed(flags))
+   {
+      auto kern = &mh::spec_crba_packed_kernel<TP, double>;
+      const size_t lds = (size_t)mh_spec_crba_lds_bytes();
+      static size_t attr_bytes = 0;
+      if (lds > 64 * 1024 && lds > attr_bytes)
+      {
+         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess)
+            return (int)e;
+         attr_bytes = lds;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, (hipStream_t)stream, A);
+   }
+   else if (flags & F_IDENT)
       hipLaunchKernelGGL((mh::spec_crba_kernel<TP, double, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
    else
       hipLaunchKernelGGL((mh::spec_crba_kernel<TP, double, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);

@@ -781,15 +781,58 @@ struct CrbaPath
 {
    JX<T> jx[D > 0 ? D : 1]; // index = depth of the ancestor
 };
-template <int R, int C, class CX, typename T>
+// Which entries of H are structurally non-zero (joint of the row is an ancestor or descendant of, or the same as, the joint of
+// the column) and where the lower-triangle ones live in the packed per-lane LDS image used by the coalesced write-out.
+template <class TP>
+struct HMap
+{
+   using TR = Tree<TP>;
+   static constexpr int N = TP::N, NV = TR::total_dofs();
+   struct Table
+   {
+      short slot[NV * NV > 0 ? NV * NV : 1] = {}; // packed slot of entry (r, c), -1 = structural zero
+      int n_slots = 0;
+   };
+   static constexpr Table make()
+   {
+      Table t;
+      int joint_of[NV > 0 ? NV : 1] = {};
+      for (int j = 0; j < N; j++)
+         for (int k = 0; k < TR::ndof(j); k++)
+            joint_of[TR::dof_ofs(j) + k] = j;
+      for (int r = 0; r < NV; r++)
+         for (int c = 0; c <= r; c++)
+         {
+            // related: joint_of[c] is joint_of[r] or one of its ancestors (dofs are numbered parents-first)
+            bool related = false;
+            for (int a = joint_of[r]; a >= 0; a = TP::parent[a])
+               if (a == joint_of[c])
+                  related = true;
+            const short s = related ? (short)t.n_slots++ : (short)-1;
+            t.slot[r * NV + c] = s;
+            t.slot[c * NV + r] = s;
+         }
+      return t;
+   }
+   static constexpr Table T = make();
+};
+
+// PACK = false: H[dof R][dof C] and its mirror image go straight to global memory (setSymmetricEntry, :841-845).
+// PACK = true : the value goes to the lane's packed LDS image; the kernel writes H out afterwards, zeros included, in address order.
+template <class TP, bool PACK, int R, int C, class CX, typename T>
 MH_DEV void h_put(const CX &cx, T v)
-{ // H[dof R][dof C] and its mirror image (setSymmetricEntry, :841-845)
-   const long r = cx.di(R), c = cx.di(C);
-   cx.orow[(r * cx.nv + c) * cx.v_es] = v;
-   if constexpr (R != C)
-      cx.orow[(c * cx.nv + r) * cx.v_es] = v;
+{
+   if constexpr (PACK)
+      cx.xbase[HMap<TP>::T.slot[R * HMap<TP>::NV + C] * 64] = v;
+   else
+   {
+      const long r = cx.di(R), c = cx.di(C);
+      cx.orow[(r * cx.nv + c) * cx.v_es] = v;
+      if constexpr (R != C)
+         cx.orow[(c * cx.nv + r) * cx.v_es] = v;
+   }
 }
-template <class TP, int J, typename T, class CX, int D>
+template <class TP, int J, typename T, class CX, int D, bool PACK>
 struct CrbaSub
 {
    using TR = Tree<TP>;
@@ -798,7 +841,7 @@ struct CrbaSub
    {
       if constexpr (K < TR::n_children(J))
       {
-         const RI<T> r = CrbaSub<TP, TR::child(J, K), T, CX, D + 1>::run(cx, path);
+         const RI<T> r = CrbaSub<TP, TR::child(J, K), T, CX, D + 1, PACK>::run(cx, path);
          if constexpr (K == 0)
             acc = r;
          else
@@ -812,13 +855,13 @@ struct CrbaSub
    {
       constexpr int TA = TP::type[A], DA = TR::dof_ofs(A);
       if constexpr (TA == JT_REVOLUTE)
-         h_put<DA, COL, CX, T>(cx, F.a.z);
+         h_put<TP, PACK, DA, COL, CX, T>(cx, F.a.z);
       else if constexpr (TA == JT_PRISMATIC)
-         h_put<DA, COL, CX, T>(cx, F.l.z);
+         h_put<TP, PACK, DA, COL, CX, T>(cx, F.l.z);
       else if constexpr (TA == JT_SIXDOF)
       {
-         h_put<DA + 0, COL, CX, T>(cx, F.a.x), h_put<DA + 1, COL, CX, T>(cx, F.a.y), h_put<DA + 2, COL, CX, T>(cx, F.a.z);
-         h_put<DA + 3, COL, CX, T>(cx, F.l.x), h_put<DA + 4, COL, CX, T>(cx, F.l.y), h_put<DA + 5, COL, CX, T>(cx, F.l.z);
+         h_put<TP, PACK, DA + 0, COL, CX, T>(cx, F.a.x), h_put<TP, PACK, DA + 1, COL, CX, T>(cx, F.a.y), h_put<TP, PACK, DA + 2, COL, CX, T>(cx, F.a.z);
+         h_put<TP, PACK, DA + 3, COL, CX, T>(cx, F.l.x), h_put<TP, PACK, DA + 4, COL, CX, T>(cx, F.l.y), h_put<TP, PACK, DA + 5, COL, CX, T>(cx, F.l.z);
       }
    }
    // climb from the body at depth DC (frame of F) to its parent, write the parent's rows, continue to the root
@@ -843,17 +886,17 @@ struct CrbaSub
          const SV<T> F = mul(Ic, unit_twist<T>(TYPE, K)); // :663-667
          // diagonal block: rows K..ND-1 of column K (the mirror image is written by h_put)
          if constexpr (TYPE == JT_REVOLUTE)
-            h_put<DO, DO, CX, T>(cx, F.a.z);
+            h_put<TP, PACK, DO, DO, CX, T>(cx, F.a.z);
          else if constexpr (TYPE == JT_PRISMATIC)
-            h_put<DO, DO, CX, T>(cx, F.l.z);
+            h_put<TP, PACK, DO, DO, CX, T>(cx, F.l.z);
          else
          {
-            if constexpr (K <= 0) h_put<DO + 0, DO + K, CX, T>(cx, F.a.x);
-            if constexpr (K <= 1) h_put<DO + 1, DO + K, CX, T>(cx, F.a.y);
-            if constexpr (K <= 2) h_put<DO + 2, DO + K, CX, T>(cx, F.a.z);
-            if constexpr (K <= 3) h_put<DO + 3, DO + K, CX, T>(cx, F.l.x);
-            if constexpr (K <= 4) h_put<DO + 4, DO + K, CX, T>(cx, F.l.y);
-            if constexpr (K <= 5) h_put<DO + 5, DO + K, CX, T>(cx, F.l.z);
+            if constexpr (K <= 0) h_put<TP, PACK, DO + 0, DO + K, CX, T>(cx, F.a.x);
+            if constexpr (K <= 1) h_put<TP, PACK, DO + 1, DO + K, CX, T>(cx, F.a.y);
+            if constexpr (K <= 2) h_put<TP, PACK, DO + 2, DO + K, CX, T>(cx, F.a.z);
+            if constexpr (K <= 3) h_put<TP, PACK, DO + 3, DO + K, CX, T>(cx, F.l.x);
+            if constexpr (K <= 4) h_put<TP, PACK, DO + 4, DO + K, CX, T>(cx, F.l.y);
+            if constexpr (K <= 5) h_put<TP, PACK, DO + 5, DO + K, CX, T>(cx, F.l.z);
          }
          climb<D, DO + K>(cx, path, F); // :783-792
          columns<K + 1>(cx, path, Ic);
@@ -885,14 +928,14 @@ struct CrbaSub
       return Ic;
    }
 };
-template <class TP, typename T, class CX, int K = 0>
+template <class TP, typename T, class CX, bool PACK, int K = 0>
 MH_DEV void crba_roots(const CX &cx)
 {
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       CrbaPath<T, 0> empty;
-      (void)CrbaSub<TP, Tree<TP>::child(-1, K), T, CX, 0>::run(cx, empty);
-      crba_roots<TP, T, CX, K + 1>(cx);
+      (void)CrbaSub<TP, Tree<TP>::child(-1, K), T, CX, 0, PACK>::run(cx, empty);
+      crba_roots<TP, T, CX, PACK, K + 1>(cx);
    }
 }
 
@@ -1177,7 +1220,8 @@ __global__ void __launch_bounds__(256) spec_split_kernel(Args<T> A)
    split_group<TP, T, ALGO, IDENT, IO_LDS>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
 }
 
-// CRBA: H [B][nv][nv] (or [nv*nv][B]) must be zero-filled by the caller; only entries of related joints are written.
+// CRBA, direct stores: H [B][nv][nv] (or [nv*nv][B]) must be zero-filled by the caller; only entries of related joints are
+// written.  Used when the index maps are not the identity.
 template <class TP, typename T, bool IDENT>
 __global__ void __launch_bounds__(64) spec_crba_kernel(Args<T> A)
 {
@@ -1190,7 +1234,59 @@ __global__ void __launch_bounds__(64) spec_crba_kernel(Args<T> A)
       fill_ctx<T>(cx, A, cfg);
       cx.nv = A.m.nv;
       cx.wave = 0;
-      crba_roots<TP, T, CX>(cx);
+      crba_roots<TP, T, CX, false>(cx);
+   }
+}
+// CRBA, packed: identity index maps.  The structurally non-zero lower-triangle entries are collected in a per-lane LDS image
+// (slot-major, 64 lanes per slot); afterwards every lane writes its own H -- all nv x nv entries, zeros included, ascending
+// addresses, 16 bytes per store -- so no memset pass is needed and every cache line is written exactly once.
+template <class TP, typename T>
+__global__ void __launch_bounds__(64) spec_crba_packed_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   using CX = Ctx<T, false, true, WholeStore<TP, ST_GLOBAL_KIND>>;
+   using HM = HMap<TP>;
+   constexpr int NV = HM::NV;
+   const lds_ptr<T> img = (lds_ptr<T>)lds_raw + threadIdx.x;
+   warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   const long wave = blockIdx.x, nwaves = gridDim.x;
+   for (long cfg0 = wave * 64; cfg0 < A.B; cfg0 += nwaves * 64)
+   {
+      const long cfg = cfg0 + threadIdx.x;
+      if (cfg < A.B)
+      {
+         CX cx;
+         fill_ctx<T>(cx, A, cfg);
+         cx.nv = NV;
+         cx.wave = 0;
+         cx.xbase = img;
+         crba_roots<TP, T, CX, true>(cx);
+         asm volatile("" ::: "memory");
+         T *H = A.out + cfg * A.v_bs;
+         const long es = A.v_es;
+         if (es == 1)
+         { // AoS: this lane's matrix is contiguous
+#pragma unroll
+            for (int e = 0; e + 1 < NV * NV; e += 2)
+            {
+               const int s0 = HM::T.slot[e], s1 = HM::T.slot[e + 1];
+               const T v0 = s0 >= 0 ? img[s0 * 64] : T(0), v1 = s1 >= 0 ? img[s1 * 64] : T(0);
+               H[e] = v0;
+               H[e + 1] = v1;
+            }
+            if constexpr ((NV * NV) % 2 == 1)
+               H[NV * NV - 1] = HM::T.slot[NV * NV - 1] >= 0 ? img[HM::T.slot[NV * NV - 1] * 64] : T(0);
+         }
+         else
+         { // SoA: entry e of all configurations is contiguous
+#pragma unroll
+            for (int e = 0; e < NV * NV; e++)
+            {
+               const int s0 = HM::T.slot[e];
+               H[e * es] = s0 >= 0 ? img[s0 * 64] : T(0);
+            }
+         }
+      }
    }
 }
 

@@ -358,6 +358,8 @@ def test_every_specialised_variant(torch_cuda, B):
         g = (0.3, -0.2, -9.81)
         idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 300)), [B - 1]]))
         t_ref, a_ref = om.rnea(q[idx], qd[idx], qdd[idx], g), om.aba(q[idx], qd[idx], tau[idx], g)
+        hidx = idx[:: max(1, len(idx) // 40)]
+        H_ref = om.crba(q[hidx])
         seen = set()
         try:
             off = {"MH_SPEC_SPLIT": "0"}
@@ -370,6 +372,8 @@ def test_every_specialised_variant(torch_cuda, B):
                 seen.add(hm.kernel_variant)
                 close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), g).cpu().numpy()[idx], t_ref)
                 close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g).cpu().numpy()[idx], a_ref)
+                if B <= 16448:
+                    close(hm.crba(dev(torch, q)).cpu().numpy()[hidx], H_ref)
                 t2, a2 = hm.rnea_aba(dev(torch, q), dev(torch, qd), dev(torch, qdd), dev(torch, tau), g)
                 close(t2.cpu().numpy()[idx], t_ref)
                 close(a2.cpu().numpy()[idx], a_ref)
