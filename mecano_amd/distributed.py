@@ -30,7 +30,8 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MECANO_DIST_BACKEND=gloo: run the multi-rank path without RCCL (e.g. several ranks sharing one GPU in a test)
+            backend = os.environ.get("MECANO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -76,7 +77,7 @@ def broadcast_model_desc(desc: Optional[ModelDesc], src: int = 0, device=None) -
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return desc
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    dev = device if device is not None else (f"cuda:{torch.cuda.current_device()}" if dist.get_backend() == "nccl" else "cpu")
     if dist.get_rank() == src:
         ints, f64 = pack_desc(desc)
         header = torch.tensor([len(ints), len(f64)], dtype=torch.int64, device=dev)
@@ -103,6 +104,8 @@ def all_gather_rows(local, B_total: int):
         return local
     world = dist.get_world_size()
     sizes = [shard_range(B_total, r, world)[1] - shard_range(B_total, r, world)[0] for r in range(world)]
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        return all_gather_rows(local.cpu(), B_total).to(local.device)
     if len(set(sizes)) == 1:
         out = torch.empty((B_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
