@@ -36,10 +36,8 @@ def _as_system(inp) -> MultiBodySystem:
 class _Base:
     def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
         self.input = _as_system(input)
-        if self.input.getJointsToIgnore() and considerIgnoredSubtreesInertia:
-            raise NotImplementedError("lumping of ignored subtrees (InverseDynamicsCalculator.java:832-860) is not implemented yet; "
-                                      "pass considerIgnoredSubtreesInertia=False")
-        self.model = HipModel(self.input.toModelDesc())
+        # ignored subtrees: their inertia is lumped into the body they hang from (InverseDynamicsCalculator.java:226-236, 832-860)
+        self.model = HipModel(self.input.toModelDesc(considerIgnoredSubtreesInertia=bool(considerIgnoredSubtreesInertia and self.input.getJointsToIgnore())))
         self._gravity = np.zeros(3)
         self._f_ext = None
         self.layout = _lib.LAYOUT_AOS

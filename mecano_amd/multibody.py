@@ -46,6 +46,57 @@ def _as_transform(transform) -> Optional[np.ndarray]:
 IDENTITY12 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
 
 
+def _skew(v):
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def _spatial_inertia6(J_origin, mass, com):
+    """6x6 [[J, m c~], [m c~^T, m 1]] with J about the frame origin (spatial/interfaces/SpatialInertiaReadOnly.java:394-415)."""
+    I = np.zeros((6, 6))
+    I[:3, :3] = J_origin
+    I[:3, 3:] = mass * _skew(com)
+    I[3:, :3] = mass * _skew(com).T
+    I[3:, 3:] = mass * np.eye(3)
+    return I
+
+
+def _xf(t12):
+    return t12[:9].reshape(3, 3), t12[9:]
+
+
+def _compose(a, b):
+    """a o b for (R, p) pairs: x -> Ra (Rb x + pb) + pa."""
+    return a[0] @ b[0], a[0] @ b[1] + a[1]
+
+
+def _inertia_to_parent(I6, R, p):
+    """Re-expresses a 6x6 inertia given in a child frame posed (R, p) in the parent frame: X^-T I X^-1 with the motion transform X."""
+    X = np.zeros((6, 6))
+    X[:3, :3] = R
+    X[3:, 3:] = R
+    X[3:, :3] = _skew(p) @ R
+    Xi = np.linalg.inv(X)
+    return Xi.T @ I6 @ Xi
+
+
+def _subtree_inertia_in_parent_body_frame(joint):
+    """MultiBodySystemTools.computeSubtreeInertia(joint) re-expressed in the body-fixed frame of joint.getPredecessor(), with every
+    joint of the subtree at its zero configuration."""
+    body = joint.successor
+    I6 = _spatial_inertia6(body.momentOfInertia, body.mass, body.centerOfMassOffset)
+    for child in body.childrenJoints:
+        I6 = I6 + _subtree_inertia_in_parent_body_frame(child)
+    # body-fixed(child body) -> after-joint (inertiaPose) -> [joint at zero: identity] -> before-joint -> predecessor's after-joint frame
+    T = _xf(body.inertiaPose)
+    if joint.transformToParent is not None:
+        T = _compose(_xf(joint.transformToParent), T)
+    pred = joint.predecessor
+    if not pred.isRootBody():  # ... -> predecessor's body-fixed frame
+        Rc, pc = _xf(pred.inertiaPose)
+        T = _compose((Rc.T, -Rc.T @ pc), T)
+    return _inertia_to_parent(I6, T[0], T[1])
+
+
 class RigidBody:
     """multiBodySystem/RigidBody.java.  ``RigidBody(name)`` creates a root body ("elevator", :79-108);
     ``RigidBody(name, parentJoint, momentOfInertia, mass, centerOfMassOffset | inertiaPose)`` a moving body whose
@@ -291,8 +342,13 @@ class MultiBodySystem:
         return sum(j.getConfigurationMatrixSize() for j in self.jointsToConsider)
 
     # ------------------------------------------------------------------ flattening (INTEGRATION.md, Appendix B of SURVEY.md)
-    def toModelDesc(self) -> ModelDesc:
-        """Model-extraction recipe of tools/MultiBodySystemFactories.java:401-470,782-868 applied to this mirror."""
+    def toModelDesc(self, considerIgnoredSubtreesInertia: bool = False) -> ModelDesc:
+        """Model-extraction recipe of tools/MultiBodySystemFactories.java:401-470,782-868 applied to this mirror.
+
+        ``considerIgnoredSubtreesInertia``: the inertia of every ignored subtree is added to the body it hangs from, as
+        InverseDynamicsCalculator.java:832-860 does with MultiBodySystemTools.computeSubtreeInertia (:47-66).  Mecano freezes that
+        lump at the joint configuration current at construction time; the joints of this mirror carry no state, so the lump is
+        taken at the zero configuration (every ignored joint at its identity transform)."""
         provider = self.jointMatrixIndexProvider
         joints = provider.getIndexedJointsInOrder()
         index_of = {id(j): i for i, j in enumerate(joints)}
@@ -326,6 +382,20 @@ class MultiBodySystem:
             J[i] = body.momentOfInertia.reshape(9)
             mass[i] = body.mass
             com[i] = body.centerOfMassOffset
+            if considerIgnoredSubtreesInertia:
+                ignored_ids = {id(x) for x in self.jointsToIgnore}
+                I6 = _spatial_inertia6(body.momentOfInertia, body.mass, body.centerOfMassOffset)
+                lumped = False
+                for child in body.childrenJoints:
+                    if id(child) in ignored_ids:
+                        I6 = I6 + _subtree_inertia_in_parent_body_frame(child)
+                        lumped = True
+                if lumped:
+                    m_tot = I6[5, 5]
+                    mc = np.array([I6[2, 4], I6[0, 5], I6[1, 3]])  # m [c]x block: (2,1)->cx, (0,2)->cy, (1,0)->cz
+                    J[i] = I6[:3, :3].reshape(9)
+                    mass[i] = m_tot
+                    com[i] = mc / m_tot if abs(m_tot) >= 1.0e-7 else np.zeros(3)
             dof.extend(provider.getJointDoFIndices(j))
             cfg.extend(provider.getJointConfigurationIndices(j))
         nv = (max(dof) + 1) if dof else 0

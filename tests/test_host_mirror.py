@@ -77,3 +77,30 @@ def test_topology_key_depends_on_structure_only():
     assert a.topology_key() == b.topology_key()
     c = MultiBodySystem.toMultiBodySystemInput(rt.nextJointChain(rng, 7)[0].getPredecessor()).toModelDesc()
     assert c.topology_key() != a.topology_key()
+
+
+def test_ignored_subtree_lumping_equals_welding():
+    """considerIgnoredSubtreesInertia (InverseDynamicsCalculator.java:832-860): ignoring a joint and lumping its subtree into the
+    parent body is the same mechanical system as welding that subtree (fixed joints) at the zero configuration."""
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(12)
+
+    from helpers import build_lump_pair as build
+
+    root_w, _ = build(True)
+    welded = MultiBodySystem.toMultiBodySystemInput(root_w)
+    root_i, k0 = build(False)
+    ignoring = MultiBodySystem.toMultiBodySystemInput(root_i, [k0])
+    d_w = welded.toModelDesc()
+    d_i = ignoring.toModelDesc(considerIgnoredSubtreesInertia=True)
+    assert d_i.n_joints == 3 and d_w.n_joints == 5 and d_i.nv == d_w.nv == 3
+    assert np.abs(d_i.inertia_com.reshape(-1, 3)[0]).max() > 1e-3  # the lump moves the CoM off the body-fixed origin
+    q, qd, qdd, tau = rt.nextState(rng, ignoring, 4)
+    om_w, om_i = OracleModel(d_w), OracleModel(d_i)
+    g = (0.1, 0.2, -9.81)
+    assert np.allclose(om_i.rnea(q, qd, qdd, g), om_w.rnea(q, qd, qdd, g), rtol=0, atol=1e-11)
+    assert np.allclose(om_i.aba(q, qd, tau, g), om_w.aba(q, qd, tau, g), rtol=0, atol=1e-10)
+    assert np.allclose(om_i.crba(q), om_w.crba(q), rtol=0, atol=1e-11)
+    # without lumping the ignored subtree's inertia is simply gone: a different system
+    d_n = ignoring.toModelDesc(considerIgnoredSubtreesInertia=False)
+    assert np.abs(OracleModel(d_n).rnea(q, qd, qdd, g) - om_w.rnea(q, qd, qdd, g)).max() > 1e-3
