@@ -173,6 +173,32 @@ mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_opt
 mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
                           const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out);
 
+/*
+ * ---- joint source modes (ForwardDynamicsCalculator.JointSourceMode, ForwardDynamicsCalculator.java:45-57, 400-444) ----
+ * modes[n_joints], one per listed joint: MH_EFFORT_SOURCE (tau is the input, qdd the output; the default) or
+ * MH_ACCELERATION_SOURCE (the joint is "locked" onto a given acceleration: qdd is the input, tau the output).  NULL resets every
+ * joint to MH_EFFORT_SOURCE (resetJointSourceModes, :441-444).  Synchronises the device; not to be called while compute calls
+ * on this model are in flight.  While any joint is an acceleration source, forward dynamics goes through mh_aba_locked_f64 and
+ * mh_aba_f64 / mh_rnea_aba_f64 return MH_ERR_INVALID_ARGUMENT (they have no acceleration input).
+ */
+enum
+{
+   MH_EFFORT_SOURCE = 0,
+   MH_ACCELERATION_SOURCE = 1
+};
+mh_status mh_model_set_joint_source_modes(mh_model_t model, const int32_t *modes);
+/* number of joints currently in MH_ACCELERATION_SOURCE mode */
+int32_t mh_model_n_acceleration_sources(mh_model_t model);
+/*
+ * Forward dynamics with acceleration-source joints (ForwardDynamicsCalculator.compute(tau, qdd), :508-520, passes two/three/four
+ * :1237-1253, 1284-1297, 1315-1363).  tau [B][nv] is read at the DoFs of the effort-source joints, qdd_in [B][nv] at the DoFs of
+ * the acceleration-source joints (it may be NULL when there are none).  qdd_out receives every joint's acceleration (the given
+ * ones copied through); tau_out, when not NULL, every joint's effort (the given ones copied through, the efforts that realise the
+ * prescribed accelerations computed).  In-place use (qdd_out == qdd_in, tau_out == tau) is allowed.
+ */
+mh_status mh_aba_locked_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double *qdd_in,
+                            const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out, double *tau_out);
+
 mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd,
                       const double gravity[3], const float *f_ext, const mh_options *opts, float *tau_out);
 mh_status mh_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau,

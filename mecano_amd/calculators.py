@@ -91,17 +91,60 @@ class InverseDynamicsCalculator(_Base):
         return self._tau
 
 
+class JointSourceMode:
+    """ForwardDynamicsCalculator.JointSourceMode (ForwardDynamicsCalculator.java:45-57)."""
+    EFFORT_SOURCE = 0
+    ACCELERATION_SOURCE = 1
+
+
 class ForwardDynamicsCalculator(_Base):
+    JointSourceMode = JointSourceMode
+
     def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
         super().__init__(input, considerIgnoredSubtreesInertia)
         self._qdd = None
+        self._tau = None
+        self._modes = [JointSourceMode.EFFORT_SOURCE] * self.model.n_joints
+        self._joint_pos = {id(j): k for k, j in enumerate(self.input.getJointsToConsider())}
 
-    def compute(self, q, qd, tau):
-        self._qdd = self.model.aba(q, qd, tau, self._gravity, self._f_ext, self.layout)
+    # ---- joint source modes: ForwardDynamicsCalculator.java:400-444
+    def setJointSourceMode(self, joint, mode: int):
+        """``joint`` is a joint of the system (or its position in getJointsToConsider()); ignored joints are rejected like in
+        the reference (:407-409)."""
+        k = joint if isinstance(joint, (int, np.integer)) else self._joint_pos.get(id(joint))
+        if k is None:
+            raise ValueError("the joint is not considered by this calculator")
+        self._modes[int(k)] = int(mode)
+        self.model.set_joint_source_modes(self._modes)
+
+    def setJointSourceModes(self, modeFunction):
+        """``modeFunction(joint) -> JointSourceMode`` evaluated on every considered joint (:423-433); a sequence works too."""
+        joints = self.input.getJointsToConsider()
+        self._modes = [int(modeFunction(j)) for j in joints] if callable(modeFunction) else [int(m) for m in modeFunction]
+        self.model.set_joint_source_modes(self._modes)
+
+    def resetJointSourceModes(self):
+        self._modes = [JointSourceMode.EFFORT_SOURCE] * self.model.n_joints
+        self.model.set_joint_source_modes(None)
+
+    def compute(self, q, qd, tau, qdd=None):
+        """``compute(q, qd, tau)`` (:475-490) or, with acceleration-source joints, ``compute(q, qd, tau, qdd)`` (:508-520): tau is
+        read for the effort sources, qdd for the acceleration sources."""
+        if any(m == JointSourceMode.ACCELERATION_SOURCE for m in self._modes):
+            if qdd is None:
+                raise ValueError("some joints are acceleration sources: their accelerations (qdd) are needed")
+            self._qdd, self._tau = self.model.aba_locked(q, qd, tau, qdd, self._gravity, self._f_ext, self.layout)
+        else:
+            self._qdd = self.model.aba(q, qd, tau, self._gravity, self._f_ext, self.layout)
+            self._tau = tau
         return self._qdd
 
     def getJointAccelerationMatrix(self):
         return self._qdd
+
+    def getJointTauMatrix(self):
+        """Efforts of all joints: the inputs for effort sources, the computed ones for acceleration sources (:556-567)."""
+        return self._tau
 
 
 class CompositeRigidBodyMassMatrixCalculator(_Base):

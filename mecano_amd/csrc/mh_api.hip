@@ -135,6 +135,7 @@ struct mh_model
    int ident_maps = 0;      // the engine-order index maps are the identity
    int dense_maps = 0;      // nq / nv equal the joints' totals (no unused matrix rows): rows can be staged as dense blocks
    int force_io = -1, force_st = -1; // MH_SPEC_IO / MH_SPEC_ST = 0 | 1 override the heuristics (measurements)
+   int n_locked = 0;        // joints in MH_ACCELERATION_SOURCE mode (mh_model_set_joint_source_modes)
 };
 
 namespace
@@ -229,7 +230,7 @@ enum Algo
 
 template <typename T>
 mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd, const T *in3, const double gravity[3], const T *fext,
-                 const mh_options *opts_in, T *out)
+                 const mh_options *opts_in, T *out, const T *locked_in = nullptr, T *locked_out = nullptr)
 {
    mh_options opts;
    if (opts_in)
@@ -243,6 +244,9 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       return MH_OK; // an empty batch has nothing to read or write: NULL pointers are fine
    if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   if (algo == ALGO_ABA && model->n_locked > 0 && !locked_in)
+      return fail(MH_ERR_INVALID_ARGUMENT, "%d joint(s) are acceleration sources: forward dynamics needs their accelerations, use mh_aba_locked_f64",
+                  model->n_locked);
    st = ensure_workspace(model, B, sizeof(T));
    if (st != MH_OK)
       return st;
@@ -266,6 +270,13 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    if (lds > 160 * 1024)
       return fail(MH_ERR_BAD_DIMENSION, "model constants (%zu B) exceed the 160 KiB LDS of a gfx950 CU", lds);
 
+   if (algo == ALGO_ABA && model->n_locked > 0)
+   { // acceleration-source joints: run-time flags per joint, generic kernel only
+      A.in3b = locked_in, A.outb = locked_out;
+      hipLaunchKernelGGL((mh::aba_kernel<T, MH_GENERIC_LDS_CONSTS, true>), dim3(L.grid), dim3(L.block), lds, stream, A);
+      HIP_TRY(hipGetLastError());
+      return MH_OK;
+   }
    if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
    {
       const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
@@ -661,6 +672,7 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       mi[mh::MI_SLOT_C] = slots, slots += 6;
       mi[mh::MI_SLOT_VA] = slots, slots += (nonadj_child ? 12 : 0);
       mi[mh::MI_SLOT_IA] = slots, slots += (nonadj_child ? 21 : 0);
+      mi[mh::MI_SLOT_LK] = slots, slots += (t == MH_JOINT_SIXDOF ? 27 : 0);
 
       // X_before' = Qp^T X_before Q : canonical before-joint frame in the parent's canonical after-joint frame
       const M3d Qp = pe < 0 ? m3_identity() : Q[pe];
@@ -823,6 +835,46 @@ mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_opt
 {
    return launch<double>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
 }
+mh_status mh_model_set_joint_source_modes(mh_model_t model, const int32_t *modes)
+{
+   if (!model)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model is NULL");
+   int cur = 0;
+   if (hipGetDevice(&cur) != hipSuccess || cur != model->device)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model lives on device %d, which is not the calling thread's device", model->device);
+   for (int e = 0; modes && e < model->n; e++)
+      if (modes[e] != MH_EFFORT_SOURCE && modes[e] != MH_ACCELERATION_SOURCE)
+         return fail(MH_ERR_INVALID_ARGUMENT, "joint %d: unknown source mode %d", e, modes[e]);
+   int n_locked = 0;
+   for (int e = 0; e < model->n; e++)
+   {
+      int *mi = &model->meta[(size_t)e * mh::MI_STRIDE];
+      const bool lk = modes && modes[mi[mh::MI_EXT]] == MH_ACCELERATION_SOURCE;
+      mi[mh::MI_FLAGS] = (mi[mh::MI_FLAGS] & ~mh::MF_LOCKED) | (lk ? mh::MF_LOCKED : 0);
+      n_locked += lk;
+   }
+   HIP_TRY(hipDeviceSynchronize());
+   HIP_TRY(hipMemcpy(model->d_meta, model->meta.data(), model->meta.size() * sizeof(int), hipMemcpyHostToDevice));
+   model->n_locked = n_locked;
+   return MH_OK;
+}
+int32_t mh_model_n_acceleration_sources(mh_model_t model) { return model ? model->n_locked : -1; }
+mh_status mh_aba_locked_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double *qdd_in,
+                            const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out, double *tau_out)
+{
+   if (!model)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model is NULL");
+   if (model->n_locked == 0)
+   { // nothing is locked: the ordinary forward dynamics, efforts copied through
+      mh_status st = launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+      if (st == MH_OK && tau_out && tau_out != tau && B > 0)
+         HIP_TRY(hipMemcpyAsync(tau_out, tau, (size_t)B * model->nv * sizeof(double), hipMemcpyDeviceToDevice, opts ? (hipStream_t)opts->stream : nullptr));
+      return st;
+   }
+   if (B > 0 && !qdd_in)
+      return fail(MH_ERR_INVALID_ARGUMENT, "qdd_in is NULL but %d joint(s) are acceleration sources", model->n_locked);
+   return launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, qdd_in, tau_out);
+}
 mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
                           const double gravity[3], const double *f_ext, const mh_options *opts_in, double *tau_out, double *qdd_out)
 {
@@ -839,7 +891,7 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    if (!q || !qd || !qdd || !tau || !gravity || !tau_out || !qdd_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    const long waves = (B + 63) / 64;
-   const bool fusable = model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
+   const bool fusable = model->n_locked == 0 && model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
                         && opts.consider_coriolis && opts.consider_accelerations && 2 * waves <= (long)model->cu_count
                         && model->spec.fused_lds_bytes(model->nq, model->nv) <= 160 * 1024;
    if (!fusable)

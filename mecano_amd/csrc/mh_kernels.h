@@ -39,6 +39,7 @@ enum : int
    MI_SLOT_VA = 8,  // 12 slots: velocity + acceleration for children that do not directly follow their parent
    MI_SLOT_C = 9,   // 6 slots: ABA bias acceleration
    MI_SLOT_IA = 10, // 21 slots: ABA articulated inertia / CRBA composite inertia accumulator
+   MI_SLOT_LK = 11, // 27 slots (6-DoF joints only): articulated inertia + bias wrench of an ACCELERATION_SOURCE joint
    MI_STRIDE = 12
 };
 enum : int
@@ -46,7 +47,8 @@ enum : int
    MF_PARENT_ADJ = 1, // parent == j - 1: hand values over in registers
    MF_STORE_VA = 2,   // some child c != j + 1 exists: it reloads (v, a) from the workspace
    MF_ACC_FIRST = 4,  // this body is the first (highest index) non-adjacent child of its parent: store, do not add
-   MF_HAS_ACC = 8     // some child c != j + 1 exists: its inertia contribution arrives through the workspace
+   MF_HAS_ACC = 8,    // some child c != j + 1 exists: its inertia contribution arrives through the workspace
+   MF_LOCKED = 16     // JointSourceMode.ACCELERATION_SOURCE (ForwardDynamicsCalculator.java:45-57): qdd is an input, tau an output
 };
 // ---- per-joint real constants (LDS)
 enum : int
@@ -86,6 +88,7 @@ struct Args
    T gx, gy, gz;
    int coriolis, accel;
    // second job of a fused RNEA+ABA launch (specialised kernels only): tau in, qdd out
+   // aba_kernel<.., LOCKED>: in3b = given accelerations of the ACCELERATION_SOURCE joints, outb = tau of all joints (may be NULL)
    const T *in3b;
    T *outb;
 };
@@ -485,7 +488,10 @@ MH_DEV SV<T> spd6_solve(const ABI<T> &I, SV<T> b)
    return SV<T>{V3<T>{x[0], x[1], x[2]}, V3<T>{x[3], x[4], x[5]}};
 }
 
-template <typename T, bool LDSC>
+// LOCKED: some joints are ACCELERATION_SOURCE (:1237-1253, 1284-1297, 1315-1363).  Mecano's pass four re-runs a Newton-Euler sweep to
+// get the efforts of those joints; here tau = S^T (IA a + pA) is read off the articulated quantities pass two already holds, which is
+// the same wrench (the articulated-body equation of the subtree) without a fourth sweep.
+template <typename T, bool LDSC, bool LOCKED = false>
 __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -577,6 +583,23 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
                ua = V3<T>{IA.C.xz, IA.C.yz, IA.C.zz}, ul = V3<T>{IA.L.xz, IA.L.yz, IA.L.zz};
                D = IA.L.zz, pz = pA.l.z;
             }
+            if (LOCKED && (flags & MF_LOCKED))
+            {
+               ws_store6(ws, ws_stride, sf, SV<T>{ua, ul});
+               MH_WS(sf + 7) = pz;
+               if (parent >= 0)
+               { // :1237-1253  Ia = IA ; pa = pA + IA (c + S qdd)
+                  SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+                  const T qg = (A.in3b + cfg * A.v_bs)[di[0] * A.v_es];
+                  if (type == JT_REVOLUTE)
+                     cj.a.z += qg;
+                  else
+                     cj.l.z += qg;
+                  pa = pA + mul(IA, cj);
+               }
+            }
+            else
+            {
             const T dinv = T(1) / D;                          // :1183
             const T u = taurow[di[0] * A.v_es] - pz;          // :1200-1215
             ws_store6(ws, ws_stride, sf, SV<T>{ua, ul});
@@ -588,6 +611,19 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
                const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
                const T ud = u * dinv;
                pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
+            }
+            }
+         }
+         else if (LOCKED && type == JT_SIXDOF && (flags & MF_LOCKED))
+         {
+            ws_store_abi(ws, ws_stride, mi[MI_SLOT_LK], IA);
+            ws_store6(ws, ws_stride, mi[MI_SLOT_LK] + 21, pA);
+            if (parent >= 0)
+            {
+               const T *gr = A.in3b + cfg * A.v_bs;
+               const SV<T> qg{V3<T>{gr[di[0] * A.v_es], gr[di[1] * A.v_es], gr[di[2] * A.v_es]},
+                              V3<T>{gr[di[3] * A.v_es], gr[di[4] * A.v_es], gr[di[5] * A.v_es]}};
+               pa = pA + mul(IA, ws_load6(ws, ws_stride, mi[MI_SLOT_C]) + qg);
             }
          }
          else if (type == JT_SIXDOF)
@@ -656,13 +692,40 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          if (type == JT_REVOLUTE || type == JT_PRISMATIC)
          {
             const SV<T> U = ws_load6(ws, ws_stride, sf);
-            const T dinv = MH_WS(sf + 6), u = MH_WS(sf + 7);
-            const T qdd = dinv * (u - (dot(U.a, a.a) + dot(U.l, a.l))); // :1280-1282
+            T qdd;
+            if (LOCKED && (flags & MF_LOCKED))
+               qdd = (A.in3b + cfg * A.v_bs)[di[0] * A.v_es]; // :1284-1297
+            else
+            {
+               const T dinv = MH_WS(sf + 6), u = MH_WS(sf + 7);
+               qdd = dinv * (u - (dot(U.a, a.a) + dot(U.l, a.l))); // :1280-1282
+            }
             orow[di[0] * A.v_es] = qdd;
             if (type == JT_REVOLUTE)
                a.a.z += qdd;
             else
                a.l.z += qdd;
+            if (LOCKED && A.outb)
+            { // effort of the joint: S^T (IA a + pA) for a locked joint (cf. :1315-1363), the input otherwise
+               T *trow = A.outb + cfg * A.v_bs;
+               trow[di[0] * A.v_es] = (flags & MF_LOCKED) ? dot(U.a, a.a) + dot(U.l, a.l) + MH_WS(sf + 7) : taurow[di[0] * A.v_es];
+            }
+         }
+         else if (LOCKED && type == JT_SIXDOF && (flags & MF_LOCKED))
+         {
+            const T *gr = A.in3b + cfg * A.v_bs;
+            const SV<T> qdd{V3<T>{gr[di[0] * A.v_es], gr[di[1] * A.v_es], gr[di[2] * A.v_es]},
+                            V3<T>{gr[di[3] * A.v_es], gr[di[4] * A.v_es], gr[di[5] * A.v_es]}};
+            a = a + qdd;
+            orow[di[0] * A.v_es] = qdd.a.x, orow[di[1] * A.v_es] = qdd.a.y, orow[di[2] * A.v_es] = qdd.a.z;
+            orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
+            if (A.outb)
+            {
+               const SV<T> w = mul(ws_load_abi(ws, ws_stride, mi[MI_SLOT_LK]), a) + ws_load6(ws, ws_stride, mi[MI_SLOT_LK] + 21);
+               T *trow = A.outb + cfg * A.v_bs;
+               trow[di[0] * A.v_es] = w.a.x, trow[di[1] * A.v_es] = w.a.y, trow[di[2] * A.v_es] = w.a.z;
+               trow[di[3] * A.v_es] = w.l.x, trow[di[4] * A.v_es] = w.l.y, trow[di[5] * A.v_es] = w.l.z;
+            }
          }
          else if (type == JT_SIXDOF)
          {
@@ -671,6 +734,12 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
             orow[di[0] * A.v_es] = qdd.a.x, orow[di[1] * A.v_es] = qdd.a.y, orow[di[2] * A.v_es] = qdd.a.z;
             orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
             a = x;
+            if (LOCKED && A.outb)
+            {
+               T *trow = A.outb + cfg * A.v_bs;
+               for (int k = 0; k < 6; k++)
+                  trow[di[k] * A.v_es] = taurow[di[k] * A.v_es];
+            }
          }
          if (flags & MF_STORE_VA)
             ws_store6(ws, ws_stride, mi[MI_SLOT_VA], a);

@@ -137,6 +137,48 @@ class HipModel:
     def aba(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS):
         return self._run("aba", q, qd, tau, gravity, f_ext, layout, True, True)
 
+    def set_joint_source_modes(self, modes: Optional[Sequence[int]]):
+        """One mode per joint of the description (0 = effort source, 1 = acceleration source); None resets all of them
+        (ForwardDynamicsCalculator.java:400-444)."""
+        lib = _lib.load()
+        if modes is None:
+            _lib.check(lib.mh_model_set_joint_source_modes(self._h, None))
+            return
+        m = _np(modes, np.int32)
+        if m.shape != (self.n_joints,):
+            raise _lib.MecanoHipError(2, f"expected {self.n_joints} joint source modes, got {m.shape}")
+        _lib.check(lib.mh_model_set_joint_source_modes(self._h, m.ctypes.data))
+
+    @property
+    def n_acceleration_sources(self) -> int:
+        return int(_lib.load().mh_model_n_acceleration_sources(self._h))
+
+    def aba_locked(self, q, qd, tau, qdd_in, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS):
+        """Forward dynamics with acceleration-source joints: returns (qdd, tau) of all DoFs (fp64).  numpy inputs are moved to
+        the current HIP device and the results back."""
+        import torch
+        lib = _lib.load()
+        host = not self._is_torch(q)
+        if host:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            q, qd, tau, qdd_in = [torch.from_numpy(_np(x, np.float64)).to(dev) for x in (q, qd, tau, qdd_in)]
+            f_ext = None if f_ext is None else torch.from_numpy(_np(f_ext, np.float64)).to(dev)
+        for t in (q, qd, tau, qdd_in) + ((f_ext,) if f_ext is not None else ()):
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("aba_locked needs contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, layout)
+        if any(self._batch(x, self.nv, layout) != B for x in (qd, tau, qdd_in)):
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(layout, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        qdd_out, tau_out = torch.empty_like(qd), torch.empty_like(qd)
+        _lib.check(lib.mh_aba_locked_f64(self._h, B, q.data_ptr(), qd.data_ptr(), tau.data_ptr(), qdd_in.data_ptr(), g,
+                                         f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts), qdd_out.data_ptr(),
+                                         tau_out.data_ptr()))
+        if host:
+            return qdd_out.cpu().numpy(), tau_out.cpu().numpy()
+        return qdd_out, tau_out
+
     def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None):
         """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call (device tensors, fp64, AoS)."""
         import torch

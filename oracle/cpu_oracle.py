@@ -38,6 +38,8 @@ def _load():
         lib.mo_aba.argtypes = [P, ctypes.c_long, P, P, P, P, P, P]
         lib.mo_aba.restype = ctypes.c_int
         lib.mo_crba.argtypes = [P, ctypes.c_long, P, P]
+        lib.mo_aba_locked.argtypes = [P, ctypes.c_long, P, P, P, P, P, P, P, P, P]
+        lib.mo_aba_locked.restype = ctypes.c_int
         _lib = lib
     return _lib
 
@@ -86,6 +88,18 @@ class OracleModel:
         if rc:
             raise ArithmeticError("oracle ABA: joint-space inertia block not positive definite")
         return qdd
+
+    def aba_locked(self, q, qd, tau, qdd_in, locked, gravity=(0.0, 0.0, -9.81), f_ext=None):
+        """ABA with ACCELERATION_SOURCE joints: locked = one flag per joint (desc order). Returns (qdd, tau) for all DoFs."""
+        q, qd, tau, qdd_in, f_ext = _c(q), _c(qd), _c(tau), _c(qdd_in), _c(f_ext)
+        lk = _c(locked, np.int32)
+        B = q.shape[0]
+        g = np.asarray(gravity, dtype=np.float64)
+        qdd, tau_out = np.zeros((B, self.nv)), np.zeros((B, self.nv))
+        rc = _load().mo_aba_locked(self._h, B, _p(q), _p(qd), _p(tau), _p(qdd_in), _p(g), _p(f_ext), _p(lk), _p(qdd), _p(tau_out))
+        if rc:
+            raise ArithmeticError("oracle ABA: joint-space inertia block not positive definite")
+        return qdd, tau_out
 
     def crba(self, q):
         q = _c(q)

@@ -651,7 +651,11 @@ static int spd_inverse(int n, const double *D, double *Dinv)
 
 /* ================================================================== ABA
  * ForwardDynamicsCalculator.java:1085-1127 (passOne), :1136-1254 (passTwo), :1259-1310 (passThree) */
-static int aba_one(const mo_model *m, const double *q, const double *qd, const double *tau, const double g[3], const double *fext, double *qdd)
+/* locked: NULL or one flag per joint (JointSourceMode.ACCELERATION_SOURCE, ForwardDynamicsCalculator.java:45-57); qdd_in gives the
+ * accelerations of the locked joints; tau_out (NULL or nv values) receives tau of every joint: the input for EFFORT_SOURCE joints, the
+ * computed effort for ACCELERATION_SOURCE joints (pass four, :1315-1363). */
+static int aba_one(const mo_model *m, const double *q, const double *qd, const double *tau, const double g[3], const double *fext, double *qdd,
+                   const int *locked, const double *qdd_in, double *tau_out)
 {
    static _Thread_local mo_kin K;
    static _Thread_local xf_t Xup[MO_MAX_JOINTS]; /* afterJoint_i -> afterJoint_parent (or root body frame) :1096-1099 */
@@ -698,6 +702,27 @@ static int aba_one(const mo_model *m, const double *q, const double *qd, const d
       int p = m->parent[i], nd = m->ndof[i];
       const int *di = m->dof_idx + m->dof_ofs[i];
       double D[36];
+      if (locked && locked[i])
+      { /* ACCELERATION_SOURCE (:1237-1253): Ia = IA ; pa = pA + IA (c + S qdd_given) */
+         if (p >= 0)
+         {
+            double aJ[6], ca[6], Iac[6], pa[6], paP[6];
+            joint_S_times(m, i, K.S[i], qdd_in, aJ);
+            for (int k = 0; k < 6; k++)
+               ca[k] = cb[i][k] + aJ[k];
+            abi_mulv(&IA[i], ca, Iac);
+            for (int k = 0; k < 6; k++)
+               pa[k] = pA[i][k] + Iac[k];
+            abi_t Ia = IA[i];
+            abi_apply_transform(&Xup[i], &Ia);
+            xf_force(&Xup[i], pa, paP);
+            for (int k = 0; k < 9; k++)
+               IA[p].A[k] += Ia.A[k], IA[p].L[k] += Ia.L[k], IA[p].C[k] += Ia.C[k];
+            for (int k = 0; k < 6; k++)
+               pA[p][k] += paP[k];
+         }
+         continue;
+      }
       /* U = IA S (:1177) ; D = S^T U (:1179) */
       for (int d = 0; d < nd; d++)
          abi_mulv(&IA[i], K.S[i][d], U[i][d]);
@@ -771,25 +796,87 @@ static int aba_one(const mo_model *m, const double *q, const double *qd, const d
       xf_motion_inv(&Xup[i], p < 0 ? a_root : acc[p], ap); /* :1270-1271 */
       for (int k = 0; k < 6; k++)
          ap[k] += cb[i][k]; /* :1273 */
-      for (int d = 0; d < nd; d++)
-      {
-         double s = 0;
-         for (int k = 0; k < 6; k++)
-            s += U[i][d][k] * ap[k];
-         r[d] = u[i][d] - s; /* :1280-1281 */
+      if (locked && locked[i])
+      { /* :1284-1297 */
+         for (int a = 0; a < nd; a++)
+         {
+            qddj[a] = qdd_in[di[a]];
+            qdd[di[a]] = qddj[a];
+         }
       }
-      for (int a = 0; a < nd; a++)
+      else
       {
-         double s = 0;
-         for (int b = 0; b < nd; b++)
-            s += Dinv[i][a * nd + b] * r[b];
-         qddj[a] = s; /* :1282 */
-         qdd[di[a]] = s;
+         for (int d = 0; d < nd; d++)
+         {
+            double s = 0;
+            for (int k = 0; k < 6; k++)
+               s += U[i][d][k] * ap[k];
+            r[d] = u[i][d] - s; /* :1280-1281 */
+         }
+         for (int a = 0; a < nd; a++)
+         {
+            double s = 0;
+            for (int b = 0; b < nd; b++)
+               s += Dinv[i][a * nd + b] * r[b];
+            qddj[a] = s; /* :1282 */
+            qdd[di[a]] = s;
+         }
       }
       memcpy(acc[i], ap, sizeof ap);
       for (int d = 0; d < nd; d++)
          for (int k = 0; k < 6; k++)
             acc[i][k] += K.S[i][d][k] * qddj[d]; /* :1300-1305 */
+   }
+   if (tau_out)
+   {
+      /* ---- pass four (:1315-1363): joint wrenches RNEA-style from the accelerations of pass three; tau = S^T wrench for the locked joints */
+      static _Thread_local double jw[MO_MAX_JOINTS][6];
+      for (int i = m->n - 1; i >= 0; i--)
+      {
+         double ab[6], w[6], wa[6];
+         xf_between(&K.W_after[i], &K.W_body[i], &T);
+         xf_motion(&T, acc[i], ab); /* rigidBodyAcceleration.changeFrame(bodyFixedFrame) :1339 */
+         xf_between(&K.W_body[i], &K.W_after[i], &T);
+         if (v3_dot(m->com[i], m->com[i]) < COM_OFFSET_ZERO_EPSILON)
+         { /* velocity terms decouple: add the bias wrench of pass one (:1342-1348) */
+            dynamic_wrench(m->J[i], m->mass[i], m->com[i], ab, NULL, w);
+            xf_force(&T, w, wa);
+            for (int k = 0; k < 6; k++)
+               jw[i][k] = wa[k] + pb[i][k];
+         }
+         else
+         { /* :1349-1355 */
+            dynamic_wrench(m->J[i], m->mass[i], m->com[i], ab, K.tw_body[i], w);
+            if (fext)
+               for (int k = 0; k < 6; k++)
+                  w[k] -= fext[6 * i + k];
+            xf_force(&T, w, jw[i]);
+         }
+      }
+      for (int i = m->n - 1; i >= 0; i--)
+      {
+         const int *di = m->dof_idx + m->dof_ofs[i];
+         for (int d = 0; d < m->ndof[i]; d++)
+         {
+            if (locked && locked[i])
+            {
+               double s = 0;
+               for (int k = 0; k < 6; k++)
+                  s += K.S[i][d][k] * jw[i][k];
+               tau_out[di[d]] = s;
+            }
+            else
+               tau_out[di[d]] = tau[di[d]];
+         }
+         int p = m->parent[i];
+         if (p >= 0)
+         {
+            double w[6];
+            xf_force(&Xup[i], jw[i], w);
+            for (int k = 0; k < 6; k++)
+               jw[p][k] += w[k];
+         }
+      }
    }
    return 0;
 }
@@ -930,7 +1017,18 @@ int mo_aba(void *h, long B, const double *q, const double *qd, const double *tau
    const mo_model *m = (const mo_model *)h;
    int rc = 0;
    for (long b = 0; b < B; b++)
-      rc |= aba_one(m, q + b * m->nq, qd + b * m->nv, tau + b * m->nv, g, fext ? fext + b * 6 * m->n : NULL, qdd + b * m->nv);
+      rc |= aba_one(m, q + b * m->nq, qd + b * m->nv, tau + b * m->nv, g, fext ? fext + b * 6 * m->n : NULL, qdd + b * m->nv, NULL, NULL, NULL);
+   return rc;
+}
+/* ABA with per-joint source modes: locked[n_joints] flags, qdd_in [B][nv] (read for locked joints), tau_out [B][nv] or NULL */
+int mo_aba_locked(void *h, long B, const double *q, const double *qd, const double *tau, const double *qdd_in, const double *g, const double *fext,
+                  const int *locked, double *qdd, double *tau_out)
+{
+   const mo_model *m = (const mo_model *)h;
+   int rc = 0;
+   for (long b = 0; b < B; b++)
+      rc |= aba_one(m, q + b * m->nq, qd + b * m->nv, tau + b * m->nv, g, fext ? fext + b * 6 * m->n : NULL, qdd + b * m->nv, locked,
+                    qdd_in + b * m->nv, tau_out ? tau_out + b * m->nv : NULL);
    return rc;
 }
 void mo_crba(void *h, long B, const double *q, double *H)

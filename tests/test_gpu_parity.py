@@ -432,6 +432,95 @@ def test_ignored_joints_with_lumped_subtree_inertia(torch_cuda):
     assert (c.compute(q, qd, qdd) - d.compute(q, qd, qdd)).abs().max().item() > 1e-3
 
 
+def _locked_case(rng, sys_, d, B, frac=0.4):
+    """Random source modes + the inputs each mode may see (ForwardDynamicsCalculatorTest.java:282-360)."""
+    n = d.n_joints
+    locked = (rng.uniform(size=n) < frac).astype(np.int32)
+    ndof = [6 if t == 2 else (0 if t == 3 else 1) for t in d.joint_type]
+    ofs = np.concatenate([[0], np.cumsum(ndof)])
+    lock_dofs = np.zeros(d.nv, dtype=bool)
+    for j in range(n):
+        lock_dofs[d.dof_indices[ofs[j]:ofs[j + 1]]] = bool(locked[j])
+    return locked, lock_dofs
+
+
+@pytest.mark.parametrize("family", ["revolute_chain", "onedof_tree", "floating_onedof_tree", "mixed_tree"])
+def test_acceleration_source_joints(torch_cuda, family):
+    """JointSourceMode.ACCELERATION_SOURCE (ForwardDynamicsCalculatorTest.java:282-488): lock a random subset of joints onto given
+    accelerations; ABA must return (i) the oracle's qdd / tau and (ii) the (qdd, tau) pair RNEA is consistent with."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.calculators import ForwardDynamicsCalculator, InverseDynamicsCalculator, JointSourceMode
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(("locked" + family).encode()))
+    for it in range(6):
+        n = int(rng.integers(1, 41))
+        sys_ = system_of(families()[family](rng, n))
+        d = sys_.toModelDesc()
+        om = OracleModel(d)
+        B = int(rng.integers(1, 150))
+        q, qd, qdd, _ = rt.nextState(rng, sys_, B)
+        locked, lock_dofs = _locked_case(rng, sys_, d, B)
+        g = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(-10, -1)))
+        fext = rng.uniform(-5, 5, (B, d.n_joints, 6)) if it % 2 else None
+        idc, fdc = InverseDynamicsCalculator(sys_), ForwardDynamicsCalculator(sys_)
+        for c in (idc, fdc):
+            c.setGravitationalAcceleration(g)
+            c.setExternalWrenches(dev(torch, fext))
+        tau = idc.compute(dev(torch, q), dev(torch, qd), dev(torch, qdd)).cpu().numpy()
+        # each joint only gets to see its own source quantity
+        tau_in, qdd_in = np.where(lock_dofs, 0.0, tau), np.where(lock_dofs, qdd, 0.0)
+        joints = sys_.getJointsToConsider()
+        fdc.setJointSourceModes(lambda j: JointSourceMode.ACCELERATION_SOURCE if locked[joints.index(j)] else JointSourceMode.EFFORT_SOURCE)
+        assert fdc.model.n_acceleration_sources == int(locked.sum())
+        out = fdc.compute(dev(torch, q), dev(torch, qd), dev(torch, tau_in), dev(torch, qdd_in)).cpu().numpy()
+        tau_out = fdc.getJointTauMatrix().cpu().numpy()
+        ref_qdd, ref_tau = om.aba_locked(q, qd, tau_in, qdd_in, locked, g, fext)
+        close(out, ref_qdd, 1e-8 if family == "mixed_tree" else TOL)
+        close(tau_out, ref_tau, 1e-8 if family == "mixed_tree" else TOL)
+        close(out, qdd, 2e-8)   # round trip through RNEA (conditioning of the random trees, as in the oracle test)
+        close(tau_out, tau, 2e-8)
+        if locked.any():
+            with pytest.raises(Exception):  # the plain call has no acceleration input
+                fdc.model.aba(dev(torch, q), dev(torch, qd), dev(torch, tau_in), g)
+        # resetJointSourceModes brings the ordinary forward dynamics back
+        fdc.resetJointSourceModes()
+        close(fdc.compute(dev(torch, q), dev(torch, qd), dev(torch, tau)).cpu().numpy(), om.aba(q, qd, tau, g, fext), 1e-8 if family == "mixed_tree" else TOL)
+
+
+def test_acceleration_source_on_the_humanoid_and_soa(torch_cuda):
+    """Locked joints on a model that otherwise runs the topology-specialised kernels (the engine must route to the run-time-flag kernel),
+    in both layouts, all joints locked (ABA degenerates to RNEA) and none locked (tau copied through)."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(77)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    om, hm = OracleModel(d), HipModel(d)
+    B = 300
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    g = (0.0, 0.0, -9.81)
+    for locked in (np.zeros(d.n_joints, np.int32), np.ones(d.n_joints, np.int32), (np.arange(d.n_joints) % 3 == 0).astype(np.int32)):
+        hm.set_joint_source_modes(locked)
+        ref_qdd, ref_tau = om.aba_locked(q, qd, tau, qdd, locked, g)
+        a, t = hm.aba_locked(dev(torch, q), dev(torch, qd), dev(torch, tau), dev(torch, qdd), g)
+        close(a.cpu().numpy(), ref_qdd)
+        close(t.cpu().numpy(), ref_tau)
+        a2, t2 = hm.aba_locked(dev(torch, q.T), dev(torch, qd.T), dev(torch, tau.T), dev(torch, qdd.T), g, layout=_lib.LAYOUT_SOA)
+        close(a2.cpu().numpy().T, ref_qdd)
+        close(t2.cpu().numpy().T, ref_tau)
+        if locked.all():
+            close(t.cpu().numpy(), om.rnea(q, qd, qdd, g))
+        an, tn = hm.aba_locked(q, qd, tau, qdd, g)  # numpy in, numpy out
+        close(an, ref_qdd)
+        close(tn, ref_tau)
+    hm.set_joint_source_modes(None)
+    assert hm.n_acceleration_sources == 0
+    close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g).cpu().numpy(), om.aba(q, qd, tau, g))
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()

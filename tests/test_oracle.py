@@ -199,3 +199,45 @@ def test_custom_index_provider_is_honoured():
     q1[:, perm], qd1[:, perm], qdd1[:, perm] = q, qd, qdd
     tau1 = om1.rnea(q1, qd1, qdd1)
     assert np.array_equal(tau1[:, perm], tau0)
+
+
+@pytest.mark.parametrize("kind", ["revolute_chain", "onedof_tree", "floating_tree", "mixed_tree"])
+def test_acceleration_source_joints_round_trip(kind):
+    """ForwardDynamicsCalculatorTest.java:282-488 restated on the oracle: lock a random subset of joints (ACCELERATION_SOURCE) onto the
+    accelerations RNEA was given; ABA must return those accelerations for the free joints and RNEA's efforts for the locked ones."""
+    rng = np.random.default_rng(zlib.crc32(("lk" + kind).encode()))
+    for it in range(12):
+        n = int(rng.integers(1, 41))
+        if kind == "revolute_chain":
+            joints = rt.nextJointChain(rng, n, ("revolute",))
+        elif kind == "onedof_tree":
+            joints = rt.nextJointTree(rng, n, ("revolute", "prismatic"))
+        elif kind == "floating_tree":
+            joints = rt.nextFloatingChain(rng, n, ("revolute", "prismatic"), tree=True)
+        else:
+            joints = rt.nextJointTree(rng, n, ("revolute", "prismatic", "sixdof", "fixed"))
+        sys_ = MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor())
+        d = sys_.toModelDesc()
+        om = OracleModel(d)
+        q, qd, qdd, _ = rt.nextState(rng, sys_, 3)
+        if it % 3 == 0:  # the reference's first variant: locked joints at rest (:296-306)
+            pass
+        locked = (rng.uniform(size=d.n_joints) < 0.4).astype(np.int32)
+        ndof = [6 if t == 2 else (0 if t == 3 else 1) for t in d.joint_type]
+        ofs = np.concatenate([[0], np.cumsum(ndof)])
+        lock_dofs = np.zeros(d.nv, dtype=bool)
+        for j in range(d.n_joints):
+            lock_dofs[d.dof_indices[ofs[j]:ofs[j + 1]]] = bool(locked[j])
+        if it % 3 == 0:
+            qd = np.where(lock_dofs, 0.0, qd)
+            qdd = np.where(lock_dofs, 0.0, qdd)
+        g = (0.0, 0.0, -9.81)
+        fext = rng.uniform(-2, 2, (3, d.n_joints, 6)) if it % 2 else None
+        tau = om.rnea(q, qd, qdd, g, fext)
+        a, t = om.aba_locked(q, qd, np.where(lock_dofs, 0.0, tau), np.where(lock_dofs, qdd, 0.0), locked, g, fext)
+        eps = 2e-8 if kind == "mixed_tree" else 1e-9
+        assert np.abs(a - qdd).max() <= eps * max(1.0, np.abs(qdd).max())
+        assert np.abs(t - tau).max() <= eps * max(1.0, np.abs(tau).max())
+        # no locked joint: identical to the plain call, efforts copied through
+        a0, t0 = om.aba_locked(q, qd, tau, qdd * 0, np.zeros(d.n_joints, np.int32), g, fext)
+        assert np.array_equal(a0, om.aba(q, qd, tau, g, fext)) and np.array_equal(t0, tau)
