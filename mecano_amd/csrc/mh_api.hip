@@ -510,6 +510,8 @@ void try_load_spec(mh_model *m, const Plan &P)
    std::string dir(info.dli_fname);
    const size_t slash = dir.find_last_of('/');
    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+   if (const char *e = getenv("MH_SPEC_DIR")) // experiment builds of the specialised code objects live elsewhere (tools/isa.py)
+      dir = e;
    const std::string path = dir + "/libmecano_hip_topo_" + P.key + ".so";
    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
    if (!h)
@@ -767,6 +769,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->lds_wave_factor = atoi(e);
    if (const char *e = getenv("MH_SPEC_IO"))
       m->force_io = atoi(e);
+   if (const char *e = getenv("MH_FAKE_CU_COUNT")) // measurements: shrink every grid so that one workgroup loops over the batch
+      m->cu_count = std::max(1, atoi(e));
    if (const char *e = getenv("MH_SPEC_ST"))
       m->force_st = atoi(e);
    try_load_spec(m, P);

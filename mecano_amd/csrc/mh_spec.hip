@@ -170,11 +170,15 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
    hipStream_t s = (hipStream_t)stream;
    if (id && io)
       return (int)go_split_algo<true, true>(algo, A, groups, s);
+#ifdef MH_SPEC_MINIMAL // experiment builds (tools/): only the variant bench.py runs, seconds instead of minutes to compile
+   return (int)hipErrorNotSupported;
+#else
    if (id)
       return (int)go_split_algo<true, false>(algo, A, groups, s);
    if (io)
       return (int)go_split_algo<false, true>(algo, A, groups, s);
    return (int)go_split_algo<false, false>(algo, A, groups, s);
+#endif
 }
 int mh_spec_n(void) { return TP::N; }
 const int *mh_spec_parents(void) { return kParents; }
@@ -198,14 +202,21 @@ long mh_spec_lds_bytes(int algo, int flags, int nq, int nv) { return lds_bytes(a
 long mh_spec_fused_lds_bytes(int nq, int nv) { return std::max(lds_bytes(0, F_IO_LDS, nq, nv), lds_bytes(1, F_ST_LDS, nq, nv)); }
 int mh_spec_launch_fused(int flags, const void *args, int waves, void *stream)
 {
+#ifdef MH_SPEC_MINIMAL
+   return (int)hipErrorNotSupported;
+#else
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    return (int)((flags & F_IDENT) ? go_fused<true>(A, waves, (hipStream_t)stream) : go_fused<false>(A, waves, (hipStream_t)stream));
+#endif
 }
 // CRBA (fp64).  Returns in *needs_zero_fill whether the caller must zero H first (direct-store kernel) or not (packed kernel).
 long mh_spec_crba_lds_bytes(void) { return (long)mh::HMap<TP>::T.n_slots * 64 * sizeof(double); }
 int mh_spec_crba_packed(int flags) { return (flags & F_IDENT) && mh_spec_crba_lds_bytes() <= 160 * 1024 ? 1 : 0; }
 int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
 {
+#ifdef MH_SPEC_MINIMAL
+   return (int)hipErrorNotSupported;
+#else
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    if (mh_spec_crba_packed(flags))
    {
@@ -226,10 +237,14 @@ int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
    else
       hipLaunchKernelGGL((mh::spec_crba_kernel<TP, double, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
    return (int)hipGetLastError();
+#endif
 }
 // algo: 0 = RNEA, 1 = ABA; fp64 only.  args points to mh::Args<double>.
 int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream)
 {
+#ifdef MH_SPEC_MINIMAL
+   return (int)hipErrorNotSupported;
+#else
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    const size_t lds = (size_t)lds_bytes(algo, flags, A.m.nq, A.m.nv);
    if (algo == 0)
@@ -237,5 +252,6 @@ int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream
    if (algo == 1)
       return (int)go_flags<1>(flags, A, grid, lds, (hipStream_t)stream);
    return (int)hipErrorNotSupported;
+#endif
 }
 }

@@ -346,21 +346,45 @@ struct Ctx
    }
 };
 
+// raw configuration of a joint: read (LDS / global) at the top of a body together with its constants, turned into the joint
+// transform after the fence so that ONE wait covers every request of the body (SMEM returns out of order: any lgkmcnt wait is a
+// wait for everything outstanding, so requests are batched up front rather than trickled in between the arithmetic)
+template <typename T>
+struct JQ
+{
+   T q[7];
+};
 template <int TYPE, int CO, class CX, typename T>
-MH_DEV JX<T> spec_joint(const CX &cx)
+MH_DEV JQ<T> spec_joint_read(const CX &cx)
+{
+   JQ<T> r;
+   if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+      r.q[0] = cx.q(CO);
+   else if constexpr (TYPE == JT_SIXDOF)
+      for (int k = 0; k < 7; k++)
+         r.q[k] = cx.q(CO + k);
+   return r;
+}
+template <int TYPE, typename T>
+MH_DEV JX<T> spec_joint_from(const JQ<T> &r)
 {
    JX<T> jx;
    jx.c = T(1), jx.s = T(0), jx.d = T(0);
    if constexpr (TYPE == JT_REVOLUTE)
-      sincos_t(cx.q(CO), jx.s, jx.c);
+      sincos_t(r.q[0], jx.s, jx.c);
    else if constexpr (TYPE == JT_PRISMATIC)
-      jx.d = cx.q(CO);
+      jx.d = r.q[0];
    else if constexpr (TYPE == JT_SIXDOF)
    {
-      jx.X.R = quat_to_R(cx.q(CO + 0), cx.q(CO + 1), cx.q(CO + 2), cx.q(CO + 3));
-      jx.X.p = V3<T>{cx.q(CO + 4), cx.q(CO + 5), cx.q(CO + 6)};
+      jx.X.R = quat_to_R(r.q[0], r.q[1], r.q[2], r.q[3]);
+      jx.X.p = V3<T>{r.q[4], r.q[5], r.q[6]};
    }
    return jx;
+}
+template <int TYPE, int CO, class CX, typename T>
+MH_DEV JX<T> spec_joint(const CX &cx)
+{
+   return spec_joint_from<TYPE, T>(spec_joint_read<TYPE, CO, CX, T>(cx));
 }
 // slice of qd (WHICH = 0) or of qdd|tau (WHICH = 1) belonging to the joint, as a spatial vector in its canonical frame
 template <int TYPE, int DO, int WHICH, class CX, typename T>
@@ -446,16 +470,18 @@ struct RneaSub
       constexpr int TYPE = TP::type[J];
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
       const CRef<T, false> c{cx.C + J * MC_STRIDE};
-      const XF<T> Xb = load_xb<T>(c);
-      const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+      const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
       const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
+      const XF<T> Xb = load_xb<T>(c);
+      const RI<T> I = load_inertia<T>(c);
+      MH_BODY_FENCE(); // everything the body reads is requested before its arithmetic starts (see JQ)
+      const JX<T> jx = spec_joint_from<TYPE, T>(jq);
       const V3<T> Z{T(0), T(0), T(0)};
       SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
       const SV<T> a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
       if (!cx.coriolis)
          v = SV<T>{Z, Z};
-      const RI<T> I = load_inertia<T>(c);
       SV<T> f = mul(I, a) + crf(v, mul(I, v));
       if (cx.frow)
          f = f - load_fext<T>(c, cx.frow, cx.f_es, cx.meta[J * MI_STRIDE + MI_EXT]);
@@ -494,10 +520,12 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
       trunk_va<TP, TP::parent[J], T, CX>(cx, vp, ap);
    MH_BODY_FENCE();
    const CRef<T, false> c{cx.C + J * MC_STRIDE};
-   const XF<T> Xb = load_xb<T>(c);
-   const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+   const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
    const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
    const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
+   const XF<T> Xb = load_xb<T>(c);
+   MH_BODY_FENCE();
+   const JX<T> jx = spec_joint_from<TYPE, T>(jq);
    v = motion_down(TYPE, jx, Xb, vp) + vJ;
    a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
    if (!cx.coriolis)
@@ -516,8 +544,12 @@ MH_DEV SV<T> trunk_v(const CX &cx)
       vp = trunk_v<TP, TP::parent[J], T, CX>(cx);
    MH_BODY_FENCE();
    const CRef<T, false> c{cx.C + J * MC_STRIDE};
-   const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
-   const SV<T> v = motion_down(TYPE, jx, load_xb<T>(c), vp) + spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+   const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
+   const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+   const XF<T> Xb = load_xb<T>(c);
+   MH_BODY_FENCE();
+   const JX<T> jx = spec_joint_from<TYPE, T>(jq);
+   const SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
    MH_BODY_FENCE();
    return v;
 }
@@ -602,13 +634,12 @@ struct AbaIn
       constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J), S0 = Tree<TP>::aba_slot(J);
       const CRef<T, false> c{cx.C + J * MC_STRIDE};
-      const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+      const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
-      SV<T> v;
-      {
-         const XF<T> Xb = load_xb<T>(c);
-         v = motion_down(TYPE, jx, Xb, vp) + vJ;
-      }
+      const XF<T> Xb0 = load_xb<T>(c);
+      MH_BODY_FENCE();
+      const JX<T> jx = spec_joint_from<TYPE, T>(jq);
+      SV<T> v = motion_down(TYPE, jx, Xb0, vp) + vJ;
       AbaUp<T> up = aba_up_zero<T>();
       MH_BODY_FENCE();
       if constexpr (!LEAF)
@@ -717,15 +748,19 @@ struct AbaOut
       constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J), S0 = Tree<TP>::aba_slot(J);
       const CRef<T, false> c{cx.C + J * MC_STRIDE};
-      const XF<T> Xb = load_xb<T>(c);
       JX<T> jx;
+      JQ<T> jq;
       if constexpr (TYPE == JT_REVOLUTE)
       {
          jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>(), jx.d = T(0);
       }
       else
-         jx = spec_joint<TYPE, CO, CX, T>(cx);
+         jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+      const XF<T> Xb = load_xb<T>(c);
+      MH_BODY_FENCE();
+      if constexpr (TYPE != JT_REVOLUTE)
+         jx = spec_joint_from<TYPE, T>(jq);
       const SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
       SV<T> a = motion_down(TYPE, jx, Xb, ap) + crm(v, vJ);
       if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
@@ -1149,11 +1184,23 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
    // LDS map: exchange [n_limbs * XW][64] | trunk hand-over slots [TRUNK_SLOTS][64] (ABA) | [64][nq] q | [64][nv] qd | [64][nv] qdd|tau -> result
    const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * XW * 64, lq = lst + (ALGO == 1 ? S::TRUNK_SLOTS * 64 : 0), lqd = lq + 64 * nq,
                     lx = lqd + 64 * nv;
+#ifdef MH_PROBE // experiment builds: s_memtime stamps per wave and phase, written behind the B * nv results (tools/exp_probe.py)
+#define MH_STAMP(k)                                                                                                                        \
+   do                                                                                                                                      \
+   {                                                                                                                                       \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                                          \
+      if (lane == 0)                                                                                                                       \
+         ((unsigned long long *)(A.out + A.B * nv))[(cfg0 / 64) * 32 + wave * 8 + (k)] = t_;                                               \
+   } while (0)
+#else
+#define MH_STAMP(k)
+#endif
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
    for (long cfg0 = group * 64; cfg0 < A.B; cfg0 += ngroups * 64)
    {
       const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
       const bool active = lane < rows;
+      MH_STAMP(0);
       if constexpr (IO_LDS)
       {
          wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
@@ -1166,6 +1213,7 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
       cx.xbase = lxc + lane;
       cx.st.lbase = lst + lane;
       cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+      MH_STAMP(1);
       if (active)
       {
          if constexpr (ALGO == 0)
@@ -1173,7 +1221,9 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
          else
             split_aba_limbs<TP, 0, T, CX>(cx);
       }
+      MH_STAMP(2);
       __syncthreads(); // every limb's hand-up is in the exchange area
+      MH_STAMP(3);
       if (active)
       {
          if constexpr (ALGO == 0)
@@ -1184,17 +1234,21 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
          else
          {
             aba_roots_in<TP, T, CX, 1>(cx);
+            MH_STAMP(4);
             asm volatile("" ::: "memory");
             asm volatile("" : "+v"(cx.qrow), "+v"(cx.qdrow), "+v"(cx.lq), "+v"(cx.lqd), "+v"(cx.st.lbase));
             aba_roots_out<TP, T, CX, 1>(cx);
          }
       }
+      MH_STAMP(5);
       __syncthreads(); // results complete; the exchange area is free for the next batch slice
+      MH_STAMP(6);
       if constexpr (IO_LDS)
       {
          wave_copy_out<T, 256>(A.out + cfg0 * nv, lx, rows * nv);
          __syncthreads();
       }
+      MH_STAMP(7);
    }
 }
 

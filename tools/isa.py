@@ -1,0 +1,20 @@
+"""Experiment helper: compile the humanoid's specialised code object with -DMH_SPEC_MINIMAL (only the ident + LDS-IO tree-split kernels)
+either to ISA text (default) or to the .so bench.py loads (--so).  python tools/isa.py [--so] [extra hipcc flags]"""
+import subprocess, sys, time, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from mecano_amd import build as b
+
+name = "humanoid30"
+desc = b.registered_models()[name]
+key, parents, kinds = b.topology_of(desc)
+defs = [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents), "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-DMH_SPEC_MINIMAL"]
+extra = [a for a in sys.argv[1:] if a != "--so"]
+t = time.time()
+if "--so" in sys.argv:
+    os.makedirs("exp_build", exist_ok=True)  # never clobbers the shipped code object: run with MH_SPEC_DIR=exp_build
+    cmd = [b.hipcc()] + b.FLAGS + defs + extra + ["-o", os.path.join("exp_build", os.path.basename(b.spec_path(key))), b.SPEC_SOURCE]
+else:
+    os.makedirs("gpurun_out/isa", exist_ok=True)
+    cmd = [b.hipcc()] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC")] + defs + extra + ["--cuda-device-only", "-S", "-o", "gpurun_out/isa/min.s", b.SPEC_SOURCE]
+subprocess.check_call(cmd)
+print("built in %.0f s" % (time.time() - t))
