@@ -199,6 +199,20 @@ int32_t mh_model_n_acceleration_sources(mh_model_t model);
 mh_status mh_aba_locked_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double *qdd_in,
                             const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out, double *tau_out);
 
+/*
+ * ---- state integration (MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration, tools/MultiBodySystemStateIntegrator.java:365-441,
+ *      503-575, 710-733): the step downstream of forward dynamics, so that a simulation loop never leaves the device ----
+ * One explicit constant-acceleration step of size dt for every joint of every configuration: 1-DoF q' = q + dt qd + dt^2/2 qdd,
+ * qd' = qd + dt qdd; 6-DoF joints integrate the pose with the rotation vector dt w + dt^2/2 dw appended to the quaternion and
+ * re-express twist and acceleration in the new frame after the joint, exactly as the reference does.  q_out [B][nq], qd_out [B][nv]
+ * and (optional, may be NULL) qdd_out [B][nv] may alias the inputs (in-place step).  Entries no considered joint owns are not written.
+ * Device pointers, asynchronous on opts->stream; opts->layout as for the other calls.
+ */
+mh_status mh_integrate_f64(mh_model_t model, int64_t B, double dt, const double *q, const double *qd, const double *qdd,
+                           const mh_options *opts, double *q_out, double *qd_out, double *qdd_out);
+mh_status mh_integrate_f32(mh_model_t model, int64_t B, double dt, const float *q, const float *qd, const float *qdd,
+                           const mh_options *opts, float *q_out, float *qd_out, float *qdd_out);
+
 mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd,
                       const double gravity[3], const float *f_ext, const mh_options *opts, float *tau_out);
 mh_status mh_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau,

@@ -163,3 +163,36 @@ class CompositeRigidBodyMassMatrixCalculator(_Base):
         if q is not None:
             return self.compute(q)
         return self._H
+
+
+class MultiBodySystemStateIntegrator:
+    """tools/MultiBodySystemStateIntegrator.java:31-75, 365-441: explicit constant-acceleration integration of the joint states, batched.
+
+    The reference walks the joints of one system and updates their state objects in place; here the state of B configurations is
+    explicit: ``doubleIntegrateFromAcceleration(input, q, qd, qdd)`` returns the integrated ``(q, qd)`` (device tensors in, device
+    tensors out; pass ``inplace=True`` to overwrite the inputs as the reference does)."""
+
+    def __init__(self, dt: float = float("nan")):
+        self.dt = float(dt)
+        self._models = {}
+
+    def setIntegrationDT(self, dt: float):
+        self.dt = float(dt)
+
+    def getIntegrationDT(self) -> float:
+        return self.dt
+
+    def _model(self, input) -> HipModel:
+        if isinstance(input, HipModel):
+            return input
+        if isinstance(input, _Base):
+            return input.model
+        sys_ = _as_system(input)
+        if id(sys_) not in self._models:
+            self._models[id(sys_)] = (sys_, HipModel(sys_.toModelDesc()))
+        return self._models[id(sys_)][1]
+
+    def doubleIntegrateFromAcceleration(self, input, q, qd, qdd, inplace: bool = False, layout=_lib.LAYOUT_AOS):
+        """``input``: a MultiBodySystem / RigidBody, one of the calculators of this module, or a HipModel."""
+        out = self._model(input).integrate(self.dt, q, qd, qdd, layout, out=(q, qd) if inplace else None)
+        return out[0], out[1]

@@ -543,6 +543,37 @@ void try_load_spec(mh_model *m, const Plan &P)
    m->spec = s;
    m->variant = "topo:" + P.key;
 }
+template <typename T>
+mh_status integrate_impl(mh_model_t model, int64_t B, double dt, const T *q, const T *qd, const T *qdd, const mh_options *opts_in, T *q_out,
+                                T *qd_out, T *qdd_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (B == 0)
+      return MH_OK;
+   if (!q || !qd || !qdd || !q_out || !qd_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   if (!(dt == dt))
+      return fail(MH_ERR_INVALID_ARGUMENT, "dt is NaN");
+   mh::IntArgs<T> A;
+   A.m = dev_model<T>(model);
+   A.B = B, A.dt = (T)dt;
+   A.q = q, A.qd = qd, A.qdd = qdd, A.q_out = q_out, A.qd_out = qd_out, A.qdd_out = qdd_out;
+   const bool soa = opts.layout == MH_LAYOUT_SOA;
+   A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
+   A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
+   const int block = 256;
+   const int grid = (int)std::max<long>(1, std::min<long>((B + block - 1) / block, (long)model->cu_count * 8));
+   hipLaunchKernelGGL((mh::integrate_kernel<T>), dim3(grid), dim3(block), 0, (hipStream_t)opts.stream, A);
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
 } // namespace
 
 // =================================================================================================== C-ABI
@@ -838,6 +869,16 @@ mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double 
 mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
 {
    return launch<double>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+}
+mh_status mh_integrate_f64(mh_model_t model, int64_t B, double dt, const double *q, const double *qd, const double *qdd, const mh_options *opts,
+                           double *q_out, double *qd_out, double *qdd_out)
+{
+   return integrate_impl<double>(model, B, dt, q, qd, qdd, opts, q_out, qd_out, qdd_out);
+}
+mh_status mh_integrate_f32(mh_model_t model, int64_t B, double dt, const float *q, const float *qd, const float *qdd, const mh_options *opts,
+                           float *q_out, float *qd_out, float *qdd_out)
+{
+   return integrate_impl<float>(model, B, dt, q, qd, qdd, opts, q_out, qd_out, qdd_out);
 }
 mh_status mh_model_set_joint_source_modes(mh_model_t model, const int32_t *modes)
 {

@@ -748,6 +748,85 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
    }
 }
 
+// ============================================================================================ state integration
+// tools/MultiBodySystemStateIntegrator.java:365-733: one explicit constant-acceleration step of every
+// joint state.  Lane = configuration; pure streaming (reads q, qd, qdd once, writes q', qd' [, qdd'] once), no workspace.
+// The arithmetic is in the joints' own (Mecano) frames: nothing here depends on the engine's canonical frames.
+template <typename T>
+struct IntArgs
+{
+   DevModel m;
+   long B;
+   T dt;
+   const T *q, *qd, *qdd;
+   T *q_out, *qd_out, *qdd_out; // qdd_out may be NULL
+   long q_bs, q_es, v_bs, v_es;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) integrate_kernel(IntArgs<T> A)
+{
+   const DevModel &m = A.m;
+   const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   const T dt = A.dt, hdd = T(0.5) * A.dt * A.dt;
+   for (long cfg = (long)blockIdx.x * blockDim.x + threadIdx.x; cfg < A.B; cfg += nlanes)
+   {
+      const T *qr = A.q + cfg * A.q_bs, *vr = A.qd + cfg * A.v_bs, *ar = A.qdd + cfg * A.v_bs;
+      T *qo = A.q_out + cfg * A.q_bs, *vo = A.qd_out + cfg * A.v_bs;
+      T *ao = A.qdd_out ? A.qdd_out + cfg * A.v_bs : nullptr;
+      for (int j = 0; j < m.n; j++)
+      {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int type = mi[MI_TYPE];
+         ciptr di = dof_map + mi[MI_DOF], ci = cfg_map + mi[MI_CFG];
+         if (type == JT_REVOLUTE || type == JT_PRISMATIC)
+         { // :433-441, 710-733
+            const T q0 = qr[ci[0] * A.q_es], v0 = vr[di[0] * A.v_es], a0 = ar[di[0] * A.v_es];
+            qo[ci[0] * A.q_es] = hdd * a0 + dt * v0 + q0;
+            vo[di[0] * A.v_es] = dt * a0 + v0;
+            if (ao)
+               ao[di[0] * A.v_es] = a0;
+         }
+         else if (type == JT_SIXDOF)
+         { // :503-575
+            const T qx = qr[ci[0] * A.q_es], qy = qr[ci[1] * A.q_es], qz = qr[ci[2] * A.q_es], qs = qr[ci[3] * A.q_es];
+            const V3<T> p{qr[ci[4] * A.q_es], qr[ci[5] * A.q_es], qr[ci[6] * A.q_es]};
+            const V3<T> w{vr[di[0] * A.v_es], vr[di[1] * A.v_es], vr[di[2] * A.v_es]}, v{vr[di[3] * A.v_es], vr[di[4] * A.v_es], vr[di[5] * A.v_es]};
+            const V3<T> al{ar[di[0] * A.v_es], ar[di[1] * A.v_es], ar[di[2] * A.v_es]}, a{ar[di[3] * A.v_es], ar[di[4] * A.v_es], ar[di[5] * A.v_es]};
+            const V3<T> a_o = a + cross(w, v); // linear acceleration at the body origin (SpatialAccelerationReadOnly.java:197-204)
+            const V3<T> rv = dt * w + hdd * al;
+            const V3<T> wn = w + dt * al;
+            const V3<T> dp = dt * v + hdd * a_o;
+            const T th = sqrt(dot(rv, rv));
+            T dx = T(0), dy = T(0), dz = T(0), ds = T(1);
+            if (th >= T(1.0e-12))
+            {
+               T sh, ch;
+               sincos_t(T(0.5) * th, sh, ch);
+               const T sc = sh / th;
+               dx = rv.x * sc, dy = rv.y * sc, dz = rv.z * sc, ds = ch;
+            }
+            const M3<T> R0 = quat_to_R(qx, qy, qz, qs), Rd = quat_to_R(dx, dy, dz, ds);
+            const V3<T> pn = p + mul(R0, dp);
+            const V3<T> vn = tmul(Rd, v + dt * a_o);
+            qo[ci[0] * A.q_es] = qs * dx + qx * ds + qy * dz - qz * dy; // q' = q * dq (Hamilton product)
+            qo[ci[1] * A.q_es] = qs * dy - qx * dz + qy * ds + qz * dx;
+            qo[ci[2] * A.q_es] = qs * dz + qx * dy - qy * dx + qz * ds;
+            qo[ci[3] * A.q_es] = qs * ds - qx * dx - qy * dy - qz * dz;
+            qo[ci[4] * A.q_es] = pn.x, qo[ci[5] * A.q_es] = pn.y, qo[ci[6] * A.q_es] = pn.z;
+            vo[di[0] * A.v_es] = wn.x, vo[di[1] * A.v_es] = wn.y, vo[di[2] * A.v_es] = wn.z;
+            vo[di[3] * A.v_es] = vn.x, vo[di[4] * A.v_es] = vn.y, vo[di[5] * A.v_es] = vn.z;
+            if (ao)
+            { // :561-562, FixedFrameSpatialAccelerationBasics.java:81-90
+               const V3<T> an = tmul(Rd, a_o) + cross(vn, wn);
+               ao[di[0] * A.v_es] = al.x, ao[di[1] * A.v_es] = al.y, ao[di[2] * A.v_es] = al.z;
+               ao[di[3] * A.v_es] = an.x, ao[di[4] * A.v_es] = an.y, ao[di[5] * A.v_es] = an.z;
+            }
+         }
+      }
+   }
+}
+
 // ============================================================================================ CRBA
 template <typename T>
 MH_DEV void ws_store_ri(T *ws, long ws_stride, int s, const RI<T> &r)

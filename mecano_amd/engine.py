@@ -179,6 +179,31 @@ class HipModel:
             return qdd_out.cpu().numpy(), tau_out.cpu().numpy()
         return qdd_out, tau_out
 
+    def integrate(self, dt, q, qd, qdd, layout=_lib.LAYOUT_AOS, out=None, return_acceleration=False):
+        """One step of MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration on device tensors (fp64 / fp32).  ``out`` =
+        (q_out, qd_out[, qdd_out]) may name the inputs themselves for an in-place step; by default new tensors are returned."""
+        import torch
+        lib = _lib.load()
+        dt_ = q.dtype
+        if dt_ not in (torch.float64, torch.float32):
+            raise TypeError("state tensors must be float64 or float32")
+        for t in (q, qd, qdd):
+            if not t.is_cuda or t.dtype != dt_ or not t.is_contiguous():
+                raise ValueError("integrate needs contiguous tensors of one dtype on the HIP device")
+        B = self._batch(q, self.nq, layout)
+        if self._batch(qd, self.nv, layout) != B or self._batch(qdd, self.nv, layout) != B:
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        if out is None:
+            # entries no joint owns are passed through unchanged
+            out = (q.clone(), qd.clone()) + ((qdd.clone(),) if return_acceleration else ())
+        q_out, qd_out = out[0], out[1]
+        qdd_out = out[2] if len(out) > 2 else None
+        opts = self._options(layout, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        fn = lib.mh_integrate_f64 if dt_ == torch.float64 else lib.mh_integrate_f32
+        _lib.check(fn(self._h, B, float(dt), q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), ctypes.byref(opts), q_out.data_ptr(), qd_out.data_ptr(),
+                      qdd_out.data_ptr() if qdd_out is not None else None))
+        return out
+
     def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None):
         """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call (device tensors, fp64, AoS)."""
         import torch

@@ -40,6 +40,8 @@ def _load():
         lib.mo_crba.argtypes = [P, ctypes.c_long, P, P]
         lib.mo_aba_locked.argtypes = [P, ctypes.c_long, P, P, P, P, P, P, P, P, P]
         lib.mo_aba_locked.restype = ctypes.c_int
+        lib.mo_integrate.argtypes = [P, ctypes.c_long, ctypes.c_double, P, P, P, P, P, P]
+        lib.mo_integrate.restype = None
         _lib = lib
     return _lib
 
@@ -100,6 +102,16 @@ class OracleModel:
         if rc:
             raise ArithmeticError("oracle ABA: joint-space inertia block not positive definite")
         return qdd, tau_out
+
+    def integrate(self, dt, q, qd, qdd):
+        """MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration: returns (q', qd', qdd')."""
+        q, qd, qdd = _c(q), _c(qd), _c(qdd)
+        qo, vo, ao = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(qd)
+        qo[:] = q  # entries no joint owns are passed through
+        vo[:] = qd
+        ao[:] = qdd
+        _load().mo_integrate(self._h, q.shape[0], float(dt), _p(q), _p(qd), _p(qdd), _p(qo), _p(vo), _p(ao))
+        return qo, vo, ao
 
     def crba(self, q):
         q = _c(q)

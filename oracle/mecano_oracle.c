@@ -1037,3 +1037,97 @@ void mo_crba(void *h, long B, const double *q, double *H)
    for (long b = 0; b < B; b++)
       crba_one(m, q + b * m->nq, H + (size_t)b * m->nv * m->nv);
 }
+
+/* ------------------------------------------------------------------ state integration
+ * tools/MultiBodySystemStateIntegrator.java: explicit constant-acceleration step.
+ *   1-DoF   (:433-441, 710-733):  q' = q + dt qd + 0.5 dt^2 qdd ;  qd' = qd + dt qdd
+ *   SixDoF  (:503-575): (w, v) = joint twist, (al, a) = joint acceleration, both in the frame after the joint
+ *      a_o  = a + w x v                                  linear acceleration at the body origin (SpatialAccelerationReadOnly.java:197-204)
+ *      dq   = quaternion of the rotation vector dt w + 0.5 dt^2 al
+ *      w'   = w + dt al                                  (not re-expressed, :535)
+ *      p'   = p + R(q) (dt v + 0.5 dt^2 a_o)             (:538-546)
+ *      v'   = R(dq)^T (v + dt a_o)                       (:548-552)
+ *      q'   = q * dq                                     (:554-559)
+ *      al'  = al ; a' = R(dq)^T a_o + v' x w'            (:561-562, FixedFrameSpatialAccelerationBasics.java:81-90)
+ * The rotation-vector -> quaternion conversion lives in Euclid 0.21.0 (un-vendored): the standard formula is used, with the
+ * identity below |rv| = 1e-12 -- that threshold is an assumption (parity unpinned there).  Fixed joints are skipped (:403-404).
+ */
+static void quat_mul(const double a[4], const double b[4], double o[4])
+{ /* Hamilton product, (x, y, z, s) */
+   double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+   double y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+   double z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+   double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+   o[0] = x, o[1] = y, o[2] = z, o[3] = w;
+}
+static void quat_to_R(const double q[4], double R[9])
+{
+   double x = q[0], y = q[1], z = q[2], s = q[3];
+   double nrm = sqrt(x * x + y * y + z * z + s * s);
+   x /= nrm, y /= nrm, z /= nrm, s /= nrm;
+   R[0] = 1 - 2 * (y * y + z * z), R[1] = 2 * (x * y - z * s), R[2] = 2 * (x * z + y * s);
+   R[3] = 2 * (x * y + z * s), R[4] = 1 - 2 * (x * x + z * z), R[5] = 2 * (y * z - x * s);
+   R[6] = 2 * (x * z - y * s), R[7] = 2 * (y * z + x * s), R[8] = 1 - 2 * (x * x + y * y);
+}
+void mo_integrate(void *h, long B, double dt, const double *q, const double *qd, const double *qdd, double *q_out, double *qd_out, double *qdd_out)
+{
+   const mo_model *m = (const mo_model *)h;
+   const double hdd = 0.5 * dt * dt;
+   for (long b = 0; b < B; b++)
+   {
+      const double *qr = q + b * m->nq, *vr = qd + b * m->nv, *ar = qdd + b * m->nv;
+      double *qo = q_out + b * m->nq, *vo = qd_out + b * m->nv, *ao = qdd_out ? qdd_out + b * m->nv : NULL;
+      for (int i = 0; i < m->n; i++)
+      {
+         const int *ci = m->cfg_idx + m->cfg_ofs[i], *di = m->dof_idx + m->dof_ofs[i];
+         if (m->type[i] == MO_REVOLUTE || m->type[i] == MO_PRISMATIC)
+         {
+            double q0 = qr[ci[0]], v0 = vr[di[0]], a0 = ar[di[0]];
+            qo[ci[0]] = hdd * a0 + dt * v0 + q0; /* :710-713 */
+            vo[di[0]] = dt * a0 + v0;            /* :730-733 */
+            if (ao)
+               ao[di[0]] = a0;
+         }
+         else if (m->type[i] == MO_SIXDOF)
+         {
+            double quat[4] = {qr[ci[0]], qr[ci[1]], qr[ci[2]], qr[ci[3]]};
+            double p[3] = {qr[ci[4]], qr[ci[5]], qr[ci[6]]};
+            double w[3] = {vr[di[0]], vr[di[1]], vr[di[2]]}, v[3] = {vr[di[3]], vr[di[4]], vr[di[5]]};
+            double al[3] = {ar[di[0]], ar[di[1]], ar[di[2]]}, a[3] = {ar[di[3]], ar[di[4]], ar[di[5]]};
+            double wxv[3], ao3[3], rv[3], dq[4] = {0, 0, 0, 1}, R0[9], Rd[9], dp[3], t[3], vn[3], wn[3], an[3], qn[4], c[3];
+            v3_cross(w, v, wxv);
+            for (int k = 0; k < 3; k++)
+            {
+               ao3[k] = a[k] + wxv[k];
+               rv[k] = dt * w[k] + hdd * al[k];
+               wn[k] = w[k] + dt * al[k];
+               dp[k] = dt * v[k] + hdd * ao3[k];
+            }
+            double th = sqrt(v3_dot(rv, rv));
+            if (th >= 1.0e-12)
+            {
+               double sc = sin(0.5 * th) / th;
+               dq[0] = rv[0] * sc, dq[1] = rv[1] * sc, dq[2] = rv[2] * sc, dq[3] = cos(0.5 * th);
+            }
+            quat_to_R(quat, R0);
+            quat_to_R(dq, Rd);
+            m3_mulv(R0, dp, t);
+            for (int k = 0; k < 3; k++)
+               t[k] += p[k], c[k] = v[k] + dt * ao3[k];
+            m3_tmulv(Rd, c, vn);
+            m3_tmulv(Rd, ao3, an);
+            v3_cross(vn, wn, c);
+            quat_mul(quat, dq, qn);
+            for (int k = 0; k < 4; k++)
+               qo[ci[k]] = qn[k];
+            for (int k = 0; k < 3; k++)
+            {
+               qo[ci[4 + k]] = t[k];
+               vo[di[k]] = wn[k], vo[di[3 + k]] = vn[k];
+               if (ao)
+                  ao[di[k]] = al[k], ao[di[3 + k]] = an[k] + c[k];
+            }
+         }
+      }
+   }
+}

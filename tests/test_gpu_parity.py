@@ -521,6 +521,63 @@ def test_acceleration_source_on_the_humanoid_and_soa(torch_cuda):
     close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g).cpu().numpy(), om.aba(q, qd, tau, g))
 
 
+def test_state_integrator_matches_oracle_and_ballistic(torch_cuda):
+    """mh_integrate_f64 against the oracle on mixed trees (both layouts, in place, optional acceleration output), then the reference's
+    ballistic known answer (MultiBodySystemStateIntegratorTest.java:200-270) with forward dynamics + integration looping on the device."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.calculators import ForwardDynamicsCalculator, MultiBodySystemStateIntegrator
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import MultiBodySystem, RigidBody, SixDoFJoint
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(991)
+    for it in range(6):
+        sys_ = system_of(families()["mixed_tree" if it % 2 else "floating_onedof_tree"](rng, int(rng.integers(1, 30))))
+        d = sys_.toModelDesc()
+        om, hm = OracleModel(d), HipModel(d)
+        B = int(rng.integers(1, 700))
+        q, qd, qdd, _ = rt.nextState(rng, sys_, B)
+        dt = float(rng.uniform(1e-4, 1e-2))
+        rq, rv, ra = om.integrate(dt, q, qd, qdd)
+        gq, gv, ga = hm.integrate(dt, dev(torch, q), dev(torch, qd), dev(torch, qdd), return_acceleration=True)
+        close(gq.cpu().numpy(), rq, 1e-13), close(gv.cpu().numpy(), rv, 1e-13), close(ga.cpu().numpy(), ra, 1e-12)
+        sq, sv = hm.integrate(dt, dev(torch, q.T), dev(torch, qd.T), dev(torch, qdd.T), layout=_lib.LAYOUT_SOA)
+        close(sq.cpu().numpy().T, rq, 1e-13), close(sv.cpu().numpy().T, rv, 1e-13)
+        tq, tv = dev(torch, q), dev(torch, qd)  # in place
+        hm.integrate(dt, tq, tv, dev(torch, qdd), out=(tq, tv))
+        close(tq.cpu().numpy(), rq, 1e-13), close(tv.cpu().numpy(), rv, 1e-13)
+        f32 = hm.integrate(dt, dev(torch, q, torch.float32), dev(torch, qd, torch.float32), dev(torch, qdd, torch.float32))
+        close(f32[0].cpu().numpy().astype(np.float64), rq, 2e-6), close(f32[1].cpu().numpy().astype(np.float64), rv, 2e-6)
+    # ballistic: 4096 spinning unit spheres, 1000 device-resident steps
+    root = RigidBody("root")
+    RigidBody("object", SixDoFJoint("joint", root), np.eye(3), 1.0, np.zeros(3))
+    sys_ = MultiBodySystem.toMultiBodySystemInput(root)
+    fdc, integ = ForwardDynamicsCalculator(sys_), MultiBodySystemStateIntegrator(7.3e-4)
+    g, B, dt = -23.7, 4096, 7.3e-4
+    fdc.setGravitationalAcceleration(g)
+    q, qd, _, _ = rt.nextState(rng, sys_, B)
+    tq, tv, zero = dev(torch, q), dev(torch, qd), torch.zeros(B, 6, device="cuda", dtype=torch.float64)
+
+    def world(tq_, v):
+        x, y, z, s = (tq_[:, k] for k in range(4))
+        n = torch.sqrt(x * x + y * y + z * z + s * s)
+        x, y, z, s = x / n, y / n, z / n, s / n
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * s), 2 * (x * z + y * s), 2 * (x * y + z * s), 1 - 2 * (x * x + z * z), 2 * (y * z - x * s),
+                         2 * (x * z - y * s), 2 * (y * z + x * s), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        return torch.einsum("bij,bj->bi", R, v)
+
+    p0, w0, v0 = tq[:, 4:].clone(), tv[:, :3].clone(), world(tq, tv[:, 3:])
+    for step in range(1000):
+        integ.doubleIntegrateFromAcceleration(fdc, tq, tv, fdc.compute(tq, tv, zero), inplace=True)
+    t = 1000 * dt
+    pe, ve = p0 + v0 * t, v0.clone()
+    pe[:, 2] += 0.5 * g * t * t
+    ve[:, 2] += g * t
+    close(tq[:, 4:].cpu().numpy(), pe.cpu().numpy(), 1e-12)
+    close(world(tq, tv[:, 3:]).cpu().numpy(), ve.cpu().numpy(), 1e-12)
+    close(tv[:, :3].cpu().numpy(), w0.cpu().numpy(), 1e-12)
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
