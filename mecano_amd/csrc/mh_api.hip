@@ -569,8 +569,18 @@ mh_status integrate_impl(mh_model_t model, int64_t B, double dt, const T *q, con
    A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
    A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
    const int block = 256;
-   const int grid = (int)std::max<long>(1, std::min<long>((B + block - 1) / block, (long)model->cu_count * 8));
-   hipLaunchKernelGGL((mh::integrate_kernel<T>), dim3(grid), dim3(block), 0, (hipStream_t)opts.stream, A);
+   if (soa)
+   {
+      const int grid = (int)std::max<long>(1, std::min<long>((B + block - 1) / block, (long)model->cu_count * 8));
+      hipLaunchKernelGGL((mh::integrate_soa_kernel<T>), dim3(grid), dim3(block), 0, (hipStream_t)opts.stream, A);
+   }
+   else
+   {
+      // tile: enough workgroups to cover the device at small B, up to 256 configurations each at large B
+      const int tile = (int)std::max<long>(16, std::min<long>(256, B / ((long)model->cu_count * 4)));
+      const int grid = (int)std::max<long>(1, std::min<long>((B + tile - 1) / tile, (long)model->cu_count * 8));
+      hipLaunchKernelGGL((mh::integrate_aos_kernel<T>), dim3(grid), dim3(block), ((size_t)model->n * 3 + 2) * sizeof(int), (hipStream_t)opts.stream, A, tile);
+   }
    HIP_TRY(hipGetLastError());
    return MH_OK;
 }

@@ -750,7 +750,7 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
 
 // ============================================================================================ state integration
 // tools/MultiBodySystemStateIntegrator.java:365-733: one explicit constant-acceleration step of every
-// joint state.  Lane = configuration; pure streaming (reads q, qd, qdd once, writes q', qd' [, qdd'] once), no workspace.
+// joint state.  Pure streaming (reads q, qd, qdd once, writes q', qd' [, qdd'] once), no workspace.
 // The arithmetic is in the joints' own (Mecano) frames: nothing here depends on the engine's canonical frames.
 template <typename T>
 struct IntArgs
@@ -762,8 +762,58 @@ struct IntArgs
    T *q_out, *qd_out, *qdd_out; // qdd_out may be NULL
    long q_bs, q_es, v_bs, v_es;
 };
+// One joint of one configuration.  ci / di: the joint's entries of the configuration / DoF index maps.
+template <typename T, class IP>
+MH_DEV void integrate_joint(int type, IP ci, IP di, const T *qr, const T *vr, const T *ar, T *qo, T *vo, T *ao, const IntArgs<T> &A, T dt, T hdd)
+{
+   if (type == JT_REVOLUTE || type == JT_PRISMATIC)
+   { // :433-441, 710-733
+      const T q0 = qr[ci[0] * A.q_es], v0 = vr[di[0] * A.v_es], a0 = ar[di[0] * A.v_es];
+      qo[ci[0] * A.q_es] = hdd * a0 + dt * v0 + q0;
+      vo[di[0] * A.v_es] = dt * a0 + v0;
+      if (ao)
+         ao[di[0] * A.v_es] = a0;
+   }
+   else if (type == JT_SIXDOF)
+   { // :503-575
+      const T qx = qr[ci[0] * A.q_es], qy = qr[ci[1] * A.q_es], qz = qr[ci[2] * A.q_es], qs = qr[ci[3] * A.q_es];
+      const V3<T> p{qr[ci[4] * A.q_es], qr[ci[5] * A.q_es], qr[ci[6] * A.q_es]};
+      const V3<T> w{vr[di[0] * A.v_es], vr[di[1] * A.v_es], vr[di[2] * A.v_es]}, v{vr[di[3] * A.v_es], vr[di[4] * A.v_es], vr[di[5] * A.v_es]};
+      const V3<T> al{ar[di[0] * A.v_es], ar[di[1] * A.v_es], ar[di[2] * A.v_es]}, a{ar[di[3] * A.v_es], ar[di[4] * A.v_es], ar[di[5] * A.v_es]};
+      const V3<T> a_o = a + cross(w, v); // linear acceleration at the body origin (SpatialAccelerationReadOnly.java:197-204)
+      const V3<T> rv = dt * w + hdd * al;
+      const V3<T> wn = w + dt * al;
+      const V3<T> dp = dt * v + hdd * a_o;
+      const T th = sqrt(dot(rv, rv));
+      T dx = T(0), dy = T(0), dz = T(0), ds = T(1);
+      if (th >= T(1.0e-12))
+      {
+         T sh, ch;
+         sincos_t(T(0.5) * th, sh, ch);
+         const T sc = sh / th;
+         dx = rv.x * sc, dy = rv.y * sc, dz = rv.z * sc, ds = ch;
+      }
+      const M3<T> R0 = quat_to_R(qx, qy, qz, qs), Rd = quat_to_R(dx, dy, dz, ds);
+      const V3<T> pn = p + mul(R0, dp);
+      const V3<T> vn = tmul(Rd, v + dt * a_o);
+      qo[ci[0] * A.q_es] = qs * dx + qx * ds + qy * dz - qz * dy; // q' = q * dq (Hamilton product)
+      qo[ci[1] * A.q_es] = qs * dy - qx * dz + qy * ds + qz * dx;
+      qo[ci[2] * A.q_es] = qs * dz + qx * dy - qy * dx + qz * ds;
+      qo[ci[3] * A.q_es] = qs * ds - qx * dx - qy * dy - qz * dz;
+      qo[ci[4] * A.q_es] = pn.x, qo[ci[5] * A.q_es] = pn.y, qo[ci[6] * A.q_es] = pn.z;
+      vo[di[0] * A.v_es] = wn.x, vo[di[1] * A.v_es] = wn.y, vo[di[2] * A.v_es] = wn.z;
+      vo[di[3] * A.v_es] = vn.x, vo[di[4] * A.v_es] = vn.y, vo[di[5] * A.v_es] = vn.z;
+      if (ao)
+      { // :561-562, FixedFrameSpatialAccelerationBasics.java:81-90
+         const V3<T> an = tmul(Rd, a_o) + cross(vn, wn);
+         ao[di[0] * A.v_es] = al.x, ao[di[1] * A.v_es] = al.y, ao[di[2] * A.v_es] = al.z;
+         ao[di[3] * A.v_es] = an.x, ao[di[4] * A.v_es] = an.y, ao[di[5] * A.v_es] = an.z;
+      }
+   }
+}
+// SoA matrices: lane = configuration (consecutive lanes read consecutive addresses of every matrix row), joints looped.
 template <typename T>
-__global__ void __launch_bounds__(256) integrate_kernel(IntArgs<T> A)
+__global__ void __launch_bounds__(256) integrate_soa_kernel(IntArgs<T> A)
 {
    const DevModel &m = A.m;
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
@@ -777,52 +827,63 @@ __global__ void __launch_bounds__(256) integrate_kernel(IntArgs<T> A)
       for (int j = 0; j < m.n; j++)
       {
          ciptr mi = meta + j * MI_STRIDE;
-         const int type = mi[MI_TYPE];
-         ciptr di = dof_map + mi[MI_DOF], ci = cfg_map + mi[MI_CFG];
+         integrate_joint<T, ciptr>(mi[MI_TYPE], cfg_map + mi[MI_CFG], dof_map + mi[MI_DOF], qr, vr, ar, qo, vo, ao, A, dt, hdd);
+      }
+   }
+}
+// AoS matrices: a workgroup takes tiles of `tile` configurations and sweeps them twice.  Pass A: thread = (configuration of the
+// tile, 1-DoF joint), joint running fastest, so that consecutive threads touch consecutive entries of a row and no lane idles behind
+// a 6-DoF neighbour.  Pass B: thread = (configuration, multi-DoF joint).  The two joint lists are built once per workgroup in LDS.
+template <typename T>
+__global__ void __launch_bounds__(256) integrate_aos_kernel(IntArgs<T> A, int tile)
+{
+   extern __shared__ int lds_meta[]; // [n] q index | [n] v index of the 1-DoF joints ; [n] engine index of the others ; counts
+   const DevModel &m = A.m;
+   int *l1_q = lds_meta, *l1_v = lds_meta + m.n, *lm = lds_meta + 2 * m.n, *cnt = lds_meta + 3 * m.n;
+   if (threadIdx.x == 0)
+   {
+      int n1 = 0, nm = 0;
+      for (int j = 0; j < m.n; j++)
+      {
+         const int type = m.meta[j * MI_STRIDE + MI_TYPE];
          if (type == JT_REVOLUTE || type == JT_PRISMATIC)
-         { // :433-441, 710-733
-            const T q0 = qr[ci[0] * A.q_es], v0 = vr[di[0] * A.v_es], a0 = ar[di[0] * A.v_es];
-            qo[ci[0] * A.q_es] = hdd * a0 + dt * v0 + q0;
-            vo[di[0] * A.v_es] = dt * a0 + v0;
-            if (ao)
-               ao[di[0] * A.v_es] = a0;
+         {
+            l1_q[n1] = m.cfg_map[m.meta[j * MI_STRIDE + MI_CFG]];
+            l1_v[n1] = m.dof_map[m.meta[j * MI_STRIDE + MI_DOF]];
+            n1++;
          }
-         else if (type == JT_SIXDOF)
-         { // :503-575
-            const T qx = qr[ci[0] * A.q_es], qy = qr[ci[1] * A.q_es], qz = qr[ci[2] * A.q_es], qs = qr[ci[3] * A.q_es];
-            const V3<T> p{qr[ci[4] * A.q_es], qr[ci[5] * A.q_es], qr[ci[6] * A.q_es]};
-            const V3<T> w{vr[di[0] * A.v_es], vr[di[1] * A.v_es], vr[di[2] * A.v_es]}, v{vr[di[3] * A.v_es], vr[di[4] * A.v_es], vr[di[5] * A.v_es]};
-            const V3<T> al{ar[di[0] * A.v_es], ar[di[1] * A.v_es], ar[di[2] * A.v_es]}, a{ar[di[3] * A.v_es], ar[di[4] * A.v_es], ar[di[5] * A.v_es]};
-            const V3<T> a_o = a + cross(w, v); // linear acceleration at the body origin (SpatialAccelerationReadOnly.java:197-204)
-            const V3<T> rv = dt * w + hdd * al;
-            const V3<T> wn = w + dt * al;
-            const V3<T> dp = dt * v + hdd * a_o;
-            const T th = sqrt(dot(rv, rv));
-            T dx = T(0), dy = T(0), dz = T(0), ds = T(1);
-            if (th >= T(1.0e-12))
-            {
-               T sh, ch;
-               sincos_t(T(0.5) * th, sh, ch);
-               const T sc = sh / th;
-               dx = rv.x * sc, dy = rv.y * sc, dz = rv.z * sc, ds = ch;
-            }
-            const M3<T> R0 = quat_to_R(qx, qy, qz, qs), Rd = quat_to_R(dx, dy, dz, ds);
-            const V3<T> pn = p + mul(R0, dp);
-            const V3<T> vn = tmul(Rd, v + dt * a_o);
-            qo[ci[0] * A.q_es] = qs * dx + qx * ds + qy * dz - qz * dy; // q' = q * dq (Hamilton product)
-            qo[ci[1] * A.q_es] = qs * dy - qx * dz + qy * ds + qz * dx;
-            qo[ci[2] * A.q_es] = qs * dz + qx * dy - qy * dx + qz * ds;
-            qo[ci[3] * A.q_es] = qs * ds - qx * dx - qy * dy - qz * dz;
-            qo[ci[4] * A.q_es] = pn.x, qo[ci[5] * A.q_es] = pn.y, qo[ci[6] * A.q_es] = pn.z;
-            vo[di[0] * A.v_es] = wn.x, vo[di[1] * A.v_es] = wn.y, vo[di[2] * A.v_es] = wn.z;
-            vo[di[3] * A.v_es] = vn.x, vo[di[4] * A.v_es] = vn.y, vo[di[5] * A.v_es] = vn.z;
-            if (ao)
-            { // :561-562, FixedFrameSpatialAccelerationBasics.java:81-90
-               const V3<T> an = tmul(Rd, a_o) + cross(vn, wn);
-               ao[di[0] * A.v_es] = al.x, ao[di[1] * A.v_es] = al.y, ao[di[2] * A.v_es] = al.z;
-               ao[di[3] * A.v_es] = an.x, ao[di[4] * A.v_es] = an.y, ao[di[5] * A.v_es] = an.z;
-            }
-         }
+         else if (type != JT_FIXED)
+            lm[nm++] = j;
+      }
+      cnt[0] = n1, cnt[1] = nm;
+   }
+   __syncthreads();
+   const unsigned n1 = (unsigned)cnt[0], nm = (unsigned)cnt[1];
+   const T dt = A.dt, hdd = T(0.5) * A.dt * A.dt;
+   const long ntiles = (A.B + tile - 1) / tile;
+   for (long t = blockIdx.x; t < ntiles; t += gridDim.x)
+   {
+      const long cfg0 = t * tile;
+      const unsigned rows = (unsigned)(A.B - cfg0 < (long)tile ? A.B - cfg0 : (long)tile);
+      for (unsigned u = threadIdx.x; u < rows * n1; u += blockDim.x)
+      { // :433-441, 710-733
+         const unsigned lc = u / n1, k = u - lc * n1;
+         const long cfg = cfg0 + lc;
+         const long qi = cfg * A.q_bs + l1_q[k], vi = cfg * A.v_bs + l1_v[k];
+         const T q0 = A.q[qi], v0 = A.qd[vi], a0 = A.qdd[vi];
+         A.q_out[qi] = hdd * a0 + dt * v0 + q0;
+         A.qd_out[vi] = dt * a0 + v0;
+         if (A.qdd_out)
+            A.qdd_out[vi] = a0;
+      }
+      for (unsigned u = threadIdx.x; u < rows * nm; u += blockDim.x)
+      {
+         const unsigned lc = u / nm, j = (unsigned)lm[u - lc * nm];
+         const long cfg = cfg0 + lc;
+         const int *mi = m.meta + j * MI_STRIDE;
+         integrate_joint<T, const int *>(mi[MI_TYPE], m.cfg_map + mi[MI_CFG], m.dof_map + mi[MI_DOF], A.q + cfg * A.q_bs, A.qd + cfg * A.v_bs,
+                                         A.qdd + cfg * A.v_bs, A.q_out + cfg * A.q_bs, A.qd_out + cfg * A.v_bs,
+                                         A.qdd_out ? A.qdd_out + cfg * A.v_bs : nullptr, A, dt, hdd);
       }
    }
 }
