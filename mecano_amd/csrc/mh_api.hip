@@ -104,6 +104,8 @@ struct SpecLib
    int (*split_usable)(void) = nullptr;
    long (*split_lds_bytes)(int algo, int flags, int nq, int nv) = nullptr;
    int (*launch_split)(int algo, int flags, const void *args, int groups, void *stream) = nullptr;
+   int (*crba_split_usable)(void) = nullptr;
+   int (*launch_crba_split)(const void *args, int groups, int lanes_per_group, void *stream) = nullptr;
 };
 enum : int
 {
@@ -340,6 +342,25 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
          if (model->spec.launch_crba && model->spec.crba_packed && model->use_spec && sizeof(T) == 8)
          {
             const int sflags = (model->ident_maps && model->dense_maps) ? SPEC_IDENT : 0;
+            // tree-split form (4 waves per 64 configurations, coalesced write-out): measured faster at every batch size
+            bool split = sflags && !soa && model->spec.launch_crba_split && model->spec.crba_split_usable && model->spec.crba_split_usable()
+                         && model->use_split != 0;
+            if (split)
+            {
+               // thin workgroups (16 / 32 of the 64 lanes) while that is what it takes to give every CU a workgroup: the write-out is
+               // bound by the stores one CU can have in flight
+               int lpg = 64;
+               if (const char *e = getenv("MH_CRBA_LPG"))
+                  lpg = std::max(1, std::min(64, atoi(e)));
+               else
+                  while (lpg > 16 && (B + lpg - 1) / lpg < (long)model->cu_count)
+                     lpg /= 2;
+               const long ng = (B + lpg - 1) / lpg;
+               const int rc = model->spec.launch_crba_split(&A, (int)std::min<long>(ng, (long)model->cu_count * 2), lpg, (void *)stream);
+               if (rc != 0)
+                  return fail(MH_ERR_HIP, "tree-split CRBA launch failed: %s", hipGetErrorString((hipError_t)rc));
+               return MH_OK;
+            }
             const bool packed = model->spec.crba_packed(sflags) != 0;
             if (!packed)
                HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream)); // direct-store kernel writes related entries only
@@ -532,6 +553,8 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.split_usable = (decltype(s.split_usable))dlsym(h, "mh_spec_split_usable");
    s.split_lds_bytes = (decltype(s.split_lds_bytes))dlsym(h, "mh_spec_split_lds_bytes");
    s.launch_split = (decltype(s.launch_split))dlsym(h, "mh_spec_launch_split");
+   s.crba_split_usable = (decltype(s.crba_split_usable))dlsym(h, "mh_spec_crba_split_usable");
+   s.launch_crba_split = (decltype(s.launch_crba_split))dlsym(h, "mh_spec_launch_crba_split");
    bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
    for (int e = 0; ok && e < m->n; e++)
       ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];

@@ -239,6 +239,33 @@ int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
    return (int)hipGetLastError();
 #endif
 }
+// tree-split CRBA: identity maps, AoS, packed image + limb exchange in LDS
+long mh_spec_crba_split_lds_bytes(void)
+{ // lane-major image (odd pitch) + limb exchange + entry -> slot table
+   return (long)((mh::HMap<TP>::T.n_slots | 1) + SPL::n_limbs() * 10) * 64 * sizeof(double) + (long)((mh::HMap<TP>::NV * mh::HMap<TP>::NV * 2 + 7) & ~7);
+}
+int mh_spec_crba_split_usable(void) { return SPL::usable() && mh_spec_crba_split_lds_bytes() <= 160 * 1024 ? 1 : 0; }
+int mh_spec_launch_crba_split(const void *args, int groups, int lanes_per_group, void *stream)
+{
+   if constexpr (SPL::usable())
+   {
+      const mh::Args<double> &A = *(const mh::Args<double> *)args;
+      auto kern = &mh::spec_crba_split_kernel<TP, double>;
+      const size_t lds = (size_t)mh_spec_crba_split_lds_bytes();
+      static size_t attr_bytes = 0;
+      if (lds > 64 * 1024 && lds > attr_bytes)
+      {
+         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess)
+            return (int)e;
+         attr_bytes = lds;
+      }
+      hipLaunchKernelGGL(kern, dim3(groups), dim3(256), lds, (hipStream_t)stream, A, lanes_per_group);
+      return (int)hipGetLastError();
+   }
+   else
+      return (int)hipErrorNotSupported;
+}
 // algo: 0 = RNEA, 1 = ABA; fp64 only.  args points to mh::Args<double>.
 int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream)
 {

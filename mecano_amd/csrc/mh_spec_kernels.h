@@ -828,6 +828,8 @@ struct HMap
       short slot[NV * NV > 0 ? NV * NV : 1] = {}; // packed slot of entry (r, c), -1 = structural zero
       int n_slots = 0;
    };
+   // run-time view of the same table for the coalesced write-out of the tree-split kernel (entry -> slot)
+   static MH_DEV int slot_at(int e) { return T.slot[e]; }
    static constexpr Table make()
    {
       Table t;
@@ -854,10 +856,12 @@ struct HMap
 
 // PACK = false: H[dof R][dof C] and its mirror image go straight to global memory (setSymmetricEntry, :841-845).
 // PACK = true : the value goes to the lane's packed LDS image; the kernel writes H out afterwards, zeros included, in address order.
-template <class TP, bool PACK, int R, int C, class CX, typename T>
+template <class TP, int PACK, int R, int C, class CX, typename T>
 MH_DEV void h_put(const CX &cx, T v)
 {
-   if constexpr (PACK)
+   if constexpr (PACK == 2) // lane-major image (tree-split kernel): xbase = image + lane * row pitch
+      cx.xbase[HMap<TP>::T.slot[R * HMap<TP>::NV + C]] = v;
+   else if constexpr (PACK == 1)
       cx.xbase[HMap<TP>::T.slot[R * HMap<TP>::NV + C] * 64] = v;
    else
    {
@@ -867,7 +871,28 @@ MH_DEV void h_put(const CX &cx, T v)
          cx.orow[(c * cx.nv + r) * cx.v_es] = v;
    }
 }
-template <class TP, int J, typename T, class CX, int D, bool PACK>
+// limb -> trunk exchange of the tree-split CRBA: the composite inertia (10 scalars) a limb hands up, behind the packed image of H
+template <class TP, int LIMB, class CX, typename T>
+MH_DEV void xc_put_ri(const CX &cx, const RI<T> &r)
+{
+   constexpr int S0 = LIMB * 10; // cx.lx = exchange area + lane
+   cx.lx[(S0 + 0) * 64] = r.m, cx.lx[(S0 + 1) * 64] = r.h.x, cx.lx[(S0 + 2) * 64] = r.h.y, cx.lx[(S0 + 3) * 64] = r.h.z;
+   cx.lx[(S0 + 4) * 64] = r.I.xx, cx.lx[(S0 + 5) * 64] = r.I.xy, cx.lx[(S0 + 6) * 64] = r.I.xz, cx.lx[(S0 + 7) * 64] = r.I.yy;
+   cx.lx[(S0 + 8) * 64] = r.I.yz, cx.lx[(S0 + 9) * 64] = r.I.zz;
+}
+template <class TP, int LIMB, class CX, typename T>
+MH_DEV RI<T> xc_get_ri(const CX &cx)
+{
+   constexpr int S0 = LIMB * 10;
+   RI<T> r;
+   r.m = cx.lx[(S0 + 0) * 64];
+   r.h = V3<T>{cx.lx[(S0 + 1) * 64], cx.lx[(S0 + 2) * 64], cx.lx[(S0 + 3) * 64]};
+   r.I = S3<T>{cx.lx[(S0 + 4) * 64], cx.lx[(S0 + 5) * 64], cx.lx[(S0 + 6) * 64], cx.lx[(S0 + 7) * 64], cx.lx[(S0 + 8) * 64], cx.lx[(S0 + 9) * 64]};
+   return r;
+}
+// MODE 1 (tree-split kernel, trunk pass): a child that is the root of a limb is not walked, its composite inertia comes from the
+// exchange area where the limb's owner left it (the limb's own columns of H are complete by then).
+template <class TP, int J, typename T, class CX, int D, int PACK, int MODE = 0>
 struct CrbaSub
 {
    using TR = Tree<TP>;
@@ -876,7 +901,11 @@ struct CrbaSub
    {
       if constexpr (K < TR::n_children(J))
       {
-         const RI<T> r = CrbaSub<TP, TR::child(J, K), T, CX, D + 1, PACK>::run(cx, path);
+         RI<T> r;
+         if constexpr (MODE == 1 && !Split<TP>::is_trunk(TR::child(J, K)))
+            r = xc_get_ri<TP, Split<TP>::limb_index(TR::child(J, K)), CX, T>(cx);
+         else
+            r = CrbaSub<TP, TR::child(J, K), T, CX, D + 1, PACK, MODE>::run(cx, path);
          if constexpr (K == 0)
             acc = r;
          else
@@ -963,14 +992,48 @@ struct CrbaSub
       return Ic;
    }
 };
-template <class TP, typename T, class CX, bool PACK, int K = 0>
+template <class TP, typename T, class CX, int PACK, int MODE = 0, int K = 0>
 MH_DEV void crba_roots(const CX &cx)
 {
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       CrbaPath<T, 0> empty;
-      (void)CrbaSub<TP, Tree<TP>::child(-1, K), T, CX, 0, PACK>::run(cx, empty);
-      crba_roots<TP, T, CX, PACK, K + 1>(cx);
+      (void)CrbaSub<TP, Tree<TP>::child(-1, K), T, CX, 0, PACK, MODE>::run(cx, empty);
+      crba_roots<TP, T, CX, PACK, MODE, K + 1>(cx);
+   }
+}
+// joint transforms of the trunk ancestors of a limb root (depth 0 .. D-1), for the owner of the limb
+template <class TP, int J, typename T, class CX, int D>
+MH_DEV void crba_trunk_path(const CX &cx, CrbaPath<T, D> &path)
+{ // J = the ancestor at depth D - 1
+   if constexpr (D > 0)
+   {
+      path.jx[D - 1] = spec_joint<TP::type[J], Tree<TP>::cfg_ofs(J), CX, T>(cx);
+      if constexpr (D > 1)
+      {
+         CrbaPath<T, D - 1> up;
+         crba_trunk_path<TP, TP::parent[J], T, CX, D - 1>(cx, up);
+#pragma unroll
+         for (int d = 0; d < D - 1; d++)
+            path.jx[d] = up.jx[d];
+      }
+   }
+}
+template <class TP, int K, typename T, class CX>
+MH_DEV void split_crba_limbs(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if (cx.wave == S::owner(K))
+      {
+         constexpr int R = S::limb_root(K), D = Tree<TP>::depth(R);
+         CrbaPath<T, D> path;
+         if constexpr (D > 0)
+            crba_trunk_path<TP, TP::parent[R], T, CX, D>(cx, path);
+         xc_put_ri<TP, K, CX, T>(cx, CrbaSub<TP, R, T, CX, D, 2, 0>::run(cx, path));
+      }
+      split_crba_limbs<TP, K + 1, T, CX>(cx);
    }
 }
 
@@ -1341,6 +1404,97 @@ __global__ void __launch_bounds__(64) spec_crba_packed_kernel(Args<T> A)
             }
          }
       }
+   }
+}
+
+// Tree-split CRBA (identity index maps, AoS): four waves share 64 configurations.  Each limb's owner walks the limb with the joint
+// transforms of its trunk ancestors in hand, which completes every column of H that belongs to a limb body and leaves the limb's
+// composite inertia in the exchange area; after one barrier wave 0 finishes the trunk bodies' columns; after a second barrier the
+// four waves write a quarter of every matrix each, straight from the packed LDS image (zeros included, no memset).
+template <class TP, typename T>
+__global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg)
+{ // lpg = configurations per workgroup (<= 64).  The write-out of 7.2 KB per configuration is bound by what ONE CU can have in
+  // flight, so a small batch is spread over more, thinner workgroups (16 lanes of each wave active) to put every CU's store path to work.
+   extern __shared__ double lds_raw[];
+   using CX = Ctx<T, false, true, WholeStore<TP, ST_GLOBAL_KIND>>;
+   using HM = HMap<TP>;
+   constexpr int NV = HM::NV, NE = NV * NV;
+   constexpr int NSP = HM::T.n_slots | 1; // odd row pitch of the lane-major image: lanes writing one slot spread over all banks
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const lds_ptr<T> img = (lds_ptr<T>)lds_raw;
+   // entry -> slot table of the write-out, staged once (the lookups sit in a dependent chain: LDS latency, not global)
+   short __attribute__((address_space(3))) *tab = (short __attribute__((address_space(3))) *)(img + 64 * NSP + Split<TP>::n_limbs() * 10 * 64);
+   for (int e = threadIdx.x; e < NE; e += 256)
+      tab[e] = (short)HM::slot_at(e);
+   warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   for (long cfg0 = (long)blockIdx.x * lpg; cfg0 < A.B; cfg0 += (long)gridDim.x * lpg)
+   {
+      const long cfg = cfg0 + lane;
+      const bool active = lane < lpg && cfg < A.B;
+#ifdef MH_PROBE
+#define MH_CSTAMP(k)                                                                                                                       \
+   do                                                                                                                                      \
+   {                                                                                                                                       \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                                          \
+      if (lane == 0)                                                                                                                       \
+         ((unsigned long long *)(A.out + A.B * NE))[(cfg0 / lpg) * 32 + wave * 8 + (k)] = t_;                                               \
+   } while (0)
+#else
+#define MH_CSTAMP(k)
+#endif
+      MH_CSTAMP(0);
+      CX cx;
+      fill_ctx<T>(cx, A, active ? cfg : cfg0);
+      cx.nv = NV;
+      cx.wave = wave;
+      cx.xbase = img + lane * NSP;
+      cx.lx = img + 64 * NSP + lane;
+      MH_CSTAMP(1);
+      if (active)
+         split_crba_limbs<TP, 0, T, CX>(cx);
+      MH_CSTAMP(2);
+      __syncthreads();
+      MH_CSTAMP(3);
+      if (active && wave == 0)
+         crba_roots<TP, T, CX, 2, 1>(cx);
+      MH_CSTAMP(4);
+      __syncthreads();
+      MH_CSTAMP(5);
+      { // coalesced write-out of the group's matrices (contiguous in the AoS result), zeros included: element g of the slice is
+        // entry g % NE of configuration g / NE; consecutive threads write consecutive addresses
+         const long rows = A.B - cfg0 < lpg ? A.B - cfg0 : lpg;
+         const int total = (int)rows * NE;
+         T *H = A.out + cfg0 * NE;
+         int g = threadIdx.x, c = g / NE, e = g - c * NE;
+         constexpr int STEP = 256, SC = STEP / NE, SE = STEP - SC * NE;
+         constexpr int UN = 8;
+         while (g < total)
+         { // UN independent look-ups, reads and stores in flight per thread
+            int sl[UN], cc[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++)
+            {
+               sl[u] = g + u * STEP < total ? (int)tab[e] : -1;
+               cc[u] = c;
+               c += SC, e += SE;
+               if (e >= NE)
+                  e -= NE, c++;
+            }
+            T v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++)
+               v[u] = sl[u] >= 0 ? img[cc[u] * NSP + sl[u]] : T(0);
+#pragma unroll
+            for (int u = 0; u < UN; u++)
+               if (g + u * STEP < total)
+                  __builtin_nontemporal_store(v[u], H + g + u * STEP); // streamed once, never read back by this kernel
+            g += UN * STEP;
+         }
+      }
+      MH_CSTAMP(6);
+      __syncthreads(); // the image is free for the next slice
+      MH_CSTAMP(7);
    }
 }
 

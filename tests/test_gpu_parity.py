@@ -219,7 +219,8 @@ def test_layouts_soa_equals_aos(torch_cuda):
     close(b.t().cpu().numpy(), a.cpu().numpy(), 1e-11)
     a = hm.crba(q)
     b = hm.crba(T(q), layout=_lib.LAYOUT_SOA)
-    assert torch.equal(a.reshape(B, -1), b.t())
+    close(b.t().cpu().numpy(), a.reshape(B, -1).cpu().numpy(), 1e-12)  # tree-split (AoS) and whole-wave (SoA) kernels: to rounding
+    assert torch.equal((a == 0), (b.t() == 0).reshape(B, 30, 30))       # the structural zeros are exact in both
 
 
 def test_switches_and_options(torch_cuda):
@@ -381,6 +382,39 @@ def test_every_specialised_variant(torch_cuda, B):
             for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT"):
                 os.environ.pop(k, None)
         assert "generic" in seen and any(v.startswith("topo:") for v in seen), seen
+
+
+@pytest.mark.parametrize("B", [1, 15, 64, 100, 4096, 5000])
+def test_crba_kernel_variants(torch_cuda, B):
+    """CRBA of the humanoid through every kernel the dispatcher can pick -- tree-split with 64 / 32 / 16 / 7 configurations per workgroup
+    (MH_CRBA_LPG), whole-wave packed (MH_SPEC_SPLIT=0), SoA, generic -- against the oracle on EVERY entry (structural zeros included: the
+    specialised kernels write the whole matrix themselves, there is no memset behind them)."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(4242 + B)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    q = rt.nextState(rng, sys_, B)[0]
+    H_ref = OracleModel(d).crba(q)
+    keys = ("MH_DISABLE_SPEC", "MH_SPEC_SPLIT", "MH_CRBA_LPG")
+    try:
+        for env in ({}, {"MH_CRBA_LPG": "64"}, {"MH_CRBA_LPG": "32"}, {"MH_CRBA_LPG": "16"}, {"MH_CRBA_LPG": "7"}, {"MH_SPEC_SPLIT": "0"}, {"MH_DISABLE_SPEC": "1"}):
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            hm = HipModel(d)
+            out = torch.full((B + 1, d.nv, d.nv), float("nan"), device="cuda", dtype=torch.float64)  # poisoned, with a guard row behind
+            _lib.check(_lib.load().mh_crba_f64(hm._h, B, dev(torch, q).data_ptr(), None, out.data_ptr()))
+            got = out.cpu().numpy()
+            assert np.isnan(got[B]).all(), f"{env}: wrote past the last matrix"
+            close(got[:B], H_ref)
+            Hs = hm.crba(dev(torch, q.T), layout=_lib.LAYOUT_SOA).cpu().numpy()
+            close(Hs.T.reshape(B, d.nv, d.nv), H_ref)
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize("B", [1, 100, 4096, 8192, 9000, 50000])
