@@ -1196,40 +1196,82 @@ __global__ void __launch_bounds__(64) spec_fused_kernel(Args<T> A)
 // each limb (leg, arm, ...) is walked by the one wave that owns it, and what a limb hands to the trunk crosses waves through a
 // small LDS exchange area behind one workgroup barrier.  The serial chain a wave executes shrinks from N bodies to
 // (trunk + its longest limb); the batch occupies 4x as many SIMDs.  Built for small batches, where latency is everything.
-template <class TP, int K, typename T, class CX>
-MH_DEV void split_rnea_limbs(const CX &cx)
+// The limbs of one owner wave W, in limb order.  PC = trunk body whose velocity (and acceleration) the previous limb of this wave
+// hung from (-2: none yet): limbs sharing a parent -- an arm and the neck on the chest -- walk the trunk down to it once.
+template <class TP, int W, int K, int PC, typename T, class CX>
+MH_DEV void split_rnea_limbs_of(const CX &cx, SV<T> &vp, SV<T> &ap)
 {
    using S = Split<TP>;
    if constexpr (K < S::n_limbs())
    {
-      if (cx.wave == S::owner(K))
+      if constexpr (S::owner(K) == W)
       {
-         constexpr int R = S::limb_root(K);
-         const V3<T> Z{T(0), T(0), T(0)};
-         SV<T> vp{Z, Z}, ap{Z, cx.a0l};
-         if constexpr (TP::parent[R] >= 0)
-            trunk_va<TP, TP::parent[R], T, CX>(cx, vp, ap);
+         constexpr int R = S::limb_root(K), P = TP::parent[R];
+         if constexpr (P != PC)
+         {
+            const V3<T> Z{T(0), T(0), T(0)};
+            vp = SV<T>{Z, Z}, ap = SV<T>{Z, cx.a0l};
+            if constexpr (P >= 0)
+               trunk_va<TP, P, T, CX>(cx, vp, ap);
+         }
          x_put6<K, 6, 0, CX, T>(cx, RneaSub<TP, R, T, CX, 0>::run(cx, vp, ap));
+         split_rnea_limbs_of<TP, W, K + 1, P, T, CX>(cx, vp, ap);
       }
-      split_rnea_limbs<TP, K + 1, T, CX>(cx);
+      else
+         split_rnea_limbs_of<TP, W, K + 1, PC, T, CX>(cx, vp, ap);
    }
 }
-template <class TP, int K, typename T, class CX>
-MH_DEV void split_aba_limbs(const CX &cx)
+template <class TP, int W, int K, int PC, typename T, class CX>
+MH_DEV void split_aba_limbs_of(const CX &cx, SV<T> &vp)
 {
    using S = Split<TP>;
    if constexpr (K < S::n_limbs())
    {
-      if (cx.wave == S::owner(K))
+      if constexpr (S::owner(K) == W)
       {
-         constexpr int R = S::limb_root(K);
+         constexpr int R = S::limb_root(K), P = TP::parent[R];
+         if constexpr (P != PC)
+         {
+            const V3<T> Z{T(0), T(0), T(0)};
+            vp = SV<T>{Z, Z};
+            if constexpr (P >= 0)
+               vp = trunk_v<TP, P, T, CX>(cx);
+         }
+         x_put_up<K, CX, T>(cx, AbaIn<TP, R, T, CX, 0>::run(cx, vp));
+         split_aba_limbs_of<TP, W, K + 1, P, T, CX>(cx, vp);
+      }
+      else
+         split_aba_limbs_of<TP, W, K + 1, PC, T, CX>(cx, vp);
+   }
+}
+template <class TP, int W, typename T, class CX>
+MH_DEV void split_rnea_limbs(const CX &cx)
+{
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+      {
+         const V3<T> Z{T(0), T(0), T(0)};
+         SV<T> vp{Z, Z}, ap{Z, Z};
+         split_rnea_limbs_of<TP, W, 0, -2, T, CX>(cx, vp, ap);
+      }
+      else
+         split_rnea_limbs<TP, W + 1, T, CX>(cx);
+   }
+}
+template <class TP, int W, typename T, class CX>
+MH_DEV void split_aba_limbs(const CX &cx)
+{
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+      {
          const V3<T> Z{T(0), T(0), T(0)};
          SV<T> vp{Z, Z};
-         if constexpr (TP::parent[R] >= 0)
-            vp = trunk_v<TP, TP::parent[R], T, CX>(cx);
-         x_put_up<K, CX, T>(cx, AbaIn<TP, R, T, CX, 0>::run(cx, vp));
+         split_aba_limbs_of<TP, W, 0, -2, T, CX>(cx, vp);
       }
-      split_aba_limbs<TP, K + 1, T, CX>(cx);
+      else
+         split_aba_limbs<TP, W + 1, T, CX>(cx);
    }
 }
 
