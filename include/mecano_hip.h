@@ -200,6 +200,19 @@ mh_status mh_aba_locked_f64(mh_model_t model, int64_t B, const double *q, const 
                             const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out, double *tau_out);
 
 /*
+ * ---- per-body outputs (RigidBodyAccelerationProvider: InverseDynamicsCalculator.getAccelerationProvider, InverseDynamicsCalculator.java:242-250,
+ *      660-663; ForwardDynamicsCalculator.getAccelerationProvider, ForwardDynamicsCalculator.java:170-180, 715-718) ----
+ * Same as mh_rnea_f64 / mh_aba_f64, plus for the successor body of every listed joint its spatial acceleration and / or twist relative
+ * to the inertial frame, expressed in the body-fixed frame: body_acc_out, body_twist_out [B][n_joints][6] (angular, linear), laid
+ * out like f_ext; either may be NULL.  As in the reference the acceleration carries the root acceleration -g, and the RNEA switches
+ * apply (consider_coriolis = 0: velocity terms dropped and twists reported as zero).  Runs the run-time-topology kernels.
+ */
+mh_status mh_rnea_bodies_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                             const double *f_ext, const mh_options *opts, double *tau_out, double *body_acc_out, double *body_twist_out);
+mh_status mh_aba_bodies_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
+                            const double *f_ext, const mh_options *opts, double *qdd_out, double *body_acc_out, double *body_twist_out);
+
+/*
  * ---- state integration (MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration, tools/MultiBodySystemStateIntegrator.java:365-441,
  *      503-575, 710-733): the step downstream of forward dynamics, so that a simulation loop never leaves the device ----
  * One explicit constant-acceleration step of size dt for every joint of every configuration: 1-DoF q' = q + dt qd + dt^2/2 qdd,

@@ -70,12 +70,39 @@ class _Base:
         self._f_ext = None
 
 
+class RigidBodyAccelerationProvider:
+    """algorithms/interfaces/RigidBodyAccelerationProvider.java:137-260, batched: the spatial acceleration (and twist) of every
+    successor body relative to the inertial frame, expressed in its body-fixed frame, as computed by the last ``compute``."""
+
+    def __init__(self, system: MultiBodySystem):
+        self._pos = {id(j.getSuccessor()): k for k, j in enumerate(system.getJointsToConsider())}
+        self._root = system.getRootBody()
+        self.body_acc = None
+        self.body_twist = None
+
+    def getAccelerationOfBody(self, body):
+        """[B, 6] (angular, linear); ``None`` for a body the calculator does not consider, like the reference (:242-246).  The root
+        body's own acceleration is the root acceleration -g and is not stored per configuration."""
+        k = self._pos.get(id(body))
+        return None if k is None or self.body_acc is None else self.body_acc[:, k, :]
+
+    def getTwistOfBody(self, body):
+        k = self._pos.get(id(body))
+        return None if k is None or self.body_twist is None else self.body_twist[:, k, :]
+
+    def getRelativeAcceleration(self, base, body):
+        """Not offered: it needs the transform between the two body frames of every configuration (forward kinematics the engine
+        keeps on the device).  The reference's version is RigidBodyAccelerationProvider.java:171-200."""
+        raise NotImplementedError("relative accelerations are not exported by the HIP engine")
+
+
 class InverseDynamicsCalculator(_Base):
     def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
         super().__init__(input, considerIgnoredSubtreesInertia)
         self._coriolis = True
         self._accel = True
         self._tau = None
+        self._provider = RigidBodyAccelerationProvider(self.input)
 
     def setConsiderCoriolisAndCentrifugalForces(self, flag: bool):
         self._coriolis = bool(flag)
@@ -83,9 +110,17 @@ class InverseDynamicsCalculator(_Base):
     def setConsiderJointAccelerations(self, flag: bool):
         self._accel = bool(flag)
 
-    def compute(self, q, qd, qdd):
-        self._tau = self.model.rnea(q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis, self._accel)
+    def compute(self, q, qd, qdd, bodies: bool = False):
+        """``bodies=True`` also fills the acceleration provider (InverseDynamicsCalculator.java:242-250, 660-663)."""
+        if bodies:
+            self._tau, self._provider.body_acc, self._provider.body_twist = self.model.rnea_bodies(
+                q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis, self._accel)
+        else:
+            self._tau = self.model.rnea(q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis, self._accel)
         return self._tau
+
+    def getAccelerationProvider(self) -> RigidBodyAccelerationProvider:
+        return self._provider
 
     def getJointTauMatrix(self):
         return self._tau
@@ -104,6 +139,7 @@ class ForwardDynamicsCalculator(_Base):
         super().__init__(input, considerIgnoredSubtreesInertia)
         self._qdd = None
         self._tau = None
+        self._provider = RigidBodyAccelerationProvider(self.input)
         self._modes = [JointSourceMode.EFFORT_SOURCE] * self.model.n_joints
         self._joint_pos = {id(j): k for k, j in enumerate(self.input.getJointsToConsider())}
 
@@ -127,13 +163,20 @@ class ForwardDynamicsCalculator(_Base):
         self._modes = [JointSourceMode.EFFORT_SOURCE] * self.model.n_joints
         self.model.set_joint_source_modes(None)
 
-    def compute(self, q, qd, tau, qdd=None):
+    def getAccelerationProvider(self) -> RigidBodyAccelerationProvider:
+        """ForwardDynamicsCalculator.java:170-180, 715-718; filled by ``compute(..., bodies=True)``."""
+        return self._provider
+
+    def compute(self, q, qd, tau, qdd=None, bodies: bool = False):
         """``compute(q, qd, tau)`` (:475-490) or, with acceleration-source joints, ``compute(q, qd, tau, qdd)`` (:508-520): tau is
         read for the effort sources, qdd for the acceleration sources."""
         if any(m == JointSourceMode.ACCELERATION_SOURCE for m in self._modes):
             if qdd is None:
                 raise ValueError("some joints are acceleration sources: their accelerations (qdd) are needed")
             self._qdd, self._tau = self.model.aba_locked(q, qd, tau, qdd, self._gravity, self._f_ext, self.layout)
+        elif bodies:
+            self._qdd, self._provider.body_acc, self._provider.body_twist = self.model.aba_bodies(q, qd, tau, self._gravity, self._f_ext, self.layout)
+            self._tau = tau
         else:
             self._qdd = self.model.aba(q, qd, tau, self._gravity, self._f_ext, self.layout)
             self._tau = tau

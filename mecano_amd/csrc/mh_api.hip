@@ -232,7 +232,8 @@ enum Algo
 
 template <typename T>
 mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd, const T *in3, const double gravity[3], const T *fext,
-                 const mh_options *opts_in, T *out, const T *locked_in = nullptr, T *locked_out = nullptr)
+                 const mh_options *opts_in, T *out, const T *locked_in = nullptr, T *locked_out = nullptr, T *body_acc = nullptr,
+                 T *body_twist = nullptr, bool bodies = false)
 {
    mh_options opts;
    if (opts_in)
@@ -260,6 +261,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    A.B = B;
    A.q = q, A.qd = qd, A.in3 = in3, A.fext = fext, A.out = out;
    A.in3b = nullptr, A.outb = nullptr;
+   A.body_acc = body_acc, A.body_twist = body_twist;
    A.ws = (T *)model->ws.ptr;
    A.ws_stride = L.lanes;
    const bool soa = opts.layout == MH_LAYOUT_SOA;
@@ -272,6 +274,17 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    if (lds > 160 * 1024)
       return fail(MH_ERR_BAD_DIMENSION, "model constants (%zu B) exceed the 160 KiB LDS of a gfx950 CU", lds);
 
+   if (bodies && algo != ALGO_CRBA)
+   { // per-body outputs: run-time-topology kernels (the model's joint source modes must all be effort sources)
+      if (model->n_locked > 0)
+         return fail(MH_ERR_INVALID_ARGUMENT, "per-body outputs are not available while joints are acceleration sources");
+      if (algo == ALGO_RNEA)
+         hipLaunchKernelGGL((mh::rnea_kernel<T, MH_GENERIC_LDS_CONSTS, true>), dim3(L.grid), dim3(L.block), lds, stream, A);
+      else
+         hipLaunchKernelGGL((mh::aba_kernel<T, MH_GENERIC_LDS_CONSTS, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A);
+      HIP_TRY(hipGetLastError());
+      return MH_OK;
+   }
    if (algo == ALGO_ABA && model->n_locked > 0)
    { // acceleration-source joints: run-time flags per joint, generic kernel only
       A.in3b = locked_in, A.outb = locked_out;
@@ -913,6 +926,16 @@ mh_status mh_integrate_f32(mh_model_t model, int64_t B, double dt, const float *
 {
    return integrate_impl<float>(model, B, dt, q, qd, qdd, opts, q_out, qd_out, qdd_out);
 }
+mh_status mh_rnea_bodies_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                             const double *f_ext, const mh_options *opts, double *tau_out, double *body_acc_out, double *body_twist_out)
+{
+   return launch<double>(ALGO_RNEA, model, B, q, qd, qdd, gravity, f_ext, opts, tau_out, nullptr, nullptr, body_acc_out, body_twist_out, true);
+}
+mh_status mh_aba_bodies_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
+                            const double *f_ext, const mh_options *opts, double *qdd_out, double *body_acc_out, double *body_twist_out)
+{
+   return launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, nullptr, nullptr, body_acc_out, body_twist_out, true);
+}
 mh_status mh_model_set_joint_source_modes(mh_model_t model, const int32_t *modes)
 {
    if (!model)
@@ -984,6 +1007,7 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    A.B = B;
    A.q = q, A.qd = qd, A.in3 = qdd, A.fext = f_ext, A.out = tau_out;
    A.in3b = tau, A.outb = qdd_out;
+   A.body_acc = nullptr, A.body_twist = nullptr;
    A.ws = nullptr, A.ws_stride = 0;
    A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
    A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];

@@ -91,6 +91,9 @@ struct Args
    // aba_kernel<.., LOCKED>: in3b = given accelerations of the ACCELERATION_SOURCE joints, outb = tau of all joints (may be NULL)
    const T *in3b;
    T *outb;
+   // optional per-body outputs (generic kernels with BODIES): spatial acceleration / twist of every successor body relative to the
+   // inertial frame, in its body-fixed frame, [B][n_joints][6] laid out like fext (f_bs, f_es); either may be NULL
+   T *body_acc, *body_twist;
 };
 
 template <typename T, class CR>
@@ -288,6 +291,20 @@ MH_DEV SV<T> load_fext(const CR &c, const T *frow, long f_es, int ext)
    return force_to_parent(X, w);
 }
 
+// motion vector of a body from the engine's canonical after-joint frame into Mecano's body-fixed frame, written to row `ext`
+// (RigidBodyAccelerationProvider: InverseDynamicsCalculator.java:242-250, ForwardDynamicsCalculator.java:170-180)
+template <typename T, class CR>
+MH_DEV void store_body_motion(const CR &c, T *row, long f_es, int ext, const SV<T> &m)
+{
+   XF<T> X;
+   X.R = M3<T>{c[MC_RF + 0], c[MC_RF + 1], c[MC_RF + 2], c[MC_RF + 3], c[MC_RF + 4], c[MC_RF + 5], c[MC_RF + 6], c[MC_RF + 7], c[MC_RF + 8]};
+   X.p = V3<T>{c[MC_PF + 0], c[MC_PF + 1], c[MC_PF + 2]};
+   const SV<T> b = motion_to_child(X, m);
+   const long e = (long)ext * 6;
+   row[(e + 0) * f_es] = b.a.x, row[(e + 1) * f_es] = b.a.y, row[(e + 2) * f_es] = b.a.z;
+   row[(e + 3) * f_es] = b.l.x, row[(e + 4) * f_es] = b.l.y, row[(e + 5) * f_es] = b.l.z;
+}
+
 template <typename T>
 MH_DEV void stage_consts(const DevModel &m, T *lds)
 {
@@ -298,7 +315,7 @@ MH_DEV void stage_consts(const DevModel &m, T *lds)
 }
 
 // ============================================================================================ RNEA
-template <typename T, bool LDSC>
+template <typename T, bool LDSC, bool BODIES = false>
 __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -356,6 +373,13 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
          SV<T> a = motion_down(type, jx, Xb, ap) + aJ + crm(v, vJ);
          if (!A.coriolis)
             v = SV<T>{Z, Z};
+         if constexpr (BODIES)
+         {
+            if (A.body_acc)
+               store_body_motion<T>(c, A.body_acc + cfg * A.f_bs, A.f_es, mi[MI_EXT], a);
+            if (A.body_twist)
+               store_body_motion<T>(c, A.body_twist + cfg * A.f_bs, A.f_es, mi[MI_EXT], v);
+         }
          const RI<T> I = load_inertia<T>(c);
          SV<T> f = mul(I, a) + crf(v, mul(I, v));
          if (frow)
@@ -491,7 +515,7 @@ MH_DEV SV<T> spd6_solve(const ABI<T> &I, SV<T> b)
 // LOCKED: some joints are ACCELERATION_SOURCE (:1237-1253, 1284-1297, 1315-1363).  Mecano's pass four re-runs a Newton-Euler sweep to
 // get the efforts of those joints; here tau = S^T (IA a + pA) is read off the articulated quantities pass two already holds, which is
 // the same wrench (the articulated-body equation of the subtree) without a fourth sweep.
-template <typename T, bool LDSC, bool LOCKED = false>
+template <typename T, bool LDSC, bool LOCKED = false, bool BODIES = false>
 __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -536,6 +560,11 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
          const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
          const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         if constexpr (BODIES)
+         {
+            if (A.body_twist)
+               store_body_motion<T>(c, A.body_twist + cfg * A.f_bs, A.f_es, mi[MI_EXT], v);
+         }
          const RI<T> I = load_inertia<T>(c);
          SV<T> p = crf(v, mul(I, v));
          if (frow)
@@ -743,6 +772,11 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          }
          if (flags & MF_STORE_VA)
             ws_store6(ws, ws_stride, mi[MI_SLOT_VA], a);
+         if constexpr (BODIES)
+         {
+            if (A.body_acc)
+               store_body_motion<T>(c, A.body_acc + cfg * A.f_bs, A.f_es, mi[MI_EXT], a);
+         }
          a_prev = a;
       }
    }

@@ -179,6 +179,34 @@ class HipModel:
             return qdd_out.cpu().numpy(), tau_out.cpu().numpy()
         return qdd_out, tau_out
 
+    def _bodies(self, kind, q, qd, x3, gravity, f_ext, layout, consider_coriolis=True, consider_accelerations=True):
+        import torch
+        lib = _lib.load()
+        for t in (q, qd, x3) + ((f_ext,) if f_ext is not None else ()):
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("per-body outputs need contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, layout)
+        if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(layout, consider_coriolis, consider_accelerations, torch.cuda.current_stream(q.device).cuda_stream)
+        out = torch.empty_like(qd)
+        shape = (B, self.n_joints, 6) if layout == _lib.LAYOUT_AOS else (self.n_joints * 6, B)
+        acc, tw = torch.empty(shape, dtype=torch.float64, device=q.device), torch.empty(shape, dtype=torch.float64, device=q.device)
+        fn = lib.mh_rnea_bodies_f64 if kind == "rnea" else lib.mh_aba_bodies_f64
+        _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), x3.data_ptr(), g, f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts),
+                      out.data_ptr(), acc.data_ptr(), tw.data_ptr()))
+        return out, acc, tw
+
+    def rnea_bodies(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS, consider_coriolis=True,
+                    consider_accelerations=True):
+        """RNEA plus per-body outputs: (tau, body_acc, body_twist), the latter [B, n_joints, 6] in the body-fixed frames."""
+        return self._bodies("rnea", q, qd, qdd, gravity, f_ext, layout, consider_coriolis, consider_accelerations)
+
+    def aba_bodies(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS):
+        """ABA plus per-body outputs: (qdd, body_acc, body_twist)."""
+        return self._bodies("aba", q, qd, tau, gravity, f_ext, layout)
+
     def integrate(self, dt, q, qd, qdd, layout=_lib.LAYOUT_AOS, out=None, return_acceleration=False):
         """One step of MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration on device tensors (fp64 / fp32).  ``out`` =
         (q_out, qd_out[, qdd_out]) may name the inputs themselves for an in-place step; by default new tensors are returned."""

@@ -42,6 +42,9 @@ def _load():
         lib.mo_aba_locked.restype = ctypes.c_int
         lib.mo_integrate.argtypes = [P, ctypes.c_long, ctypes.c_double, P, P, P, P, P, P]
         lib.mo_integrate.restype = None
+        lib.mo_rnea_bodies.argtypes = [P, ctypes.c_long, P, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P, P]
+        lib.mo_aba_bodies.argtypes = [P, ctypes.c_long, P, P, P, P, P, P, P, P]
+        lib.mo_aba_bodies.restype = ctypes.c_int
         _lib = lib
     return _lib
 
@@ -102,6 +105,26 @@ class OracleModel:
         if rc:
             raise ArithmeticError("oracle ABA: joint-space inertia block not positive definite")
         return qdd, tau_out
+
+    def rnea_bodies(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None, consider_coriolis=True, consider_accelerations=True):
+        """RNEA plus the per-body outputs: (tau, body_acc [B, n, 6], body_twist [B, n, 6]), body-fixed frames."""
+        q, qd, qdd, f_ext = _c(q), _c(qd), _c(qdd), _c(f_ext)
+        B = q.shape[0]
+        g = np.asarray(gravity, dtype=np.float64)
+        tau, acc, tw = np.zeros((B, self.nv)), np.zeros((B, self.n, 6)), np.zeros((B, self.n, 6))
+        _load().mo_rnea_bodies(self._h, B, _p(q), _p(qd), _p(qdd), _p(g), _p(f_ext), int(consider_coriolis), int(consider_accelerations), _p(tau),
+                               _p(acc), _p(tw))
+        return tau, acc, tw
+
+    def aba_bodies(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None):
+        q, qd, tau, f_ext = _c(q), _c(qd), _c(tau), _c(f_ext)
+        B = q.shape[0]
+        g = np.asarray(gravity, dtype=np.float64)
+        qdd, acc, tw = np.zeros((B, self.nv)), np.zeros((B, self.n, 6)), np.zeros((B, self.n, 6))
+        rc = _load().mo_aba_bodies(self._h, B, _p(q), _p(qd), _p(tau), _p(g), _p(f_ext), _p(qdd), _p(acc), _p(tw))
+        if rc:
+            raise ArithmeticError("oracle ABA: joint-space inertia block not positive definite")
+        return qdd, acc, tw
 
     def integrate(self, dt, q, qd, qdd):
         """MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration: returns (q', qd', qdd')."""

@@ -399,6 +399,12 @@ static void dynamic_wrench(const double J[9], double mass, const double c[3], co
 
 /* ================================================================== RNEA
  * InverseDynamicsCalculator.java:873-917 (passOne), :930-959 (passTwo), :961-966 (children) */
+/* optional per-body outputs (RigidBodyAccelerationProvider): when set, rnea_one / aba_one also write the
+ * spatial acceleration (InverseDynamicsCalculator.java:242-250; ForwardDynamicsCalculator.java:170-180: changed to the body-fixed
+ * frame on request) and the twist (frames/MovingReferenceFrame.java:279-311) of every successor body, both relative to the inertial
+ * frame and expressed in the body-fixed frame, 6 numbers (angular, linear) per listed joint */
+static _Thread_local double *tap_acc = NULL, *tap_twist = NULL;
+
 static void rnea_one(const mo_model *m, const double *q, const double *qd, const double *qdd, const double g[3], const double *fext,
                      int coriolis, int accel, double *tau)
 {
@@ -444,6 +450,13 @@ static void rnea_one(const mo_model *m, const double *q, const double *qd, const
          for (int k = 0; k < 6; k++)
             acc[i][k] += aJb[k];
       }
+   }
+   for (int i = 0; i < m->n; i++)
+   {
+      if (tap_acc)
+         memcpy(tap_acc + 6 * i, acc[i], 6 * sizeof(double));
+      if (tap_twist)
+         memcpy(tap_twist + 6 * i, K.tw_body[i], 6 * sizeof(double));
    }
    for (int i = m->n - 1; i >= 0; i--)
    {
@@ -827,6 +840,16 @@ static int aba_one(const mo_model *m, const double *q, const double *qd, const d
          for (int k = 0; k < 6; k++)
             acc[i][k] += K.S[i][d][k] * qddj[d]; /* :1300-1305 */
    }
+   for (int i = 0; i < m->n && (tap_acc || tap_twist); i++)
+   {
+      if (tap_acc)
+      { /* :170-180 rigidBodyAcceleration.changeFrame(bodyFixedFrame) */
+         xf_between(&K.W_after[i], &K.W_body[i], &T);
+         xf_motion(&T, acc[i], tap_acc + 6 * i);
+      }
+      if (tap_twist)
+         memcpy(tap_twist + 6 * i, K.tw_body[i], 6 * sizeof(double));
+   }
    if (tau_out)
    {
       /* ---- pass four (:1315-1363): joint wrenches RNEA-style from the accelerations of pass three; tau = S^T wrench for the locked joints */
@@ -1130,4 +1153,33 @@ void mo_integrate(void *h, long B, double dt, const double *q, const double *qd,
          }
       }
    }
+}
+
+/* RNEA / ABA with the per-body outputs (either may be NULL): body_acc, body_twist [B][n][6] */
+void mo_rnea_bodies(void *h, long B, const double *q, const double *qd, const double *qdd, const double *g, const double *fext, int coriolis,
+                    int accel, double *tau, double *body_acc, double *body_twist)
+{
+   const mo_model *m = (const mo_model *)h;
+   for (long b = 0; b < B; b++)
+   {
+      tap_acc = body_acc ? body_acc + b * 6 * m->n : NULL;
+      tap_twist = body_twist ? body_twist + b * 6 * m->n : NULL;
+      rnea_one(m, q + b * m->nq, qd + b * m->nv, qdd ? qdd + b * m->nv : NULL, g, fext ? fext + b * 6 * m->n : NULL, coriolis, accel && qdd,
+               tau + b * m->nv);
+   }
+   tap_acc = tap_twist = NULL;
+}
+int mo_aba_bodies(void *h, long B, const double *q, const double *qd, const double *tau, const double *g, const double *fext, double *qdd,
+                  double *body_acc, double *body_twist)
+{
+   const mo_model *m = (const mo_model *)h;
+   int rc = 0;
+   for (long b = 0; b < B; b++)
+   {
+      tap_acc = body_acc ? body_acc + b * 6 * m->n : NULL;
+      tap_twist = body_twist ? body_twist + b * 6 * m->n : NULL;
+      rc |= aba_one(m, q + b * m->nq, qd + b * m->nv, tau + b * m->nv, g, fext ? fext + b * 6 * m->n : NULL, qdd + b * m->nv, NULL, NULL, NULL);
+   }
+   tap_acc = tap_twist = NULL;
+   return rc;
 }

@@ -612,6 +612,58 @@ def test_state_integrator_matches_oracle_and_ballistic(torch_cuda):
     close(tv[:, :3].cpu().numpy(), w0.cpu().numpy(), 1e-12)
 
 
+@pytest.mark.parametrize("family", ["revolute_tree", "floating_onedof_tree", "mixed_tree"])
+def test_body_accelerations_and_twists(torch_cuda, family):
+    """RigidBodyAccelerationProvider outputs (ForwardDynamicsCalculatorTest.java:845-865): per-body spatial accelerations and twists in
+    the body-fixed frames from RNEA and from ABA against the oracle, ABA's equal to RNEA's for consistent (qdd, tau), both layouts."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.calculators import ForwardDynamicsCalculator, InverseDynamicsCalculator
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(("bodies" + family).encode()))
+    for it in range(5):
+        sys_ = system_of(families()[family](rng, int(rng.integers(1, 35))))
+        d = sys_.toModelDesc()
+        om = OracleModel(d)
+        B = int(rng.integers(1, 300))
+        q, qd, qdd, _ = rt.nextState(rng, sys_, B)
+        g = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(-10, -1)))
+        fext = rng.uniform(-3, 3, (B, d.n_joints, 6)) if it % 2 else None
+        idc, fdc = InverseDynamicsCalculator(sys_), ForwardDynamicsCalculator(sys_)
+        for c in (idc, fdc):
+            c.setGravitationalAcceleration(g)
+            c.setExternalWrenches(dev(torch, fext))
+        tau = idc.compute(dev(torch, q), dev(torch, qd), dev(torch, qdd), bodies=True)
+        r_tau, r_acc, r_tw = om.rnea_bodies(q, qd, qdd, g, fext)
+        close(tau.cpu().numpy(), r_tau)
+        prov = idc.getAccelerationProvider()
+        close(prov.body_acc.cpu().numpy(), r_acc)
+        close(prov.body_twist.cpu().numpy(), r_tw)
+        joints = sys_.getJointsToConsider()
+        k = int(rng.integers(0, len(joints)))
+        close(prov.getAccelerationOfBody(joints[k].getSuccessor()).cpu().numpy(), r_acc[:, k])
+        assert prov.getAccelerationOfBody(sys_.getRootBody()) is None
+        out = fdc.compute(dev(torch, q), dev(torch, qd), tau, bodies=True)
+        a_qdd, a_acc, a_tw = om.aba_bodies(q, qd, r_tau, g, fext)
+        tol = 1e-8 if family == "mixed_tree" else TOL
+        close(out.cpu().numpy(), a_qdd, tol)
+        close(fdc.getAccelerationProvider().body_acc.cpu().numpy(), a_acc, tol)
+        close(fdc.getAccelerationProvider().body_twist.cpu().numpy(), a_tw)
+        close(fdc.getAccelerationProvider().body_acc.cpu().numpy(), prov.body_acc.cpu().numpy(), 2e-8)  # ABA's == RNEA's (:853-865)
+        # SoA
+        hm = idc.model
+        T = lambda x: x.t().contiguous()
+        t2, acc2, tw2 = hm.rnea_bodies(T(dev(torch, q)), T(dev(torch, qd)), T(dev(torch, qdd)), g,
+                                       None if fext is None else T(dev(torch, fext).reshape(B, -1)), layout=_lib.LAYOUT_SOA)
+        close(acc2.t().reshape(B, d.n_joints, 6).cpu().numpy(), r_acc)
+        close(tw2.t().reshape(B, d.n_joints, 6).cpu().numpy(), r_tw)
+        # switches: no Coriolis terms -> velocity-free accelerations (RigidBodyAccelerationProvider considerVelocities = false)
+        idc.setConsiderCoriolisAndCentrifugalForces(False)
+        idc.compute(dev(torch, q), dev(torch, qd), dev(torch, qdd), bodies=True)
+        _, z_acc, _ = om.rnea_bodies(q, qd, qdd, g, fext, consider_coriolis=False)
+        close(idc.getAccelerationProvider().body_acc.cpu().numpy(), z_acc)
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()

@@ -313,3 +313,30 @@ def test_integrator_one_dof_and_finite_differences():
             w_fd = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / (2.0 * dt)
             v_fd = R0.T @ (qn[b, 4:] - q[b, 4:]) / dt
             assert np.abs(w_fd - qd[b, :3]).max() <= 20 * dt and np.abs(v_fd - qd[b, 3:]).max() <= 20 * dt
+
+
+def test_body_accelerations_rnea_equals_aba_and_free_fall():
+    """RigidBodyAccelerationProvider on the oracle: ABA's body accelerations equal RNEA's for consistent (qdd, tau)
+    (ForwardDynamicsCalculatorTest.java:845-865); a free-floating body at rest under gravity has the spatial acceleration
+    (0, R^T (a_root + g)) = 0 once qdd = ABA(tau = 0) is applied, and the root acceleration -g with qdd = 0."""
+    rng = np.random.default_rng(99)
+    for kind in range(3):
+        joints = [rt.nextJointTree(rng, 20, ("revolute", "prismatic")), rt.nextFloatingChain(rng, 12, ("revolute",), tree=True),
+                  rt.nextJointTree(rng, 15, ("revolute", "prismatic", "sixdof", "fixed"))][kind]
+        sys_ = MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor())
+        om = OracleModel(sys_.toModelDesc())
+        q, qd, qdd, _ = rt.nextState(rng, sys_, 4)
+        tau, acc, tw = om.rnea_bodies(q, qd, qdd)
+        a2, acc2, tw2 = om.aba_bodies(q, qd, tau)
+        eps = 2e-8 if kind == 2 else 1e-9
+        assert np.abs(acc - acc2).max() <= eps * max(1.0, np.abs(acc).max()) and np.array_equal(tw, tw2)
+    sys6 = _free_sphere()
+    o6 = OracleModel(sys6.toModelDesc())
+    q, _, _, _ = rt.nextState(rng, sys6, 6)
+    z = np.zeros((6, 6))
+    g = (0.0, 0.0, -9.81)
+    _, acc, _ = o6.rnea_bodies(q, z, z, g)
+    for b in range(6):  # root acceleration -g seen from the body: R^T (0, 0, +9.81)
+        assert np.abs(acc[b, 0, 3:] - _quat_R(q[b, :4]).T @ np.array([0.0, 0.0, 9.81])).max() < 1e-12 and np.abs(acc[b, 0, :3]).max() == 0
+    qdd, acc, _ = o6.aba_bodies(q, z, z, g)
+    assert np.abs(acc).max() < 1e-12  # free fall: no acceleration relative to the (accelerating) inertial description
