@@ -223,6 +223,17 @@ mh_status mh_aba_bodies_f64(mh_model_t model, int64_t B, const double *q, const 
  */
 mh_status mh_integrate_f64(mh_model_t model, int64_t B, double dt, const double *q, const double *qd, const double *qdd,
                            const mh_options *opts, double *q_out, double *qd_out, double *qdd_out);
+/*
+ * One simulation step on the device: qdd_out = ABA(q, qd, tau) followed by one integrator step of size dt, q_next / qd_next =
+ * integrate(q, qd, qdd_out).  Same results as mh_aba_f64 followed by mh_integrate_f64 (ForwardDynamicsCalculator.compute +
+ * MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration; the loop of MultiBodySystemStateIntegratorTest.java:245-250).  Models
+ * with a tree-split code object, identity index maps and AoS matrices run it as ONE launch (the new state is formed from the rows the
+ * forward-dynamics kernel already holds in LDS); every other case issues the two launches.  q_next / qd_next may alias q / qd;
+ * qdd_out is the forward-dynamics result (not re-expressed by the step).
+ */
+mh_status mh_aba_integrate_f64(mh_model_t model, int64_t B, double dt, const double *q, const double *qd, const double *tau,
+                               const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out, double *q_next,
+                               double *qd_next);
 mh_status mh_integrate_f32(mh_model_t model, int64_t B, double dt, const float *q, const float *qd, const float *qdd,
                            const mh_options *opts, float *q_out, float *qd_out, float *qdd_out);
 

@@ -233,7 +233,8 @@ enum Algo
 template <typename T>
 mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd, const T *in3, const double gravity[3], const T *fext,
                  const mh_options *opts_in, T *out, const T *locked_in = nullptr, T *locked_out = nullptr, T *body_acc = nullptr,
-                 T *body_twist = nullptr, bool bodies = false)
+                 T *body_twist = nullptr, bool bodies = false, double step_dt = 0.0, T *q_next = nullptr, T *qd_next = nullptr,
+                 bool *stepped = nullptr)
 {
    mh_options opts;
    if (opts_in)
@@ -262,6 +263,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    A.q = q, A.qd = qd, A.in3 = in3, A.fext = fext, A.out = out;
    A.in3b = nullptr, A.outb = nullptr;
    A.body_acc = body_acc, A.body_twist = body_twist;
+   A.dt = T(0), A.q_next = nullptr, A.qd_next = nullptr;
    A.ws = (T *)model->ws.ptr;
    A.ws_stride = L.lanes;
    const bool soa = opts.layout == MH_LAYOUT_SOA;
@@ -295,6 +297,13 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
    {
       const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
+      const int sf = split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa);
+      if (algo == ALGO_ABA && q_next && (sf & SPEC_IDENT) && (sf & SPEC_IO_LDS))
+      { // fused simulation step: the kernel integrates the rows it holds in LDS and writes the new state too
+         A.dt = (T)step_dt, A.q_next = q_next, A.qd_next = qd_next;
+         if (stepped)
+            *stepped = true;
+      }
       const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa), &A, (int)groups, (void *)stream);
       if (rc != 0)
          return fail(MH_ERR_HIP, "tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -921,6 +930,21 @@ mh_status mh_integrate_f64(mh_model_t model, int64_t B, double dt, const double 
 {
    return integrate_impl<double>(model, B, dt, q, qd, qdd, opts, q_out, qd_out, qdd_out);
 }
+mh_status mh_aba_integrate_f64(mh_model_t model, int64_t B, double dt, const double *q, const double *qd, const double *tau,
+                               const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out, double *q_next,
+                               double *qd_next)
+{
+   if (B > 0 && (!q_next || !qd_next))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   if (!(dt == dt))
+      return fail(MH_ERR_INVALID_ARGUMENT, "dt is NaN");
+   bool stepped = false;
+   mh_status st = launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, nullptr, nullptr, nullptr, nullptr, false, dt, q_next,
+                                 qd_next, &stepped);
+   if (st != MH_OK || stepped || B == 0)
+      return st;
+   return mh_integrate_f64(model, B, dt, q, qd, qdd_out, opts, q_next, qd_next, nullptr);
+}
 mh_status mh_integrate_f32(mh_model_t model, int64_t B, double dt, const float *q, const float *qd, const float *qdd, const mh_options *opts,
                            float *q_out, float *qd_out, float *qdd_out)
 {
@@ -1008,6 +1032,7 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    A.q = q, A.qd = qd, A.in3 = qdd, A.fext = f_ext, A.out = tau_out;
    A.in3b = tau, A.outb = qdd_out;
    A.body_acc = nullptr, A.body_twist = nullptr;
+   A.dt = 0.0, A.q_next = nullptr, A.qd_next = nullptr;
    A.ws = nullptr, A.ws_stride = 0;
    A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
    A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];

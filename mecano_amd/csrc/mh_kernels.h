@@ -94,6 +94,10 @@ struct Args
    // optional per-body outputs (generic kernels with BODIES): spatial acceleration / twist of every successor body relative to the
    // inertial frame, in its body-fixed frame, [B][n_joints][6] laid out like fext (f_bs, f_es); either may be NULL
    T *body_acc, *body_twist;
+   // fused simulation step (tree-split ABA kernel): when q_next is not NULL the new state after one MultiBodySystemStateIntegrator
+   // step of size dt is written as well (q_next [B][nq], qd_next [B][nv]; may alias q / qd)
+   T dt;
+   T *q_next, *qd_next;
 };
 
 template <typename T, class CR>
@@ -796,6 +800,36 @@ struct IntArgs
    T *q_out, *qd_out, *qdd_out; // qdd_out may be NULL
    long q_bs, q_es, v_bs, v_es;
 };
+// 6-DoF joint, MultiBodySystemStateIntegrator.java:503-575 on plain values: (quat x y z s, p) pose, (w, v) twist, (al, a) acceleration
+// in the frame after the joint.  Returns the new pose and twist (and the re-expressed acceleration when an != nullptr).
+template <typename T>
+MH_DEV void integrate_sixdof(T dt, T hdd, T &qx, T &qy, T &qz, T &qs, V3<T> &p, V3<T> &w, V3<T> &v, const V3<T> &al, const V3<T> &a, V3<T> *an)
+{
+   const V3<T> a_o = a + cross(w, v); // linear acceleration at the body origin (SpatialAccelerationReadOnly.java:197-204)
+   const V3<T> rv = dt * w + hdd * al;
+   const V3<T> wn = w + dt * al;
+   const V3<T> dp = dt * v + hdd * a_o;
+   const T th = sqrt(dot(rv, rv));
+   T dx = T(0), dy = T(0), dz = T(0), ds = T(1);
+   if (th >= T(1.0e-12))
+   {
+      T sh, ch;
+      sincos_t(T(0.5) * th, sh, ch);
+      const T sc = sh / th;
+      dx = rv.x * sc, dy = rv.y * sc, dz = rv.z * sc, ds = ch;
+   }
+   const M3<T> R0 = quat_to_R(qx, qy, qz, qs), Rd = quat_to_R(dx, dy, dz, ds);
+   p = p + mul(R0, dp);
+   v = tmul(Rd, v + dt * a_o);
+   w = wn;
+   const T nx = qs * dx + qx * ds + qy * dz - qz * dy; // q' = q * dq (Hamilton product)
+   const T ny = qs * dy - qx * dz + qy * ds + qz * dx;
+   const T nz = qs * dz + qx * dy - qy * dx + qz * ds;
+   const T ns = qs * ds - qx * dx - qy * dy - qz * dz;
+   qx = nx, qy = ny, qz = nz, qs = ns;
+   if (an)
+      *an = tmul(Rd, a_o) + cross(v, w); // :561-562, FixedFrameSpatialAccelerationBasics.java:81-90
+}
 // One joint of one configuration.  ci / di: the joint's entries of the configuration / DoF index maps.
 template <typename T, class IP>
 MH_DEV void integrate_joint(int type, IP ci, IP di, const T *qr, const T *vr, const T *ar, T *qo, T *vo, T *ao, const IntArgs<T> &A, T dt, T hdd)
@@ -810,36 +844,18 @@ MH_DEV void integrate_joint(int type, IP ci, IP di, const T *qr, const T *vr, co
    }
    else if (type == JT_SIXDOF)
    { // :503-575
-      const T qx = qr[ci[0] * A.q_es], qy = qr[ci[1] * A.q_es], qz = qr[ci[2] * A.q_es], qs = qr[ci[3] * A.q_es];
-      const V3<T> p{qr[ci[4] * A.q_es], qr[ci[5] * A.q_es], qr[ci[6] * A.q_es]};
-      const V3<T> w{vr[di[0] * A.v_es], vr[di[1] * A.v_es], vr[di[2] * A.v_es]}, v{vr[di[3] * A.v_es], vr[di[4] * A.v_es], vr[di[5] * A.v_es]};
+      T qx = qr[ci[0] * A.q_es], qy = qr[ci[1] * A.q_es], qz = qr[ci[2] * A.q_es], qs = qr[ci[3] * A.q_es];
+      V3<T> p{qr[ci[4] * A.q_es], qr[ci[5] * A.q_es], qr[ci[6] * A.q_es]};
+      V3<T> w{vr[di[0] * A.v_es], vr[di[1] * A.v_es], vr[di[2] * A.v_es]}, v{vr[di[3] * A.v_es], vr[di[4] * A.v_es], vr[di[5] * A.v_es]};
       const V3<T> al{ar[di[0] * A.v_es], ar[di[1] * A.v_es], ar[di[2] * A.v_es]}, a{ar[di[3] * A.v_es], ar[di[4] * A.v_es], ar[di[5] * A.v_es]};
-      const V3<T> a_o = a + cross(w, v); // linear acceleration at the body origin (SpatialAccelerationReadOnly.java:197-204)
-      const V3<T> rv = dt * w + hdd * al;
-      const V3<T> wn = w + dt * al;
-      const V3<T> dp = dt * v + hdd * a_o;
-      const T th = sqrt(dot(rv, rv));
-      T dx = T(0), dy = T(0), dz = T(0), ds = T(1);
-      if (th >= T(1.0e-12))
-      {
-         T sh, ch;
-         sincos_t(T(0.5) * th, sh, ch);
-         const T sc = sh / th;
-         dx = rv.x * sc, dy = rv.y * sc, dz = rv.z * sc, ds = ch;
-      }
-      const M3<T> R0 = quat_to_R(qx, qy, qz, qs), Rd = quat_to_R(dx, dy, dz, ds);
-      const V3<T> pn = p + mul(R0, dp);
-      const V3<T> vn = tmul(Rd, v + dt * a_o);
-      qo[ci[0] * A.q_es] = qs * dx + qx * ds + qy * dz - qz * dy; // q' = q * dq (Hamilton product)
-      qo[ci[1] * A.q_es] = qs * dy - qx * dz + qy * ds + qz * dx;
-      qo[ci[2] * A.q_es] = qs * dz + qx * dy - qy * dx + qz * ds;
-      qo[ci[3] * A.q_es] = qs * ds - qx * dx - qy * dy - qz * dz;
-      qo[ci[4] * A.q_es] = pn.x, qo[ci[5] * A.q_es] = pn.y, qo[ci[6] * A.q_es] = pn.z;
-      vo[di[0] * A.v_es] = wn.x, vo[di[1] * A.v_es] = wn.y, vo[di[2] * A.v_es] = wn.z;
-      vo[di[3] * A.v_es] = vn.x, vo[di[4] * A.v_es] = vn.y, vo[di[5] * A.v_es] = vn.z;
+      V3<T> an;
+      integrate_sixdof<T>(dt, hdd, qx, qy, qz, qs, p, w, v, al, a, ao ? &an : nullptr);
+      qo[ci[0] * A.q_es] = qx, qo[ci[1] * A.q_es] = qy, qo[ci[2] * A.q_es] = qz, qo[ci[3] * A.q_es] = qs;
+      qo[ci[4] * A.q_es] = p.x, qo[ci[5] * A.q_es] = p.y, qo[ci[6] * A.q_es] = p.z;
+      vo[di[0] * A.v_es] = w.x, vo[di[1] * A.v_es] = w.y, vo[di[2] * A.v_es] = w.z;
+      vo[di[3] * A.v_es] = v.x, vo[di[4] * A.v_es] = v.y, vo[di[5] * A.v_es] = v.z;
       if (ao)
-      { // :561-562, FixedFrameSpatialAccelerationBasics.java:81-90
-         const V3<T> an = tmul(Rd, a_o) + cross(vn, wn);
+      {
          ao[di[0] * A.v_es] = al.x, ao[di[1] * A.v_es] = al.y, ao[di[2] * A.v_es] = al.z;
          ao[di[3] * A.v_es] = an.x, ao[di[4] * A.v_es] = an.y, ao[di[5] * A.v_es] = an.z;
       }

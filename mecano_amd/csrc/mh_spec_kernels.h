@@ -46,6 +46,23 @@ struct Tree
       return s;
    }
    static constexpr int total_dofs() { return dof_ofs(N); }
+   // joint that owns DoF d of the engine-order velocity vector (run-time look-up in the fused integration step)
+   struct DofTable
+   {
+      short joint[dof_ofs(N) > 0 ? dof_ofs(N) : 1] = {};
+      short d0[N] = {}, c0[N] = {}, type[N] = {}; // per joint: first DoF, first configuration entry, kind
+   };
+   static constexpr DofTable make_dof_table()
+   {
+      DofTable t;
+      for (int j = 0; j < N; j++)
+      {
+         t.d0[j] = (short)dof_ofs(j), t.c0[j] = (short)cfg_ofs(j), t.type[j] = (short)TP::type[j];
+         for (int k = 0; k < ndof(j); k++)
+            t.joint[dof_ofs(j) + k] = (short)j;
+      }
+      return t;
+   }
    static constexpr int total_cfgs() { return cfg_ofs(N); }
    // ABA hand-over slots: revolute 9 (U/D, u/D, cos, sin), prismatic 7, sixdof 6 (IA^-1 u), fixed 0
    static constexpr int aba_slots_of(int j)
@@ -1275,6 +1292,37 @@ MH_DEV void split_aba_limbs(const CX &cx)
    }
 }
 
+// Fused simulation step: lane = configuration of the slice, the joints are dealt round-robin to the four waves; offsets are
+// compile-time constants (identity index maps), so a 1-DoF joint is three LDS reads, two FMAs and two LDS writes.
+template <class TP, int J, typename T>
+MH_DEV void integrate_rows(int wave, lds_ptr<T> q, lds_ptr<T> v, lds_ptr<T> a, T dt, T hdd)
+{
+   using TR = Tree<TP>;
+   if constexpr (J < TP::N)
+   {
+      if ((J & 3) == wave)
+      {
+         constexpr int TYPE = TP::type[J], D0 = TR::dof_ofs(J), C0 = TR::cfg_ofs(J);
+         if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+         { // MultiBodySystemStateIntegrator.java:433-441, 710-733
+            const T q0 = q[C0], v0 = v[D0], a0 = a[D0];
+            q[C0] = hdd * a0 + dt * v0 + q0;
+            v[D0] = dt * a0 + v0;
+         }
+         else if constexpr (TYPE == JT_SIXDOF)
+         { // :503-575
+            T qx = q[C0], qy = q[C0 + 1], qz = q[C0 + 2], qs = q[C0 + 3];
+            V3<T> p{q[C0 + 4], q[C0 + 5], q[C0 + 6]}, w{v[D0], v[D0 + 1], v[D0 + 2]}, vl{v[D0 + 3], v[D0 + 4], v[D0 + 5]};
+            const V3<T> al{a[D0], a[D0 + 1], a[D0 + 2]}, ac{a[D0 + 3], a[D0 + 4], a[D0 + 5]};
+            integrate_sixdof<T>(dt, hdd, qx, qy, qz, qs, p, w, vl, al, ac, nullptr);
+            q[C0] = qx, q[C0 + 1] = qy, q[C0 + 2] = qz, q[C0 + 3] = qs, q[C0 + 4] = p.x, q[C0 + 5] = p.y, q[C0 + 6] = p.z;
+            v[D0] = w.x, v[D0 + 1] = w.y, v[D0 + 2] = w.z, v[D0 + 3] = vl.x, v[D0 + 4] = vl.y, v[D0 + 5] = vl.z;
+         }
+      }
+      integrate_rows<TP, J + 1, T>(wave, q, v, a, dt, hdd);
+   }
+}
+
 // One workgroup's share of a batch.  ALGO: 0 = RNEA, 1 = ABA.  IO_LDS: the 64 rows of q, qd, qdd|tau are staged once in LDS
 // by all 256 threads (the four waves share them) and the results leave through LDS as one coalesced copy.
 template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS>
@@ -1348,6 +1396,18 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
       MH_STAMP(5);
       __syncthreads(); // results complete; the exchange area is free for the next batch slice
       MH_STAMP(6);
+      if constexpr (ALGO == 1 && IO_LDS && IDENT)
+      {
+         if (A.q_next)
+         { // fused simulation step: q, qd and the fresh qdd rows of the 64 configurations all sit in LDS -- integrate them in place
+           // (MultiBodySystemStateIntegrator.java:365-441, 503-575, 710-733) and stream the new state out with the accelerations
+            if (lane < rows)
+               integrate_rows<TP, 0, T>(wave, lq + lane * nq, lqd + lane * nv, lx + lane * nv, A.dt, T(0.5) * A.dt * A.dt);
+            __syncthreads();
+            wave_copy_out<T, 256>(A.q_next + cfg0 * nq, lq, rows * nq);
+            wave_copy_out<T, 256>(A.qd_next + cfg0 * nv, lqd, rows * nv);
+         }
+      }
       if constexpr (IO_LDS)
       {
          wave_copy_out<T, 256>(A.out + cfg0 * nv, lx, rows * nv);

@@ -232,6 +232,26 @@ class HipModel:
                       qdd_out.data_ptr() if qdd_out is not None else None))
         return out
 
+    def step(self, dt, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, inplace=False):
+        """One simulation step (forward dynamics + state integration, mh_aba_integrate_f64): returns (q_next, qd_next, qdd).  AoS fp64
+        device tensors; ``inplace=True`` overwrites q and qd."""
+        import torch
+        lib = _lib.load()
+        for t in (q, qd, tau) + ((f_ext,) if f_ext is not None else ()):
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("step needs contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
+        if self._batch(qd, self.nv, _lib.LAYOUT_AOS) != B or self._batch(tau, self.nv, _lib.LAYOUT_AOS) != B:
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        qn, vn = (q, qd) if inplace else (q.clone(), qd.clone())
+        qdd = torch.empty_like(qd)
+        _lib.check(lib.mh_aba_integrate_f64(self._h, B, float(dt), q.data_ptr(), qd.data_ptr(), tau.data_ptr(), g,
+                                            f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts), qdd.data_ptr(), qn.data_ptr(),
+                                            vn.data_ptr()))
+        return qn, vn, qdd
+
     def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None):
         """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call (device tensors, fp64, AoS)."""
         import torch

@@ -664,6 +664,47 @@ def test_body_accelerations_and_twists(torch_cuda, family):
         close(idc.getAccelerationProvider().body_acc.cpu().numpy(), z_acc)
 
 
+@pytest.mark.parametrize("B", [1, 64, 100, 4096, 20000])
+def test_simulation_step_equals_aba_then_integrate(torch_cuda, B):
+    """mh_aba_integrate_f64 (one launch on the humanoid: the tree-split ABA kernel integrates the rows it holds in LDS; two launches for
+    models without a specialised code object) against oracle ABA + oracle integrator, out of place and in place, several steps."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(31 + B)
+    for sys_ in (rt.nextHumanoid(rng), system_of(rt.nextFloatingChain(rng, 9, ("revolute", "prismatic"), tree=True))):
+        d = sys_.toModelDesc()
+        om, hm = OracleModel(d), HipModel(d)
+        q, qd, _, tau = rt.nextState(rng, sys_, B)
+        g, dt = (0.1, -0.2, -9.81), 1.3e-3
+        fext = rng.uniform(-2, 2, (B, d.n_joints, 6))
+        r_qdd = om.aba(q, qd, tau, g, fext)
+        r_q, r_v, _ = om.integrate(dt, q, qd, r_qdd)
+        tq, tv, tt, tf = dev(torch, q), dev(torch, qd), dev(torch, tau), dev(torch, fext)
+        nq, nv, qdd = hm.step(dt, tq, tv, tt, g, tf)
+        close(qdd.cpu().numpy(), r_qdd), close(nq.cpu().numpy(), r_q, 1e-12), close(nv.cpu().numpy(), r_v, 1e-11)
+        assert torch.equal(tq, dev(torch, q)) and torch.equal(tv, dev(torch, qd))  # inputs untouched
+        # three in-place steps against three oracle steps
+        rq, rv = q, qd
+        for _ in range(3):
+            a = om.aba(rq, rv, tau, g)
+            rq, rv, _ = om.integrate(dt, rq, rv, a)
+            hm.step(dt, tq, tv, tt, g, inplace=True)
+        close(tq.cpu().numpy(), rq, 1e-11), close(tv.cpu().numpy(), rv, 1e-10)
+    os.environ["MH_SPEC_SPLIT"] = "0"  # forced two-launch path on the humanoid: same answer
+    try:
+        sys_ = rt.nextHumanoid(np.random.default_rng(5))
+        d = sys_.toModelDesc()
+        q, qd, _, tau = rt.nextState(rng, sys_, min(B, 300))
+        a = OracleModel(d).aba(q, qd, tau, g)
+        r_q, r_v, _ = OracleModel(d).integrate(dt, q, qd, a)
+        nq, nv, _ = HipModel(d).step(dt, dev(torch, q), dev(torch, qd), dev(torch, tau), g)
+        close(nq.cpu().numpy(), r_q, 1e-12), close(nv.cpu().numpy(), r_v, 1e-11)
+    finally:
+        os.environ.pop("MH_SPEC_SPLIT", None)
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
