@@ -155,11 +155,33 @@ MH_DEV SV<T> force_up(int type, const JX<T> &jx, const XF<T> &Xb, SV<T> w)
       b = w;
    return force_to_parent(Xb, b);
 }
+// R_b Rz(q): orientation of a revolute joint's after-joint frame in the parent's frame (12 flops)
+template <typename T>
+MH_DEV M3<T> revolute_rotation(const JX<T> &jx, const M3<T> &B)
+{
+   const T c = jx.c, s = jx.s;
+   return M3<T>{c * B.xx + s * B.xy, c * B.xy - s * B.xx, B.xz, c * B.yx + s * B.yy, c * B.yy - s * B.yx, B.yz,
+                c * B.zx + s * B.zy, c * B.zy - s * B.zx, B.zz};
+}
+// articulated inertia and bias wrench of a revolute body handed to the parent: ONE congruence / one rotation with R_b Rz(q) instead
+// of a planar one (~48 + 8 instructions) followed by the constant one
+template <typename T>
+MH_DEV void revolute_up(const JX<T> &jx, const XF<T> &Xb, ABI<T> &I, SV<T> &w)
+{
+   const XF<T> X{revolute_rotation(jx, Xb.R), Xb.p};
+   rotate(I, X.R);
+   translate(I, X.p);
+   w = force_to_parent(X, w);
+}
 template <typename T>
 MH_DEV void abi_up(int type, const JX<T> &jx, const XF<T> &Xb, ABI<T> &I)
 {
    if (type == JT_REVOLUTE)
-      rotate_z(I, jx.c, jx.s);
+   {
+      rotate(I, revolute_rotation(jx, Xb.R));
+      translate(I, Xb.p);
+      return;
+   }
    else if (type == JT_PRISMATIC)
       translate_z(I, jx.d);
    else if (type == JT_SIXDOF)
@@ -682,8 +704,14 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          {
             const XF<T> Xb = load_xb<T>(c);
             const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
-            abi_up(type, jx, Xb, Ia);                            // :1156-1166
-            const SV<T> pp = force_up(type, jx, Xb, pa);
+            SV<T> pp = pa;
+            if (type == JT_REVOLUTE)
+               revolute_up(jx, Xb, Ia, pp);
+            else
+            {
+               abi_up(type, jx, Xb, Ia); // :1156-1166
+               pp = force_up(type, jx, Xb, pa);
+            }
             if (flags & MF_PARENT_ADJ)
             {
                Icarry = Ia, pcarry = pp, have_carry = true;

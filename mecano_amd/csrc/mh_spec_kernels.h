@@ -713,9 +713,17 @@ struct AbaIn
             rank1_down(IA, ua, ul, dinv);
             const SV<T> pa = pA + mul(IA, crm(v, vJ)) + SV<T>{ud * ua, ud * ul};
             const XF<T> Xb = load_xb<T>(c);
-            abi_up(TYPE, jx, Xb, IA);
+            if constexpr (TYPE == JT_REVOLUTE)
+            {
+               out.p = pa;
+               revolute_up(jx, Xb, IA, out.p);
+            }
+            else
+            {
+               abi_up(TYPE, jx, Xb, IA);
+               out.p = force_up(TYPE, jx, Xb, pa);
+            }
             out.I = IA;
-            out.p = force_up(TYPE, jx, Xb, pa);
          }
       }
       else if constexpr (TYPE == JT_SIXDOF)
