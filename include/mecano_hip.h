@@ -62,7 +62,7 @@ typedef enum mh_status
    MH_OK = 0,
    MH_ERR_INVALID_ARGUMENT = 1,   /* IllegalArgumentException / NullPointerException        */
    MH_ERR_BAD_DIMENSION = 2,      /* MatrixDimensionException (ForwardDynamicsCalculator.java:522-533) */
-   MH_ERR_UNSUPPORTED_JOINT = 3,  /* joint kind outside {REVOLUTE, PRISMATIC, SIXDOF, ...}  */
+   MH_ERR_UNSUPPORTED_JOINT = 3,  /* joint kind outside the mh_joint_type enumeration         */
    MH_ERR_LOOP_CLOSURE = 4,       /* kinematic loops: unsupported, as in ForwardDynamicsCalculator.java:207-211 */
    MH_ERR_BAD_TOPOLOGY = 5,       /* parent[] is not a forest / index maps are not a permutation */
    MH_ERR_BAD_AXIS = 6,           /* 1-DoF axis is not a unit vector                          */
@@ -79,7 +79,9 @@ typedef enum mh_joint_type
    MH_JOINT_REVOLUTE = 0,  /* multiBodySystem/RevoluteJoint.java   nq=1 nv=1 */
    MH_JOINT_PRISMATIC = 1, /* multiBodySystem/PrismaticJoint.java  nq=1 nv=1 */
    MH_JOINT_SIXDOF = 2,    /* multiBodySystem/SixDoFJoint.java     nq=7 nv=6 */
-   MH_JOINT_FIXED = 3      /* multiBodySystem/FixedJoint.java      nq=0 nv=0 */
+   MH_JOINT_FIXED = 3,     /* multiBodySystem/FixedJoint.java      nq=0 nv=0 */
+   MH_JOINT_PLANAR = 4,    /* multiBodySystem/PlanarJoint.java     nq=3 nv=3   q = (pitch, x, z), qd = (w_y, v_x, v_z) */
+   MH_JOINT_SPHERICAL = 5  /* multiBodySystem/SphericalJoint.java  nq=4 nv=3   q = quaternion (x, y, z, s), qd = angular velocity */
 } mh_joint_type;
 
 /* ---- memory layout of batched state matrices ---- */

@@ -3,8 +3,8 @@
 Importing this package does not load the HIP library; the first model creation does, and fails loudly
 (ImportError) when mecano_amd/libmecano_hip.so has not been built.  There is no CPU fallback.
 """
-from .multibody import (FixedJoint, JointMatrixIndexProvider, ModelDesc, MultiBodySystem, PrismaticJoint, RevoluteJoint, RigidBody,
-                        SixDoFJoint)
+from .multibody import (FixedJoint, JointMatrixIndexProvider, ModelDesc, MultiBodySystem, PlanarJoint, PrismaticJoint, RevoluteJoint,
+                        RigidBody, SixDoFJoint, SphericalJoint)
 
-__all__ = ["FixedJoint", "JointMatrixIndexProvider", "ModelDesc", "MultiBodySystem", "PrismaticJoint", "RevoluteJoint", "RigidBody",
-           "SixDoFJoint"]
+__all__ = ["FixedJoint", "JointMatrixIndexProvider", "ModelDesc", "MultiBodySystem", "PlanarJoint", "PrismaticJoint", "RevoluteJoint",
+           "RigidBody", "SixDoFJoint", "SphericalJoint"]

@@ -85,6 +85,8 @@ def spec_path(key: str) -> str:
 def build_spec(desc, force: bool = False, verbose: bool = False) -> str:
     """Builds the topology-specialised code object of a model (any ModelDesc).  Returns its path."""
     key, parents, kinds = topology_of(desc)
+    if any(int(k) > 3 for k in kinds):
+        raise ValueError("specialised code objects cover revolute, prismatic, 6-DoF and fixed joints; planar / spherical joints run on the generic kernels")
     out = spec_path(key)
     if not force and not _stale(out, [SPEC_SOURCE] + SPEC_HEADERS):
         return out

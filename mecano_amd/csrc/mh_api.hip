@@ -79,8 +79,8 @@ M3d frame_with_z(const double k[3])
    return M3d{{x[0], y[0], k[0], x[1], y[1], k[1], x[2], y[2], k[2]}};
 }
 
-int joint_ndof(int t) { return t == MH_JOINT_SIXDOF ? 6 : (t == MH_JOINT_FIXED ? 0 : 1); }
-int joint_ncfg(int t) { return t == MH_JOINT_SIXDOF ? 7 : (t == MH_JOINT_FIXED ? 0 : 1); }
+int joint_ndof(int t) { return mh::dof_count(t); }
+int joint_ncfg(int t) { return mh::cfg_count(t); }
 
 struct Workspace
 {
@@ -473,7 +473,7 @@ mh_status plan_model(const mh_model_desc *d, Plan &P)
    for (int i = 0; i < n; i++)
    {
       const int t = d->joint_type[i];
-      if (t < MH_JOINT_REVOLUTE || t > MH_JOINT_FIXED)
+      if (t < MH_JOINT_REVOLUTE || t > MH_JOINT_SPHERICAL)
          return fail(MH_ERR_UNSUPPORTED_JOINT, "joint %d has unsupported kind %d", i, t);
       if (d->parent[i] < -1 || d->parent[i] >= n || d->parent[i] == i)
          return fail(MH_ERR_BAD_TOPOLOGY, "joint %d has parent %d", i, d->parent[i]);
@@ -760,7 +760,7 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       mi[mh::MI_SLOT_C] = slots, slots += 6;
       mi[mh::MI_SLOT_VA] = slots, slots += (nonadj_child ? 12 : 0);
       mi[mh::MI_SLOT_IA] = slots, slots += (nonadj_child ? 21 : 0);
-      mi[mh::MI_SLOT_LK] = slots, slots += (t == MH_JOINT_SIXDOF ? 27 : 0);
+      mi[mh::MI_SLOT_LK] = slots, slots += (mh::dof_count(t) >= 3 ? 27 : 0); // multi-DoF joints: U, D^-1, u | locked: IA, pA
 
       // X_before' = Qp^T X_before Q : canonical before-joint frame in the parent's canonical after-joint frame
       const M3d Qp = pe < 0 ? m3_identity() : Q[pe];

@@ -165,6 +165,11 @@ MH_DEV SV<T> operator+(SV<T> a, SV<T> b)
    return {a.a + b.a, a.l + b.l};
 }
 template <typename T>
+MH_DEV SV<T> operator*(T s, SV<T> a)
+{
+   return SV<T>{s * a.a, s * a.l};
+}
+template <typename T>
 MH_DEV SV<T> operator-(SV<T> a, SV<T> b)
 {
    return {a.a - b.a, a.l - b.l};

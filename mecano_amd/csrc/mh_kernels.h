@@ -22,8 +22,20 @@ enum : int
    JT_REVOLUTE = 0,
    JT_PRISMATIC = 1,
    JT_SIXDOF = 2,
-   JT_FIXED = 3
+   JT_FIXED = 3,
+   JT_PLANAR = 4,   // q = (pitch, x, z); qd = (w_y, v_x, v_z)          multiBodySystem/interfaces/PlanarJointReadOnly.java:17-72
+   JT_SPHERICAL = 5 // q = quaternion (x, y, z, s); qd = angular velocity   multiBodySystem/interfaces/SphericalJointReadOnly.java:18-104
 };
+// joints whose transform is a general (R, p) pair held in JX::X, and the layout of their DoFs in a spatial vector
+__host__ __device__ constexpr bool general_x(int type) { return type == JT_SIXDOF || type == JT_PLANAR || type == JT_SPHERICAL; }
+__host__ __device__ constexpr int dof_count(int type) { return type == JT_SIXDOF ? 6 : (type == JT_FIXED ? 0 : (type == JT_PLANAR || type == JT_SPHERICAL ? 3 : 1)); }
+__host__ __device__ constexpr int cfg_count(int type) { return type == JT_SIXDOF ? 7 : (type == JT_FIXED ? 0 : (type == JT_PLANAR ? 3 : (type == JT_SPHERICAL ? 4 : 1))); }
+// component (0..2 angular x y z, 3..5 linear x y z) of the canonical after-joint frame that DoF k of a joint moves along: the motion
+// subspaces are unit vectors (JointReadOnly.java:201-207; planar w_y, v_x, v_z: tools/MecanoTools.java:920-952; spherical: :1002-1043)
+__host__ __device__ constexpr int dof_comp(int type, int k)
+{
+   return type == JT_REVOLUTE ? 2 : (type == JT_PRISMATIC ? 5 : (type == JT_PLANAR ? (k == 0 ? 1 : (k == 1 ? 3 : 5)) : k));
+}
 
 // ---- per-joint integer record (wave-uniform, scalar loads)
 enum : int
@@ -136,7 +148,7 @@ MH_DEV SV<T> motion_down(int type, const JX<T> &jx, const XF<T> &Xb, SV<T> m)
       return SV<T>{rotzT(jx.c, jx.s, b.a), rotzT(jx.c, jx.s, b.l)};
    if (type == JT_PRISMATIC)
       return SV<T>{b.a, V3<T>{b.l.x + b.a.y * jx.d, b.l.y - b.a.x * jx.d, b.l.z}};
-   if (type == JT_SIXDOF)
+   if (general_x(type))
       return motion_to_child(jx.X, b);
    return b;
 }
@@ -149,7 +161,7 @@ MH_DEV SV<T> force_up(int type, const JX<T> &jx, const XF<T> &Xb, SV<T> w)
       b = SV<T>{rotz(jx.c, jx.s, w.a), rotz(jx.c, jx.s, w.l)};
    else if (type == JT_PRISMATIC)
       b = SV<T>{V3<T>{w.a.x - jx.d * w.l.y, w.a.y + jx.d * w.l.x, w.a.z}, w.l};
-   else if (type == JT_SIXDOF)
+   else if (general_x(type))
       b = force_to_parent(jx.X, w);
    else
       b = w;
@@ -184,7 +196,7 @@ MH_DEV void abi_up(int type, const JX<T> &jx, const XF<T> &Xb, ABI<T> &I)
    }
    else if (type == JT_PRISMATIC)
       translate_z(I, jx.d);
-   else if (type == JT_SIXDOF)
+   else if (general_x(type))
    {
       rotate(I, jx.X.R);
       translate(I, jx.X.p);
@@ -202,7 +214,7 @@ MH_DEV void rigid_up(int type, const JX<T> &jx, const XF<T> &Xb, RI<T> &r)
    }
    else if (type == JT_PRISMATIC)
       shift_origin(r, V3<T>{T(0), T(0), jx.d});
-   else if (type == JT_SIXDOF)
+   else if (general_x(type))
    {
       r.h = mul(jx.X.R, r.h);
       r.I = conj(jx.X.R, r.I);
@@ -239,6 +251,20 @@ MH_DEV JX<T> joint_from_q(int type, ciptr cfg_map, int cfg_ofs, const T *qrow, l
       jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
       jx.X.p = V3<T>{qrow[ci[4] * q_es], qrow[ci[5] * q_es], qrow[ci[6] * q_es]};
    }
+   else if (type == JT_SPHERICAL)
+   {
+      ciptr ci = cfg_map + cfg_ofs;
+      jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
+      jx.X.p = V3<T>{T(0), T(0), T(0)};
+   }
+   else if (type == JT_PLANAR)
+   { // rotation about y by the pitch, translation (x, 0, z)
+      ciptr ci = cfg_map + cfg_ofs;
+      T sp, cp;
+      sincos_t(qrow[ci[0] * q_es], sp, cp);
+      jx.X.R = M3<T>{cp, T(0), sp, T(0), T(1), T(0), -sp, T(0), cp};
+      jx.X.p = V3<T>{qrow[ci[1] * q_es], T(0), qrow[ci[2] * q_es]};
+   }
    return jx;
 }
 // joint transform on a later visit: revolute (cos, sin) come back from the workspace, the rest is re-read from q
@@ -259,6 +285,20 @@ MH_DEV JX<T> joint_again(int type, ciptr cfg_map, int cfg_ofs, const T *qrow, lo
       ciptr ci = cfg_map + cfg_ofs;
       jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
       jx.X.p = V3<T>{qrow[ci[4] * q_es], qrow[ci[5] * q_es], qrow[ci[6] * q_es]};
+   }
+   else if (type == JT_SPHERICAL)
+   {
+      ciptr ci = cfg_map + cfg_ofs;
+      jx.X.R = quat_to_R(qrow[ci[0] * q_es], qrow[ci[1] * q_es], qrow[ci[2] * q_es], qrow[ci[3] * q_es]);
+      jx.X.p = V3<T>{T(0), T(0), T(0)};
+   }
+   else if (type == JT_PLANAR)
+   { // rotation about y by the pitch, translation (x, 0, z)
+      ciptr ci = cfg_map + cfg_ofs;
+      T sp, cp;
+      sincos_t(qrow[ci[0] * q_es], sp, cp);
+      jx.X.R = M3<T>{cp, T(0), sp, T(0), T(1), T(0), -sp, T(0), cp};
+      jx.X.p = V3<T>{qrow[ci[1] * q_es], T(0), qrow[ci[2] * q_es]};
    }
    return jx;
 }
@@ -301,7 +341,62 @@ MH_DEV SV<T> joint_vec(int type, ciptr dof_map, int dof_ofs, const T *row, long 
       o.a = V3<T>{row[di[0] * es], row[di[1] * es], row[di[2] * es]};
       o.l = V3<T>{row[di[3] * es], row[di[4] * es], row[di[5] * es]};
    }
+   else if (type == JT_SPHERICAL)
+   {
+      ciptr di = dof_map + dof_ofs;
+      o.a = V3<T>{row[di[0] * es], row[di[1] * es], row[di[2] * es]};
+   }
+   else if (type == JT_PLANAR)
+   {
+      ciptr di = dof_map + dof_ofs;
+      o.a.y = row[di[0] * es], o.l.x = row[di[1] * es], o.l.z = row[di[2] * es];
+   }
    return o;
+}
+// unit motion vector of DoF k of a joint of the given kind, canonical frame
+template <typename T>
+MH_DEV SV<T> unit_twist(int type, int k)
+{
+   SV<T> s{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
+   if (type == JT_REVOLUTE)
+      s.a.z = T(1);
+   else if (type == JT_PRISMATIC)
+      s.l.z = T(1);
+   else
+   {
+      const int e = dof_comp(type, k);
+      s.a.x = e == 0 ? T(1) : T(0), s.a.y = e == 1 ? T(1) : T(0), s.a.z = e == 2 ? T(1) : T(0);
+      s.l.x = e == 3 ? T(1) : T(0), s.l.y = e == 4 ? T(1) : T(0), s.l.z = e == 5 ? T(1) : T(0);
+   }
+   return s;
+}
+// component k (0..2 angular, 3..5 linear) of a spatial vector; Sᵀ w of a joint = the components dof_comp(type, .) of w
+template <typename T>
+MH_DEV T comp(SV<T> w, int k)
+{
+   return k == 0 ? w.a.x : k == 1 ? w.a.y : k == 2 ? w.a.z : k == 3 ? w.l.x : k == 4 ? w.l.y : w.l.z;
+}
+// the three DoF components of a planar / spherical joint
+template <typename T>
+MH_DEV V3<T> comp3(int type, SV<T> w)
+{
+   return type == JT_PLANAR ? V3<T>{w.a.y, w.l.x, w.l.z} : w.a;
+}
+template <typename T>
+MH_DEV SV<T> from_comp3(int type, V3<T> x)
+{
+   const V3<T> Z{T(0), T(0), T(0)};
+   return type == JT_PLANAR ? SV<T>{V3<T>{T(0), x.x, T(0)}, V3<T>{x.y, T(0), x.z}} : SV<T>{x, Z};
+}
+// inverse of a symmetric positive-definite 3x3 (adjugate / determinant): the joint-space inertia block D of a 3-DoF joint
+// (the reference inverts it with UnrolledInverseFromMinor, ForwardDynamicsCalculator.java:1183-1196)
+template <typename T>
+MH_DEV S3<T> spd3_inverse(const S3<T> &D)
+{
+   const T cxx = D.yy * D.zz - D.yz * D.yz, cxy = D.xz * D.yz - D.xy * D.zz, cxz = D.xy * D.yz - D.xz * D.yy;
+   const T cyy = D.xx * D.zz - D.xz * D.xz, cyz = D.xy * D.xz - D.xx * D.yz, czz = D.xx * D.yy - D.xy * D.xy;
+   const T inv = T(1) / (D.xx * cxx + D.xy * cxy + D.xz * cxz);
+   return S3<T>{cxx * inv, cxy * inv, cxz * inv, cyy * inv, cyz * inv, czz * inv};
 }
 // external wrench of the body (body-fixed frame) brought to the canonical after-joint frame
 template <typename T, class CR>
@@ -439,6 +534,11 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
             trow[di[0] * A.v_es] = f.a.x, trow[di[1] * A.v_es] = f.a.y, trow[di[2] * A.v_es] = f.a.z;
             trow[di[3] * A.v_es] = f.l.x, trow[di[4] * A.v_es] = f.l.y, trow[di[5] * A.v_es] = f.l.z;
          }
+         else if (type == JT_PLANAR || type == JT_SPHERICAL)
+         {
+            const V3<T> t3 = comp3(type, f);
+            trow[di[0] * A.v_es] = t3.x, trow[di[1] * A.v_es] = t3.y, trow[di[2] * A.v_es] = t3.z;
+         }
          have_carry = false;
          if (parent >= 0)
          {
@@ -484,6 +584,20 @@ MH_DEV void add(ABI<T> &a, const ABI<T> &b)
    a.C.zx += b.C.zx, a.C.zy += b.C.zy, a.C.zz += b.C.zz;
 }
 // Ia = IA - U U^T / D for a 1-DoF joint whose U = (ua, ul)
+// I -= w u^T symmetrised over the (A, L, C) blocks, for w = U D^-1 column and u = U column of a multi-DoF joint: summed over the
+// DoFs the updates are symmetric, each one alone is not -- only the entries the block layout stores are touched
+template <typename T>
+MH_DEV void rank1_pair_down(ABI<T> &I, const SV<T> &w, const SV<T> &u)
+{
+   I.A.xx -= w.a.x * u.a.x, I.A.xy -= T(0.5) * (w.a.x * u.a.y + w.a.y * u.a.x), I.A.xz -= T(0.5) * (w.a.x * u.a.z + w.a.z * u.a.x);
+   I.A.yy -= w.a.y * u.a.y, I.A.yz -= T(0.5) * (w.a.y * u.a.z + w.a.z * u.a.y), I.A.zz -= w.a.z * u.a.z;
+   I.L.xx -= w.l.x * u.l.x, I.L.xy -= T(0.5) * (w.l.x * u.l.y + w.l.y * u.l.x), I.L.xz -= T(0.5) * (w.l.x * u.l.z + w.l.z * u.l.x);
+   I.L.yy -= w.l.y * u.l.y, I.L.yz -= T(0.5) * (w.l.y * u.l.z + w.l.z * u.l.y), I.L.zz -= w.l.z * u.l.z;
+   // C couples angular rows with linear columns: (U D^-1 U^T)_al = sum_k w_k.a u_k.l^T, symmetrised with the transposed pairing
+   I.C.xx -= T(0.5) * (w.a.x * u.l.x + u.a.x * w.l.x), I.C.xy -= T(0.5) * (w.a.x * u.l.y + u.a.x * w.l.y), I.C.xz -= T(0.5) * (w.a.x * u.l.z + u.a.x * w.l.z);
+   I.C.yx -= T(0.5) * (w.a.y * u.l.x + u.a.y * w.l.x), I.C.yy -= T(0.5) * (w.a.y * u.l.y + u.a.y * w.l.y), I.C.yz -= T(0.5) * (w.a.y * u.l.z + u.a.y * w.l.z);
+   I.C.zx -= T(0.5) * (w.a.z * u.l.x + u.a.z * w.l.x), I.C.zy -= T(0.5) * (w.a.z * u.l.y + u.a.z * w.l.y), I.C.zz -= T(0.5) * (w.a.z * u.l.z + u.a.z * w.l.z);
+}
 template <typename T>
 MH_DEV void rank1_down(ABI<T> &I, V3<T> ua, V3<T> ul, T dinv)
 {
@@ -669,16 +783,33 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
             }
             }
          }
-         else if (LOCKED && type == JT_SIXDOF && (flags & MF_LOCKED))
+         else if (LOCKED && dof_count(type) >= 3 && (flags & MF_LOCKED))
          {
             ws_store_abi(ws, ws_stride, mi[MI_SLOT_LK], IA);
             ws_store6(ws, ws_stride, mi[MI_SLOT_LK] + 21, pA);
             if (parent >= 0)
             {
-               const T *gr = A.in3b + cfg * A.v_bs;
-               const SV<T> qg{V3<T>{gr[di[0] * A.v_es], gr[di[1] * A.v_es], gr[di[2] * A.v_es]},
-                              V3<T>{gr[di[3] * A.v_es], gr[di[4] * A.v_es], gr[di[5] * A.v_es]}};
+               const SV<T> qg = joint_vec<T>(type, dof_map, mi[MI_DOF], A.in3b + cfg * A.v_bs, A.v_es, true); // S qdd_given
                pa = pA + mul(IA, ws_load6(ws, ws_stride, mi[MI_SLOT_C]) + qg);
+            }
+         }
+         else if (type == JT_PLANAR || type == JT_SPHERICAL)
+         { // 3-DoF joint: U = IA S (6 x 3), D = S^T U (3 x 3), u = tau - S^T pA   (:1177-1215 with N = 3)
+            const SV<T> U0 = mul(IA, unit_twist<T>(type, 0)), U1 = mul(IA, unit_twist<T>(type, 1)), U2 = mul(IA, unit_twist<T>(type, 2));
+            const V3<T> d0 = comp3(type, U0), d1 = comp3(type, U1), d2 = comp3(type, U2);
+            const S3<T> Di = spd3_inverse(S3<T>{d0.x, d0.y, d0.z, d1.y, d1.z, d2.z});
+            const V3<T> tau3{taurow[di[0] * A.v_es], taurow[di[1] * A.v_es], taurow[di[2] * A.v_es]};
+            const V3<T> u3 = tau3 - comp3(type, pA);
+            const int sl = mi[MI_SLOT_LK];
+            ws_store6(ws, ws_stride, sl, U0), ws_store6(ws, ws_stride, sl + 6, U1), ws_store6(ws, ws_stride, sl + 12, U2);
+            MH_WS(sl + 18) = Di.xx, MH_WS(sl + 19) = Di.xy, MH_WS(sl + 20) = Di.xz, MH_WS(sl + 21) = Di.yy, MH_WS(sl + 22) = Di.yz, MH_WS(sl + 23) = Di.zz;
+            MH_WS(sl + 24) = u3.x, MH_WS(sl + 25) = u3.y, MH_WS(sl + 26) = u3.z;
+            if (parent >= 0)
+            { // Ia = IA - U D^-1 U^T ; pa = pA + Ia c + U D^-1 u   (:1220-1234)
+               const SV<T> W0 = Di.xx * U0 + Di.xy * U1 + Di.xz * U2, W1 = Di.xy * U0 + Di.yy * U1 + Di.yz * U2, W2 = Di.xz * U0 + Di.yz * U1 + Di.zz * U2;
+               rank1_pair_down(Ia, W0, U0), rank1_pair_down(Ia, W1, U1), rank1_pair_down(Ia, W2, U2);
+               const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+               pa = pA + mul(Ia, cj) + u3.x * W0 + u3.y * W1 + u3.z * W2;
             }
          }
          else if (type == JT_SIXDOF)
@@ -772,20 +903,35 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
                trow[di[0] * A.v_es] = (flags & MF_LOCKED) ? dot(U.a, a.a) + dot(U.l, a.l) + MH_WS(sf + 7) : taurow[di[0] * A.v_es];
             }
          }
-         else if (LOCKED && type == JT_SIXDOF && (flags & MF_LOCKED))
+         else if (LOCKED && dof_count(type) >= 3 && (flags & MF_LOCKED))
          {
             const T *gr = A.in3b + cfg * A.v_bs;
-            const SV<T> qdd{V3<T>{gr[di[0] * A.v_es], gr[di[1] * A.v_es], gr[di[2] * A.v_es]},
-                            V3<T>{gr[di[3] * A.v_es], gr[di[4] * A.v_es], gr[di[5] * A.v_es]}};
-            a = a + qdd;
-            orow[di[0] * A.v_es] = qdd.a.x, orow[di[1] * A.v_es] = qdd.a.y, orow[di[2] * A.v_es] = qdd.a.z;
-            orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
+            a = a + joint_vec<T>(type, dof_map, mi[MI_DOF], gr, A.v_es, true);
+            for (int k = 0; k < dof_count(type); k++)
+               orow[di[k] * A.v_es] = gr[di[k] * A.v_es];
             if (A.outb)
             {
                const SV<T> w = mul(ws_load_abi(ws, ws_stride, mi[MI_SLOT_LK]), a) + ws_load6(ws, ws_stride, mi[MI_SLOT_LK] + 21);
                T *trow = A.outb + cfg * A.v_bs;
-               trow[di[0] * A.v_es] = w.a.x, trow[di[1] * A.v_es] = w.a.y, trow[di[2] * A.v_es] = w.a.z;
-               trow[di[3] * A.v_es] = w.l.x, trow[di[4] * A.v_es] = w.l.y, trow[di[5] * A.v_es] = w.l.z;
+               for (int k = 0; k < dof_count(type); k++)
+                  trow[di[k] * A.v_es] = comp(w, dof_comp(type, k));
+            }
+         }
+         else if (type == JT_PLANAR || type == JT_SPHERICAL)
+         { // qdd = D^-1 (u - U^T a')   (:1280-1282)
+            const int sl = mi[MI_SLOT_LK];
+            const SV<T> U0 = ws_load6(ws, ws_stride, sl), U1 = ws_load6(ws, ws_stride, sl + 6), U2 = ws_load6(ws, ws_stride, sl + 12);
+            const S3<T> Di{MH_WS(sl + 18), MH_WS(sl + 19), MH_WS(sl + 20), MH_WS(sl + 21), MH_WS(sl + 22), MH_WS(sl + 23)};
+            const V3<T> r{MH_WS(sl + 24) - (dot(U0.a, a.a) + dot(U0.l, a.l)), MH_WS(sl + 25) - (dot(U1.a, a.a) + dot(U1.l, a.l)),
+                          MH_WS(sl + 26) - (dot(U2.a, a.a) + dot(U2.l, a.l))};
+            const V3<T> qdd = mul(Di, r);
+            orow[di[0] * A.v_es] = qdd.x, orow[di[1] * A.v_es] = qdd.y, orow[di[2] * A.v_es] = qdd.z;
+            a = a + from_comp3(type, qdd);
+            if (LOCKED && A.outb)
+            {
+               T *trow = A.outb + cfg * A.v_bs;
+               for (int k = 0; k < 3; k++)
+                  trow[di[k] * A.v_es] = taurow[di[k] * A.v_es];
             }
          }
          else if (type == JT_SIXDOF)
@@ -869,6 +1015,52 @@ MH_DEV void integrate_joint(int type, IP ci, IP di, const T *qr, const T *vr, co
       vo[di[0] * A.v_es] = dt * a0 + v0;
       if (ao)
          ao[di[0] * A.v_es] = a0;
+   }
+   else if (type == JT_SPHERICAL)
+   { // :445-449, 578-625: q' = q * quat(dt w + dt^2/2 al), w' = w + dt al
+      const T qx = qr[ci[0] * A.q_es], qy = qr[ci[1] * A.q_es], qz = qr[ci[2] * A.q_es], qs = qr[ci[3] * A.q_es];
+      const V3<T> w{vr[di[0] * A.v_es], vr[di[1] * A.v_es], vr[di[2] * A.v_es]}, al{ar[di[0] * A.v_es], ar[di[1] * A.v_es], ar[di[2] * A.v_es]};
+      const V3<T> rv = dt * w + hdd * al, wn = w + dt * al;
+      const T th = sqrt(dot(rv, rv));
+      T dx = T(0), dy = T(0), dz = T(0), ds = T(1);
+      if (th >= T(1.0e-12))
+      {
+         T sh, ch;
+         sincos_t(T(0.5) * th, sh, ch);
+         const T sc = sh / th;
+         dx = rv.x * sc, dy = rv.y * sc, dz = rv.z * sc, ds = ch;
+      }
+      qo[ci[0] * A.q_es] = qs * dx + qx * ds + qy * dz - qz * dy;
+      qo[ci[1] * A.q_es] = qs * dy - qx * dz + qy * ds + qz * dx;
+      qo[ci[2] * A.q_es] = qs * dz + qx * dy - qy * dx + qz * ds;
+      qo[ci[3] * A.q_es] = qs * ds - qx * dx - qy * dy - qz * dz;
+      vo[di[0] * A.v_es] = wn.x, vo[di[1] * A.v_es] = wn.y, vo[di[2] * A.v_es] = wn.z;
+      if (ao)
+         ao[di[0] * A.v_es] = al.x, ao[di[1] * A.v_es] = al.y, ao[di[2] * A.v_es] = al.z;
+   }
+   else if (type == JT_PLANAR)
+   { // the 6-DoF scheme (:503-575) confined to the XZ plane: rotation vector (0, th, 0), a_o = a + w x v
+      const T pitch = qr[ci[0] * A.q_es], px = qr[ci[1] * A.q_es], pz = qr[ci[2] * A.q_es];
+      const T wy = vr[di[0] * A.v_es], vx = vr[di[1] * A.v_es], vz = vr[di[2] * A.v_es];
+      const T aly = ar[di[0] * A.v_es], ax = ar[di[1] * A.v_es], az = ar[di[2] * A.v_es];
+      const T aox = ax + wy * vz, aoz = az - wy * vx;
+      const T th = dt * wy + hdd * aly;
+      const T dpx = dt * vx + hdd * aox, dpz = dt * vz + hdd * aoz;
+      T s0, c0, sd, cd;
+      sincos_t(pitch, s0, c0);
+      sincos_t(th, sd, cd);
+      const T wn = wy + dt * aly, cx = vx + dt * aox, cz = vz + dt * aoz;
+      const T vnx = cd * cx - sd * cz, vnz = sd * cx + cd * cz;
+      qo[ci[0] * A.q_es] = pitch + th;
+      qo[ci[1] * A.q_es] = px + c0 * dpx + s0 * dpz;
+      qo[ci[2] * A.q_es] = pz - s0 * dpx + c0 * dpz;
+      vo[di[0] * A.v_es] = wn, vo[di[1] * A.v_es] = vnx, vo[di[2] * A.v_es] = vnz;
+      if (ao)
+      {
+         ao[di[0] * A.v_es] = aly;
+         ao[di[1] * A.v_es] = cd * aox - sd * aoz - vnz * wn;
+         ao[di[2] * A.v_es] = sd * aox + cd * aoz + vnx * wn;
+      }
    }
    else if (type == JT_SIXDOF)
    { // :503-575
@@ -982,28 +1174,6 @@ MH_DEV RI<T> ws_load_ri(const T *ws, long ws_stride, int s)
    r.I = S3<T>{MH_WS(s + 4), MH_WS(s + 5), MH_WS(s + 6), MH_WS(s + 7), MH_WS(s + 8), MH_WS(s + 9)};
    return r;
 }
-// unit motion vector of DoF k of a joint of the given kind, canonical frame
-template <typename T>
-MH_DEV SV<T> unit_twist(int type, int k)
-{
-   SV<T> s{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
-   if (type == JT_REVOLUTE)
-      s.a.z = T(1);
-   else if (type == JT_PRISMATIC)
-      s.l.z = T(1);
-   else
-   {
-      s.a.x = k == 0 ? T(1) : T(0), s.a.y = k == 1 ? T(1) : T(0), s.a.z = k == 2 ? T(1) : T(0);
-      s.l.x = k == 3 ? T(1) : T(0), s.l.y = k == 4 ? T(1) : T(0), s.l.z = k == 5 ? T(1) : T(0);
-   }
-   return s;
-}
-template <typename T>
-MH_DEV T comp(SV<T> w, int k)
-{
-   return k == 0 ? w.a.x : k == 1 ? w.a.y : k == 2 ? w.a.z : k == 3 ? w.l.x : k == 4 ? w.l.y : w.l.z;
-}
-
 // H is [B][nv][nv] row-major (h_bs = nv*nv, element (r,c) at r*nv + c) and must be zero-filled before the launch:
 // the kernel writes only the entries of related joints (CompositeRigidBodyMassMatrixCalculator.java:298,841-845).
 template <typename T, bool LDSC>
@@ -1048,7 +1218,7 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
          if (flags & MF_HAS_ACC)
             add(Ic, ws_load_ri(ws, ws_stride, mi[MI_SLOT_IA]));
          have_carry = false;
-         const int nd = type == JT_SIXDOF ? 6 : (type == JT_FIXED ? 0 : 1);
+         const int nd = dof_count(type);
          ciptr dj = dof_map + mi[MI_DOF];
          const XF<T> Xb = load_xb<T>(c);
          const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
@@ -1062,8 +1232,8 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
             else if (type == JT_PRISMATIC)
                H[((long)col * nv + col) * h_es] = F.l.z;
             else
-               for (int r = 0; r < 6; r++)
-                  H[((long)dj[r] * nv + col) * h_es] = comp(F, r);
+               for (int r = 0; r < nd; r++)
+                  H[((long)dj[r] * nv + col) * h_es] = comp(F, dof_comp(type, r));
             // ancestors (:783-792)
             int prev = j, anc = parent;
             XF<T> Xp = Xb;
@@ -1085,10 +1255,10 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
                   H[((long)da[0] * nv + col) * h_es] = F.l.z;
                   H[((long)col * nv + da[0]) * h_es] = F.l.z;
                }
-               else if (ta == JT_SIXDOF)
-                  for (int r = 0; r < 6; r++)
+               else
+                  for (int r = 0; r < dof_count(ta); r++)
                   {
-                     const T hv = comp(F, r);
+                     const T hv = comp(F, dof_comp(ta, r));
                      H[((long)da[r] * nv + col) * h_es] = hv;
                      H[((long)col * nv + da[r]) * h_es] = hv;
                   }

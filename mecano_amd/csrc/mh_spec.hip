@@ -24,6 +24,14 @@ struct TP
 constexpr int kParents[TP::N] = {MH_TOPO_PARENTS};
 constexpr int kTypes[TP::N] = {MH_TOPO_TYPES};
 using TR = mh::Tree<TP>;
+constexpr bool kinds_supported()
+{
+   for (int j = 0; j < TP::N; j++)
+      if (TP::type[j] < mh::JT_REVOLUTE || TP::type[j] > mh::JT_FIXED)
+         return false;
+   return true;
+}
+static_assert(kinds_supported(), "specialised code objects cover revolute, prismatic, 6-DoF and fixed joints; planar / spherical joints run on the generic kernels");
 
 enum : int
 {

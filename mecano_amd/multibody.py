@@ -25,7 +25,7 @@ from typing import Iterable, List, Optional, Sequence
 
 import numpy as np
 
-REVOLUTE, PRISMATIC, SIXDOF, FIXED = 0, 1, 2, 3
+REVOLUTE, PRISMATIC, SIXDOF, FIXED, PLANAR, SPHERICAL = 0, 1, 2, 3, 4, 5
 
 
 def _as_transform(transform) -> Optional[np.ndarray]:
@@ -241,6 +241,22 @@ class FixedJoint(Joint):
     configurationMatrixSize = 0
 
 
+class PlanarJoint(Joint):
+    """multiBodySystem/PlanarJoint.java, interfaces/PlanarJointReadOnly.java:17-72: motion in the XZ plane of the frame before the
+    joint; q = (pitch, x, z), qd / qdd / tau = (about y, along x, along z) in the frame after the joint."""
+    joint_type = PLANAR
+    degreesOfFreedom = 3
+    configurationMatrixSize = 3
+
+
+class SphericalJoint(Joint):
+    """multiBodySystem/SphericalJoint.java, interfaces/SphericalJointReadOnly.java:18-104: q = quaternion (x, y, z, s), qd / qdd /
+    tau = angular velocity / acceleration / moment in the frame after the joint."""
+    joint_type = SPHERICAL
+    degreesOfFreedom = 3
+    configurationMatrixSize = 4
+
+
 class JointMatrixIndexProvider:
     """multiBodySystem/interfaces/JointMatrixIndexProvider.java:71-123: running sums in list order."""
 
@@ -363,7 +379,7 @@ class MultiBodySystem:
         com = np.zeros((n, 3))
         dof, cfg = [], []
         for i, j in enumerate(joints):
-            if j.joint_type not in (REVOLUTE, PRISMATIC, SIXDOF, FIXED):
+            if j.joint_type not in (REVOLUTE, PRISMATIC, SIXDOF, FIXED, PLANAR, SPHERICAL):
                 raise NotImplementedError(f"unsupported joint kind: {j}")
             jtype[i] = j.joint_type
             pj = j.getPredecessor().getParentJoint()

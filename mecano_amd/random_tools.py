@@ -18,7 +18,7 @@ from typing import List, Sequence
 
 import numpy as np
 
-from .multibody import (FixedJoint, Joint, MultiBodySystem, PrismaticJoint, RevoluteJoint, RigidBody, SixDoFJoint)
+from .multibody import (FixedJoint, Joint, MultiBodySystem, PlanarJoint, PrismaticJoint, RevoluteJoint, RigidBody, SixDoFJoint, SphericalJoint)
 
 
 def nextVector3D(rng, lo=-1.0, hi=1.0):
@@ -87,7 +87,16 @@ def nextFixedJoint(rng, name, predecessor):
     return FixedJoint(name, predecessor, _offset(rng, predecessor))
 
 
-_KINDS = {"revolute": nextRevoluteJoint, "prismatic": nextPrismaticJoint, "sixdof": nextSixDoFJoint, "fixed": nextFixedJoint}
+def nextPlanarJoint(rng, name, predecessor):
+    return PlanarJoint(name, predecessor, _offset(rng, predecessor))
+
+
+def nextSphericalJoint(rng, name, predecessor):
+    return SphericalJoint(name, predecessor, _offset(rng, predecessor))
+
+
+_KINDS = {"revolute": nextRevoluteJoint, "prismatic": nextPrismaticJoint, "sixdof": nextSixDoFJoint, "fixed": nextFixedJoint,
+          "planar": nextPlanarJoint, "spherical": nextSphericalJoint}
 
 
 def _next_joint(rng, kinds: Sequence[str], name, predecessor):
@@ -170,6 +179,13 @@ def nextState(rng, system: MultiBodySystem, batch: int, q_range=np.pi):
             quat /= np.linalg.norm(quat, axis=1, keepdims=True)
             q[:, ci[:4]] = quat
             q[:, ci[4:]] = rng.uniform(-1, 1, (batch, 3))
+        elif isinstance(j, SphericalJoint):
+            quat = rng.normal(size=(batch, 4))
+            quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+            q[:, ci] = quat
+        elif isinstance(j, PlanarJoint):
+            q[:, ci[0]] = rng.uniform(-q_range, q_range, batch)
+            q[:, ci[1:]] = rng.uniform(-1, 1, (batch, 2))
         elif isinstance(j, RevoluteJoint):
             q[:, ci[0]] = rng.uniform(-q_range, q_range, batch)
         elif isinstance(j, PrismaticJoint):

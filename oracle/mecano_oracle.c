@@ -48,6 +48,8 @@
 #define MO_PRISMATIC 1
 #define MO_SIXDOF 2
 #define MO_FIXED 3
+#define MO_PLANAR 4    /* q = (pitch, x, z), qd = (w_y, v_x, v_z): multiBodySystem/interfaces/PlanarJointReadOnly.java:17-72 */
+#define MO_SPHERICAL 5 /* q = quaternion (x, y, z, s), qd = angular velocity: multiBodySystem/interfaces/SphericalJointReadOnly.java:18-104 */
 
 #define MO_MAX_JOINTS 512
 #define COM_OFFSET_ZERO_EPSILON 1.0e-11 /* SpatialInertiaReadOnly.java:56 */
@@ -228,6 +230,26 @@ static void joint_transform(const mo_model *m, int i, const double *qrow, xf_t *
          X->p[0] = qrow[ci[4]], X->p[1] = qrow[ci[5]], X->p[2] = qrow[ci[6]];
          break;
       }
+      case MO_PLANAR:
+      { /* rotation about y by the pitch, translation (x, 0, z): the pose restricted to the XZ plane (multiBodySystem/PlanarJoint.java:25-26) */
+         double pitch = qrow[ci[0]];
+         double c = cos(pitch), sn = sin(pitch);
+         X->R[0] = c, X->R[1] = 0, X->R[2] = sn;
+         X->R[3] = 0, X->R[4] = 1, X->R[5] = 0;
+         X->R[6] = -sn, X->R[7] = 0, X->R[8] = c;
+         X->p[0] = qrow[ci[1]], X->p[1] = 0, X->p[2] = qrow[ci[2]];
+         break;
+      }
+      case MO_SPHERICAL:
+      { /* SphericalJointReadOnly.java:50-53 */
+         double x = qrow[ci[0]], y = qrow[ci[1]], z = qrow[ci[2]], s = qrow[ci[3]];
+         double nrm = sqrt(x * x + y * y + z * z + s * s);
+         x /= nrm, y /= nrm, z /= nrm, s /= nrm;
+         X->R[0] = 1 - 2 * (y * y + z * z), X->R[1] = 2 * (x * y - z * s), X->R[2] = 2 * (x * z + y * s);
+         X->R[3] = 2 * (x * y + z * s), X->R[4] = 1 - 2 * (x * x + z * z), X->R[5] = 2 * (y * z - x * s);
+         X->R[6] = 2 * (x * z - y * s), X->R[7] = 2 * (y * z + x * s), X->R[8] = 1 - 2 * (x * x + y * y);
+         break;
+      }
       default:
          break;
    }
@@ -250,6 +272,12 @@ static void joint_subspace(const mo_model *m, int i, double S[6][6])
       case MO_SIXDOF:
          for (int k = 0; k < 6; k++)
             S[k][k] = 1.0;
+         break;
+      case MO_PLANAR: /* w_y, v_x, v_z (tools/MecanoTools.java:920-952) */
+         S[0][1] = 1.0, S[1][3] = 1.0, S[2][5] = 1.0;
+         break;
+      case MO_SPHERICAL: /* w_x, w_y, w_z (tools/MecanoTools.java:1002-1043) */
+         S[0][0] = 1.0, S[1][1] = 1.0, S[2][2] = 1.0;
          break;
       default:
          break;
@@ -978,8 +1006,8 @@ static void crba_one(const mo_model *m, const double *q, double *H)
 }
 
 /* ================================================================== public C API (ctypes / bench) */
-static int joint_ndof(int type) { return type == MO_SIXDOF ? 6 : (type == MO_FIXED ? 0 : 1); }
-static int joint_ncfg(int type) { return type == MO_SIXDOF ? 7 : (type == MO_FIXED ? 0 : 1); }
+static int joint_ndof(int type) { return type == MO_SIXDOF ? 6 : (type == MO_FIXED ? 0 : (type == MO_PLANAR || type == MO_SPHERICAL ? 3 : 1)); }
+static int joint_ncfg(int type) { return type == MO_SIXDOF ? 7 : (type == MO_FIXED ? 0 : (type == MO_PLANAR ? 3 : (type == MO_SPHERICAL ? 4 : 1))); }
 
 /* Joints must be listed parents-first (Mecano's default DFS pre-order is; IT/JointIterator.java:155-161). */
 void *mo_model_create(int n, int nq, int nv, const int *parent, const int *type, const double *axis, const double *X_before,
@@ -993,7 +1021,7 @@ void *mo_model_create(int n, int nq, int nv, const int *parent, const int *type,
    int dofs = 0, cfgs = 0;
    for (int i = 0; i < n; i++)
    {
-      if (parent[i] >= i || type[i] < 0 || type[i] > MO_FIXED)
+      if (parent[i] >= i || type[i] < 0 || type[i] > MO_SPHERICAL)
       {
          free(m);
          return NULL;
@@ -1110,6 +1138,50 @@ void mo_integrate(void *h, long B, double dt, const double *q, const double *qd,
             vo[di[0]] = dt * a0 + v0;            /* :730-733 */
             if (ao)
                ao[di[0]] = a0;
+         }
+         else if (m->type[i] == MO_SPHERICAL)
+         { /* :445-449, 578-625: q' = q * quat(dt w + 0.5 dt^2 al), w' = w + dt al */
+            double quat[4] = {qr[ci[0]], qr[ci[1]], qr[ci[2]], qr[ci[3]]}, rv[3], dq[4] = {0, 0, 0, 1}, qn[4];
+            for (int k = 0; k < 3; k++)
+               rv[k] = dt * vr[di[k]] + hdd * ar[di[k]];
+            double th = sqrt(v3_dot(rv, rv));
+            if (th >= 1.0e-12)
+            {
+               double sc = sin(0.5 * th) / th;
+               dq[0] = rv[0] * sc, dq[1] = rv[1] * sc, dq[2] = rv[2] * sc, dq[3] = cos(0.5 * th);
+            }
+            quat_mul(quat, dq, qn);
+            for (int k = 0; k < 4; k++)
+               qo[ci[k]] = qn[k];
+            for (int k = 0; k < 3; k++)
+            {
+               vo[di[k]] = vr[di[k]] + dt * ar[di[k]];
+               if (ao)
+                  ao[di[k]] = ar[di[k]];
+            }
+         }
+         else if (m->type[i] == MO_PLANAR)
+         { /* the 6-DoF scheme (:503-575) with pose, twist and acceleration confined to the XZ plane (PlanarJoint is a FloatingJointBasics,
+            * :415-418): rotation vector (0, th, 0), a_o = a + w x v = (ax + wy vz, az - wy vx), in-plane rotations by the pitch */
+            double pitch = qr[ci[0]], px = qr[ci[1]], pz = qr[ci[2]];
+            double wy = vr[di[0]], vx = vr[di[1]], vz = vr[di[2]], aly = ar[di[0]], ax = ar[di[1]], az = ar[di[2]];
+            double aox = ax + wy * vz, aoz = az - wy * vx;
+            double th = dt * wy + hdd * aly;
+            double dpx = dt * vx + hdd * aox, dpz = dt * vz + hdd * aoz;
+            double c0 = cos(pitch), s0 = sin(pitch), cd = cos(th), sd = sin(th);
+            /* R_y(pitch) (x, z) = (c x + s z, -s x + c z) ; R_y(th)^T (x, z) = (c x - s z, s x + c z) */
+            double wn = wy + dt * aly;
+            double cx = vx + dt * aox, cz = vz + dt * aoz;
+            double vnx = cd * cx - sd * cz, vnz = sd * cx + cd * cz;
+            qo[ci[0]] = pitch + th;
+            qo[ci[1]] = px + c0 * dpx + s0 * dpz;
+            qo[ci[2]] = pz - s0 * dpx + c0 * dpz;
+            vo[di[0]] = wn, vo[di[1]] = vnx, vo[di[2]] = vnz;
+            if (ao)
+            { /* a' = R(dq)^T a_o + v' x w' : (v' x w')_x = -vnz wn, (v' x w')_z = vnx wn */
+               double anx = cd * aox - sd * aoz, anz = sd * aox + cd * aoz;
+               ao[di[0]] = aly, ao[di[1]] = anx - vnz * wn, ao[di[2]] = anz + vnx * wn;
+            }
          }
          else if (m->type[i] == MO_SIXDOF)
          {

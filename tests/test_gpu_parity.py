@@ -705,6 +705,46 @@ def test_simulation_step_equals_aba_then_integrate(torch_cuda, B):
         os.environ.pop("MH_SPEC_SPLIT", None)
 
 
+@pytest.mark.parametrize("kinds", [("planar",), ("spherical",), ("revolute", "prismatic", "planar", "spherical", "sixdof", "fixed")])
+def test_planar_and_spherical_joints(torch_cuda, kinds):
+    """PlanarJoint / SphericalJoint trees (run-time-topology kernels): RNEA, ABA, CRBA, locked joints, per-body outputs and the state
+    integrator against the oracle; fp32 within its tolerance."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(("n4gpu" + "".join(kinds)).encode()))
+    tol = 1e-8 if len(kinds) > 1 else TOL
+    for it in range(6):
+        sys_ = system_of(rt.nextJointTree(rng, int(rng.integers(1, 30)), kinds))
+        d = sys_.toModelDesc()
+        om, hm = OracleModel(d), HipModel(d)
+        assert hm.kernel_variant == "generic"
+        B = int(rng.integers(1, 200))
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        g = (0.2, -0.4, -9.81)
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6)) if it % 2 else None
+        close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), g, dev(torch, fext)).cpu().numpy(), om.rnea(q, qd, qdd, g, fext))
+        close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g, dev(torch, fext)).cpu().numpy(), om.aba(q, qd, tau, g, fext), tol)
+        close(hm.crba(dev(torch, q)).cpu().numpy(), om.crba(q))
+        t2, acc, tw = hm.rnea_bodies(dev(torch, q), dev(torch, qd), dev(torch, qdd), g, dev(torch, fext))
+        r_t, r_acc, r_tw = om.rnea_bodies(q, qd, qdd, g, fext)
+        close(acc.cpu().numpy(), r_acc), close(tw.cpu().numpy(), r_tw)
+        locked, _ = _locked_case(rng, sys_, d, B)
+        hm.set_joint_source_modes(locked)
+        a_l, t_l = hm.aba_locked(dev(torch, q), dev(torch, qd), dev(torch, tau), dev(torch, qdd), g, dev(torch, fext))
+        r_a, r_tl = om.aba_locked(q, qd, tau, qdd, locked, g, fext)
+        close(a_l.cpu().numpy(), r_a, tol), close(t_l.cpu().numpy(), r_tl, tol)
+        hm.set_joint_source_modes(None)
+        dt = 2.0e-3
+        rq, rv, ra = om.integrate(dt, q, qd, qdd)
+        gq, gv, ga = hm.integrate(dt, dev(torch, q), dev(torch, qd), dev(torch, qdd), return_acceleration=True)
+        close(gq.cpu().numpy(), rq, 1e-13), close(gv.cpu().numpy(), rv, 1e-13), close(ga.cpu().numpy(), ra, 1e-12)
+        f32 = hm.rnea(dev(torch, q, torch.float32), dev(torch, qd, torch.float32), dev(torch, qdd, torch.float32), g).cpu().numpy()
+        ref = om.rnea(q, qd, qdd, g)
+        assert np.abs(f32 - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max())
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()

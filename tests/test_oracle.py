@@ -340,3 +340,38 @@ def test_body_accelerations_rnea_equals_aba_and_free_fall():
         assert np.abs(acc[b, 0, 3:] - _quat_R(q[b, :4]).T @ np.array([0.0, 0.0, 9.81])).max() < 1e-12 and np.abs(acc[b, 0, :3]).max() == 0
     qdd, acc, _ = o6.aba_bodies(q, z, z, g)
     assert np.abs(acc).max() < 1e-12  # free fall: no acceleration relative to the (accelerating) inertial description
+
+
+@pytest.mark.parametrize("kinds", [("planar",), ("spherical",), ("revolute", "prismatic", "planar", "spherical", "sixdof", "fixed")])
+def test_planar_and_spherical_joints(kinds):
+    """Trees with PlanarJoint / SphericalJoint: the reference's invariants -- ABA inverts RNEA
+    (ForwardDynamicsCalculatorTest.java:767-817 on its all-joint-kinds family), H qdd + bias = RNEA, H symmetric -- plus a power balance
+    through the integrator that ties joint transform, motion subspace and state integration of the new kinds together:
+    d/dt (1/2 qd^T H qd) = qd . tau with no gravity, to first order in dt."""
+    rng = np.random.default_rng(zlib.crc32(("n4" + "".join(kinds)).encode()))
+    for it in range(8):
+        joints = rt.nextJointTree(rng, int(rng.integers(1, 25)), kinds)
+        sys_ = MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor())
+        om = OracleModel(sys_.toModelDesc())
+        q, qd, qdd, _ = rt.nextState(rng, sys_, 3)
+        g = (0.3, 0.1, -9.81)
+        fext = rng.uniform(-1, 1, (3, om.n, 6))
+        tau = om.rnea(q, qd, qdd, g, fext)
+        eps = 2e-8 if len(kinds) > 1 else 1e-9
+        assert np.abs(om.aba(q, qd, tau, g, fext) - qdd).max() <= eps * max(1.0, np.abs(qdd).max())
+        H = om.crba(q)
+        bias = om.rnea(q, qd, np.zeros_like(qdd), g, fext)
+        assert np.abs(np.einsum("bij,bj->bi", H, qdd) + bias - tau).max() <= 1e-10 * max(1.0, np.abs(tau).max())
+        assert np.array_equal(H, H.transpose(0, 2, 1))
+    joints = rt.nextJointTree(rng, 6, kinds)
+    sys_ = MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor())
+    om = OracleModel(sys_.toModelDesc())
+    q, qd, _, tau = rt.nextState(rng, sys_, 4)
+    ke = lambda q_, v_: 0.5 * np.einsum("bi,bij,bj->b", v_, om.crba(q_), v_)
+    qdd = om.aba(q, qd, tau, (0.0, 0.0, 0.0))
+    power = np.einsum("bi,bi->b", qd, tau)
+    errs = []
+    for dt in (2e-5, 1e-5):
+        qn, vn, _ = om.integrate(dt, q, qd, qdd)
+        errs.append(np.abs((ke(qn, vn) - ke(q, qd)) / dt - power).max())
+    assert errs[1] <= 0.6 * errs[0] + 1e-7 and errs[1] <= 5e-3 * max(1.0, np.abs(power).max())  # first-order convergence to the power
