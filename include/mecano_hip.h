@@ -215,6 +215,38 @@ mh_status mh_aba_bodies_f64(mh_model_t model, int64_t B, const double *q, const 
                             const double *f_ext, const mh_options *opts, double *qdd_out, double *body_acc_out, double *body_twist_out);
 
 /*
+ * ---- Coriolis matrix (CompositeRigidBodyMassMatrixCalculator.setEnableCoriolisMatrixCalculation(true) + getMassMatrix / getCoriolisMatrix,
+ *      algorithms/CompositeRigidBodyMassMatrixCalculator.java:271-274, 344-365, 604-630, 669-768; algorithms/FactorizedBodyInertia.java) ----
+ * H_out and C_out [B][nv][nv] row-major (MH_LAYOUT_SOA: [nv*nv][B]):  tau = H qdd + C qd + G.  C is the reference's matrix entry for entry
+ * (the factorisation B = v x* I of the body-level Coriolis terms: C qd = RNEA(q, qd, qdd = 0, g = 0), dH/dt = C + C^T); entries of
+ * unrelated joints are zero.  Device pointers, asynchronous on opts->stream.  Runs the run-time-topology kernel.
+ */
+mh_status mh_crba_coriolis_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const mh_options *opts, double *H_out,
+                               double *C_out);
+mh_status mh_crba_coriolis_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const mh_options *opts, float *H_out, float *C_out);
+
+/*
+ * ---- centroidal momentum (CompositeRigidBodyMassMatrixCalculator.getCentroidalMomentumMatrix / getCentroidalConvectiveTermMatrix,
+ *      algorithms/CompositeRigidBodyMassMatrixCalculator.java:316-342, 375-420, 801-839) ----
+ * A_out [B][6][nv]: h = A qd is the momentum (angular, linear) of the considered bodies in the centroidal momentum frame; b_out [B][6]
+ * (may be NULL; needs qd otherwise): dh/dt = A qdd + b.  frame[12] (HOST pointer, R row-major then p; NULL = identity) is the pose of the
+ * centroidal momentum frame in the root body frame -- the reference's setCentroidalMomentumFrame(ReferenceFrame) for a frame fixed in the
+ * root body; the default NULL is the calculator's default frame (the root body-fixed frame, :190-193).  frame_mode
+ * MH_CENTROIDAL_FRAME_AT_COM re-centres that frame on the centre of mass of the considered bodies, i.e. a
+ * frames/CenterOfMassReferenceFrame whose parent is `frame`; com_out [B][3] (may be NULL) then receives the centre of mass in `frame`
+ * coordinates (algorithms/CenterOfMassCalculator.java:70-91), zeros in MH_CENTROIDAL_FRAME_FIXED mode.
+ */
+enum
+{
+   MH_CENTROIDAL_FRAME_FIXED = 0,
+   MH_CENTROIDAL_FRAME_AT_COM = 1
+};
+mh_status mh_centroidal_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double frame[12], int32_t frame_mode,
+                            const mh_options *opts, double *A_out, double *b_out, double *com_out);
+mh_status mh_centroidal_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const double frame[12], int32_t frame_mode,
+                            const mh_options *opts, float *A_out, float *b_out, float *com_out);
+
+/*
  * ---- state integration (MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration, tools/MultiBodySystemStateIntegrator.java:365-441,
  *      503-575, 710-733): the step downstream of forward dynamics, so that a simulation loop never leaves the device ----
  * One explicit constant-acceleration step of size dt for every joint of every configuration: 1-DoF q' = q + dt qd + dt^2/2 qdd,

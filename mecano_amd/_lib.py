@@ -18,7 +18,7 @@ LAYOUT_AOS, LAYOUT_SOA = 0, 1
 ABI_SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
     "mh_topology_key", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64",
-    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_timer_create",
+    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_timer_create",
     "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
 ]
 
@@ -33,6 +33,9 @@ class MhModelDesc(ctypes.Structure):
 class MhOptions(ctypes.Structure):
     _fields_ = [("consider_coriolis", ctypes.c_int32), ("consider_accelerations", ctypes.c_int32), ("layout", ctypes.c_int32),
                 ("reserved0", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+
+
+CENTROIDAL_FRAME_FIXED, CENTROIDAL_FRAME_AT_COM = 0, 1
 
 
 class MecanoHipError(RuntimeError):
@@ -52,6 +55,16 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m mecano_amd.build` (hipcc, gfx950). "
                           "mecano_amd has no CPU fallback.")
+    # PyTorch wheels bundle their own HIP / HSA runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in one process cannot both open
+    # the GPU (whichever initialises second reports "no ROCm-capable device"), so when torch is importable it is imported FIRST: the
+    # library's libamdhip64.so.7 dependency then binds to the copy torch already loaded and the process holds a single runtime.
+    # Hosts without torch (the Java / C++ side of the C-ABI) simply get the system runtime.
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.mh_abi_version.restype = I32
@@ -82,6 +95,10 @@ def load():
     lib.mh_aba_locked_f64.argtypes = [P, I64, P, P, P, P, P, P, opt, P, P]
     for f in ("mh_rnea_bodies_f64", "mh_aba_bodies_f64"):
         getattr(lib, f).argtypes = [P, I64, P, P, P, P, P, opt, P, P, P]
+    for f in ("mh_crba_coriolis_f64", "mh_crba_coriolis_f32"):
+        getattr(lib, f).argtypes = [P, I64, P, P, opt, P, P]
+    for f in ("mh_centroidal_f64", "mh_centroidal_f32"):
+        getattr(lib, f).argtypes = [P, I64, P, P, P, I32, opt, P, P, P]
     for f in ("mh_integrate_f64", "mh_integrate_f32"):
         getattr(lib, f).argtypes = [P, I64, ctypes.c_double, P, P, P, opt, P, P, P]
     lib.mh_aba_integrate_f64.argtypes = [P, I64, ctypes.c_double, P, P, P, P, P, opt, P, P, P]

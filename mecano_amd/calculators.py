@@ -191,21 +191,79 @@ class ForwardDynamicsCalculator(_Base):
 
 
 class CompositeRigidBodyMassMatrixCalculator(_Base):
-    def __init__(self, input, considerIgnoredSubtreesInertia: bool = True):
+    """algorithms/CompositeRigidBodyMassMatrixCalculator.java: mass matrix, Coriolis matrix (:271-274, 352-365), centroidal momentum
+    matrix and convective term (:367-420), batched.  The reference reads q, qd from the joints; here ``compute(q, qd)`` takes them and
+    the getters return what that call produced (``reset()`` forgets it, :282-291)."""
+
+    def __init__(self, input, centroidalMomentumFrame=None, considerIgnoredSubtreesInertia: bool = True):
         super().__init__(input, considerIgnoredSubtreesInertia)
-        self._H = None
+        self._coriolis_enabled = False
+        self._frame, self._at_com = None, False
+        self.setCentroidalMomentumFrame(centroidalMomentumFrame)
+        self.reset()
 
     def reset(self):
-        self._H = None
+        self._H = self._C = self._A = self._b = self._com = None
+        self._q = self._qd = None
 
-    def compute(self, q):
-        self._H = self.model.crba(q, self.layout)
+    def setEnableCoriolisMatrixCalculation(self, enable: bool):
+        """:271-274"""
+        self._coriolis_enabled = bool(enable)
+
+    def setCentroidalMomentumFrame(self, frame, atCenterOfMass: bool = False):
+        """:375-384.  ``frame``: None (the root body frame, the reference's default :190-193), a RigidBodyTransform-like pose of a
+        frame fixed in the root body (12 numbers: R row-major, p; or an object with ``.R`` / ``.p``), and ``atCenterOfMass=True`` to
+        get a frames/CenterOfMassReferenceFrame under it."""
+        if frame is not None and hasattr(frame, "R"):
+            frame = np.concatenate([np.asarray(frame.R, dtype=np.float64).reshape(9), np.asarray(frame.p, dtype=np.float64).reshape(3)])
+        self._frame, self._at_com = frame, bool(atCenterOfMass)
+        self._A = self._b = self._com = None
+
+    def compute(self, q, qd=None):
+        self.reset()
+        self._q, self._qd = q, qd
+        if self._coriolis_enabled:
+            if qd is None:
+                raise ValueError("the Coriolis matrix needs the joint velocities")
+            self._H, self._C = self.model.crba_coriolis(q, qd, self.layout)
+        else:
+            self._H = self.model.crba(q, self.layout)
         return self._H
 
     def getMassMatrix(self, q=None):
         if q is not None:
             return self.compute(q)
         return self._H
+
+    def getCoriolisMatrix(self):
+        """:352-365: UnsupportedOperationException when the calculation is disabled"""
+        if not self._coriolis_enabled:
+            raise NotImplementedError("Coriolis matrix calculation is disabled.")
+        return self._C
+
+    def _centroidal(self):
+        if self._A is None:
+            if self._q is None:
+                raise ValueError("call compute(q, qd) first")
+            self._A, self._b, self._com = self.model.centroidal(self._q, self._qd, self._frame, self._at_com, self.layout)
+
+    def getCentroidalMomentumMatrix(self):
+        """:386-398"""
+        self._centroidal()
+        return self._A
+
+    def getCentroidalConvectiveTermMatrix(self):
+        """:413-420"""
+        self._centroidal()
+        return self._b
+
+    def getCentroidalConvectiveTerm(self):
+        return self.getCentroidalConvectiveTermMatrix()
+
+    def getCenterOfMass(self):
+        """origin of a centre-of-mass centroidal frame in its parent frame (algorithms/CenterOfMassCalculator.java:70-91)"""
+        self._centroidal()
+        return self._com
 
 
 class MultiBodySystemStateIntegrator:

@@ -588,6 +588,91 @@ void try_load_spec(mh_model *m, const Plan &P)
    m->spec = s;
    m->variant = "topo:" + P.key;
 }
+// Mass matrix + Coriolis matrix (CompositeRigidBodyMassMatrixCalculator with the Coriolis calculation enabled): run-time-topology kernel
+template <typename T>
+mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, const mh_options *opts_in, T *H_out, T *C_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (B == 0)
+      return MH_OK;
+   if (!q || !qd || !H_out || !C_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   st = ensure_workspace(model, B, sizeof(T));
+   if (st != MH_OK)
+      return st;
+   const Launch L = plan_launch(model, B);
+   hipStream_t stream = (hipStream_t)opts.stream;
+   mh::Args<T> A{};
+   A.m = dev_model<T>(model);
+   A.B = B;
+   A.q = q, A.qd = qd, A.out = H_out, A.outb = C_out;
+   A.ws = (T *)model->ws.ptr;
+   A.ws_stride = L.lanes;
+   const bool soa = opts.layout == MH_LAYOUT_SOA;
+   A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
+   A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
+   A.f_bs = soa ? 1 : (long)model->nv * model->nv, A.f_es = soa ? B : 1; // strides of H and C
+   const size_t lds = MH_GENERIC_LDS_CONSTS ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
+   const size_t hbytes = (size_t)B * model->nv * model->nv * sizeof(T);
+   HIP_TRY(hipMemsetAsync(H_out, 0, hbytes, stream)); // the kernel writes the entries of related joints only (:298-300)
+   HIP_TRY(hipMemsetAsync(C_out, 0, hbytes, stream));
+   hipLaunchKernelGGL((mh::coriolis_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
+template <typename T>
+mh_status centroidal_impl(mh_model_t model, int64_t B, const T *q, const T *qd, const double *frame, int32_t frame_mode, const mh_options *opts_in,
+                          T *A_out, T *b_out, T *com_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (frame_mode != MH_CENTROIDAL_FRAME_FIXED && frame_mode != MH_CENTROIDAL_FRAME_AT_COM)
+      return fail(MH_ERR_INVALID_ARGUMENT, "unknown centroidal frame mode %d", frame_mode);
+   if (B == 0)
+      return MH_OK;
+   if (!q || !A_out || (b_out && !qd))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer (the convective term needs qd)");
+   st = ensure_workspace(model, B, sizeof(T));
+   if (st != MH_OK)
+      return st;
+   const Launch L = plan_launch(model, B);
+   hipStream_t stream = (hipStream_t)opts.stream;
+   mh::CentArgs<T> A{};
+   A.m = dev_model<T>(model);
+   A.B = B;
+   A.q = q, A.qd = qd, A.A = A_out, A.b = b_out, A.com = com_out;
+   A.ws = (T *)model->ws.ptr;
+   A.ws_stride = L.lanes;
+   const bool soa = opts.layout == MH_LAYOUT_SOA;
+   A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
+   A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
+   A.a_bs = soa ? 1 : 6L * model->nv, A.a_es = soa ? B : 1;
+   A.b_bs = soa ? 1 : 6, A.b_es = soa ? B : 1;
+   A.c_bs = soa ? 1 : 3, A.c_es = soa ? B : 1;
+   for (int k = 0; k < 9; k++)
+      A.fR[k] = frame ? (T)frame[k] : (T)(k % 4 == 0 ? 1 : 0);
+   for (int k = 0; k < 3; k++)
+      A.fp[k] = frame ? (T)frame[9 + k] : T(0);
+   A.at_com = frame_mode == MH_CENTROIDAL_FRAME_AT_COM;
+   const size_t lds = MH_GENERIC_LDS_CONSTS ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
+   HIP_TRY(hipMemsetAsync(A_out, 0, (size_t)B * 6 * model->nv * sizeof(T), stream)); // columns no considered joint owns stay zero
+   hipLaunchKernelGGL((mh::centroidal_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
 template <typename T>
 mh_status integrate_impl(mh_model_t model, int64_t B, double dt, const T *q, const T *qd, const T *qdd, const mh_options *opts_in, T *q_out,
                                 T *qd_out, T *qdd_out)
@@ -759,7 +844,7 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       mi[mh::MI_SLOT_F] = slots, slots += 8;
       mi[mh::MI_SLOT_C] = slots, slots += 6;
       mi[mh::MI_SLOT_VA] = slots, slots += (nonadj_child ? 12 : 0);
-      mi[mh::MI_SLOT_IA] = slots, slots += (nonadj_child ? 21 : 0);
+      mi[mh::MI_SLOT_IA] = slots, slots += (nonadj_child ? 40 : 0); // ABA: 21 | CRBA: 10 | Coriolis: 10 + 30
       mi[mh::MI_SLOT_LK] = slots, slots += (mh::dof_count(t) >= 3 ? 27 : 0); // multi-DoF joints: U, D^-1, u | locked: IA, pA
 
       // X_before' = Qp^T X_before Q : canonical before-joint frame in the parent's canonical after-joint frame
@@ -809,10 +894,11 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
 
    // ---- device side
    int dev = 0, ndev = 0;
-   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+   const hipError_t dc = hipGetDeviceCount(&ndev);
+   if (dc != hipSuccess || ndev == 0)
    {
       delete m;
-      return fail(MH_ERR_NO_DEVICE, "no HIP device: the model cannot be uploaded (there is no CPU path)");
+      return fail(MH_ERR_NO_DEVICE, "no HIP device (%s, %d device(s)): the model cannot be uploaded (there is no CPU path)", hipGetErrorString(dc), ndev);
    }
    hipError_t e = hipGetDevice(&dev);
    if (e == hipSuccess)
@@ -924,6 +1010,24 @@ mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double 
 mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
 {
    return launch<double>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+}
+mh_status mh_crba_coriolis_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const mh_options *opts, double *H_out, double *C_out)
+{
+   return coriolis_impl<double>(model, B, q, qd, opts, H_out, C_out);
+}
+mh_status mh_crba_coriolis_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const mh_options *opts, float *H_out, float *C_out)
+{
+   return coriolis_impl<float>(model, B, q, qd, opts, H_out, C_out);
+}
+mh_status mh_centroidal_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double frame[12], int32_t frame_mode,
+                            const mh_options *opts, double *A_out, double *b_out, double *com_out)
+{
+   return centroidal_impl<double>(model, B, q, qd, frame, frame_mode, opts, A_out, b_out, com_out);
+}
+mh_status mh_centroidal_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const double frame[12], int32_t frame_mode,
+                            const mh_options *opts, float *A_out, float *b_out, float *com_out)
+{
+   return centroidal_impl<float>(model, B, q, qd, frame, frame_mode, opts, A_out, b_out, com_out);
 }
 mh_status mh_integrate_f64(mh_model_t model, int64_t B, double dt, const double *q, const double *qd, const double *qdd, const mh_options *opts,
                            double *q_out, double *qd_out, double *qdd_out)

@@ -339,6 +339,96 @@ MH_DEV void add(RI<T> &a, const RI<T> &b)
    a.I.xx += b.I.xx, a.I.xy += b.I.xy, a.I.xz += b.I.xz, a.I.yy += b.I.yy, a.I.yz += b.I.yz, a.I.zz += b.I.zz;
 }
 
+// ---- factorised body inertia B = v x* I of the Coriolis-matrix recursion (algorithms/FactorizedBodyInertia.java:136-158): a general
+//      6x6 [[A, TR], [BL, L]] whose bottom-right block stays skew under sums and rigid transforms, L = [l]x with l = sum m w
+template <typename T>
+struct FB
+{
+   M3<T> A, TR, BL;
+   V3<T> l;
+};
+// a b^T - (a.b) 1  =  [b]x [a]x
+template <typename T>
+MH_DEV M3<T> outer_minus_dot(V3<T> a, V3<T> b)
+{
+   const T d = dot(a, b);
+   return M3<T>{a.x * b.x - d, a.x * b.y, a.x * b.z, a.y * b.x, a.y * b.y - d, a.y * b.z, a.z * b.x, a.z * b.y, a.z * b.z - d};
+}
+template <typename T>
+MH_DEV void add(M3<T> &a, const M3<T> &b)
+{
+   a.xx += b.xx, a.xy += b.xy, a.xz += b.xz, a.yx += b.yx, a.yy += b.yy, a.yz += b.yz, a.zx += b.zx, a.zy += b.zy, a.zz += b.zz;
+}
+template <typename T>
+MH_DEV void sub(M3<T> &a, const M3<T> &b)
+{
+   a.xx -= b.xx, a.xy -= b.xy, a.xz -= b.xz, a.yx -= b.yx, a.yy -= b.yy, a.yz -= b.yz, a.zx -= b.zx, a.zy -= b.zy, a.zz -= b.zz;
+}
+// [p]x M
+template <typename T>
+MH_DEV M3<T> tilde_mul(V3<T> p, const M3<T> &M)
+{
+   return M3<T>{p.y * M.zx - p.z * M.yx, p.y * M.zy - p.z * M.yy, p.y * M.zz - p.z * M.yz,
+                p.z * M.xx - p.x * M.zx, p.z * M.xy - p.x * M.zy, p.z * M.xz - p.x * M.zz,
+                p.x * M.yx - p.y * M.xx, p.x * M.yy - p.y * M.xy, p.x * M.yz - p.y * M.xz};
+}
+// M [p]x
+template <typename T>
+MH_DEV M3<T> mul_tilde(const M3<T> &M, V3<T> p)
+{
+   return M3<T>{M.xy * p.z - M.xz * p.y, M.xz * p.x - M.xx * p.z, M.xx * p.y - M.xy * p.x,
+                M.yy * p.z - M.yz * p.y, M.yz * p.x - M.yx * p.z, M.yx * p.y - M.yy * p.x,
+                M.zy * p.z - M.zz * p.y, M.zz * p.x - M.zx * p.z, M.zx * p.y - M.zy * p.x};
+}
+// B = v x* I for the rigid inertia (m, h, I about the frame origin) of a body moving with v = (w, u):
+//   A = [w]x I - [u]x [h]x ;  TR = [w]x [h]x + m [u]x ;  BL = -[w]x [h]x ;  L = m [w]x
+template <typename T>
+MH_DEV FB<T> fb_from_rigid(const RI<T> &r, SV<T> v)
+{
+   FB<T> B;
+   const M3<T> I{r.I.xx, r.I.xy, r.I.xz, r.I.xy, r.I.yy, r.I.yz, r.I.xz, r.I.yz, r.I.zz};
+   const M3<T> wh = outer_minus_dot(r.h, v.a); // [w]x [h]x
+   B.A = tilde_mul(v.a, I);
+   sub(B.A, outer_minus_dot(r.h, v.l));
+   B.BL = M3<T>{-wh.xx, -wh.xy, -wh.xz, -wh.yx, -wh.yy, -wh.yz, -wh.zx, -wh.zy, -wh.zz};
+   const V3<T> mu = r.m * v.l;
+   B.TR = M3<T>{wh.xx, wh.xy - mu.z, wh.xz + mu.y, wh.yx + mu.z, wh.yy, wh.yz - mu.x, wh.zx - mu.y, wh.zy + mu.x, wh.zz};
+   B.l = r.m * v.a;
+   return B;
+}
+template <typename T>
+MH_DEV void add(FB<T> &a, const FB<T> &b)
+{
+   add(a.A, b.A), add(a.TR, b.TR), add(a.BL, b.BL);
+   a.l = a.l + b.l;
+}
+template <typename T>
+MH_DEV void rotate(FB<T> &B, const M3<T> &R)
+{
+   B.A = conj(R, B.A), B.TR = conj(R, B.TR), B.BL = conj(R, B.BL);
+   B.l = mul(R, B.l);
+}
+// the four in-place translation updates of FactorizedBodyInertia.java:323-330: TR += [p]x L ; A += [p]x BL ; A -= TR [p]x ; BL -= L [p]x
+template <typename T>
+MH_DEV void translate(FB<T> &B, V3<T> p)
+{
+   add(B.TR, outer_minus_dot(B.l, p)); // [p]x [l]x = l p^T - (p.l) 1
+   add(B.A, tilde_mul(p, B.BL));
+   sub(B.A, mul_tilde(B.TR, p));
+   sub(B.BL, outer_minus_dot(p, B.l)); // [l]x [p]x = p l^T - (l.p) 1
+}
+// B s and B^T s
+template <typename T>
+MH_DEV SV<T> mul(const FB<T> &B, SV<T> s)
+{
+   return SV<T>{mul(B.A, s.a) + mul(B.TR, s.l), mul(B.BL, s.a) + cross(B.l, s.l)};
+}
+template <typename T>
+MH_DEV SV<T> tmul(const FB<T> &B, SV<T> s)
+{
+   return SV<T>{tmul(B.A, s.a) + tmul(B.BL, s.l), tmul(B.TR, s.a) - cross(B.l, s.l)};
+}
+
 // ---- wave-uniform read-only data (model constants, index maps): read through the constant address space so that the
 //      compiler emits scalar loads (s_load) into SGPRs instead of 64 identical vector loads
 template <typename T>

@@ -1296,5 +1296,394 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
    }
 }
 
+
+// ============================================================================================ Coriolis matrix
+// Mass matrix H and Coriolis / centrifugal matrix C of CompositeRigidBodyMassMatrixCalculator with setEnableCoriolisMatrixCalculation(true)
+// (CompositeRigidBodyMassMatrixCalculator.java:604-630, 669-692, 709-768; factorisation B = v x* I of FactorizedBodyInertia.java).
+// One inward sweep carries the composite rigid inertia Ic (10 scalars) and the composite factorised inertia Bc (30); for DoF k of body j
+//     F1 = Ic Sd + Bc S,  F2 = Ic S,  F3 = Bc^T S          (Sd = v_j x S, the derivative of the constant unit twist)
+// climb to the root through force transforms; at an ancestor i:  H_ik = S_i.F2,  C_ik = S_i.F1,  C_ki = Sd_i.F2 + S_i.F3
+// = S_i.(F3 - v_i x* F2)  since (v x m).f = -m.(v x* f): every entry is a component pick in the canonical joint frames.
+// Outputs [B][nv][nv] row-major (strides as in crba_kernel), zero-filled before the launch.  A.out = H, A.outb = C.
+template <typename T>
+MH_DEV void ws_store_m3(T *ws, long ws_stride, int s, const M3<T> &M)
+{
+   MH_WS(s + 0) = M.xx, MH_WS(s + 1) = M.xy, MH_WS(s + 2) = M.xz, MH_WS(s + 3) = M.yx, MH_WS(s + 4) = M.yy, MH_WS(s + 5) = M.yz;
+   MH_WS(s + 6) = M.zx, MH_WS(s + 7) = M.zy, MH_WS(s + 8) = M.zz;
+}
+template <typename T>
+MH_DEV M3<T> ws_load_m3(const T *ws, long ws_stride, int s)
+{
+   return M3<T>{MH_WS(s + 0), MH_WS(s + 1), MH_WS(s + 2), MH_WS(s + 3), MH_WS(s + 4), MH_WS(s + 5), MH_WS(s + 6), MH_WS(s + 7), MH_WS(s + 8)};
+}
+template <typename T>
+MH_DEV void ws_store_fb(T *ws, long ws_stride, int s, const FB<T> &B)
+{
+   ws_store_m3(ws, ws_stride, s, B.A), ws_store_m3(ws, ws_stride, s + 9, B.TR), ws_store_m3(ws, ws_stride, s + 18, B.BL);
+   MH_WS(s + 27) = B.l.x, MH_WS(s + 28) = B.l.y, MH_WS(s + 29) = B.l.z;
+}
+template <typename T>
+MH_DEV FB<T> ws_load_fb(const T *ws, long ws_stride, int s)
+{
+   FB<T> B;
+   B.A = ws_load_m3(ws, ws_stride, s), B.TR = ws_load_m3(ws, ws_stride, s + 9), B.BL = ws_load_m3(ws, ws_stride, s + 18);
+   B.l = V3<T>{MH_WS(s + 27), MH_WS(s + 28), MH_WS(s + 29)};
+   return B;
+}
+template <typename T>
+MH_DEV void fb_up(int type, const JX<T> &jx, const XF<T> &Xb, FB<T> &B)
+{
+   if (type == JT_REVOLUTE)
+   {
+      rotate(B, revolute_rotation(jx, Xb.R));
+      translate(B, Xb.p);
+      return;
+   }
+   else if (type == JT_PRISMATIC)
+      translate(B, V3<T>{T(0), T(0), jx.d});
+   else if (general_x(type))
+   {
+      rotate(B, jx.X.R);
+      translate(B, jx.X.p);
+   }
+   rotate(B, Xb.R);
+   translate(B, Xb.p);
+}
+
+template <typename T, bool LDSC>
+__global__ void __launch_bounds__(256) coriolis_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   if constexpr (LDSC)
+   {
+      T *C = (T *)lds_raw;
+      stage_consts<T>(m, C);
+      CB = C;
+   }
+   const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
+   const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   const long ws_stride = A.ws_stride;
+   T *ws = A.ws + lane;
+   const int nv = m.nv;
+   const V3<T> Z{T(0), T(0), T(0)};
+
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *qdrow = A.qd + cfg * A.v_bs;
+      const long h_bs = A.f_bs, h_es = A.f_es; // per-configuration / per-entry strides of the two matrices
+      T *H = A.out + cfg * h_bs;
+      T *Cm = A.outb + cfg * h_bs;
+      // ---- outward sweep: joint transforms and body velocities (kept for the inward sweep: Sd of every ancestor needs them)
+      SV<T> v_prev{Z, Z};
+      for (int j = 0; j < m.n; j++)
+      {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         SV<T> vp{Z, Z};
+         if (parent >= 0)
+            vp = (flags & MF_PARENT_ADJ) ? v_prev : ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_C]);
+         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> v = motion_down(type, jx, load_xb<T>(c), vp) + joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_C], v);
+         v_prev = v;
+      }
+      // ---- inward sweep
+      RI<T> rcarry;
+      FB<T> bcarry;
+      bool have_carry = false;
+      for (int j = m.n - 1; j >= 0; j--)
+      {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         const SV<T> vj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+         RI<T> Ic = load_inertia<T>(c);
+         FB<T> Bc = fb_from_rigid(Ic, vj); // :671-673
+         if (have_carry)
+         {
+            add(Ic, rcarry);
+            add(Bc, bcarry);
+         }
+         if (flags & MF_HAS_ACC)
+         {
+            add(Ic, ws_load_ri(ws, ws_stride, mi[MI_SLOT_IA]));
+            add(Bc, ws_load_fb(ws, ws_stride, mi[MI_SLOT_IA] + 10));
+         }
+         have_carry = false;
+         const int nd = dof_count(type);
+         ciptr dj = dof_map + mi[MI_DOF];
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         for (int k = 0; k < nd; k++)
+         {
+            const SV<T> S = unit_twist<T>(type, k);
+            const SV<T> Sd = crm(vj, S);            // :620-626
+            SV<T> F2 = mul(Ic, S);                  // :663-667
+            SV<T> F1 = mul(Ic, Sd) + mul(Bc, S);    // :686-688
+            SV<T> F3 = tmul(Bc, S);                 // :690-691
+            const int col = dj[k];
+            for (int r = 0; r < nd; r++)
+            { // the joint's own block (:698-724)
+               const int e = dof_comp(type, r);
+               H[((long)dj[r] * nv + col) * h_es] = comp(F2, e);
+               Cm[((long)dj[r] * nv + col) * h_es] = comp(F1, e);
+            }
+            int prev = j, anc = parent;
+            XF<T> Xp = Xb;
+            JX<T> jp = jx;
+            int tp = type;
+            while (anc >= 0)
+            { // :729-768
+               F1 = force_up(tp, jp, Xp, F1);
+               F2 = force_up(tp, jp, Xp, F2);
+               F3 = force_up(tp, jp, Xp, F3);
+               ciptr ma = meta + anc * MI_STRIDE;
+               const int ta = ma[MI_TYPE];
+               ciptr da = dof_map + ma[MI_DOF];
+               const SV<T> G = F3 - crf(ws_load6(ws, ws_stride, ma[MI_SLOT_C]), F2);
+               for (int r = 0; r < dof_count(ta); r++)
+               {
+                  const int e = dof_comp(ta, r);
+                  const T hv = comp(F2, e);
+                  H[((long)da[r] * nv + col) * h_es] = hv;
+                  H[((long)col * nv + da[r]) * h_es] = hv;
+                  Cm[((long)da[r] * nv + col) * h_es] = comp(F1, e);
+                  Cm[((long)col * nv + da[r]) * h_es] = comp(G, e);
+               }
+               prev = anc;
+               anc = ma[MI_PARENT];
+               if (anc >= 0)
+               {
+                  Xp = load_xb<T>(CRef<T, LDSC>{CB + prev * MC_STRIDE});
+                  jp = joint_again<T>(ta, cfg_map, ma[MI_CFG], qrow, A.q_es, ws, ws_stride, ma[MI_SLOT_JP]);
+                  tp = ta;
+               }
+            }
+         }
+         if (parent >= 0)
+         {
+            rigid_up(type, jx, Xb, Ic); // :651-661
+            fb_up(type, jx, Xb, Bc);    // :675-683
+            if (flags & MF_PARENT_ADJ)
+            {
+               rcarry = Ic, bcarry = Bc, have_carry = true;
+            }
+            else
+            {
+               const int sp = meta[parent * MI_STRIDE + MI_SLOT_IA];
+               if (flags & MF_ACC_FIRST)
+               {
+                  ws_store_ri(ws, ws_stride, sp, Ic);
+                  ws_store_fb(ws, ws_stride, sp + 10, Bc);
+               }
+               else
+               {
+                  RI<T> acc = ws_load_ri(ws, ws_stride, sp);
+                  add(acc, Ic);
+                  ws_store_ri(ws, ws_stride, sp, acc);
+                  FB<T> bacc = ws_load_fb(ws, ws_stride, sp + 10);
+                  add(bacc, Bc);
+                  ws_store_fb(ws, ws_stride, sp + 10, bacc);
+               }
+            }
+         }
+      }
+   }
+}
+
+// ============================================================================================ centroidal momentum
+// Centroidal momentum matrix A (6 x nv, h = A qd) and convective term b (dh/dt = A qdd + b) of CompositeRigidBodyMassMatrixCalculator
+// (CompositeRigidBodyMassMatrixCalculator.java:316-342, 801-839).  Column k of A is the unit momentum F2 = Ic S_k of the mass-matrix sweep,
+// climbed to the root body frame and re-expressed in the centroidal momentum frame; b is the sum over the bodies of their dynamic
+// wrenches under the Coriolis accelerations (zero root and joint accelerations), which the inward sweep of the wrenches delivers at the
+// root.  The frame is a constant pose (fR, fp) in the root body frame, optionally re-centred on the centre of mass of the considered
+// bodies (frames/CenterOfMassReferenceFrame.java) -- known only once the sweep has reached the root, so A is then fixed up in place.
+template <typename T>
+struct CentArgs
+{
+   DevModel m;
+   long B;
+   const T *q, *qd; // qd may be NULL when b is not asked for
+   T *A, *b, *com;  // [B][6][nv], [B][6] or NULL, [B][3] or NULL
+   T *ws;
+   long ws_stride;
+   long q_bs, q_es, v_bs, v_es;
+   long a_bs, a_es, b_bs, b_es, c_bs, c_es; // batch / element strides of A, b, com
+   T fR[9], fp[3];                          // pose of the (parent of the) centroidal momentum frame in the root body frame
+   int at_com;
+};
+
+template <typename T, bool LDSC>
+__global__ void __launch_bounds__(256) centroidal_kernel(CentArgs<T> A)
+{
+   extern __shared__ double lds_raw[];
+   const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   if constexpr (LDSC)
+   {
+      T *C = (T *)lds_raw;
+      stage_consts<T>(m, C);
+      CB = C;
+   }
+   const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
+   const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   const long ws_stride = A.ws_stride;
+   T *ws = A.ws + lane;
+   const int nv = m.nv;
+   const V3<T> Z{T(0), T(0), T(0)};
+   XF<T> Xf; // centroidal frame -> root body frame
+   Xf.R = M3<T>{A.fR[0], A.fR[1], A.fR[2], A.fR[3], A.fR[4], A.fR[5], A.fR[6], A.fR[7], A.fR[8]};
+   Xf.p = V3<T>{A.fp[0], A.fp[1], A.fp[2]};
+   const bool with_b = A.b != nullptr;
+
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *qdrow = with_b ? A.qd + cfg * A.v_bs : nullptr;
+      T *Am = A.A + cfg * A.a_bs;
+      // ---- outward sweep: joint transforms; with b also velocities, Coriolis accelerations and the bodies' dynamic wrenches
+      SV<T> v_prev{Z, Z}, a_prev{Z, Z};
+      for (int j = 0; j < m.n; j++)
+      {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         if (!with_b)
+            continue;
+         SV<T> vp{Z, Z}, ap{Z, Z};
+         if (parent >= 0 && (flags & MF_PARENT_ADJ))
+            vp = v_prev, ap = a_prev;
+         else if (parent >= 0)
+         {
+            const int sp = meta[parent * MI_STRIDE + MI_SLOT_VA];
+            vp = ws_load6(ws, ws_stride, sp);
+            ap = ws_load6(ws, ws_stride, sp + 6);
+         }
+         const XF<T> Xb = load_xb<T>(c);
+         const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+         const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         const SV<T> a = motion_down(type, jx, Xb, ap) + crm(v, vJ); // :826-831
+         const RI<T> I = load_inertia<T>(c);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_F], mul(I, a) + crf(v, mul(I, v))); // :833
+         if (flags & MF_STORE_VA)
+         {
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA] + 6, a);
+         }
+         v_prev = v, a_prev = a;
+      }
+      // ---- inward sweep: composite inertias, columns of A, wrenches
+      RI<T> rcarry, root_I{T(0), Z, S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)}};
+      SV<T> fcarry{Z, Z}, root_f{Z, Z};
+      bool have_carry = false;
+      for (int j = m.n - 1; j >= 0; j--)
+      {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         RI<T> Ic = load_inertia<T>(c);
+         SV<T> f{Z, Z};
+         if (with_b)
+            f = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         if (have_carry)
+         {
+            add(Ic, rcarry);
+            f = f + fcarry;
+         }
+         if (flags & MF_HAS_ACC)
+            add(Ic, ws_load_ri(ws, ws_stride, mi[MI_SLOT_IA]));
+         have_carry = false;
+         const int nd = dof_count(type);
+         ciptr dj = dof_map + mi[MI_DOF];
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         for (int k = 0; k < nd; k++)
+         {
+            SV<T> F = mul(Ic, unit_twist<T>(type, k)); // :663-667
+            int prev = j, anc = parent;
+            XF<T> Xp = Xb;
+            JX<T> jp = jx;
+            int tp = type;
+            for (;;)
+            { // climb to the root body frame (the mass-matrix walk :783-792 plus the last step of changeFrame, :805)
+               F = force_up(tp, jp, Xp, F);
+               if (anc < 0)
+                  break;
+               ciptr ma = meta + anc * MI_STRIDE;
+               tp = ma[MI_TYPE];
+               Xp = load_xb<T>(CRef<T, LDSC>{CB + anc * MC_STRIDE});
+               jp = joint_again<T>(tp, cfg_map, ma[MI_CFG], qrow, A.q_es, ws, ws_stride, ma[MI_SLOT_JP]);
+               prev = anc;
+               anc = ma[MI_PARENT];
+            }
+            (void)prev;
+            // root body frame -> centroidal frame: f' = R^T f ; n' = R^T (n - p x f)
+            const V3<T> fl = tmul(Xf.R, F.l), fa = tmul(Xf.R, F.a - cross(Xf.p, F.l));
+            const long col = dj[k];
+            Am[(0 * nv + col) * A.a_es] = fa.x, Am[(1 * nv + col) * A.a_es] = fa.y, Am[(2 * nv + col) * A.a_es] = fa.z;
+            Am[(3 * nv + col) * A.a_es] = fl.x, Am[(4 * nv + col) * A.a_es] = fl.y, Am[(5 * nv + col) * A.a_es] = fl.z;
+         }
+         rigid_up(type, jx, Xb, Ic);
+         const SV<T> fp = force_up(type, jx, Xb, f);
+         if (parent < 0)
+         {
+            add(root_I, Ic);
+            root_f = root_f + fp;
+         }
+         else if (flags & MF_PARENT_ADJ)
+         {
+            rcarry = Ic, fcarry = fp, have_carry = true;
+         }
+         else
+         {
+            const int sp = meta[parent * MI_STRIDE + MI_SLOT_IA];
+            if (flags & MF_ACC_FIRST)
+               ws_store_ri(ws, ws_stride, sp, Ic);
+            else
+            {
+               RI<T> acc = ws_load_ri(ws, ws_stride, sp);
+               add(acc, Ic);
+               ws_store_ri(ws, ws_stride, sp, acc);
+            }
+            if (with_b)
+               ws_add6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_F], fp);
+         }
+      }
+      // ---- the frame's origin: centre of mass of the considered bodies, given in the frame (CenterOfMassCalculator.java:70-91)
+      V3<T> shift{T(0), T(0), T(0)}; // in frame coordinates
+      if (A.at_com)
+      {
+         const T inv_m = T(1) / root_I.m;
+         shift = tmul(Xf.R, inv_m * root_I.h - Xf.p);
+         for (int col = 0; col < nv; col++)
+         { // moving the origin by `shift`: n' = n - shift x f
+            const V3<T> fl{Am[(3 * nv + col) * A.a_es], Am[(4 * nv + col) * A.a_es], Am[(5 * nv + col) * A.a_es]};
+            const V3<T> d = cross(shift, fl);
+            Am[(0 * nv + col) * A.a_es] -= d.x, Am[(1 * nv + col) * A.a_es] -= d.y, Am[(2 * nv + col) * A.a_es] -= d.z;
+         }
+      }
+      if (A.com)
+      {
+         T *crow = A.com + cfg * A.c_bs;
+         crow[0] = shift.x, crow[A.c_es] = shift.y, crow[2 * A.c_es] = shift.z;
+      }
+      if (with_b)
+      {
+         const V3<T> fl = tmul(Xf.R, root_f.l);
+         const V3<T> fa = tmul(Xf.R, root_f.a - cross(Xf.p, root_f.l)) - cross(shift, fl);
+         T *brow = A.b + cfg * A.b_bs;
+         brow[0] = fa.x, brow[A.b_es] = fa.y, brow[2 * A.b_es] = fa.z;
+         brow[3 * A.b_es] = fl.x, brow[4 * A.b_es] = fl.y, brow[5 * A.b_es] = fl.z;
+      }
+   }
+}
+
 #undef MH_WS
 } // namespace mh

@@ -301,6 +301,58 @@ class HipModel:
         return self._run("crba", q, None, None, (0.0, 0.0, 0.0), None, layout, True, True)
 
 
+    # ------------------------------------------------------------------ Coriolis matrix, centroidal momentum
+    def _device_inputs(self, tensors, layout):
+        import torch
+        dt = tensors[0].dtype
+        if dt not in (torch.float64, torch.float32):
+            raise TypeError("state tensors must be float64 or float32")
+        for t in tensors:
+            if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise ValueError("device tensors must be contiguous, on the HIP device and of one dtype")
+        B = self._batch(tensors[0], self.nq, layout)
+        for t in tensors[1:]:
+            if self._batch(t, self.nv, layout) != B:
+                raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        return B, dt, ("f64" if dt == torch.float64 else "f32"), torch.cuda.current_stream(tensors[0].device).cuda_stream
+
+    def crba_coriolis(self, q, qd, layout=_lib.LAYOUT_AOS):
+        """Mass matrix and Coriolis matrix (CompositeRigidBodyMassMatrixCalculator with the Coriolis calculation enabled,
+        CompositeRigidBodyMassMatrixCalculator.java:271-274, 344-365): (H, C), device tensors [B, nv, nv]."""
+        import torch
+        if not self._is_torch(q):
+            raise TypeError("crba_coriolis takes device tensors")
+        B, dt, sfx, stream = self._device_inputs([q, qd], layout)
+        shape = (B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B)
+        H, C = torch.empty(shape, dtype=dt, device=q.device), torch.empty(shape, dtype=dt, device=q.device)
+        opts = self._options(layout, stream=stream)
+        _lib.check(getattr(_lib.load(), f"mh_crba_coriolis_{sfx}")(self._h, B, q.data_ptr(), qd.data_ptr(), ctypes.byref(opts), H.data_ptr(),
+                                                                  C.data_ptr()))
+        return H, C
+
+    def centroidal(self, q, qd=None, frame=None, at_com=False, layout=_lib.LAYOUT_AOS):
+        """Centroidal momentum matrix, convective term and frame origin (CompositeRigidBodyMassMatrixCalculator.java:375-420, 801-839):
+        (A [B, 6, nv], b [B, 6] or None without qd, com [B, 3]).  ``frame``: 12 numbers (R row-major, p), pose of the centroidal momentum
+        frame in the root body frame, None = the root body frame; ``at_com`` re-centres it on the centre of mass."""
+        import torch
+        if not self._is_torch(q):
+            raise TypeError("centroidal takes device tensors")
+        B, dt, sfx, stream = self._device_inputs([q] if qd is None else [q, qd], layout)
+        aos = layout == _lib.LAYOUT_AOS
+        A = torch.empty((B, 6, self.nv) if aos else (6 * self.nv, B), dtype=dt, device=q.device)
+        b = None if qd is None else torch.empty((B, 6) if aos else (6, B), dtype=dt, device=q.device)
+        com = torch.empty((B, 3) if aos else (3, B), dtype=dt, device=q.device)
+        fr = None
+        if frame is not None:
+            fr = (ctypes.c_double * 12)(*[float(v) for v in np.asarray(frame, dtype=np.float64).reshape(12)])
+        opts = self._options(layout, stream=stream)
+        mode = _lib.CENTROIDAL_FRAME_AT_COM if at_com else _lib.CENTROIDAL_FRAME_FIXED
+        _lib.check(getattr(_lib.load(), f"mh_centroidal_{sfx}")(self._h, B, q.data_ptr(), None if qd is None else qd.data_ptr(), fr, mode,
+                                                               ctypes.byref(opts), A.data_ptr(), None if b is None else b.data_ptr(),
+                                                               com.data_ptr()))
+        return A, b, com
+
+
 class HipTimer:
     """HIP events recorded on the stream the kernels are launched on (bench.py, SURVEY.md section 8d timing protocol)."""
 

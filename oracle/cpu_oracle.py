@@ -45,6 +45,10 @@ def _load():
         lib.mo_rnea_bodies.argtypes = [P, ctypes.c_long, P, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P, P]
         lib.mo_aba_bodies.argtypes = [P, ctypes.c_long, P, P, P, P, P, P, P, P]
         lib.mo_aba_bodies.restype = ctypes.c_int
+        lib.mo_crba_coriolis.argtypes = [P, ctypes.c_long, P, P, P, P]
+        lib.mo_crba_coriolis.restype = None
+        lib.mo_centroidal.argtypes = [P, ctypes.c_long, P, P, P, ctypes.c_int, P, P, P]
+        lib.mo_centroidal.restype = None
         _lib = lib
     return _lib
 
@@ -142,3 +146,21 @@ class OracleModel:
         H = np.zeros((B, self.nv, self.nv))
         _load().mo_crba(self._h, B, _p(q), _p(H))
         return H
+
+    def crba_coriolis(self, q, qd):
+        """Mass matrix and Coriolis matrix with setEnableCoriolisMatrixCalculation(true): (H, C), both [B, nv, nv]."""
+        q, qd = _c(q), _c(qd)
+        B = q.shape[0]
+        H, C = np.zeros((B, self.nv, self.nv)), np.zeros((B, self.nv, self.nv))
+        _load().mo_crba_coriolis(self._h, B, _p(q), _p(qd), _p(H), _p(C))
+        return H, C
+
+    def centroidal(self, q, qd=None, frame=None, at_com=False):
+        """Centroidal momentum matrix A [B, 6, nv], convective term b [B, 6] (None without qd) and the origin of the centroidal
+        frame in ``frame`` [B, 3].  ``frame`` = 12 numbers (R row-major, p), pose of the centroidal momentum frame in the root body
+        frame (None = the root body frame); ``at_com`` moves its origin to the centre of mass (CenterOfMassReferenceFrame)."""
+        q, qd, frame = _c(q), _c(qd), _c(frame)
+        B = q.shape[0]
+        A, b, com = np.zeros((B, 6, self.nv)), (np.zeros((B, 6)) if qd is not None else None), np.zeros((B, 3))
+        _load().mo_centroidal(self._h, B, _p(q), _p(qd), _p(frame), int(bool(at_com)), _p(A), _p(b), _p(com))
+        return A, b, com

@@ -214,3 +214,62 @@ def aba(m: Model, q, qd, tau, g, fext=None):
         qdd[m.dofs(i)] = qi
         a[i] = ap + m.S(i) @ qi
     return qdd
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Coriolis matrix and centroidal momentum from dense body Jacobians (independent of the recursive composite / factorised
+# inertia sweep of CompositeRigidBodyMassMatrixCalculator): with J_k the 6 x nv Jacobian of body k in its own after-joint
+# coordinates and Jd_k its derivative (column j = kXj (v_j x S_j) for every ancestor-or-self joint j with a constant S_j),
+#     C = sum_k J_k^T (I_k Jd_k + B_k J_k),     B_k = crf(v_k) I_k     (Echeandia & Wensing 2021, eq. 23 with B = v x* I)
+#     A = sum_k cmX*_k I_k J_k,                  b = sum_k cmX*_k (I_k Jd_k qd + crf(v_k) I_k v_k)
+def _body_jacobians(m: Model, q, qd):
+    n = m.n
+    Xup = [np.linalg.inv(m.X_child_to_parent(i, q)) for i in range(n)]  # parent -> child motion transforms
+    v, J, Jd, X0 = [None] * n, [None] * n, [None] * n, [None] * n
+    for i in range(n):
+        p = m.parent[i]
+        S = m.S(i)
+        di = m.dofs(i)
+        v[i] = Xup[i] @ (np.zeros(6) if p < 0 else v[p]) + S @ qd[di]
+        J[i] = np.zeros((6, m.nv)) if p < 0 else Xup[i] @ J[p]
+        Jd[i] = np.zeros((6, m.nv)) if p < 0 else Xup[i] @ Jd[p]
+        J[i][:, di] = S
+        Jd[i][:, di] = crm(v[i]) @ S
+        X0[i] = Xup[i] @ (np.eye(6) if p < 0 else X0[p])  # root -> body i motion transform
+    return v, J, Jd, X0
+
+
+def coriolis_dense(m: Model, q, qd):
+    v, J, Jd, _ = _body_jacobians(m, q, qd)
+    C = np.zeros((m.nv, m.nv))
+    for k in range(m.n):
+        C += J[k].T @ (m.I[k] @ Jd[k] + crf(v[k]) @ m.I[k] @ J[k])
+    return C
+
+
+def centroidal_dense(m: Model, q, qd, frame=None, at_com=False):
+    """(A [6, nv], b [6], origin of the centroidal frame in ``frame`` coordinates)."""
+    v, J, Jd, X0 = _body_jacobians(m, q, qd)
+    R, p = (np.eye(3), np.zeros(3)) if frame is None else (np.asarray(frame[:9], dtype=float).reshape(3, 3), np.asarray(frame[9:], dtype=float))
+    origin = np.zeros(3)
+    if at_com:
+        mass, first = 0.0, np.zeros(3)
+        for k in range(m.n):
+            Xk0 = np.linalg.inv(X0[k])  # body k -> root: E = rotation of the body frame in the root, r = its position
+            E, r = Xk0[:3, :3], None
+            rx = Xk0[3:, :3] @ E.T
+            r = np.array([rx[2, 1], rx[0, 2], rx[1, 0]])
+            mk = m.I[k][3, 3]
+            ck = np.array([m.I[k][2, 4], m.I[k][0, 5], m.I[k][1, 3]]) / mk  # from the m [c]x block
+            first += mk * (E @ ck + r)
+            mass += mk
+        com_root = first / mass
+        origin = R.T @ (com_root - p)
+        p = com_root
+    Xf = plucker_motion(R, p).T  # force transform root -> centroidal frame
+    A, b = np.zeros((6, m.nv)), np.zeros(6)
+    for k in range(m.n):
+        to_root = X0[k].T  # force transform body k -> root = (motion transform root -> k)^T
+        A += Xf @ to_root @ m.I[k] @ J[k]
+        b += Xf @ to_root @ (m.I[k] @ (Jd[k] @ qd) + crf(v[k]) @ (m.I[k] @ v[k]))
+    return A, b, origin

@@ -1005,6 +1005,269 @@ static void crba_one(const mo_model *m, const double *q, double *H)
    }
 }
 
+/* ================================================================== Coriolis matrix, centroidal momentum
+ * algorithms/FactorizedBodyInertia.java: B = v x* I kept as four 3x3 blocks (angular, linear, top-right, bottom-left) */
+typedef struct
+{
+   double A[9], L[9], TR[9], BL[9];
+} fbi_t;
+/* FactorizedBodyInertia.setIncludingFrame(SpatialInertiaReadOnly, TwistReadOnly), FactorizedBodyInertia.java:136-158 */
+static void fbi_from_rigid(const rigid_t *I, const double tw[6], fbi_t *B)
+{
+   double Wx[9], Vx[9], Cx[9], t[9];
+   m3_tilde(tw, Wx);
+   m3_tilde(tw + 3, Vx);
+   m3_tilde(I->c, Cx);
+   m3_mul(Vx, Cx, B->A); /* w x J - m v x c x */
+   m3_mul(Wx, I->J, t);
+   for (int k = 0; k < 9; k++)
+      B->A[k] = -I->m * B->A[k] + t[k];
+   m3_mul(Wx, Cx, B->BL); /* -m w x c x */
+   for (int k = 0; k < 9; k++)
+      B->BL[k] *= -I->m;
+   for (int k = 0; k < 9; k++)
+      B->TR[k] = I->m * Vx[k] - B->BL[k]; /* m v x + m w x c x */
+   for (int k = 0; k < 9; k++)
+      B->L[k] = I->m * Wx[k]; /* m w x */
+}
+static void fbi_add(fbi_t *B, const fbi_t *o)
+{
+   for (int k = 0; k < 9; k++)
+      B->A[k] += o->A[k], B->L[k] += o->L[k], B->TR[k] += o->TR[k], B->BL[k] += o->BL[k];
+}
+/* FactorizedBodyInertia.applyTransform(RigidBodyTransform), :314-331: rotate the four blocks, then the four in-place translation updates */
+static void fbi_apply_transform(const xf_t *X, fbi_t *B)
+{
+   double P[9], t[9];
+   m3_conj(X->R, B->A);
+   m3_conj(X->R, B->L);
+   m3_conj(X->R, B->TR);
+   m3_conj(X->R, B->BL);
+   m3_tilde(X->p, P);
+   m3_mul(P, B->L, t);
+   for (int k = 0; k < 9; k++)
+      B->TR[k] += t[k];
+   m3_mul(P, B->BL, t);
+   for (int k = 0; k < 9; k++)
+      B->A[k] += t[k];
+   m3_mul(B->TR, P, t);
+   for (int k = 0; k < 9; k++)
+      B->A[k] -= t[k];
+   m3_mul(B->L, P, t);
+   for (int k = 0; k < 9; k++)
+      B->BL[k] -= t[k];
+}
+/* out (+)= B x, :239-263 */
+static void fbi_mulv_add(const fbi_t *B, const double x[6], double out[6])
+{
+   double a[3], b[3];
+   m3_mulv(B->A, x, a), m3_mulv(B->TR, x + 3, b);
+   for (int k = 0; k < 3; k++)
+      out[k] += a[k] + b[k];
+   m3_mulv(B->BL, x, a), m3_mulv(B->L, x + 3, b);
+   for (int k = 0; k < 3; k++)
+      out[3 + k] += a[k] + b[k];
+}
+/* out = B^T x, :265-276 */
+static void fbi_tmulv(const fbi_t *B, const double x[6], double out[6])
+{
+   double a[3], b[3];
+   m3_tmulv(B->A, x, a), m3_tmulv(B->BL, x + 3, b);
+   for (int k = 0; k < 3; k++)
+      out[k] = a[k] + b[k];
+   m3_tmulv(B->TR, x, a), m3_tmulv(B->L, x + 3, b);
+   for (int k = 0; k < 3; k++)
+      out[3 + k] = a[k] + b[k];
+}
+static double dot6(const double a[6], const double b[6])
+{
+   double s = 0;
+   for (int k = 0; k < 6; k++)
+      s += a[k] * b[k];
+   return s;
+}
+
+/* Mass matrix, Coriolis matrix and (optionally) the centroidal momentum matrix in one sweep, with the Coriolis calculation enabled:
+ * CompositeRigidBodyMassMatrixCalculator.java:588-630 (unit twist derivatives), :642-667 (composite inertia), :669-692 (factorised
+ * composite inertia, F1 / F2 / F3), :698-724 (own block), :729-768 (ancestor walk), :801-809 (centroidal momentum matrix = the
+ * climbed F2 changed to the centroidal frame).  W_cm = pose of the centroidal momentum frame in the root body ("world") frame.
+ * C, Acm may be NULL. */
+static void crba_coriolis_one(const mo_model *m, const double *q, const double *qd, const xf_t *W_cm, double *H, double *C, double *Acm)
+{
+   static _Thread_local mo_kin K;
+   static _Thread_local xf_t Xup[MO_MAX_JOINTS];
+   static _Thread_local rigid_t Ib[MO_MAX_JOINTS], Ic[MO_MAX_JOINTS];
+   static _Thread_local fbi_t Bc[MO_MAX_JOINTS];
+   static _Thread_local double Sd[MO_MAX_JOINTS][6][6];
+   xf_t T;
+   const size_t nv = (size_t)m->nv;
+   kinematics(m, q, qd, &K);
+   memset(H, 0, sizeof(double) * nv * nv); /* :298-300 */
+   if (C)
+      memset(C, 0, sizeof(double) * nv * nv);
+   if (Acm)
+      memset(Acm, 0, sizeof(double) * 6 * nv);
+   for (int i = 0; i < m->n; i++)
+   {
+      int p = m->parent[i];
+      if (p >= 0)
+         xf_between(&K.W_after[i], &K.W_after[p], &Xup[i]); /* :592-593 */
+      else
+         xf_identity(&Xup[i]);
+      /* derivative of the unit twists of a constant motion subspace: body twist x S (:620-626) */
+      const double *tw = K.tw_after[i];
+      for (int d = 0; d < m->ndof[i]; d++)
+      {
+         const double *S = K.S[i][d];
+         double c1[3], c2[3];
+         v3_cross(tw, S, Sd[i][d]);
+         v3_cross(tw + 3, S, c1);
+         v3_cross(tw, S + 3, c2);
+         for (int k = 0; k < 3; k++)
+            Sd[i][d][3 + k] = c1[k] + c2[k];
+      }
+      memcpy(Ib[i].J, m->J[i], sizeof Ib[i].J);
+      Ib[i].m = m->mass[i];
+      memcpy(Ib[i].c, m->com[i], sizeof Ib[i].c);
+      xf_between(&K.W_body[i], &K.W_after[i], &T);
+      rigid_apply_transform(&T, &Ib[i]); /* :646-650 */
+      Ic[i] = Ib[i];
+      fbi_from_rigid(&Ib[i], tw, &Bc[i]); /* :671-673 */
+   }
+   for (int i = m->n - 1; i >= 0; i--)
+   { /* descending index = children before their parent; Ic[i], Bc[i] already hold the children's contributions */
+      int nd = m->ndof[i];
+      const int *di = m->dof_idx + m->dof_ofs[i];
+      double F1[6][6], F2[6][6], F3[6][6];
+      for (int d = 0; d < nd; d++)
+      {
+         rigid_mulv(&Ic[i], K.S[i][d], F2[d]); /* :663-667 */
+         rigid_mulv(&Ic[i], Sd[i][d], F1[d]);  /* :686-688 */
+         fbi_mulv_add(&Bc[i], K.S[i][d], F1[d]);
+         fbi_tmulv(&Bc[i], K.S[i][d], F3[d]); /* :690-691 */
+      }
+      for (int a = 0; a < nd; a++)
+         for (int b = 0; b < nd; b++)
+         {
+            double s = dot6(K.S[i][a], F2[b]);
+            H[(size_t)di[a] * nv + di[b]] = s; /* :698-707 */
+            H[(size_t)di[b] * nv + di[a]] = s;
+         }
+      if (C)
+         for (int a = 0; a < nd; a++)
+            for (int b = 0; b < nd; b++)
+            { /* :709-724, in the reference's write order */
+               C[(size_t)di[a] * nv + di[b]] = dot6(K.S[i][a], F1[b]);
+               if (a != b)
+                  C[(size_t)di[b] * nv + di[a]] = dot6(Sd[i][a], F2[b]) + dot6(K.S[i][a], F3[b]);
+            }
+      int prev = i, anc = m->parent[i];
+      while (anc >= 0)
+      { /* :729-768 */
+         const int *dj = m->dof_idx + m->dof_ofs[anc];
+         for (int b = 0; b < nd; b++)
+         {
+            double t[6];
+            xf_force(&Xup[prev], F1[b], t), memcpy(F1[b], t, sizeof t);
+            xf_force(&Xup[prev], F2[b], t), memcpy(F2[b], t, sizeof t);
+            xf_force(&Xup[prev], F3[b], t), memcpy(F3[b], t, sizeof t);
+            for (int a = 0; a < m->ndof[anc]; a++)
+            {
+               double s = dot6(K.S[anc][a], F2[b]);
+               H[(size_t)dj[a] * nv + di[b]] = s;
+               H[(size_t)di[b] * nv + dj[a]] = s;
+               if (C)
+               {
+                  C[(size_t)dj[a] * nv + di[b]] = dot6(K.S[anc][a], F1[b]);
+                  C[(size_t)di[b] * nv + dj[a]] = dot6(Sd[anc][a], F2[b]) + dot6(K.S[anc][a], F3[b]);
+               }
+            }
+         }
+         prev = anc;
+         anc = m->parent[anc];
+      }
+      if (Acm)
+      { /* :801-809: F2 now lives in the frame after the root-most ancestor joint `prev` */
+         xf_between(&K.W_after[prev], W_cm, &T);
+         for (int b = 0; b < nd; b++)
+         {
+            double t[6];
+            xf_force(&T, F2[b], t);
+            for (int k = 0; k < 6; k++)
+               Acm[(size_t)k * nv + di[b]] = t[k];
+         }
+      }
+      int p = m->parent[i];
+      if (p >= 0)
+      {
+         rigid_t child = Ic[i];
+         fbi_t childB = Bc[i];
+         rigid_apply_transform(&Xup[i], &child); /* :651-661 */
+         rigid_add(&Ic[p], &child);
+         fbi_apply_transform(&Xup[i], &childB); /* :675-683 */
+         fbi_add(&Bc[p], &childB);
+      }
+   }
+}
+
+/* centre of mass of the considered bodies in the root frame (algorithms/CenterOfMassCalculator.java:70-91) */
+static void center_of_mass(const mo_model *m, const mo_kin *K, double com[3], double *mass_out)
+{
+   double M = 0;
+   com[0] = com[1] = com[2] = 0;
+   for (int i = 0; i < m->n; i++)
+   {
+      double c[3];
+      m3_mulv(K->W_body[i].R, m->com[i], c);
+      for (int k = 0; k < 3; k++)
+         com[k] += m->mass[i] * (c[k] + K->W_body[i].p[k]);
+      M += m->mass[i];
+   }
+   for (int k = 0; k < 3; k++)
+      com[k] *= 1.0 / M;
+   if (mass_out)
+      *mass_out = M;
+}
+
+/* Centroidal convective term b (d/dt h = A qdd + b): CompositeRigidBodyMassMatrixCalculator.java:811-839 -- the Coriolis body
+ * accelerations of InverseDynamicsCalculator's first pass with zero root and joint accelerations, each body's dynamic wrench changed
+ * to the centroidal frame and summed */
+static void convective_one(const mo_model *m, const double *q, const double *qd, const xf_t *W_cm, double b[6])
+{
+   static _Thread_local mo_kin K;
+   static _Thread_local double acc[MO_MAX_JOINTS][6];
+   xf_t W_world, T;
+   double zero6[6] = {0};
+   xf_identity(&W_world);
+   kinematics(m, q, qd, &K);
+   memset(b, 0, 6 * sizeof(double));
+   for (int i = 0; i < m->n; i++)
+   {
+      int p = m->parent[i];
+      const xf_t *Wp_body = p < 0 ? &W_world : &K.W_body[p];
+      const double *a_par = p < 0 ? zero6 : acc[p];
+      const double *tw_par = p < 0 ? zero6 : K.tw_body[p];
+      double a[6], d[6], c1[3], c2[3], c3[3], w[6], wc[6];
+      memcpy(a, a_par, sizeof a);
+      xf_between(&K.W_after[i], Wp_body, &T);
+      xf_motion(&T, K.vJ[i], d);
+      for (int k = 0; k < 6; k++)
+         d[k] = -d[k];
+      v3_cross(d + 3, tw_par, c1);
+      v3_cross(d, tw_par + 3, c2);
+      v3_cross(d, tw_par, c3);
+      for (int k = 0; k < 3; k++)
+         a[3 + k] += c1[k] + c2[k], a[k] += c3[k];
+      xf_between(Wp_body, &K.W_body[i], &T);
+      xf_motion(&T, a, acc[i]); /* :828-831 */
+      dynamic_wrench(m->J[i], m->mass[i], m->com[i], acc[i], K.tw_body[i], w); /* :833 */
+      xf_between(&K.W_body[i], W_cm, &T);
+      xf_force(&T, w, wc); /* :834-835 */
+      for (int k = 0; k < 6; k++)
+         b[k] += wc[k];
+   }
+}
+
 /* ================================================================== public C API (ctypes / bench) */
 static int joint_ndof(int type) { return type == MO_SIXDOF ? 6 : (type == MO_FIXED ? 0 : (type == MO_PLANAR || type == MO_SPHERICAL ? 3 : 1)); }
 static int joint_ncfg(int type) { return type == MO_SIXDOF ? 7 : (type == MO_FIXED ? 0 : (type == MO_PLANAR ? 3 : (type == MO_SPHERICAL ? 4 : 1))); }
@@ -1087,6 +1350,55 @@ void mo_crba(void *h, long B, const double *q, double *H)
    const mo_model *m = (const mo_model *)h;
    for (long b = 0; b < B; b++)
       crba_one(m, q + b * m->nq, H + (size_t)b * m->nv * m->nv);
+}
+
+/* H, C [B][nv][nv] (C may be NULL) */
+void mo_crba_coriolis(void *h, long B, const double *q, const double *qd, double *H, double *C)
+{
+   const mo_model *m = (const mo_model *)h;
+   xf_t W;
+   xf_identity(&W);
+   for (long b = 0; b < B; b++)
+      crba_coriolis_one(m, q + b * m->nq, qd ? qd + b * m->nv : NULL, &W, H + (size_t)b * m->nv * m->nv, C ? C + (size_t)b * m->nv * m->nv : NULL, NULL);
+}
+/* Centroidal momentum matrix A [B][6][nv], convective term b [B][6] (may be NULL), frame origin com_out [B][3] (may be NULL).
+ * frame12 = pose (R row-major, p) of the centroidal momentum frame in the root body frame, NULL = the root body frame itself
+ * (the calculator's default, CompositeRigidBodyMassMatrixCalculator.java:190-193); at_com != 0 additionally moves the origin to the
+ * centre of mass of the considered bodies given in that frame, i.e. a frames/CenterOfMassReferenceFrame whose parent is frame12. */
+void mo_centroidal(void *h, long B, const double *q, const double *qd, const double *frame12, int at_com, double *A, double *bout, double *com_out)
+{
+   const mo_model *m = (const mo_model *)h;
+   static _Thread_local mo_kin K;
+   double *Htmp = (double *)malloc(sizeof(double) * (size_t)m->nv * (size_t)m->nv);
+   for (long b = 0; b < B; b++)
+   {
+      xf_t W;
+      xf_identity(&W);
+      if (frame12)
+      {
+         memcpy(W.R, frame12, 9 * sizeof(double));
+         memcpy(W.p, frame12 + 9, 3 * sizeof(double));
+      }
+      if (at_com)
+      {
+         double c[3], cf[3], d[3];
+         kinematics(m, q + b * m->nq, NULL, &K);
+         center_of_mass(m, &K, c, NULL);
+         /* CoM in the parent frame: R^T (c - p); the CoM frame is that translation under the parent frame */
+         for (int k = 0; k < 3; k++)
+            d[k] = c[k] - W.p[k];
+         m3_tmulv(W.R, d, cf);
+         if (com_out)
+            memcpy(com_out + 3 * b, cf, sizeof cf);
+         memcpy(W.p, c, sizeof c);
+      }
+      else if (com_out)
+         com_out[3 * b] = com_out[3 * b + 1] = com_out[3 * b + 2] = 0;
+      crba_coriolis_one(m, q + b * m->nq, qd ? qd + b * m->nv : NULL, &W, Htmp, NULL, A + (size_t)b * 6 * m->nv);
+      if (bout)
+         convective_one(m, q + b * m->nq, qd + b * m->nv, &W, bout + 6 * b);
+   }
+   free(Htmp);
 }
 
 /* ------------------------------------------------------------------ state integration

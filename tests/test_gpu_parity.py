@@ -745,6 +745,107 @@ def test_planar_and_spherical_joints(torch_cuda, kinds):
         assert np.abs(f32 - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max())
 
 
+CORIOLIS_FAMILIES = ["revolute_chain", "onedof_tree", "floating_onedof_tree", "mixed_tree", "all_kinds_tree"]
+
+
+@pytest.mark.parametrize("family", CORIOLIS_FAMILIES)
+def test_coriolis_matrix_and_centroidal_momentum(torch_cuda, family):
+    """SURVEY.md section 8f N3 (CompositeRigidBodyMassMatrixCalculator with the Coriolis calculation enabled, centroidal momentum matrix and
+    convective term): every entry of H, C, A, b and the centre of mass against the oracle; the reference's own invariant C qd =
+    RNEA(qdd = 0, no gravity) (CompositeRigidBodyMassMatrixCalculatorTest.java:84-141, 1e-11) on the device results; SoA layout; fp32."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd import _lib
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    fam = dict(families())
+    fam["all_kinds_tree"] = lambda rng, n: rt.nextJointTree(rng, n, ("revolute", "prismatic", "planar", "spherical", "sixdof", "fixed"))
+    rng = np.random.default_rng(zlib.crc32(("n3gpu" + family).encode()))
+    for it in range(6):
+        sys_ = system_of(fam[family](rng, int(rng.integers(1, 31))))
+        d = sys_.toModelDesc()
+        om, hm = OracleModel(d), HipModel(d)
+        B = int(rng.integers(1, 200))
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        tq, tqd = dev(torch, q), dev(torch, qd)
+        H, C = hm.crba_coriolis(tq, tqd)
+        rH, rC = om.crba_coriolis(q, qd)
+        close(H.cpu().numpy(), rH), close(C.cpu().numpy(), rC)
+        if d.nv:
+            bias = hm.rnea(tq, tqd, torch.zeros_like(tqd), (0.0, 0.0, 0.0))
+            err = (torch.einsum("bij,bj->bi", C, tqd) - bias).abs().max().item()
+            assert err <= 1.0e-11 * max(1.0, bias.abs().max().item()), err
+        Rf = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        Rf *= np.sign(np.linalg.det(Rf))
+        frame = np.concatenate([Rf.ravel(), rng.uniform(-1, 1, 3)])
+        for fr, at_com in ((None, False), (frame, False), (None, True), (frame, True)):
+            A, b, com = hm.centroidal(tq, tqd, fr, at_com)
+            rA, rb, rcom = om.centroidal(q, qd, fr, at_com)
+            scale = max(1.0, np.abs(rA).max(initial=0.0))
+            close(A.cpu().numpy(), rA), close(com.cpu().numpy(), rcom)
+            assert np.abs(b.cpu().numpy() - rb).max(initial=0.0) <= TOL * max(scale, np.abs(rb).max(initial=0.0))
+        A_only, b_none, _ = hm.centroidal(tq)
+        assert b_none is None
+        close(A_only.cpu().numpy(), om.centroidal(q)[0])
+        # SoA: same numbers, transposed storage
+        Hs, Cs = hm.crba_coriolis(tq.T.contiguous(), tqd.T.contiguous(), _lib.LAYOUT_SOA)
+        assert torch.equal(Hs.T.reshape(B, d.nv, d.nv), H) and torch.equal(Cs.T.reshape(B, d.nv, d.nv), C)
+        As, bs, cs = hm.centroidal(tq.T.contiguous(), tqd.T.contiguous(), frame, True, _lib.LAYOUT_SOA)
+        A4, b4, c4 = hm.centroidal(tq, tqd, frame, True)
+        assert torch.equal(As.T.reshape(B, 6, d.nv), A4) and torch.equal(bs.T, b4) and torch.equal(cs.T, c4)
+        # fp32 within its tolerance
+        H32, C32 = hm.crba_coriolis(dev(torch, q, torch.float32), dev(torch, qd, torch.float32))
+        assert np.abs(C32.cpu().numpy() - rC).max(initial=0.0) <= 2e-3 * max(1.0, np.abs(rC).max(initial=0.0))
+        assert np.abs(H32.cpu().numpy() - rH).max(initial=0.0) <= 2e-3 * max(1.0, np.abs(rH).max(initial=0.0))
+
+
+def test_coriolis_on_the_humanoid_with_the_calculator_mirror(torch_cuda):
+    """The 30-DoF humanoid at the benchmark's batch through the drop-in class: getMassMatrix / getCoriolisMatrix /
+    getCentroidalMomentumMatrix / getCentroidalConvectiveTermMatrix; oracle on a strided sample, size-independent properties on all of it
+    (H symmetric and equal to the CRBA-only result, C qd = RNEA bias, h = A qd conserved check: linear part = total mass x CoM velocity)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.calculators import CompositeRigidBodyMassMatrixCalculator, InverseDynamicsCalculator
+    from oracle.cpu_oracle import OracleModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    d = sys_.toModelDesc()
+    B = 4096
+    q, qd, qdd, _ = rt.nextState(np.random.default_rng(2342), sys_, B)
+    tq, tqd, tqdd = dev(torch, q), dev(torch, qd), dev(torch, qdd)
+    calc = CompositeRigidBodyMassMatrixCalculator(sys_)
+    with pytest.raises(NotImplementedError):
+        calc.getCoriolisMatrix()
+    calc.setEnableCoriolisMatrixCalculation(True)
+    calc.setCentroidalMomentumFrame(None, atCenterOfMass=True)
+    H = calc.compute(tq, tqd)
+    C = calc.getCoriolisMatrix()
+    A, b = calc.getCentroidalMomentumMatrix(), calc.getCentroidalConvectiveTermMatrix()
+    om = OracleModel(d)
+    sl = slice(0, B, 97)
+    rH, rC = om.crba_coriolis(q[sl], qd[sl])
+    rA, rb, rcom = om.centroidal(q[sl], qd[sl], None, True)
+    close(H[sl].cpu().numpy(), rH), close(C[sl].cpu().numpy(), rC), close(A[sl].cpu().numpy(), rA)
+    close(calc.getCenterOfMass()[sl].cpu().numpy(), rcom)
+    assert np.abs(b[sl].cpu().numpy() - rb).max() <= TOL * max(1.0, np.abs(rA).max())
+    assert torch.equal(H, H.transpose(1, 2))
+    plain = CompositeRigidBodyMassMatrixCalculator(sys_)
+    assert (plain.getMassMatrix(tq) - H).abs().max().item() <= 1e-11 * H.abs().max().item()
+    idc = InverseDynamicsCalculator(sys_)
+    idc.setGravitationalAcceleration(0.0)
+    bias = idc.compute(tq, tqd, torch.zeros_like(tqd))
+    assert (torch.einsum("bij,bj->bi", C, tqd) - bias).abs().max().item() <= 1e-11 * max(1.0, bias.abs().max().item())
+    # momentum rate: A qdd + b equals the root joint's wrench in RNEA without gravity, moved to the centre of mass (root frame axes)
+    tau = idc.compute(tq, tqd, tqdd).cpu().numpy()
+    rate = (torch.einsum("bij,bj->bi", A, tqdd) + b).cpu().numpy()
+    com = calc.getCenterOfMass().cpu().numpy()
+    from oracle import featherstone_np as fs
+    for k in range(0, B, 517):
+        R, p = fs.quat_to_R(q[k, :4]), q[k, 4:7]
+        f_root = R @ tau[k, 3:6]
+        n_root = R @ tau[k, 0:3] + np.cross(p - com[k], f_root)
+        assert np.abs(rate[k] - np.concatenate([n_root, f_root])).max() <= 1e-9 * max(1.0, np.abs(tau[k]).max())
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()

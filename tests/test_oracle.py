@@ -375,3 +375,88 @@ def test_planar_and_spherical_joints(kinds):
         qn, vn, _ = om.integrate(dt, q, qd, qdd)
         errs.append(np.abs((ke(qn, vn) - ke(q, qd)) / dt - power).max())
     assert errs[1] <= 0.6 * errs[0] + 1e-7 and errs[1] <= 5e-3 * max(1.0, np.abs(power).max())  # first-order convergence to the power
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Coriolis matrix and centroidal momentum: the reference's own pins restated
+#   CompositeRigidBodyMassMatrixCalculatorTest.java:84-141  C qd = RNEA(qdd = 0, no gravity) on chains and trees of up to 20 joints, 1e-11
+#   CompositeRigidBodyMassMatrixCalculatorTest.java:25-82   centroidal momentum matrix / convective term against a second algorithm
+#                                                           (CentroidalMomentumRateCalculator there, the dense-Jacobian form here), 1e-12
+# plus: every entry of C against the dense body-Jacobian form, dH/dt = C + C^T by central differences, A qdd + b against the wrench the
+# floating root joint transmits in RNEA.
+CORIOLIS_FAMILIES = ["revolute_chain", "onedof_chain", "onedof_tree", "floating_onedof_tree", "mixed_tree"]
+
+
+@pytest.mark.parametrize("family", CORIOLIS_FAMILIES)
+def test_coriolis_matrix_times_velocity_is_rnea_bias(family):
+    rng = np.random.default_rng(547467 + zlib.crc32(family.encode()) % 1000)  # CompositeRigidBodyMassMatrixCalculatorTest.java:87
+    for it in range(25):
+        n = int(rng.integers(1, 21))
+        sys_ = system_of(FAMILIES[family](rng, n))
+        om = OracleModel(sys_.toModelDesc())
+        q, qd, qdd, tau = rt.nextState(rng, sys_, 3)
+        H, C = om.crba_coriolis(q, qd)
+        bias = om.rnea(q, qd, np.zeros_like(qd), gravity=(0.0, 0.0, 0.0))  # setConsiderJointAccelerations(false), :103-105
+        actual = np.einsum("bij,bj->bi", C, qd)
+        assert np.abs(actual - bias).max(initial=0.0) <= 1.0e-11 * max(1.0, np.abs(bias).max(initial=0.0)), (family, it)
+        assert np.array_equal(H, om.crba(q)) or np.abs(H - om.crba(q)).max(initial=0.0) <= 1e-13 * max(1.0, np.abs(H).max(initial=0.0))
+
+
+@pytest.mark.parametrize("family", CORIOLIS_FAMILIES)
+def test_coriolis_and_centroidal_match_dense_jacobian_forms(family):
+    rng = np.random.default_rng(zlib.crc32(("dense" + family).encode()))
+    for it in range(6):
+        n = int(rng.integers(1, 14))
+        sys_ = system_of(FAMILIES[family](rng, n))
+        d = sys_.toModelDesc()
+        om, fm = OracleModel(d), fs.Model(d)
+        q, qd, qdd, tau = rt.nextState(rng, sys_, 2)
+        H, C = om.crba_coriolis(q, qd)
+        frame = np.concatenate([fs.rot_axis_angle(rng.normal(size=3), float(rng.uniform(-3, 3))).ravel(), rng.uniform(-1, 1, size=3)])
+        for fr, at_com in ((None, False), (frame, False), (None, True), (frame, True)):
+            A, b, com = om.centroidal(q, qd, fr, at_com)
+            for k in range(2):
+                Ad, bd, od = fs.centroidal_dense(fm, q[k], qd[k], fr, at_com)
+                assert np.abs(A[k] - Ad).max(initial=0.0) <= 1e-12 * max(1.0, np.abs(Ad).max(initial=0.0))
+                assert np.abs(b[k] - bd).max(initial=0.0) <= 1e-12 * max(1.0, np.abs(bd).max(initial=0.0), np.abs(Ad).max(initial=0.0))
+                assert np.abs(com[k] - od).max(initial=0.0) <= 1e-13 * max(1.0, np.abs(od).max(initial=0.0))
+        for k in range(2):
+            Cd = fs.coriolis_dense(fm, q[k], qd[k])
+            assert np.abs(C[k] - Cd).max(initial=0.0) <= 1e-12 * max(1.0, np.abs(Cd).max(initial=0.0))
+
+
+def test_mass_matrix_rate_is_coriolis_plus_transpose():
+    """dH/dt = C + C^T for the factorisation B = v x* I (dI/dt = B + B^T): central differences of H along qd, 1-DoF joints only so that
+    q(t) = q + t qd."""
+    rng = np.random.default_rng(99)
+    for it in range(6):
+        sys_ = system_of(rt.nextJointTree(rng, int(rng.integers(2, 12)), ("revolute", "prismatic")))
+        om = OracleModel(sys_.toModelDesc())
+        q, qd, _, _ = rt.nextState(rng, sys_, 2)
+        _, C = om.crba_coriolis(q, qd)
+        eps = 1e-6
+        Hd = (om.crba(q + eps * qd) - om.crba(q - eps * qd)) / (2 * eps)
+        assert np.abs(Hd - (C + np.swapaxes(C, 1, 2))).max(initial=0.0) <= 2e-7 * max(1.0, np.abs(C).max(initial=0.0))
+
+
+def test_centroidal_momentum_rate_is_the_root_joint_wrench():
+    """h = A qd and dh/dt = A qdd + b: for a floating root joint without offset the rate of change of momentum is the wrench the root
+    joint transmits, i.e. RNEA's root effort (no gravity), expressed in the frame after the root joint; checked in the root frame."""
+    rng = np.random.default_rng(7)
+    for it in range(8):
+        sys_ = system_of(rt.nextFloatingChain(rng, int(rng.integers(1, 15)), ("revolute", "prismatic"), tree=True))
+        d = sys_.toModelDesc()
+        om = OracleModel(d)
+        q, qd, qdd, _ = rt.nextState(rng, sys_, 3)
+        A, b, _ = om.centroidal(q, qd)
+        tau = om.rnea(q, qd, qdd, gravity=(0.0, 0.0, 0.0))
+        rate = np.einsum("bij,bj->bi", A, qdd) + b
+        di = np.asarray(d.dof_indices)[:6]
+        ci = np.asarray(d.cfg_indices)[:7]
+        for k in range(3):
+            R, p = fs.quat_to_R(q[k, ci[:4]]), q[k, ci[4:7]]
+            n_, f_ = tau[k, di[:3]], tau[k, di[3:6]]
+            f_root = R @ f_
+            n_root = R @ n_ + np.cross(p, f_root)
+            expected = np.concatenate([n_root, f_root])
+            assert np.abs(rate[k] - expected).max(initial=0.0) <= 1e-10 * max(1.0, np.abs(expected).max(initial=0.0))
