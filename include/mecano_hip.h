@@ -288,6 +288,11 @@ mh_status mh_aba_f64_host(mh_model_t model, int64_t B, const double *q, const do
                           const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out);
 mh_status mh_crba_f64_host(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out);
 
+mh_status mh_crba_coriolis_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const mh_options *opts, double *H_out,
+                                    double *C_out);
+mh_status mh_centroidal_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double frame[12], int32_t frame_mode,
+                                 const mh_options *opts, double *A_out, double *b_out, double *com_out);
+
 /* ---- measurement helper: HIP-event timing of launches on a stream (bench.py, §8d timing protocol) ---- */
 typedef struct mh_timer *mh_timer_t;
 mh_status mh_timer_create(mh_timer_t *timer_out);

@@ -36,6 +36,17 @@ public final class MecanoHipNative
    static final MethodHandle RNEA_HOST = handle("mh_rnea_f64_host", DYNAMICS);
    static final MethodHandle ABA_HOST = handle("mh_aba_f64_host", DYNAMICS);
    static final MethodHandle CRBA_HOST = handle("mh_crba_f64_host", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS));
+   /** CompositeRigidBodyMassMatrixCalculator with setEnableCoriolisMatrixCalculation(true): (model, B, q, qd, opts, H_out, C_out). */
+   static final MethodHandle CRBA_CORIOLIS_HOST = handle("mh_crba_coriolis_f64_host",
+                                                         FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+   /**
+    * getCentroidalMomentumMatrix / getCentroidalConvectiveTermMatrix: (model, B, q, qd, frame[12] or NULL, frame_mode, opts, A_out, b_out,
+    * com_out); frame = centroidalMomentumFrame.getTransformToDesiredFrame(rootBody.getBodyFixedFrame()) as R row-major + p, frame_mode 1
+    * for a CenterOfMassReferenceFrame under it.
+    */
+   static final MethodHandle CENTROIDAL_HOST = handle("mh_centroidal_f64_host", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS,
+                                                                                                       ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS,
+                                                                                                       ADDRESS));
 
    /** mh_status -> the exception Mecano's own calculators would have thrown (SURVEY.md section 8b, "Errors"). */
    static void check(int status)

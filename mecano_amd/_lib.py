@@ -18,7 +18,7 @@ LAYOUT_AOS, LAYOUT_SOA = 0, 1
 ABI_SYMBOLS = [
     "mh_abi_version", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
     "mh_topology_key", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64",
-    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_timer_create",
+    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
     "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
 ]
 
@@ -95,9 +95,9 @@ def load():
     lib.mh_aba_locked_f64.argtypes = [P, I64, P, P, P, P, P, P, opt, P, P]
     for f in ("mh_rnea_bodies_f64", "mh_aba_bodies_f64"):
         getattr(lib, f).argtypes = [P, I64, P, P, P, P, P, opt, P, P, P]
-    for f in ("mh_crba_coriolis_f64", "mh_crba_coriolis_f32"):
+    for f in ("mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_crba_coriolis_f64_host"):
         getattr(lib, f).argtypes = [P, I64, P, P, opt, P, P]
-    for f in ("mh_centroidal_f64", "mh_centroidal_f32"):
+    for f in ("mh_centroidal_f64", "mh_centroidal_f32", "mh_centroidal_f64_host"):
         getattr(lib, f).argtypes = [P, I64, P, P, P, I32, opt, P, P, P]
     for f in ("mh_integrate_f64", "mh_integrate_f32"):
         getattr(lib, f).argtypes = [P, I64, ctypes.c_double, P, P, P, opt, P, P, P]

@@ -138,6 +138,7 @@ struct mh_model
    int dense_maps = 0;      // nq / nv equal the joints' totals (no unused matrix rows): rows can be staged as dense blocks
    int force_io = -1, force_st = -1; // MH_SPEC_IO / MH_SPEC_ST = 0 | 1 override the heuristics (measurements)
    int n_locked = 0;        // joints in MH_ACCELERATION_SOURCE mode (mh_model_set_joint_source_modes)
+   int waves_per_cu = 8;    // resident waves per CU the run-time-topology kernels are launched with (MH_WAVES_PER_CU)
 };
 
 namespace
@@ -164,7 +165,7 @@ Launch plan_launch(const mh_model *m, int64_t B)
    Launch L;
    L.block = 64; // one wave per workgroup: a small batch spreads over as many CUs as it has waves
    long waves = (B + 63) / 64;
-   long cap = (long)m->cu_count * 8; // 8 waves per CU resident at most for these register budgets
+   long cap = (long)m->cu_count * m->waves_per_cu; // resident waves: the workspace is sized by the grid, not by B
    L.grid = (int)std::max<long>(1, std::min(waves, cap));
    L.lanes = (long)L.grid * L.block;
    return L;
@@ -218,9 +219,11 @@ bool split_ok(const mh_model *m, int algo, int64_t B, bool soa)
       return false;
    if (m->use_split == 1 || algo == 1)
       return true; // ABA: the split form also needs fewer registers and measured faster at every batch size
+   if (algo == 0 && (split_flags(m, algo, soa) & SPEC_IO_LDS))
+      return true; // RNEA with rows staged in LDS: 183 registers = two waves per SIMD, measured 1.25x the whole-tree kernel at B = 32768 .. 262144
    const long groups = (B + 63) / 64;
    const long waves = groups * 4 * (algo == 2 ? 2 : 1);
-   return waves <= (long)m->cu_count * 4; // RNEA / fused: while the batch cannot give every SIMD a wave of its own
+   return waves <= (long)m->cu_count * 4; // fused / SoA RNEA: while the batch cannot give every SIMD a wave of its own
 }
 
 enum Algo
@@ -943,6 +946,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->force_io = atoi(e);
    if (const char *e = getenv("MH_FAKE_CU_COUNT")) // measurements: shrink every grid so that one workgroup loops over the batch
       m->cu_count = std::max(1, atoi(e));
+   if (const char *e = getenv("MH_WAVES_PER_CU"))
+      m->waves_per_cu = std::max(1, std::min(32, atoi(e)));
    if (const char *e = getenv("MH_SPEC_ST"))
       m->force_st = atoi(e);
    try_load_spec(m, P);
@@ -1188,6 +1193,73 @@ struct mh_timer
 {
    hipEvent_t start, stop;
 };
+mh_status mh_crba_coriolis_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const mh_options *opts_in, double *H_out,
+                                    double *C_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (B == 0)
+      return MH_OK;
+   if (!q || !qd || !H_out || !C_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   const size_t s_q = (size_t)B * model->nq, s_v = (size_t)B * model->nv, s_h = (size_t)B * model->nv * model->nv;
+   st = ensure_bytes(model->stage, (s_q + s_v + 2 * s_h) * sizeof(double));
+   if (st != MH_OK)
+      return st;
+   hipStream_t stream = (hipStream_t)opts.stream;
+   double *d_q = (double *)model->stage.ptr, *d_qd = d_q + s_q, *d_H = d_qd + s_v, *d_C = d_H + s_h;
+   HIP_TRY(hipMemcpyAsync(d_q, q, s_q * sizeof(double), hipMemcpyHostToDevice, stream));
+   HIP_TRY(hipMemcpyAsync(d_qd, qd, s_v * sizeof(double), hipMemcpyHostToDevice, stream));
+   st = coriolis_impl<double>(model, B, d_q, d_qd, &opts, d_H, d_C);
+   if (st != MH_OK)
+      return st;
+   HIP_TRY(hipMemcpyAsync(H_out, d_H, s_h * sizeof(double), hipMemcpyDeviceToHost, stream));
+   HIP_TRY(hipMemcpyAsync(C_out, d_C, s_h * sizeof(double), hipMemcpyDeviceToHost, stream));
+   HIP_TRY(hipStreamSynchronize(stream));
+   return MH_OK;
+}
+mh_status mh_centroidal_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double frame[12], int32_t frame_mode,
+                                 const mh_options *opts_in, double *A_out, double *b_out, double *com_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (B == 0)
+      return MH_OK;
+   if (!q || !A_out || (b_out && !qd))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer (the convective term needs qd)");
+   const size_t s_q = (size_t)B * model->nq, s_v = (size_t)B * model->nv, s_a = (size_t)B * 6 * model->nv, s_b = (size_t)B * 6, s_c = (size_t)B * 3;
+   st = ensure_bytes(model->stage, (s_q + s_v + s_a + s_b + s_c) * sizeof(double));
+   if (st != MH_OK)
+      return st;
+   hipStream_t stream = (hipStream_t)opts.stream;
+   double *d_q = (double *)model->stage.ptr, *d_qd = d_q + s_q, *d_A = d_qd + s_v, *d_b = d_A + s_a, *d_c = d_b + s_b;
+   HIP_TRY(hipMemcpyAsync(d_q, q, s_q * sizeof(double), hipMemcpyHostToDevice, stream));
+   if (qd)
+      HIP_TRY(hipMemcpyAsync(d_qd, qd, s_v * sizeof(double), hipMemcpyHostToDevice, stream));
+   st = centroidal_impl<double>(model, B, d_q, qd ? d_qd : nullptr, frame, frame_mode, &opts, d_A, b_out ? d_b : nullptr, com_out ? d_c : nullptr);
+   if (st != MH_OK)
+      return st;
+   HIP_TRY(hipMemcpyAsync(A_out, d_A, s_a * sizeof(double), hipMemcpyDeviceToHost, stream));
+   if (b_out)
+      HIP_TRY(hipMemcpyAsync(b_out, d_b, s_b * sizeof(double), hipMemcpyDeviceToHost, stream));
+   if (com_out)
+      HIP_TRY(hipMemcpyAsync(com_out, d_c, s_c * sizeof(double), hipMemcpyDeviceToHost, stream));
+   HIP_TRY(hipStreamSynchronize(stream));
+   return MH_OK;
+}
+
 mh_status mh_timer_create(mh_timer_t *out)
 {
    if (!out)

@@ -319,9 +319,18 @@ class HipModel:
     def crba_coriolis(self, q, qd, layout=_lib.LAYOUT_AOS):
         """Mass matrix and Coriolis matrix (CompositeRigidBodyMassMatrixCalculator with the Coriolis calculation enabled,
         CompositeRigidBodyMassMatrixCalculator.java:271-274, 344-365): (H, C), device tensors [B, nv, nv]."""
+        if not self._is_torch(q):  # numpy: host-pointer entry point (fp64)
+            q, qd = _np(q, np.float64), _np(qd, np.float64)
+            B = self._batch(q, self.nq, layout)
+            if self._batch(qd, self.nv, layout) != B:
+                raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+            shape = (B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B)
+            H, C = np.empty(shape), np.empty(shape)
+            opts = self._options(layout)
+            _lib.check(_lib.load().mh_crba_coriolis_f64_host(self._h, B, q.ctypes.data, qd.ctypes.data, ctypes.byref(opts), H.ctypes.data,
+                                                             C.ctypes.data))
+            return H, C
         import torch
-        if not self._is_torch(q):
-            raise TypeError("crba_coriolis takes device tensors")
         B, dt, sfx, stream = self._device_inputs([q, qd], layout)
         shape = (B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B)
         H, C = torch.empty(shape, dtype=dt, device=q.device), torch.empty(shape, dtype=dt, device=q.device)
@@ -334,19 +343,30 @@ class HipModel:
         """Centroidal momentum matrix, convective term and frame origin (CompositeRigidBodyMassMatrixCalculator.java:375-420, 801-839):
         (A [B, 6, nv], b [B, 6] or None without qd, com [B, 3]).  ``frame``: 12 numbers (R row-major, p), pose of the centroidal momentum
         frame in the root body frame, None = the root body frame; ``at_com`` re-centres it on the centre of mass."""
+        fr = None
+        if frame is not None:
+            fr = (ctypes.c_double * 12)(*[float(v) for v in np.asarray(frame, dtype=np.float64).reshape(12)])
+        mode = _lib.CENTROIDAL_FRAME_AT_COM if at_com else _lib.CENTROIDAL_FRAME_FIXED
+        if not self._is_torch(q):  # numpy: host-pointer entry point (fp64)
+            q = _np(q, np.float64)
+            qd = None if qd is None else _np(qd, np.float64)
+            B = self._batch(q, self.nq, layout)
+            aos = layout == _lib.LAYOUT_AOS
+            A = np.empty((B, 6, self.nv) if aos else (6 * self.nv, B))
+            b = None if qd is None else np.empty((B, 6) if aos else (6, B))
+            com = np.empty((B, 3) if aos else (3, B))
+            opts = self._options(layout)
+            _lib.check(_lib.load().mh_centroidal_f64_host(self._h, B, q.ctypes.data, None if qd is None else qd.ctypes.data, fr, mode,
+                                                          ctypes.byref(opts), A.ctypes.data, None if b is None else b.ctypes.data,
+                                                          com.ctypes.data))
+            return A, b, com
         import torch
-        if not self._is_torch(q):
-            raise TypeError("centroidal takes device tensors")
         B, dt, sfx, stream = self._device_inputs([q] if qd is None else [q, qd], layout)
         aos = layout == _lib.LAYOUT_AOS
         A = torch.empty((B, 6, self.nv) if aos else (6 * self.nv, B), dtype=dt, device=q.device)
         b = None if qd is None else torch.empty((B, 6) if aos else (6, B), dtype=dt, device=q.device)
         com = torch.empty((B, 3) if aos else (3, B), dtype=dt, device=q.device)
-        fr = None
-        if frame is not None:
-            fr = (ctypes.c_double * 12)(*[float(v) for v in np.asarray(frame, dtype=np.float64).reshape(12)])
         opts = self._options(layout, stream=stream)
-        mode = _lib.CENTROIDAL_FRAME_AT_COM if at_com else _lib.CENTROIDAL_FRAME_FIXED
         _lib.check(getattr(_lib.load(), f"mh_centroidal_{sfx}")(self._h, B, q.data_ptr(), None if qd is None else qd.data_ptr(), fr, mode,
                                                                ctypes.byref(opts), A.data_ptr(), None if b is None else b.data_ptr(),
                                                                com.data_ptr()))

@@ -793,6 +793,12 @@ def test_coriolis_matrix_and_centroidal_momentum(torch_cuda, family):
         As, bs, cs = hm.centroidal(tq.T.contiguous(), tqd.T.contiguous(), frame, True, _lib.LAYOUT_SOA)
         A4, b4, c4 = hm.centroidal(tq, tqd, frame, True)
         assert torch.equal(As.T.reshape(B, 6, d.nv), A4) and torch.equal(bs.T, b4) and torch.equal(cs.T, c4)
+        # host-pointer entry points (what a JNI / Panama shim calls): numpy in, numpy out, same numbers
+        if it == 0:
+            Hh, Ch = hm.crba_coriolis(q, qd)
+            assert np.array_equal(Hh, H.cpu().numpy()) and np.array_equal(Ch, C.cpu().numpy())
+            Ah, bh, ch = hm.centroidal(q, qd, frame, True)
+            assert np.array_equal(Ah, A4.cpu().numpy()) and np.array_equal(bh, b4.cpu().numpy()) and np.array_equal(ch, c4.cpu().numpy())
         # fp32 within its tolerance
         H32, C32 = hm.crba_coriolis(dev(torch, q, torch.float32), dev(torch, qd, torch.float32))
         assert np.abs(C32.cpu().numpy() - rC).max(initial=0.0) <= 2e-3 * max(1.0, np.abs(rC).max(initial=0.0))
