@@ -138,6 +138,7 @@ struct mh_model
    int dense_maps = 0;      // nq / nv equal the joints' totals (no unused matrix rows): rows can be staged as dense blocks
    int force_io = -1, force_st = -1; // MH_SPEC_IO / MH_SPEC_ST = 0 | 1 override the heuristics (measurements)
    int n_locked = 0;        // joints in MH_ACCELERATION_SOURCE mode (mh_model_set_joint_source_modes)
+   int lds_consts = 0;      // run-time-topology kernels: per-joint constants staged in LDS (large models: they overflow the scalar cache) or read by scalar loads
    int waves_per_cu = 8;    // resident waves per CU the run-time-topology kernels are launched with (MH_WAVES_PER_CU)
 };
 
@@ -275,7 +276,8 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    A.f_bs = soa ? 1 : (long)model->n * 6, A.f_es = soa ? B : 1;
    A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
    A.coriolis = opts.consider_coriolis, A.accel = opts.consider_accelerations;
-   const size_t lds = MH_GENERIC_LDS_CONSTS ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
+   const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
+   const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
    if (lds > 160 * 1024)
       return fail(MH_ERR_BAD_DIMENSION, "model constants (%zu B) exceed the 160 KiB LDS of a gfx950 CU", lds);
 
@@ -284,16 +286,16 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       if (model->n_locked > 0)
          return fail(MH_ERR_INVALID_ARGUMENT, "per-body outputs are not available while joints are acceleration sources");
       if (algo == ALGO_RNEA)
-         hipLaunchKernelGGL((mh::rnea_kernel<T, MH_GENERIC_LDS_CONSTS, true>), dim3(L.grid), dim3(L.block), lds, stream, A);
+         { if (ldsc) hipLaunchKernelGGL((mh::rnea_kernel<T, true, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::rnea_kernel<T, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A); }
       else
-         hipLaunchKernelGGL((mh::aba_kernel<T, MH_GENERIC_LDS_CONSTS, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A);
+         { if (ldsc) hipLaunchKernelGGL((mh::aba_kernel<T, true, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::aba_kernel<T, false, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A); }
       HIP_TRY(hipGetLastError());
       return MH_OK;
    }
    if (algo == ALGO_ABA && model->n_locked > 0)
    { // acceleration-source joints: run-time flags per joint, generic kernel only
       A.in3b = locked_in, A.outb = locked_out;
-      hipLaunchKernelGGL((mh::aba_kernel<T, MH_GENERIC_LDS_CONSTS, true>), dim3(L.grid), dim3(L.block), lds, stream, A);
+      { if (ldsc) hipLaunchKernelGGL((mh::aba_kernel<T, true, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::aba_kernel<T, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A); }
       HIP_TRY(hipGetLastError());
       return MH_OK;
    }
@@ -336,6 +338,8 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
          if (st)
             flags |= SPEC_ST_LDS;
       }
+      if (model->spec.supports(a, flags))
+      {
       const long lds = model->spec.lds_bytes(a, flags, model->nq, model->nv);
       const long per_cu = lds > 0 ? std::max<long>(1, std::min<long>(8, LDS_MAX / lds)) : 8;
       const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * per_cu));
@@ -351,14 +355,15 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       if (rc != 0)
          return fail(MH_ERR_HIP, "specialised kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
       return MH_OK;
+      } // else: this (algorithm, memory plan) is not in the code object -- the run-time-topology kernels below serve the call
    }
    switch (algo)
    {
       case ALGO_RNEA:
-         hipLaunchKernelGGL((mh::rnea_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
+         { if (ldsc) hipLaunchKernelGGL((mh::rnea_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::rnea_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
          break;
       case ALGO_ABA:
-         hipLaunchKernelGGL((mh::aba_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
+         { if (ldsc) hipLaunchKernelGGL((mh::aba_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::aba_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
          break;
       case ALGO_CRBA:
       {
@@ -396,7 +401,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             return MH_OK;
          }
          HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
-         hipLaunchKernelGGL((mh::crba_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
+         { if (ldsc) hipLaunchKernelGGL((mh::crba_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::crba_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
          break;
       }
    }
@@ -622,11 +627,12 @@ mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, co
    A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
    A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
    A.f_bs = soa ? 1 : (long)model->nv * model->nv, A.f_es = soa ? B : 1; // strides of H and C
-   const size_t lds = MH_GENERIC_LDS_CONSTS ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
+   const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
+   const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
    const size_t hbytes = (size_t)B * model->nv * model->nv * sizeof(T);
    HIP_TRY(hipMemsetAsync(H_out, 0, hbytes, stream)); // the kernel writes the entries of related joints only (:298-300)
    HIP_TRY(hipMemsetAsync(C_out, 0, hbytes, stream));
-   hipLaunchKernelGGL((mh::coriolis_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
+   { if (ldsc) hipLaunchKernelGGL((mh::coriolis_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::coriolis_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
    HIP_TRY(hipGetLastError());
    return MH_OK;
 }
@@ -670,9 +676,10 @@ mh_status centroidal_impl(mh_model_t model, int64_t B, const T *q, const T *qd, 
    for (int k = 0; k < 3; k++)
       A.fp[k] = frame ? (T)frame[9 + k] : T(0);
    A.at_com = frame_mode == MH_CENTROIDAL_FRAME_AT_COM;
-   const size_t lds = MH_GENERIC_LDS_CONSTS ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
+   const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
+   const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
    HIP_TRY(hipMemsetAsync(A_out, 0, (size_t)B * 6 * model->nv * sizeof(T), stream)); // columns no considered joint owns stay zero
-   hipLaunchKernelGGL((mh::centroidal_kernel<T, MH_GENERIC_LDS_CONSTS>), dim3(L.grid), dim3(L.block), lds, stream, A);
+   { if (ldsc) hipLaunchKernelGGL((mh::centroidal_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::centroidal_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
    HIP_TRY(hipGetLastError());
    return MH_OK;
 }
@@ -946,6 +953,9 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->force_io = atoi(e);
    if (const char *e = getenv("MH_FAKE_CU_COUNT")) // measurements: shrink every grid so that one workgroup loops over the batch
       m->cu_count = std::max(1, atoi(e));
+   m->lds_consts = 0; // measured on the 128-body tree (fp32, B = 131072): no difference to scalar loads
+   if (const char *e = getenv("MH_GENERIC_LDS"))
+      m->lds_consts = atoi(e) != 0;
    if (const char *e = getenv("MH_WAVES_PER_CU"))
       m->waves_per_cu = std::max(1, std::min(32, atoi(e)));
    if (const char *e = getenv("MH_SPEC_ST"))
@@ -1152,6 +1162,13 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
       if (rc2 != 0)
          return fail(MH_ERR_HIP, "fused tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc2));
       return MH_OK;
+   }
+   if (!model->spec.supports(1, SPEC_ST_LDS | (model->ident_maps ? SPEC_IDENT : 0)))
+   { // no whole-tree ABA in this code object (trees with a tree-split form) and the tree-split launch was ruled out: two calls
+      st = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
+      if (st != MH_OK)
+         return st;
+      return mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &opts, qdd_out);
    }
    const int rc = model->spec.launch_fused(model->ident_maps ? SPEC_IDENT : 0, &A, (int)waves, opts.stream);
    if (rc != 0)

@@ -608,6 +608,21 @@ MH_DEV void rank1_down(ABI<T> &I, V3<T> ua, V3<T> ul, T dinv)
    I.C.yx -= sa.y * ul.x, I.C.yy -= sa.y * ul.y, I.C.yz -= sa.y * ul.z;
    I.C.zx -= sa.z * ul.x, I.C.zy -= sa.z * ul.y, I.C.zz -= sa.z * ul.z;
 }
+// The same for a revolute joint about z (ua = A e_z, ul = C^T e_z, D = A.zz): Ia S = 0, so the z row / column of A and the z row of C
+// cancel exactly -- they are set to zero instead of being computed, and (with -fno-signed-zeros -ffinite-math-only) every product with
+// them in the congruence that follows folds away: 15 live entries instead of 21.
+template <typename T>
+MH_DEV void rank1_down_revolute(ABI<T> &I, V3<T> ua, V3<T> ul, T dinv)
+{
+   const T sx = dinv * ua.x, sy = dinv * ua.y;
+   const V3<T> sl = dinv * ul;
+   I.A.xx -= sx * ua.x, I.A.xy -= sx * ua.y, I.A.yy -= sy * ua.y;
+   I.A.xz = T(0), I.A.yz = T(0), I.A.zz = T(0);
+   I.L.xx -= sl.x * ul.x, I.L.xy -= sl.x * ul.y, I.L.xz -= sl.x * ul.z, I.L.yy -= sl.y * ul.y, I.L.yz -= sl.y * ul.z, I.L.zz -= sl.z * ul.z;
+   I.C.xx -= sx * ul.x, I.C.xy -= sx * ul.y, I.C.xz -= sx * ul.z;
+   I.C.yx -= sy * ul.x, I.C.yy -= sy * ul.y, I.C.yz -= sy * ul.z;
+   I.C.zx = T(0), I.C.zy = T(0), I.C.zz = T(0);
+}
 // solve IA x = b for a symmetric positive definite 6x6 (floating joint: ForwardDynamicsCalculator.java:1195-1196 uses a
 // Cholesky inverse); LDL^T without square roots, fully unrolled so that M stays in registers
 template <typename T>

@@ -65,15 +65,26 @@ hipError_t go(const mh::Args<double> &A, int grid, size_t lds, hipStream_t strea
    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, A);
    return hipGetLastError();
 }
+// Whole-tree (one wave per 64 configurations) ABA is built only for trees WITHOUT a tree-split form (chains): where the tree-split
+// kernel exists the dispatcher prefers it at every batch size, and the whole-tree ABA of a 25-body tree needs the full 512-register
+// budget plus 50-130 spills -- the one place where hipcc 7.2 handed back wrong results for some memory plans (open issues).
+constexpr bool kWholeTreeAba = !mh::Split<TP>::usable();
 template <int ALGO, bool IO, bool ID>
 hipError_t go_st(int flags, const mh::Args<double> &A, int grid, size_t lds, hipStream_t s)
 {
    if constexpr (ALGO == 1)
    {
-      if (flags & F_ST_LDS)
-         return go<ALGO, IO, ID, true>(A, grid, lds, s);
+      if constexpr (!kWholeTreeAba)
+         return hipErrorNotSupported;
+      else
+      {
+         if (flags & F_ST_LDS)
+            return go<ALGO, IO, ID, true>(A, grid, lds, s);
+         return go<ALGO, IO, ID, false>(A, grid, lds, s);
+      }
    }
-   return go<ALGO, IO, ID, false>(A, grid, lds, s);
+   else
+      return go<ALGO, IO, ID, false>(A, grid, lds, s);
 }
 template <int ALGO>
 hipError_t go_flags(int flags, const mh::Args<double> &A, int grid, size_t lds, hipStream_t s)
@@ -92,6 +103,10 @@ hipError_t go_flags(int flags, const mh::Args<double> &A, int grid, size_t lds, 
 template <bool ID>
 hipError_t go_fused(const mh::Args<double> &A, int waves, hipStream_t stream)
 {
+   if constexpr (!kWholeTreeAba)
+      return hipErrorNotSupported;
+   else
+   {
    auto kern = &mh::spec_fused_kernel<TP, double, ID>;
    const size_t lds = (size_t)std::max(lds_bytes(0, F_IO_LDS, A.m.nq, A.m.nv), lds_bytes(1, F_ST_LDS, A.m.nq, A.m.nv));
    static size_t attr_bytes = 0;
@@ -104,6 +119,7 @@ hipError_t go_fused(const mh::Args<double> &A, int waves, hipStream_t stream)
    }
    hipLaunchKernelGGL(kern, dim3(2 * waves), dim3(64), lds, stream, A);
    return hipGetLastError();
+   }
 }
 
 using SPL = mh::Split<TP>;
@@ -202,6 +218,8 @@ int mh_spec_supports(int algo, int flags)
    // the two LDS uses is exact on its own (tests/test_gpu_parity.py::test_every_specialised_variant); see DESIGN.md.
    if (algo == 1 && (flags & F_IO_LDS) && (flags & F_ST_LDS))
       return 0;
+   if (algo == 1 && !kWholeTreeAba)
+      return 0; // trees with a tree-split form: whole-tree ABA is not built (see kWholeTreeAba)
    return algo == 0 || algo == 1;
 }
 // dynamic LDS one workgroup (one wave) needs for (algo, flags) with the model's matrix sizes

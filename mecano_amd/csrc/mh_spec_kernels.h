@@ -710,7 +710,10 @@ struct AbaIn
          }
          if constexpr (HAS_PARENT)
          {
-            rank1_down(IA, ua, ul, dinv);
+            if constexpr (TYPE == JT_REVOLUTE)
+               rank1_down_revolute(IA, ua, ul, dinv);
+            else
+               rank1_down(IA, ua, ul, dinv);
             const SV<T> pa = pA + mul(IA, crm(v, vJ)) + SV<T>{ud * ua, ud * ul};
             const XF<T> Xb = load_xb<T>(c);
             if constexpr (TYPE == JT_REVOLUTE)

@@ -25,5 +25,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         timeit(lambda: hm.rnea(q, qd, qdd, g), stream), timeit(lambda: hm.rnea(qs, qds, qdds, g, layout=1), stream),
         timeit(lambda: hm.aba(q, qd, tau, g), stream), timeit(lambda: hm.aba(qs, qds, taus, g, layout=1), stream)), flush=True)
 else:
-    for w in (4, 8, 12, 16, 24, 32):
-        subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, MH_WAVES_PER_CU=str(w)))
+    for lds in (0, 1):
+        print("MH_GENERIC_LDS =", lds, flush=True)
+        subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, MH_GENERIC_LDS=str(lds)))
