@@ -78,13 +78,14 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=10.0):
 
 
 def measured_traffic(fused_launch, B):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
-    separate passes, same command); only quoted for the configuration they were collected on, else null."""
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE,
+    separate passes, same command; FETCH_SIZE x 2 as calibrated on this access pattern, profiles/r01_pmc_calibration_8B_per_lane.txt);
+    only quoted for the configuration they were collected on, else null."""
     path = os.path.join(ROOT, "profiles", "r01_fused_split_b4096_hbm_pmc.json")
     if not (fused_launch and B == BATCH and os.path.exists(path)):
         return None
     pmc = json.load(open(path))
-    return (pmc["FETCH_SIZE_KB_per_launch_mean"] + pmc["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0
+    return (pmc.get("FETCH_SIZE_correction", 1.0) * pmc["FETCH_SIZE_KB_per_launch_mean"] + pmc["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0
 
 
 def main():

@@ -456,12 +456,25 @@ struct CRef
 // ---- sincos.  fp64: Cody-Waite reduction by pi/2 (exact products through FMA) + the classic minimax kernels on
 //      [-pi/4, pi/4]; about 30 instructions instead of the ~120 of the library routine with its Payne-Hanek path.
 //      Error <= ~2 ulp for |x| < 2^19; larger arguments take the library path (out of line).
-__device__ __attribute__((noinline)) void sincos_slow(double x, double *s, double *c) { sincos(x, s, c); }
+//      The out-of-line routine returns (sin, cos) BY VALUE, in registers: with pointer outputs the caller's s / c get stack slots and
+//      every call site -- one per body -- carries an unconditional 16-byte scratch store on the hot path (seen in the ISA and as
+//      1.4 MB of WRITE_SIZE per 4096-configuration launch on top of the 0.96 MB of results).
+struct SinCos
+{
+   double s, c;
+};
+__device__ __attribute__((noinline)) SinCos sincos_slow(double x)
+{
+   SinCos r;
+   sincos(x, &r.s, &r.c);
+   return r;
+}
 MH_DEV void sincos_t(double x, double &s, double &c)
 {
    if (__builtin_expect(!(fabs(x) < 524288.0), 0))
    {
-      sincos_slow(x, &s, &c);
+      const SinCos r = sincos_slow(x);
+      s = r.s, c = r.c;
       return;
    }
    const double k = rint(x * 6.36619772367581382433e-01);
