@@ -117,3 +117,56 @@ def test_no_cpu_fallback_without_device(hip_lib):
     with pytest.raises(_lib.MecanoHipError) as e:
         HipModel(_chain_desc())
     assert e.value.status == 7
+
+
+def test_header_is_plain_c_and_a_c_host_links(hip_lib, tmp_path):
+    """The boundary is a C ABI: include/mecano_hip.h must compile as C99 (no C++-isms, no torch types), and a C host that calls the
+    device-free entry points must link against the shared library and run (model validation is host-only; without a HIP device
+    mh_model_create reports MH_ERR_NO_DEVICE, on a GPU box MH_OK)."""
+    import shutil
+    import subprocess
+    from mecano_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "mecano_hip.h"
+int main(void)
+{
+   /* a two-joint arm: revolute about z, then prismatic along x */
+   int32_t parent[2] = {-1, 0}, type[2] = {MH_JOINT_REVOLUTE, MH_JOINT_PRISMATIC}, dof[2] = {0, 1}, cfg[2] = {0, 1};
+   double axis[6] = {0, 0, 1, 1, 0, 0}, X[24] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0.5, 0, 0};
+   double J[18] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 1, 0, 0, 0, 1}, mass[2] = {1, 2}, com[6] = {0};
+   mh_model_desc d;
+   memset(&d, 0, sizeof d);
+   d.n_joints = 2, d.nq = 2, d.nv = 2;
+   d.parent = parent, d.joint_type = type, d.axis = axis, d.X_before = X, d.X_com = X, d.inertia_J = J, d.inertia_mass = mass;
+   d.inertia_com = com, d.dof_indices = dof, d.cfg_indices = cfg;
+   char key[17];
+   int32_t ep[2], et[2], count = -1;
+   if (mh_abi_version() != MH_ABI_VERSION) return 1;
+   if (mh_topology_key(&d, key, ep, et) != MH_OK || strlen(key) != 16 || ep[0] != -1 || ep[1] != 0) return 2;
+   parent[1] = 1; /* its own parent */
+   if (mh_topology_key(&d, key, ep, et) != MH_ERR_BAD_TOPOLOGY || strlen(mh_last_error()) == 0) return 3;
+   parent[1] = 0;
+   if (mh_device_count(&count) != MH_OK || count < 0) return 4;
+   mh_model_t m = NULL;
+   mh_status st = mh_model_create(&d, &m);
+   if (count == 0 && st != MH_ERR_NO_DEVICE) return 5;
+   if (count > 0 && (st != MH_OK || mh_model_nv(m) != 2)) return 6;
+   if (m) mh_model_destroy(m);
+   printf("ok %s %d\n", key, (int)count);
+   return 0;
+}
+''')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "host"
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lmecano_hip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.startswith("ok ")
