@@ -157,7 +157,143 @@ struct Split
       int reg_slot[N] = {};
       int n_limbs = 0, reg_slots = 0;
       bool usable = false;
+      // RNEA / CRBA keep the plain greedy assignment; `owner` is the ABA's, phase-aware when the trunk is staged
+      int owner_plain[N] = {};
+      // ---- staged trunk (ABA): see make_stages()
+      bool staged = false;
+      int root = -1;          // the root trunk body R
+      bool late[N] = {};      // limb k hangs off R itself: its owner can still be walking it while a sub-trunk is folded
+      int n_sub = 0;
+      int sub_top[N] = {};    // trunk children of R
+      int sub_owner[N] = {};  // [body] wave that folds the sub-trunk rooted at that body, between the two barriers
+      int sub_slot[N] = {};   // [body] exchange slot (an early limb's, consumed by then) its hand-up travels in
+      int cut_body[WAVES] = {}; // [wave] body of its late limb after whose children the first barrier sits, -1: explicit barrier
+      int cut_limb[WAVES] = {}; // [wave] that late limb, -1: none
    };
+   // Longest chain of TRUNK bodies from j downwards (j included).
+   static constexpr int trunk_len(const Plan &P, int j)
+   {
+      int best = 0;
+      for (int i = j + 1; i < N; i++)
+         if (TP::parent[i] == j && P.trunk[i])
+         {
+            const int l = trunk_len(P, i);
+            best = l > best ? l : best;
+         }
+      return 1 + best;
+   }
+   // Staged trunk.  In the plain scheme every wave walks its limbs, ONE barrier, then every wave folds the whole trunk inward
+   // (replicated): the serial chain is (longest limb) + (trunk depth) heavy steps -- 6 + 4 for the humanoid.  But only the root R needs
+   // every limb; the sub-trunks below it (spine 1-3 under the pelvis) need just the limbs hanging off them (arms, neck).  So:
+   //    phase 1  every wave: its early limbs; owners of late limbs (legs, hanging off R): the lower part of the limb
+   //    -------- barrier 1 (for a late-limb owner it sits INSIDE the limb's recursion, between two body steps)
+   //    phase 2  late-limb owners: the upper part of the limb; one wave without a late limb: the sub-trunk, inward, handing its
+   //             articulated inertia up through an exchange slot like a limb does
+   //    -------- barrier 2
+   //    phase 3  every wave: R alone (children read from the exchange area), then the outward sweep as before
+   // Serial chain: max(early limbs, lower parts) + max(upper parts, sub-trunk) + 1 = 4 + 3 + 1 for the humanoid, and the trunk bodies
+   // below R are folded once instead of four times.  Early limbs are balanced over the waves by their PHASE-1 load.
+   static constexpr void make_stages(Plan &P)
+   {
+      int nroot = 0;
+      for (int j = 0; j < N; j++)
+         if (TP::parent[j] < 0)
+         {
+            nroot++;
+            P.root = j;
+         }
+      for (int w = 0; w < WAVES; w++)
+         P.cut_body[w] = -1, P.cut_limb[w] = -1;
+      if (!P.usable || nroot != 1 || !P.trunk[P.root])
+         return;
+      const int R = P.root;
+      int sub_depth = 0, n_late = 0;
+      for (int j = 0; j < N; j++)
+         if (TP::parent[j] == R && P.trunk[j])
+         {
+            P.sub_top[P.n_sub++] = j;
+            const int l = trunk_len(P, j);
+            sub_depth = l > sub_depth ? l : sub_depth;
+         }
+      for (int k = 0; k < P.n_limbs; k++)
+      {
+         P.late[k] = TP::parent[P.root_of[k]] == R;
+         n_late += P.late[k] ? 1 : 0;
+      }
+      if (P.n_sub < 1 || n_late < 1 || n_late > WAVES - 1)
+         return;
+      // late limbs: one per wave, largest first
+      int load1[WAVES] = {}; // phase-1 load
+      bool has_late[WAVES] = {};
+      bool done[N] = {};
+      int next_wave = 0;
+      for (int round = 0; round < n_late; round++)
+      {
+         int best = -1, bs = -1;
+         for (int k = 0; k < P.n_limbs; k++)
+            if (P.late[k] && !done[k] && P.size_of[k] > bs)
+               bs = P.size_of[k], best = k;
+         const int w = next_wave++;
+         done[best] = true;
+         P.owner[best] = w;
+         has_late[w] = true;
+         // the cut: `low` bodies of the limb's tallest chain below it, so that the upper part is about as long as the sub-trunk
+         const int len = 1 + TR::height(P.root_of[best]);
+         if (len >= 2)
+         {
+            int low = len - sub_depth;
+            low = low < 1 ? 1 : (low > len - 1 ? len - 1 : low);
+            int j = P.root_of[best];
+            for (int step = 0; step < len - low - 1; step++)
+               j = TR::child(j, 0);
+            P.cut_body[w] = j;
+            P.cut_limb[w] = best;
+            load1[w] += low;
+         }
+      }
+      // early limbs: decreasing size, each to the wave with the least phase-1 load
+      for (;;)
+      {
+         int best = -1, bs = -1;
+         for (int k = 0; k < P.n_limbs; k++)
+            if (!P.late[k] && !done[k] && P.size_of[k] > bs)
+               bs = P.size_of[k], best = k;
+         if (best < 0)
+            break;
+         int w = 0;
+         for (int i = 1; i < WAVES; i++)
+            if (load1[i] < load1[w])
+               w = i;
+         done[best] = true;
+         P.owner[best] = w;
+         load1[w] += bs;
+      }
+      // sub-trunks: waves without a late limb, least loaded first
+      int extra[WAVES] = {};
+      for (int i = 0; i < P.n_sub; i++)
+      {
+         int w = -1;
+         for (int c = 0; c < WAVES; c++)
+            if (!has_late[c] && (w < 0 || load1[c] + extra[c] < load1[w] + extra[w]))
+               w = c;
+         const int s = P.sub_top[i];
+         P.sub_owner[s] = w;
+         extra[w] += trunk_len(P, s);
+         // its hand-up travels in the exchange slot of the first early limb of its own subtree (read by then, by this very wave)
+         P.sub_slot[s] = -1;
+         for (int k = 0; k < P.n_limbs && P.sub_slot[s] < 0; k++)
+            if (!P.late[k])
+               for (int a = TP::parent[P.root_of[k]]; a >= 0; a = TP::parent[a])
+                  if (a == s)
+                  {
+                     P.sub_slot[s] = k;
+                     break;
+                  }
+         if (P.sub_slot[s] < 0)
+            return; // a sub-trunk without a limb of its own cannot happen (trunk = branching), but stay plain if it does
+      }
+      P.staged = true;
+   }
    static constexpr Plan make()
    {
       Plan P;
@@ -221,6 +357,16 @@ struct Split
          load[w] += bs;
          done[best] = true;
       }
+      for (int k = 0; k < P.n_limbs; k++)
+         P.owner_plain[k] = P.owner[k];
+      P.usable = P.n_limbs >= 2;
+      for (int j = 0; j < N; j++)
+         if (TP::parent[j] < 0 && !P.trunk[j])
+            P.usable = false; // every root must be a trunk body
+      make_stages(P);
+      if (!P.staged)
+         for (int k = 0; k < P.n_limbs; k++)
+            P.owner[k] = P.owner_plain[k];
       // ABA hand-over placement: trunk bodies in LDS (all waves write the same values), limb bodies in the owner's registers
       int regs[WAVES] = {};
       for (int j = 0; j < N; j++)
@@ -235,10 +381,6 @@ struct Split
       }
       for (int w = 0; w < WAVES; w++)
          P.reg_slots = regs[w] > P.reg_slots ? regs[w] : P.reg_slots;
-      P.usable = P.n_limbs >= 2;
-      for (int j = 0; j < N; j++)
-         if (TP::parent[j] < 0 && !P.trunk[j])
-            P.usable = false; // every root must be a trunk body
       return P;
    }
    static constexpr Plan P = make();
@@ -246,7 +388,23 @@ struct Split
    static constexpr int n_limbs() { return P.n_limbs; }
    static constexpr int limb_root(int k) { return P.root_of[k]; }
    static constexpr int limb_index(int root) { return P.limb_of[root]; }
-   static constexpr int owner(int k) { return P.owner[k]; }
+   static constexpr int owner(int k) { return P.owner[k]; }             // ABA
+   static constexpr int owner_plain(int k) { return P.owner_plain[k]; } // RNEA, CRBA
+   static constexpr bool staged() { return P.staged; }
+   static constexpr int root() { return P.root; }
+   static constexpr bool is_late(int k) { return P.late[k]; }
+   static constexpr int n_sub() { return P.n_sub; }
+   static constexpr int sub_top(int i) { return P.sub_top[i]; }
+   static constexpr int sub_owner(int j) { return P.sub_owner[j]; }
+   static constexpr int sub_slot(int j) { return P.sub_slot[j]; }
+   static constexpr int cut_limb(int w) { return P.cut_limb[w]; }
+   static constexpr bool is_cut(int j)
+   {
+      for (int w = 0; w < WAVES; w++)
+         if (P.staged && P.cut_body[w] == j)
+            return true;
+      return false;
+   }
    static constexpr bool usable() { return P.usable; }
    static constexpr int trunk_slot(int j) { return P.trunk_slot[j]; }
    static constexpr int TRUNK_SLOTS = P.trunk_slot[N];
@@ -622,6 +780,9 @@ template <class TP, int J, typename T, class CX, int MODE = 0>
 struct AbaIn
 { // inward sweep (ForwardDynamicsCalculator.java:1085-1254) as a depth-first recursion.  Only (v, cos, sin, qd) of a body
   // stay live while its subtree is walked; everything that depends on the inertia is formed after the children returned.
+  // MODE 0: whole subtree.  1: trunk pass of the tree-split kernels (limb roots come from the exchange area).  2: staged trunk, the
+  // root body alone (limbs AND sub-trunks come from the exchange area).  3: a late limb of the staged scheme -- as 0, with the
+  // workgroup's first barrier between the steps of two of its bodies (Split<TP>::is_cut).
    template <int K>
    static MH_DEV void children(const CX &cx, const SV<T> &v, AbaUp<T> &acc)
    {
@@ -629,8 +790,10 @@ struct AbaIn
       {
          constexpr int C = Tree<TP>::child(J, K);
          AbaUp<T> c;
-         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+         if constexpr ((MODE == 1 || MODE == 2) && !Split<TP>::is_trunk(C))
             c = x_get_up<Split<TP>::limb_index(C), CX, T>(cx);
+         else if constexpr (MODE == 2)
+            c = x_get_up<Split<TP>::sub_slot(C), CX, T>(cx); // staged trunk: the sub-trunk below R was folded by one wave
          else
             c = AbaIn<TP, C, T, CX, MODE>::run(cx, v);
          if constexpr (K == 0)
@@ -661,6 +824,8 @@ struct AbaIn
       MH_BODY_FENCE();
       if constexpr (!LEAF)
          children<0>(cx, v, up);
+      if constexpr (MODE == 3 && Split<TP>::is_cut(J))
+         __syncthreads(); // barrier 1 of the staged trunk: the early limbs of every wave are in the exchange area
       MH_BODY_FENCE();
       if constexpr (!LEAF)
       {
@@ -1053,7 +1218,7 @@ MH_DEV void split_crba_limbs(const CX &cx)
    using S = Split<TP>;
    if constexpr (K < S::n_limbs())
    {
-      if (cx.wave == S::owner(K))
+      if (cx.wave == S::owner_plain(K))
       {
          constexpr int R = S::limb_root(K), D = Tree<TP>::depth(R);
          CrbaPath<T, D> path;
@@ -1232,7 +1397,7 @@ MH_DEV void split_rnea_limbs_of(const CX &cx, SV<T> &vp, SV<T> &ap)
    using S = Split<TP>;
    if constexpr (K < S::n_limbs())
    {
-      if constexpr (S::owner(K) == W)
+      if constexpr (S::owner_plain(K) == W)
       {
          constexpr int R = S::limb_root(K), P = TP::parent[R];
          if constexpr (P != PC)
@@ -1300,6 +1465,69 @@ MH_DEV void split_aba_limbs(const CX &cx)
       }
       else
          split_aba_limbs<TP, W + 1, T, CX>(cx);
+   }
+}
+
+// ---- staged trunk (Split<TP>::make_stages): the limbs of wave W, early (LATE = 0) or late (LATE = 1), in limb order; the late limb
+//      that carries the wave's cut runs in MODE 3 (barrier 1 inside)
+template <class TP, int W, int K, int PC, int LATE, typename T, class CX>
+MH_DEV void staged_limbs_of(const CX &cx, SV<T> &vp)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if constexpr (S::owner(K) == W && (S::is_late(K) ? 1 : 0) == LATE)
+      {
+         constexpr int R = S::limb_root(K), P = TP::parent[R];
+         if constexpr (P != PC)
+         {
+            const V3<T> Z{T(0), T(0), T(0)};
+            vp = SV<T>{Z, Z};
+            if constexpr (P >= 0)
+               vp = trunk_v<TP, P, T, CX>(cx);
+         }
+         x_put_up<K, CX, T>(cx, AbaIn<TP, R, T, CX, (S::cut_limb(W) == K ? 3 : 0)>::run(cx, vp));
+         staged_limbs_of<TP, W, K + 1, P, LATE, T, CX>(cx, vp);
+      }
+      else
+         staged_limbs_of<TP, W, K + 1, PC, LATE, T, CX>(cx, vp);
+   }
+}
+// the sub-trunks wave W folds between the two barriers
+template <class TP, int W, int I, typename T, class CX>
+MH_DEV void staged_subtrunks_of(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (I < S::n_sub())
+   {
+      constexpr int ST = S::sub_top(I);
+      if constexpr (S::sub_owner(ST) == W)
+      {
+         const SV<T> vr = trunk_v<TP, S::root(), T, CX>(cx);
+         x_put_up<S::sub_slot(ST), CX, T>(cx, AbaIn<TP, ST, T, CX, 1>::run(cx, vr));
+      }
+      staged_subtrunks_of<TP, W, I + 1, T, CX>(cx);
+   }
+}
+// Phases 1 and 2 of wave W.  Every wave passes barrier 1 exactly once: inside its cut limb, or explicitly after its early limbs.
+template <class TP, int W, typename T, class CX>
+MH_DEV void split_aba_staged(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+      {
+         const V3<T> Z{T(0), T(0), T(0)};
+         SV<T> vp{Z, Z};
+         staged_limbs_of<TP, W, 0, -2, 0, T, CX>(cx, vp);
+         if constexpr (S::cut_limb(W) < 0)
+            __syncthreads();
+         staged_limbs_of<TP, W, 0, -2, 1, T, CX>(cx, vp);
+         staged_subtrunks_of<TP, W, 0, T, CX>(cx);
+      }
+      else
+         split_aba_staged<TP, W + 1, T, CX>(cx);
    }
 }
 
@@ -1379,9 +1607,11 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
       cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
       MH_STAMP(1);
       if (active)
-      {
+      { // (lane 0 of every wave is active in every slice, so each wave does reach the barrier the staged ABA carries in here)
          if constexpr (ALGO == 0)
             split_rnea_limbs<TP, 0, T, CX>(cx);
+         else if constexpr (S::staged())
+            split_aba_staged<TP, 0, T, CX>(cx);
          else
             split_aba_limbs<TP, 0, T, CX>(cx);
       }
@@ -1397,7 +1627,7 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
          }
          else
          {
-            aba_roots_in<TP, T, CX, 1>(cx);
+            aba_roots_in<TP, T, CX, (S::staged() ? 2 : 1)>(cx);
             MH_STAMP(4);
             asm volatile("" ::: "memory");
             asm volatile("" : "+v"(cx.qrow), "+v"(cx.qdrow), "+v"(cx.lq), "+v"(cx.lqd), "+v"(cx.st.lbase));
