@@ -105,7 +105,10 @@ def registered_models():
     rng = np.random.default_rng(0)
     humanoid = rt.nextHumanoid(rng).toModelDesc()                                                     # configs[2], configs[3], the metric
     arm7 = MultiBodySystem.toMultiBodySystemInput(rt.nextJointChain(rng, 7)[0].getPredecessor()).toModelDesc()  # configs[0], configs[1]
-    return {"humanoid30": humanoid, "arm7": arm7}
+    # two more tree shapes, so that every branch of the tree-split planner has a code object the GPU tests run (seconds to compile):
+    quadruped = rt.nextQuadruped(rng).toModelDesc()       # limbs on the root only: plain split, no staged trunk
+    torso = rt.nextFixedBaseTorso(rng).toModelDesc()      # revolute root, sub-trunk, mixed joints, a one-body late limb
+    return {"humanoid30": humanoid, "arm7": arm7, "quadruped18": quadruped, "torso13": torso}
 
 
 def build_all(force: bool = False, verbose: bool = False):

@@ -204,6 +204,24 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
    return (int)go_split_algo<false, false>(algo, A, groups, s);
 #endif
 }
+// the tree-split plan of this topology, for tests and documentation: out[0] = usable, [1] = staged trunk, [2] = limbs, [3] = sub-trunks,
+// [4] = root trunk body, then per limb (root body, bodies, ABA owner wave, RNEA / CRBA owner wave, late) and per wave the body after
+// whose children its cut barrier sits (-1: explicit barrier).  Returns the number of ints written (<= cap).
+int mh_spec_split_plan(int *out, int cap)
+{
+   int n = 0;
+   auto put = [&](int v) {
+      if (n < cap)
+         out[n] = v;
+      n++;
+   };
+   put(SPL::usable() ? 1 : 0), put(SPL::staged() ? 1 : 0), put(SPL::n_limbs()), put(SPL::n_sub()), put(SPL::root());
+   for (int k = 0; k < SPL::n_limbs(); k++)
+      put(SPL::limb_root(k)), put(SPL::P.size_of[k]), put(SPL::owner(k)), put(SPL::owner_plain(k)), put(SPL::is_late(k) ? 1 : 0);
+   for (int w = 0; w < 4; w++)
+      put(SPL::P.cut_body[w]);
+   return n < cap ? n : cap;
+}
 int mh_spec_n(void) { return TP::N; }
 const int *mh_spec_parents(void) { return kParents; }
 const int *mh_spec_types(void) { return kTypes; }

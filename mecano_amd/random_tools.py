@@ -163,6 +163,41 @@ def nextHumanoid(rng) -> MultiBodySystem:
     return MultiBodySystem.toMultiBodySystemInput(root)
 
 
+def nextQuadruped(rng) -> MultiBodySystem:
+    """SixDoF trunk + four 3-joint legs (13 bodies, nv = 18): the only branching body is the root, so a tree-split code object has limbs
+    but no sub-trunk (plain, un-staged plan)."""
+    root = RigidBody("elevator")
+    trunk = nextRigidBody(rng, "trunkBody", SixDoFJoint("trunk", root))
+    for leg in ("frontLeft", "frontRight", "hindLeft", "hindRight"):
+        body = trunk
+        for k in range(3):
+            body = nextRigidBody(rng, f"{leg}{k}Body", nextRevoluteJoint(rng, f"{leg}{k}", body))
+    return MultiBodySystem.toMultiBodySystemInput(root)
+
+
+def nextFixedBaseTorso(rng) -> MultiBodySystem:
+    """A fixed-base machine that exercises the other corners of the tree-split planner: a REVOLUTE root body carrying (i) a two-body
+    sub-trunk that ends in two mixed revolute / prismatic arms of different length plus a one-body head, (ii) a four-body late limb and
+    (iii) a ONE-body late limb (no room for a cut: its owner takes the explicit barrier).  13 bodies, all 1-DoF."""
+    root = RigidBody("base")
+    waist = nextRigidBody(rng, "waistBody", nextRevoluteJoint(rng, "waist", root))
+
+    def chain(prefix, base, kinds):
+        body = base
+        for k, kind in enumerate(kinds):
+            j = (nextRevoluteJoint if kind == "r" else nextPrismaticJoint)(rng, f"{prefix}{k}", body)
+            body = nextRigidBody(rng, f"{prefix}{k}Body", j)
+        return body
+
+    chest = chain("spine", waist, "rp")
+    chain("leftArm", chest, "rrp")
+    chain("rightArm", chest, "rr")
+    chain("head", chest, "r")
+    chain("boom", waist, "rprr")
+    chain("stub", waist, "p")
+    return MultiBodySystem.toMultiBodySystemInput(root)
+
+
 def nextState(rng, system: MultiBodySystem, batch: int, q_range=np.pi):
     """Random batched (q, qd, qdd, tau) matrices [B, nq] / [B, nv] honouring the system's index provider."""
     provider = system.getJointMatrixIndexProvider()

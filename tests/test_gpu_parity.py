@@ -852,6 +852,46 @@ def test_coriolis_on_the_humanoid_with_the_calculator_mirror(torch_cuda):
         assert np.abs(rate[k] - np.concatenate([n_root, f_root])).max() <= 1e-9 * max(1.0, np.abs(tau[k]).max())
 
 
+@pytest.mark.parametrize("shape", ["quadruped", "torso"])
+def test_other_tree_shapes_with_specialised_code_objects(torch_cuda, shape):
+    """The tree-split planner on shapes other than the humanoid (mecano_amd/build.py registers their code objects): a quadruped (limbs on
+    the root only: plain split) and a fixed-base torso (revolute root, sub-trunk, revolute + prismatic limbs, a one-body late limb: staged
+    trunk with an explicit barrier for that limb's owner).  RNEA, ABA, CRBA, the fused call and the fused simulation step against the
+    oracle at ragged and full batch sizes, AoS and SoA, with external wrenches; physical parameters differ from the build-time model."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd import _lib
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
+    sys_ = (rt.nextQuadruped if shape == "quadruped" else rt.nextFixedBaseTorso)(rng)
+    d = sys_.toModelDesc()
+    hm, om = HipModel(d), OracleModel(d)
+    assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant
+    g = (0.4, -0.1, -9.81)
+    for B in (1, 63, 64, 200, 4096, 20000):
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 200)), [B - 1]]))
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6)) if B in (63, 4096) else None
+        fi = None if fext is None else fext[idx]
+        tq, tqd, tqdd, ttau, tf = dev(torch, q), dev(torch, qd), dev(torch, qdd), dev(torch, tau), dev(torch, fext)
+        t_ref, a_ref = om.rnea(q[idx], qd[idx], qdd[idx], g, fi), om.aba(q[idx], qd[idx], tau[idx], g, fi)
+        close(hm.rnea(tq, tqd, tqdd, g, tf).cpu().numpy()[idx], t_ref)
+        close(hm.aba(tq, tqd, ttau, g, tf).cpu().numpy()[idx], a_ref)
+        t2, a2 = hm.rnea_aba(tq, tqd, tqdd, ttau, g, tf)
+        close(t2.cpu().numpy()[idx], t_ref), close(a2.cpu().numpy()[idx], a_ref)
+        hidx = idx[:: max(1, len(idx) // 30)]
+        close(hm.crba(tq).cpu().numpy()[hidx], om.crba(q[hidx]))
+        if fext is None:
+            T = lambda x: x.t().contiguous()
+            close(hm.aba(T(tq), T(tqd), T(ttau), g, layout=_lib.LAYOUT_SOA).t().cpu().numpy()[idx], a_ref)
+            close(hm.rnea(T(tq), T(tqd), T(tqdd), g, layout=_lib.LAYOUT_SOA).t().cpu().numpy()[idx], t_ref)
+            dt = 1.0e-3
+            r_q, r_v, _ = om.integrate(dt, q[idx], qd[idx], a_ref)
+            nq_, nv_, _ = hm.step(dt, tq, tqd, ttau, g)
+            close(nq_.cpu().numpy()[idx], r_q, 1e-12), close(nv_.cpu().numpy()[idx], r_v, 1e-11)
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()

@@ -104,3 +104,38 @@ def test_ignored_subtree_lumping_equals_welding():
     # without lumping the ignored subtree's inertia is simply gone: a different system
     d_n = ignoring.toModelDesc(considerIgnoredSubtreesInertia=False)
     assert np.abs(OracleModel(d_n).rnea(q, qd, qdd, g) - om_w.rnea(q, qd, qdd, g)).max() > 1e-3
+
+
+def test_tree_split_plans_of_the_registered_code_objects():
+    """The compile-time partition each specialised code object was built with (mh_spec_split_plan, host-only): the humanoid and the
+    fixed-base torso get the staged trunk (a sub-trunk folded between two barriers), the quadruped the plain split (no sub-trunk), the
+    7-joint arm none (a chain).  Checks the invariants the kernels rely on: one late limb per wave at most, a free wave for the sub-trunk,
+    every limb owned, the cut inside its wave's late limb."""
+    import ctypes
+    from mecano_amd import build as b
+    try:
+        paths = {name: b.build_spec(desc) for name, desc in b.registered_models().items()}
+    except Exception as e:  # no hipcc and no prebuilt objects
+        pytest.skip(f"specialised code objects unavailable: {e}")
+    expect = {"humanoid30": (1, 1), "arm7": (0, 0), "quadruped18": (1, 0), "torso13": (1, 1)}
+    for name, path in paths.items():
+        lib = ctypes.CDLL(path)
+        buf = (ctypes.c_int * 256)()
+        n = lib.mh_spec_split_plan(buf, 256)
+        v = list(buf[:n])
+        usable, staged, n_limbs, n_sub, root = v[:5]
+        assert (usable, staged) == expect[name], (name, v)
+        limbs = [v[5 + 5 * k: 10 + 5 * k] for k in range(n_limbs)]
+        cuts = v[5 + 5 * n_limbs: 9 + 5 * n_limbs]
+        if not usable:
+            continue
+        assert all(0 <= l[2] < 4 and 0 <= l[3] < 4 for l in limbs)
+        if staged:
+            late_owners = [l[2] for l in limbs if l[4]]
+            assert len(late_owners) == len(set(late_owners)) <= 3 and n_sub >= 1 and root >= 0
+            for w, c in enumerate(cuts):
+                if c >= 0:  # the cut body belongs to a late limb of wave w
+                    assert any(l[4] and l[2] == w and l[0] <= c < l[0] + l[1] for l in limbs), (name, w, c, limbs)
+        else:
+            assert all(l[2] == l[3] for l in limbs)
+        print(name, "staged" if staged else "plain", limbs, cuts)
