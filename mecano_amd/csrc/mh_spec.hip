@@ -127,7 +127,7 @@ long split_lds_bytes(int algo, int flags, int nq, int nv)
 {
    if (algo == 2)
       return std::max(split_lds_bytes(0, flags, nq, nv), split_lds_bytes(1, flags, nq, nv));
-   long b = (long)(SPL::n_limbs() * (algo == 0 ? 6 : 27) + (algo == 1 ? SPL::TRUNK_SLOTS : 0)) * 64 * sizeof(double);
+   long b = (long)(SPL::n_limbs() * (algo == 0 ? 6 : 27) + (algo == 1 ? SPL::TRUNK_SLOTS : SPL::RNEA_TRUNK_SLOTS)) * 64 * sizeof(double);
    if (flags & F_IO_LDS)
       b += (long)(nq + 2 * nv) * 64 * sizeof(double);
    return b;

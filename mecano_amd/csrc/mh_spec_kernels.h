@@ -159,6 +159,11 @@ struct Split
       bool usable = false;
       // RNEA / CRBA keep the plain greedy assignment; `owner` is the ABA's, phase-aware when the trunk is staged
       int owner_plain[N] = {};
+      // RNEA: the Newton-Euler wrench of every trunk body is formed during the limb phase, by the wave that walks through the body first
+      // on its way to a limb (f_limb: that limb), and parked in LDS (8 slots per trunk body: wrench, cos, sin)
+      int trunk_rank[N] = {};
+      int f_limb[N] = {};
+      int n_trunk = 0;
       // ---- staged trunk (ABA): see make_stages()
       bool staged = false;
       int root = -1;          // the root trunk body R
@@ -359,6 +364,38 @@ struct Split
       }
       for (int k = 0; k < P.n_limbs; k++)
          P.owner_plain[k] = P.owner[k];
+      {
+         // which limbs really walk the trunk down to their parent (a limb that follows, on the same wave, one with the same parent reuses
+         // that walk), and how loaded their owners are: the wrench of trunk body j is formed by the least loaded wave that passes it
+         bool walks[N] = {};
+         int plain_load[WAVES] = {}, last_parent[WAVES] = {};
+         for (int w = 0; w < WAVES; w++)
+            last_parent[w] = -2;
+         for (int k = 0; k < P.n_limbs; k++)
+         {
+            const int w = P.owner_plain[k], par = TP::parent[P.root_of[k]];
+            walks[k] = par != last_parent[w] && par >= 0;
+            last_parent[w] = par;
+            plain_load[w] += P.size_of[k];
+         }
+         for (int j = 0; j < N; j++)
+         {
+            P.f_limb[j] = -1;
+            if (!P.trunk[j])
+               continue;
+            P.trunk_rank[j] = P.n_trunk++;
+            for (int k = 0; k < P.n_limbs; k++)
+            {
+               if (!walks[k])
+                  continue;
+               bool through = false;
+               for (int a = TP::parent[P.root_of[k]]; a >= 0; a = TP::parent[a])
+                  through = through || a == j;
+               if (through && (P.f_limb[j] < 0 || plain_load[P.owner_plain[k]] < plain_load[P.owner_plain[P.f_limb[j]]]))
+                  P.f_limb[j] = k;
+            }
+         }
+      }
       P.usable = P.n_limbs >= 2;
       for (int j = 0; j < N; j++)
          if (TP::parent[j] < 0 && !P.trunk[j])
@@ -390,6 +427,9 @@ struct Split
    static constexpr int limb_index(int root) { return P.limb_of[root]; }
    static constexpr int owner(int k) { return P.owner[k]; }             // ABA
    static constexpr int owner_plain(int k) { return P.owner_plain[k]; } // RNEA, CRBA
+   static constexpr int f_limb(int j) { return P.f_limb[j]; }
+   static constexpr int rnea_trunk_slot(int j) { return 8 * P.trunk_rank[j]; }
+   static constexpr int RNEA_TRUNK_SLOTS = 8 * P.n_trunk;
    static constexpr bool staged() { return P.staged; }
    static constexpr int root() { return P.root; }
    static constexpr bool is_late(int k) { return P.late[k]; }
@@ -684,7 +724,10 @@ MH_DEV void rnea_roots(const CX &cx)
    }
 }
 // velocity and acceleration of trunk body J, walked down from the root (tree-split kernels: every wave needs them for its limbs)
-template <class TP, int J, typename T, class CX>
+// FK = the limb this walk is for: the walk of limb Split<TP>::f_limb(J) also forms the body's own Newton-Euler wrench
+// f = I a + v x* I v - f_ext (InverseDynamicsCalculator.java:935-947) and parks it with (cos, sin) in the LDS trunk area, so that
+// the trunk pass after the barrier is a pure fold of 6-vectors (RneaTrunkUp) instead of a second full walk by one wave
+template <class TP, int J, typename T, class CX, int FK = -1>
 MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
 {
    constexpr int TYPE = TP::type[J];
@@ -692,7 +735,7 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
    const V3<T> Z{T(0), T(0), T(0)};
    SV<T> vp{Z, Z}, ap{Z, cx.a0l};
    if constexpr (TP::parent[J] >= 0)
-      trunk_va<TP, TP::parent[J], T, CX>(cx, vp, ap);
+      trunk_va<TP, TP::parent[J], T, CX, FK>(cx, vp, ap);
    MH_BODY_FENCE();
    const CRef<T, false> c{cx.C + J * MC_STRIDE};
    const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
@@ -705,7 +748,67 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
    a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
    if (!cx.coriolis)
       v = SV<T>{Z, Z};
+   if constexpr (FK >= 0 && Split<TP>::f_limb(J) == FK)
+   {
+      const RI<T> I = load_inertia<T>(c);
+      SV<T> f = mul(I, a) + crf(v, mul(I, v));
+      if (cx.frow)
+         f = f - load_fext<T>(c, cx.frow, cx.f_es, cx.meta[J * MI_STRIDE + MI_EXT]);
+      constexpr int S0 = Split<TP>::rnea_trunk_slot(J);
+      const lds_ptr<T> t = cx.st.lbase;
+      t[(S0 + 0) * 64] = f.a.x, t[(S0 + 1) * 64] = f.a.y, t[(S0 + 2) * 64] = f.a.z;
+      t[(S0 + 3) * 64] = f.l.x, t[(S0 + 4) * 64] = f.l.y, t[(S0 + 5) * 64] = f.l.z;
+      t[(S0 + 6) * 64] = jx.c, t[(S0 + 7) * 64] = jx.s;
+   }
    MH_BODY_FENCE();
+}
+// The trunk pass of the tree-split RNEA (wave 0, after the barrier): wrench of trunk body J = its own (parked by trunk_va) + what its
+// limbs (exchange area) and trunk children hand up; joint effort; hand-up to the parent (InverseDynamicsCalculator.java:949-966).
+template <class TP, int J, typename T, class CX>
+struct RneaTrunkUp
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx, SV<T> &f)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         constexpr int C = Tree<TP>::child(J, K);
+         if constexpr (!Split<TP>::is_trunk(C))
+            f = f + x_get6<Split<TP>::limb_index(C), 6, 0, CX, T>(cx);
+         else
+            f = f + RneaTrunkUp<TP, C, T, CX>::run(cx);
+         children<K + 1>(cx, f);
+      }
+   }
+   static MH_DEV SV<T> run(const CX &cx)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J), S0 = Split<TP>::rnea_trunk_slot(J);
+      const lds_ptr<T> t = cx.st.lbase;
+      SV<T> f{V3<T>{t[(S0 + 0) * 64], t[(S0 + 1) * 64], t[(S0 + 2) * 64]}, V3<T>{t[(S0 + 3) * 64], t[(S0 + 4) * 64], t[(S0 + 5) * 64]}};
+      JX<T> jx;
+      jx.c = t[(S0 + 6) * 64], jx.s = t[(S0 + 7) * 64], jx.d = T(0);
+      if constexpr (TYPE != JT_REVOLUTE && TP::parent[J] >= 0)
+         jx = spec_joint_from<TYPE, T>(spec_joint_read<TYPE, CO, CX, T>(cx));
+      children<0>(cx, f);
+      MH_BODY_FENCE();
+      spec_write<TYPE, DO, CX, T>(cx, f);
+      SV<T> up = f;
+      if constexpr (TP::parent[J] >= 0)
+         up = force_up(TYPE, jx, load_xb<T>(CRef<T, false>{cx.C + J * MC_STRIDE}), f);
+      MH_BODY_FENCE();
+      return up;
+   }
+};
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void rnea_trunk_roots(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      (void)RneaTrunkUp<TP, Tree<TP>::child(-1, K), T, CX>::run(cx);
+      rnea_trunk_roots<TP, T, CX, K + 1>(cx);
+   }
 }
 // velocity only (ABA)
 template <class TP, int J, typename T, class CX>
@@ -1405,7 +1508,7 @@ MH_DEV void split_rnea_limbs_of(const CX &cx, SV<T> &vp, SV<T> &ap)
             const V3<T> Z{T(0), T(0), T(0)};
             vp = SV<T>{Z, Z}, ap = SV<T>{Z, cx.a0l};
             if constexpr (P >= 0)
-               trunk_va<TP, P, T, CX>(cx, vp, ap);
+               trunk_va<TP, P, T, CX, K>(cx, vp, ap);
          }
          x_put6<K, 6, 0, CX, T>(cx, RneaSub<TP, R, T, CX, 0>::run(cx, vp, ap));
          split_rnea_limbs_of<TP, W, K + 1, P, T, CX>(cx, vp, ap);
@@ -1573,9 +1676,9 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
    const int nq = A.m.nq, nv = A.m.nv;
-   // LDS map: exchange [n_limbs * XW][64] | trunk hand-over slots [TRUNK_SLOTS][64] (ABA) | [64][nq] q | [64][nv] qd | [64][nv] qdd|tau -> result
-   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * XW * 64, lq = lst + (ALGO == 1 ? S::TRUNK_SLOTS * 64 : 0), lqd = lq + 64 * nq,
-                    lx = lqd + 64 * nv;
+   // LDS map: exchange [n_limbs * XW][64] | trunk hand-over slots [TRUNK_SLOTS][64] (ABA) or parked trunk wrenches [RNEA_TRUNK_SLOTS][64] (RNEA) | [64][nq] q | [64][nv] qd | [64][nv] qdd|tau -> result
+   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * XW * 64, lq = lst + (ALGO == 1 ? S::TRUNK_SLOTS : S::RNEA_TRUNK_SLOTS) * 64,
+                    lqd = lq + 64 * nq, lx = lqd + 64 * nv;
 #ifdef MH_PROBE // experiment builds: s_memtime stamps per wave and phase, written behind the B * nv results (tools/exp_probe.py)
 #define MH_STAMP(k)                                                                                                                        \
    do                                                                                                                                      \
@@ -1623,7 +1726,7 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
          if constexpr (ALGO == 0)
          {
             if (wave == 0)
-               rnea_roots<TP, T, CX, 1>(cx);
+               rnea_trunk_roots<TP, T, CX>(cx);
          }
          else
          {
