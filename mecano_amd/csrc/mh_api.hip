@@ -218,10 +218,9 @@ bool split_ok(const mh_model *m, int algo, int64_t B, bool soa)
       return false;
    if (m->spec.split_lds_bytes(algo, split_flags(m, algo, soa), m->nq, m->nv) > 160 * 1024)
       return false;
-   if (m->use_split == 1 || algo == 1)
-      return true; // ABA: the split form also needs fewer registers and measured faster at every batch size
-   if (algo == 0 && (split_flags(m, algo, soa) & SPEC_IO_LDS))
-      return true; // RNEA with rows staged in LDS: 183 registers = two waves per SIMD, measured 1.25x the whole-tree kernel at B = 32768 .. 262144
+   if (m->use_split == 1 || algo == 1 || algo == 0)
+      return true; // ABA: the split form needs fewer registers; RNEA: two waves per SIMD and a trunk pass that is a fold of parked
+                   // wrenches -- both measured faster than the whole-tree kernels at every batch size and in both layouts
    const long groups = (B + 63) / 64;
    const long waves = groups * 4 * (algo == 2 ? 2 : 1);
    return waves <= (long)m->cu_count * 4; // fused / SoA RNEA: while the batch cannot give every SIMD a wave of its own
