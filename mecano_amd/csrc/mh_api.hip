@@ -129,6 +129,9 @@ struct mh_model
    Workspace ws;
    // staging buffers of the *_host entry points
    Workspace stage;
+   // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices)
+   Workspace tr;
+   int use_transpose = -1; // MH_GENERIC_TRANSPOSE = 0 | 1 overrides the size heuristic
    std::string variant = "generic";
    int use_split = -1;      // MH_SPEC_SPLIT = 0 | 1: never / whenever possible use the tree-split kernels (default: small batches)
    int use_fused = 1;       // MH_DISABLE_FUSED=1: mh_rnea_aba_f64 always issues two launches
@@ -356,6 +359,28 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       return MH_OK;
       } // else: this (algorithm, memory plan) is not in the code object -- the run-time-topology kernels below serve the call
    }
+   // Run-time-topology RNEA / ABA on AoS matrices: for big batches of wide matrices go through transposed scratch copies
+   // (mh::transpose_kernel).  External wrenches keep their own strides.
+   T *t_out = nullptr;
+   if (algo != ALGO_CRBA && !soa)
+   {
+      const bool want = model->use_transpose >= 0 ? model->use_transpose != 0 : (B >= 8192 && model->nq + model->nv >= 64);
+      if (want)
+      {
+         const size_t nq = model->nq, nv = model->nv;
+         mh_status s3 = ensure_bytes(model->tr, (size_t)B * (nq + 3 * nv) * sizeof(T));
+         if (s3 != MH_OK)
+            return s3;
+         T *t_q = (T *)model->tr.ptr, *t_qd = t_q + (size_t)B * nq, *t_in3 = t_qd + (size_t)B * nv;
+         t_out = t_in3 + (size_t)B * nv;
+         const dim3 gq((unsigned)(((B + 63) / 64) * ((nq + 63) / 64))), gv((unsigned)(((B + 63) / 64) * ((nv + 63) / 64)));
+         hipLaunchKernelGGL((mh::transpose_kernel<T>), gq, dim3(256), 0, stream, q, t_q, (long)B, (long)nq);
+         hipLaunchKernelGGL((mh::transpose_kernel<T>), gv, dim3(256), 0, stream, qd, t_qd, (long)B, (long)nv);
+         hipLaunchKernelGGL((mh::transpose_kernel<T>), gv, dim3(256), 0, stream, in3, t_in3, (long)B, (long)nv);
+         A.q = t_q, A.qd = t_qd, A.in3 = t_in3, A.out = t_out;
+         A.q_bs = 1, A.q_es = B, A.v_bs = 1, A.v_es = B;
+      }
+   }
    switch (algo)
    {
       case ALGO_RNEA:
@@ -403,6 +428,11 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
          { if (ldsc) hipLaunchKernelGGL((mh::crba_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::crba_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
          break;
       }
+   }
+   if (t_out)
+   {
+      const dim3 go((unsigned)(((model->nv + 63) / 64) * ((B + 63) / 64)));
+      hipLaunchKernelGGL((mh::transpose_kernel<T>), go, dim3(256), 0, stream, (const T *)t_out, out, (long)model->nv, (long)B);
    }
    HIP_TRY(hipGetLastError());
    return MH_OK;
@@ -955,6 +985,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    m->lds_consts = 0; // measured on the 128-body tree (fp32, B = 131072): no difference to scalar loads
    if (const char *e = getenv("MH_GENERIC_LDS"))
       m->lds_consts = atoi(e) != 0;
+   if (const char *e = getenv("MH_GENERIC_TRANSPOSE"))
+      m->use_transpose = atoi(e) != 0;
    if (const char *e = getenv("MH_WAVES_PER_CU"))
       m->waves_per_cu = std::max(1, std::min(32, atoi(e)));
    if (const char *e = getenv("MH_SPEC_ST"))
@@ -977,6 +1009,7 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
    (void)hipFree(m->stage.ptr);
+   (void)hipFree(m->tr.ptr);
    if (m->spec.handle)
       dlclose(m->spec.handle);
    delete m;

@@ -194,6 +194,22 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
     assert np.abs(a64 - qdd).max() < 1e-5  # ill-conditioned deep random tree; the reference asks 1e-4 on such systems
     a32 = hm.aba(dev(torch, q, f32), dev(torch, qd, f32), dev(torch, tau, f32), g).cpu().numpy()
     assert np.isfinite(a32).all()
+    # big AoS batches of wide matrices go through transposed scratch copies (mh::transpose_kernel): same numbers as the direct AoS
+    # path (B < 8192 above), as the SoA path, and as the oracle; ragged batch size, external wrenches keep their AoS strides
+    from mecano_amd import _lib
+    B2 = 8192 + 37
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B2)
+    fext = rng.uniform(-1, 1, (B2, d.n_joints, 6))
+    tq, tqd, tqdd, ttau, tf = (dev(torch, x) for x in (q, qd, qdd, tau, fext))
+    idx = np.arange(0, B2, 211)
+    t_aos = hm.rnea(tq, tqd, tqdd, g, tf)
+    close(t_aos.cpu().numpy()[idx], om.rnea(q[idx], qd[idx], qdd[idx], g, fext[idx]), 1e-9)
+    T = lambda x: x.t().contiguous()
+    t_soa = hm.rnea(T(tq), T(tqd), T(tqdd), g, layout=_lib.LAYOUT_SOA)
+    assert torch.equal(hm.rnea(tq, tqd, tqdd, g), t_soa.t())
+    a_aos = hm.aba(tq, tqd, t_aos, g, tf)
+    assert (a_aos - tqdd).abs().max().item() < 1e-5
+    assert torch.equal(hm.aba(tq, tqd, ttau, g), hm.aba(T(tq), T(tqd), T(ttau), g, layout=_lib.LAYOUT_SOA).t())
 
 
 def test_layouts_soa_equals_aos(torch_cuda):
