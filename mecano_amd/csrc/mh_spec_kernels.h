@@ -1912,6 +1912,48 @@ __global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg
          const long rows = A.B - cfg0 < lpg ? A.B - cfg0 : lpg;
          const int total = (int)rows * NE;
          T *H = A.out + cfg0 * NE;
+         if constexpr (NE % 2 == 0 && sizeof(T) == 8)
+         { // two entries = 16 bytes per lane and store (a pair never straddles two matrices): half the instructions of the loop and
+           // twice the bytes each store instruction keeps in flight -- the write-out is bound by the latter
+            if ((((unsigned long long)A.out) & 15) == 0)
+            {
+               typedef double __attribute__((ext_vector_type(2))) d2;
+               constexpr int NP = NE / 2, STEP2 = 256, SC2 = STEP2 / NP, SE2 = STEP2 - SC2 * NP, UN2 = 4;
+               const int pairs = (int)rows * NP;
+               int gp = threadIdx.x, c2 = gp / NP, p2 = gp - c2 * NP;
+               while (gp < pairs)
+               {
+                  int s0[UN2], s1[UN2], cc[UN2];
+#pragma unroll
+                  for (int u = 0; u < UN2; u++)
+                  {
+                     const bool in = gp + u * STEP2 < pairs;
+                     s0[u] = in ? (int)tab[2 * p2] : -1;
+                     s1[u] = in ? (int)tab[2 * p2 + 1] : -1;
+                     cc[u] = c2;
+                     c2 += SC2, p2 += SE2;
+                     if (p2 >= NP)
+                        p2 -= NP, c2++;
+                  }
+                  d2 v[UN2];
+#pragma unroll
+                  for (int u = 0; u < UN2; u++)
+                  {
+                     v[u].x = s0[u] >= 0 ? img[cc[u] * NSP + s0[u]] : 0.0;
+                     v[u].y = s1[u] >= 0 ? img[cc[u] * NSP + s1[u]] : 0.0;
+                  }
+#pragma unroll
+                  for (int u = 0; u < UN2; u++)
+                     if (gp + u * STEP2 < pairs)
+                        __builtin_nontemporal_store(v[u], (d2 *)H + gp + u * STEP2);
+                  gp += UN2 * STEP2;
+               }
+               MH_CSTAMP(6);
+               __syncthreads();
+               MH_CSTAMP(7);
+               continue;
+            }
+         }
          int g = threadIdx.x, c = g / NE, e = g - c * NE;
          constexpr int STEP = 256, SC = STEP / NE, SE = STEP - SC * NE;
          constexpr int UN = 8;
