@@ -169,8 +169,8 @@ mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double 
 mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out);
 /*
  * RNEA and ABA of the same B configurations in one call: tau_out = RNEA(q, qd, qdd), qdd_out = ABA(q, qd, tau).  The two are
- * independent; small batches run them side by side in a single launch (a 4096-configuration batch is 64 waves, a quarter of
- * what fills an MI355X), large batches as two back-to-back launches.  Same results as mh_rnea_f64 followed by mh_aba_f64.
+ * independent; batches up to 32768 configurations run them side by side in a single launch (a 4096-configuration batch is 64 waves,
+ * a quarter of what fills an MI355X), larger batches as two back-to-back launches.  Same results as mh_rnea_f64 followed by mh_aba_f64.
  */
 mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
                           const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out);

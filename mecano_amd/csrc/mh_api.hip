@@ -135,6 +135,7 @@ struct mh_model
    std::string variant = "generic";
    int use_split = -1;      // MH_SPEC_SPLIT = 0 | 1: never / whenever possible use the tree-split kernels (default: small batches)
    int use_fused = 1;       // MH_DISABLE_FUSED=1: mh_rnea_aba_f64 always issues two launches
+   int fused_factor = 4;    // one launch for RNEA + ABA while 2 * ceil(B / 64) workgroups <= cu_count * factor (MH_FUSED_FACTOR)
    int use_spec = 1;        // MH_DISABLE_SPEC=1 in the environment forces the generic kernels (A/B measurements)
    int lds_wave_factor = 1; // ABA hand-over in LDS while waves <= cu_count * factor (MH_ABA_LDS_FACTOR)
    int ident_maps = 0;      // the engine-order index maps are the identity
@@ -226,7 +227,7 @@ bool split_ok(const mh_model *m, int algo, int64_t B, bool soa)
                    // wrenches -- both measured faster than the whole-tree kernels at every batch size and in both layouts
    const long groups = (B + 63) / 64;
    const long waves = groups * 4 * (algo == 2 ? 2 : 1);
-   return waves <= (long)m->cu_count * 4; // fused / SoA RNEA: while the batch cannot give every SIMD a wave of its own
+   return waves <= (long)m->cu_count * 4 * m->fused_factor; // fused: while the batch cannot give every SIMD a wave of its own
 }
 
 enum Algo
@@ -985,6 +986,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    m->lds_consts = 0; // measured on the 128-body tree (fp32, B = 131072): no difference to scalar loads
    if (const char *e = getenv("MH_GENERIC_LDS"))
       m->lds_consts = atoi(e) != 0;
+   if (const char *e = getenv("MH_FUSED_FACTOR"))
+      m->fused_factor = std::max(1, atoi(e));
    if (const char *e = getenv("MH_GENERIC_TRANSPOSE"))
       m->use_transpose = atoi(e) != 0;
    if (const char *e = getenv("MH_WAVES_PER_CU"))
@@ -1168,7 +1171,7 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    const long waves = (B + 63) / 64;
    const bool fusable = model->n_locked == 0 && model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
-                        && opts.consider_coriolis && opts.consider_accelerations && 2 * waves <= (long)model->cu_count
+                        && opts.consider_coriolis && opts.consider_accelerations && 2 * waves <= (long)model->cu_count * model->fused_factor
                         && model->spec.fused_lds_bytes(model->nq, model->nv) <= 160 * 1024;
    if (!fusable)
    {
