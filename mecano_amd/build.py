@@ -108,7 +108,8 @@ def registered_models():
     # two more tree shapes, so that every branch of the tree-split planner has a code object the GPU tests run (seconds to compile):
     quadruped = rt.nextQuadruped(rng).toModelDesc()       # limbs on the root only: plain split, no staged trunk
     torso = rt.nextFixedBaseTorso(rng).toModelDesc()      # revolute root, sub-trunk, mixed joints, a one-body late limb
-    return {"humanoid30": humanoid, "arm7": arm7, "quadruped18": quadruped, "torso13": torso}
+    centaur = rt.nextCentaur(rng).toModelDesc()           # two sub-trunks folded by two waves, a one-body late limb on the root
+    return {"humanoid30": humanoid, "arm7": arm7, "quadruped18": quadruped, "torso13": torso, "centaur20": centaur}
 
 
 def build_all(force: bool = False, verbose: bool = False):

@@ -198,6 +198,30 @@ def nextFixedBaseTorso(rng) -> MultiBodySystem:
     return MultiBodySystem.toMultiBodySystemInput(root)
 
 
+def nextCentaur(rng) -> MultiBodySystem:
+    """SixDoF barrel with TWO sub-trunks -- a two-body torso carrying two 2-joint arms, a one-body rump carrying two 3-joint hind legs --
+    and a one-body prismatic tail on the barrel itself (the only late limb): the staged tree-split plan with two sub-trunks folded by two
+    different waves between the barriers.  15 bodies, nv = 20."""
+    root = RigidBody("elevator")
+    barrel = nextRigidBody(rng, "barrelBody", SixDoFJoint("barrel", root))
+
+    def chain(prefix, base, count, prismatic=False):
+        body = base
+        for k in range(count):
+            j = (nextPrismaticJoint if prismatic else nextRevoluteJoint)(rng, f"{prefix}{k}", body)
+            body = nextRigidBody(rng, f"{prefix}{k}Body", j)
+        return body
+
+    chest = chain("torso", barrel, 2)
+    chain("leftArm", chest, 2)
+    chain("rightArm", chest, 2)
+    rump = chain("rump", barrel, 1)
+    chain("leftHind", rump, 3)
+    chain("rightHind", rump, 3)
+    chain("tail", barrel, 1, prismatic=True)
+    return MultiBodySystem.toMultiBodySystemInput(root)
+
+
 def nextState(rng, system: MultiBodySystem, batch: int, q_range=np.pi):
     """Random batched (q, qd, qdd, tau) matrices [B, nq] / [B, nv] honouring the system's index provider."""
     provider = system.getJointMatrixIndexProvider()

@@ -868,10 +868,10 @@ def test_coriolis_on_the_humanoid_with_the_calculator_mirror(torch_cuda):
         assert np.abs(rate[k] - np.concatenate([n_root, f_root])).max() <= 1e-9 * max(1.0, np.abs(tau[k]).max())
 
 
-@pytest.mark.parametrize("shape", ["quadruped", "torso"])
+@pytest.mark.parametrize("shape", ["quadruped", "torso", "centaur"])
 def test_other_tree_shapes_with_specialised_code_objects(torch_cuda, shape):
     """The tree-split planner on shapes other than the humanoid (mecano_amd/build.py registers their code objects): a quadruped (limbs on
-    the root only: plain split) and a fixed-base torso (revolute root, sub-trunk, revolute + prismatic limbs, a one-body late limb: staged
+    the root only: plain split), a centaur (two sub-trunks folded by two waves) and a fixed-base torso (revolute root, sub-trunk, revolute + prismatic limbs, a one-body late limb: staged
     trunk with an explicit barrier for that limb's owner).  RNEA, ABA, CRBA, the fused call and the fused simulation step against the
     oracle at ragged and full batch sizes, AoS and SoA, with external wrenches; physical parameters differ from the build-time model."""
     torch = torch_cuda
@@ -880,7 +880,7 @@ def test_other_tree_shapes_with_specialised_code_objects(torch_cuda, shape):
     from mecano_amd.engine import HipModel
     from oracle.cpu_oracle import OracleModel
     rng = np.random.default_rng(zlib.crc32(shape.encode()))
-    sys_ = (rt.nextQuadruped if shape == "quadruped" else rt.nextFixedBaseTorso)(rng)
+    sys_ = {"quadruped": rt.nextQuadruped, "torso": rt.nextFixedBaseTorso, "centaur": rt.nextCentaur}[shape](rng)
     d = sys_.toModelDesc()
     hm, om = HipModel(d), OracleModel(d)
     assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant

@@ -117,7 +117,7 @@ def test_tree_split_plans_of_the_registered_code_objects():
         paths = {name: b.build_spec(desc) for name, desc in b.registered_models().items()}
     except Exception as e:  # no hipcc and no prebuilt objects
         pytest.skip(f"specialised code objects unavailable: {e}")
-    expect = {"humanoid30": (1, 1), "arm7": (0, 0), "quadruped18": (1, 0), "torso13": (1, 1)}
+    expect = {"humanoid30": (1, 1), "arm7": (0, 0), "quadruped18": (1, 0), "torso13": (1, 1), "centaur20": (1, 1)}
     for name, path in paths.items():
         lib = ctypes.CDLL(path)
         buf = (ctypes.c_int * 256)()
