@@ -106,6 +106,7 @@ struct SpecLib
    int (*launch_split)(int algo, int flags, const void *args, int groups, void *stream) = nullptr;
    int (*crba_split_usable)(void) = nullptr;
    int (*launch_crba_split)(const void *args, int groups, int lanes_per_group, void *stream) = nullptr;
+   int (*launch_coriolis)(int flags, const void *args, int grid, void *stream) = nullptr;
 };
 enum : int
 {
@@ -615,6 +616,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.launch_split = (decltype(s.launch_split))dlsym(h, "mh_spec_launch_split");
    s.crba_split_usable = (decltype(s.crba_split_usable))dlsym(h, "mh_spec_crba_split_usable");
    s.launch_crba_split = (decltype(s.launch_crba_split))dlsym(h, "mh_spec_launch_crba_split");
+   s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
    for (int e = 0; ok && e < m->n; e++)
       ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];
@@ -662,6 +664,19 @@ mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, co
    const size_t hbytes = (size_t)B * model->nv * model->nv * sizeof(T);
    HIP_TRY(hipMemsetAsync(H_out, 0, hbytes, stream)); // the kernel writes the entries of related joints only (:298-300)
    HIP_TRY(hipMemsetAsync(C_out, 0, hbytes, stream));
+   if constexpr (sizeof(T) == 8)
+   {
+      if (model->spec.launch_coriolis && model->use_spec)
+      { // topology-specialised recursion: ancestors' transforms and velocities in registers, no workspace
+         const long waves = (B + 63) / 64;
+         const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * 4));
+         const int rc = model->spec.launch_coriolis(model->ident_maps ? SPEC_IDENT : 0, &A, grid, (void *)stream);
+         if (rc == 0)
+            return MH_OK;
+         if (rc != (int)hipErrorNotSupported)
+            return fail(MH_ERR_HIP, "specialised Coriolis kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+      }
+   }
    { if (ldsc) hipLaunchKernelGGL((mh::coriolis_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::coriolis_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
    HIP_TRY(hipGetLastError());
    return MH_OK;

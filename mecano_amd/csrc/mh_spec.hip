@@ -283,6 +283,20 @@ int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
    return (int)hipGetLastError();
 #endif
 }
+// mass + Coriolis matrix (fp64): one wave per 64 configurations, direct stores into zero-filled H and C (A.out, A.outb; strides f_bs, f_es)
+int mh_spec_launch_coriolis(int flags, const void *args, int grid, void *stream)
+{
+#ifdef MH_SPEC_MINIMAL
+   return (int)hipErrorNotSupported;
+#else
+   const mh::Args<double> &A = *(const mh::Args<double> *)args;
+   if (flags & F_IDENT)
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   else
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   return (int)hipGetLastError();
+#endif
+}
 // tree-split CRBA: identity maps, AoS, packed image + limb exchange in LDS
 long mh_spec_crba_split_lds_bytes(void)
 { // lane-major image (odd pitch) + limb exchange + entry -> slot table

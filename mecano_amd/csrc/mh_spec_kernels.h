@@ -520,6 +520,7 @@ struct Ctx
    ciptr dof_map, cfg_map, meta;
    const T *qrow, *qdrow, *in3row, *frow;
    T *orow;
+   T *orow2;     // Coriolis kernel: this configuration's C (orow: its H); entry stride f_es
    long q_es, v_es, f_es;
    lds_ptr<T> lq, lqd, lx, lo; // this lane's rows in LDS (IO_LDS); lo = output row (may alias lx)
    V3<T> a0l;              // linear part of the root acceleration (-g)
@@ -1333,6 +1334,158 @@ MH_DEV void split_crba_limbs(const CX &cx)
    }
 }
 
+// ============================================================================================ Coriolis matrix
+// Mass matrix and Coriolis matrix in one depth-first recursion (CompositeRigidBodyMassMatrixCalculator.java:604-630, 669-768 with
+// FactorizedBodyInertia.java; the arithmetic of coriolis_kernel in mh_kernels.h, see there).  Like CrbaSub the joint transforms of the
+// ancestors travel down in a compile-time-sized path -- here together with the ancestors' velocities, which the derivative of every
+// ancestor's motion subspace needs -- and a subtree hands (Ic, Bc), 10 + 30 scalars, to its parent.  Entries go straight to global
+// memory (both matrices zero-filled by the caller; entry (r, c) at (r * nv + c) * f_es of the configuration's block).
+template <typename T, int D>
+struct CorPath
+{
+   JX<T> jx[D > 0 ? D : 1]; // index = depth of the ancestor
+   SV<T> v[D > 0 ? D : 1];
+};
+template <typename T>
+struct CorUp
+{
+   RI<T> I;
+   FB<T> B;
+};
+template <class TP, int J, typename T, class CX, int D>
+struct CorSub
+{
+   using TR = Tree<TP>;
+   template <int R, int C>
+   static MH_DEV void put(const CX &cx, T *base, T v)
+   {
+      base[((long)cx.di(R) * cx.nv + cx.di(C)) * cx.f_es] = v;
+   }
+   template <int K>
+   static MH_DEV void children(const CX &cx, const CorPath<T, D + 1> &path, CorUp<T> &acc)
+   {
+      if constexpr (K < TR::n_children(J))
+      {
+         const CorUp<T> r = CorSub<TP, TR::child(J, K), T, CX, D + 1>::run(cx, path);
+         if constexpr (K == 0)
+            acc = r;
+         else
+         {
+            add(acc.I, r.I);
+            add(acc.B, r.B);
+         }
+         children<K + 1>(cx, path, acc);
+      }
+   }
+   // rows of ancestor A against column COL of joint J; the three momenta arrive expressed in A's frame, G = F3 - v_A x* F2
+   template <int A, int COL, int R = 0>
+   static MH_DEV void write_ancestor(const CX &cx, const SV<T> &F1, const SV<T> &F2, const SV<T> &G)
+   {
+      constexpr int TA = TP::type[A], DA = TR::dof_ofs(A);
+      if constexpr (R < TR::ndof(A))
+      {
+         constexpr int E = dof_comp(TA, R);
+         const T h = comp(F2, E);
+         put<DA + R, COL>(cx, cx.orow, h);
+         put<COL, DA + R>(cx, cx.orow, h);
+         put<DA + R, COL>(cx, cx.orow2, comp(F1, E)); // C_ik = S_i . F1   (:756)
+         put<COL, DA + R>(cx, cx.orow2, comp(G, E));  // C_ki = Sd_i . F2 + S_i . F3   (:757)
+         write_ancestor<A, COL, R + 1>(cx, F1, F2, G);
+      }
+   }
+   template <int DC, int COL>
+   static MH_DEV void climb(const CX &cx, const CorPath<T, D + 1> &path, SV<T> F1, SV<T> F2, SV<T> F3)
+   {
+      if constexpr (DC > 0)
+      {
+         constexpr int CUR = TR::ancestor_at_depth(J, DC), PAR = TR::ancestor_at_depth(J, DC - 1);
+         const XF<T> Xb = load_xb<T>(CRef<T, false>{cx.C + CUR * MC_STRIDE});
+         F1 = force_up(TP::type[CUR], path.jx[DC], Xb, F1);
+         F2 = force_up(TP::type[CUR], path.jx[DC], Xb, F2);
+         F3 = force_up(TP::type[CUR], path.jx[DC], Xb, F3);
+         write_ancestor<PAR, COL>(cx, F1, F2, F3 - crf(path.v[DC - 1], F2));
+         climb<DC - 1, COL>(cx, path, F1, F2, F3);
+      }
+   }
+   template <int K, int R = 0>
+   static MH_DEV void own_block(const CX &cx, const SV<T> &F1, const SV<T> &F2)
+   {
+      constexpr int TYPE = TP::type[J], DO = TR::dof_ofs(J);
+      if constexpr (R < TR::ndof(J))
+      {
+         constexpr int E = dof_comp(TYPE, R);
+         put<DO + R, DO + K>(cx, cx.orow, comp(F2, E));  // :698-707
+         put<DO + R, DO + K>(cx, cx.orow2, comp(F1, E)); // :709-724
+         own_block<K, R + 1>(cx, F1, F2);
+      }
+   }
+   template <int K>
+   static MH_DEV void columns(const CX &cx, const CorPath<T, D + 1> &path, const RI<T> &Ic, const FB<T> &Bc)
+   {
+      constexpr int TYPE = TP::type[J], DO = TR::dof_ofs(J);
+      if constexpr (K < TR::ndof(J))
+      {
+         const SV<T> S = unit_twist<T>(TYPE, K);
+         const SV<T> Sd = crm(path.v[D], S);            // :620-626
+         const SV<T> F2 = mul(Ic, S);                   // :663-667
+         const SV<T> F1 = mul(Ic, Sd) + mul(Bc, S);     // :686-688
+         const SV<T> F3 = tmul(Bc, S);                  // :690-691
+         own_block<K>(cx, F1, F2);
+         climb<D, DO + K>(cx, path, F1, F2, F3);        // :729-768
+         columns<K + 1>(cx, path, Ic, Bc);
+      }
+   }
+   static MH_DEV CorUp<T> run(const CX &cx, const CorPath<T, D> &up)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J], CO = TR::cfg_ofs(J), DO = TR::dof_ofs(J);
+      constexpr bool LEAF = TR::n_children(J) == 0;
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      CorPath<T, D + 1> path;
+#pragma unroll
+      for (int d = 0; d < D; d++)
+         path.jx[d] = up.jx[d], path.v[d] = up.v[d];
+      path.jx[D] = spec_joint<TYPE, CO, CX, T>(cx);
+      const V3<T> Z{T(0), T(0), T(0)};
+      SV<T> vp{Z, Z};
+      if constexpr (D > 0)
+         vp = up.v[D - 1];
+      path.v[D] = motion_down(TYPE, path.jx[D], load_xb<T>(c), vp) + spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+      CorUp<T> acc;
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+         children<0>(cx, path, acc);
+      MH_BODY_FENCE();
+      CorUp<T> out;
+      out.I = load_inertia<T>(c);
+      out.B = fb_from_rigid(out.I, path.v[D]); // :671-673: the body's own inertia, before the children are added
+      if constexpr (!LEAF)
+      {
+         add(out.I, acc.I);
+         add(out.B, acc.B);
+      }
+      columns<0>(cx, path, out.I, out.B);
+      if constexpr (TP::parent[J] >= 0)
+      {
+         const XF<T> Xb = load_xb<T>(c);
+         rigid_up(TYPE, path.jx[D], Xb, out.I); // :651-661
+         fb_up(TYPE, path.jx[D], Xb, out.B);    // :675-683
+      }
+      MH_BODY_FENCE();
+      return out;
+   }
+};
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void coriolis_roots(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      CorPath<T, 0> empty;
+      (void)CorSub<TP, Tree<TP>::child(-1, K), T, CX, 0>::run(cx, empty);
+      coriolis_roots<TP, T, CX, K + 1>(cx);
+   }
+}
+
 // ============================================================================================ kernels
 // Coalesced copy of the wave's rows of q, qd and qdd|tau (contiguous blocks of the AoS matrices) into LDS.  ALL loads are
 // issued before the first LDS write, so the whole staging costs one memory round trip (about a microsecond) instead of one
@@ -1983,6 +2136,27 @@ __global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg
       MH_CSTAMP(6);
       __syncthreads(); // the image is free for the next slice
       MH_CSTAMP(7);
+   }
+}
+
+// Mass + Coriolis matrix, one wave per 64 configurations, direct stores: A.out = H, A.outb = C, both [B][nv][nv] with per-configuration /
+// per-entry strides f_bs / f_es and zero-filled by the caller (only entries of related joints are written).
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(64) spec_coriolis_kernel(Args<T> A)
+{
+   using CX = Ctx<T, false, IDENT, WholeStore<TP, ST_GLOBAL_KIND>>;
+   const long lane = (long)blockIdx.x * 64 + threadIdx.x, nlanes = (long)gridDim.x * 64;
+   warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      CX cx;
+      fill_ctx<T>(cx, A, cfg);
+      cx.frow = nullptr;
+      cx.orow = A.out + cfg * A.f_bs;
+      cx.orow2 = A.outb + cfg * A.f_bs;
+      cx.nv = A.m.nv;
+      cx.wave = 0;
+      coriolis_roots<TP, T, CX>(cx);
    }
 }
 

@@ -908,6 +908,58 @@ def test_other_tree_shapes_with_specialised_code_objects(torch_cuda, shape):
             close(nq_.cpu().numpy()[idx], r_q, 1e-12), close(nv_.cpu().numpy()[idx], r_v, 1e-11)
 
 
+@pytest.mark.parametrize("shape", ["humanoid", "torso", "arm"])
+def test_specialised_coriolis_kernel_variants(torch_cuda, shape):
+    """The topology-specialised mass + Coriolis kernel (spec_coriolis_kernel: identity and permuted index maps, AoS and SoA) against
+    the oracle and against the run-time-topology kernel (MH_DISABLE_SPEC) on the same inputs, at ragged and full batch sizes."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd import _lib
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(("speccor" + shape).encode()))
+    if shape == "humanoid":
+        sys_ = rt.nextHumanoid(rng)
+    elif shape == "torso":
+        sys_ = rt.nextFixedBaseTorso(rng)
+    else:
+        sys_ = system_of(rt.nextJointChain(rng, 7, ("revolute",)))
+    d = sys_.toModelDesc()
+    om = OracleModel(d)
+    for B in (1, 100, 4096):
+        q, qd, _, _ = rt.nextState(rng, sys_, B)
+        idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 40)), [B - 1]]))
+        rH, rC = om.crba_coriolis(q[idx], qd[idx])
+        tq, tqd = dev(torch, q), dev(torch, qd)
+        hm = HipModel(d)
+        assert hm.kernel_variant.startswith("topo:")
+        H, C = hm.crba_coriolis(tq, tqd)
+        close(H.cpu().numpy()[idx], rH), close(C.cpu().numpy()[idx], rC)
+        Hs, Cs = hm.crba_coriolis(tq.t().contiguous(), tqd.t().contiguous(), _lib.LAYOUT_SOA)
+        assert torch.equal(Hs.t().reshape(B, d.nv, d.nv), H) and torch.equal(Cs.t().reshape(B, d.nv, d.nv), C)
+        os.environ["MH_DISABLE_SPEC"] = "1"
+        try:
+            Hg, Cg = HipModel(d).crba_coriolis(tq, tqd)
+        finally:
+            os.environ.pop("MH_DISABLE_SPEC", None)
+        assert (Hg - H).abs().max().item() <= 1e-11 * max(1.0, H.abs().max().item())
+        assert (Cg - C).abs().max().item() <= 1e-11 * max(1.0, C.abs().max().item())
+    # permuted index maps: same topology (same code object), rows of every matrix in another order
+    perm_v, perm_q = rng.permutation(d.nv).astype(np.int32), rng.permutation(d.nq).astype(np.int32)
+    d2 = sys_.toModelDesc()
+    d2.dof_indices = perm_v[np.asarray(d.dof_indices)]
+    d2.cfg_indices = perm_q[np.asarray(d.cfg_indices)]
+    B = 300
+    q, qd, _, _ = rt.nextState(rng, sys_, B)
+    q2, qd2 = np.zeros_like(q), np.zeros_like(qd)
+    q2[:, perm_q], qd2[:, perm_v] = q, qd
+    hm2 = HipModel(d2)
+    assert hm2.kernel_variant.startswith("topo:")
+    H2, C2 = hm2.crba_coriolis(dev(torch, q2), dev(torch, qd2))
+    rH, rC = om.crba_coriolis(q, qd)
+    close(H2.cpu().numpy()[:, perm_v][:, :, perm_v], rH), close(C2.cpu().numpy()[:, perm_v][:, :, perm_v], rC)
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
