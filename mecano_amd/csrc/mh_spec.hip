@@ -290,10 +290,13 @@ int mh_spec_launch_coriolis(int flags, const void *args, int grid, void *stream)
    return (int)hipErrorNotSupported;
 #else
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
-   if (flags & F_IDENT)
-      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   // the fast variant: identity index maps, AoS matrices (entry stride 1, nv = the tree's DoFs): compile-time entry offsets
+   if ((flags & F_IDENT) && A.f_es == 1 && A.m.nv == TR::total_dofs())
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   else if (flags & F_IDENT)
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
    else
-      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, false, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
    return (int)hipGetLastError();
 #endif
 }

@@ -1352,21 +1352,27 @@ struct CorUp
    RI<T> I;
    FB<T> B;
 };
-template <class TP, int J, typename T, class CX, int D>
+// FAST: identity index maps and AoS matrices -- the offset of an entry is a compile-time constant, an immediate of the store; otherwise it
+// is wave-uniform scalar arithmetic on (nv, f_es), which the kernel launders per configuration (hoisted out of the grid-stride loop the
+// ~1 200 offsets of the humanoid's two matrices would live in SGPRs: ~2 000 scalar spills)
+template <class TP, int J, typename T, class CX, int D, bool FAST>
 struct CorSub
 {
    using TR = Tree<TP>;
    template <int R, int C>
    static MH_DEV void put(const CX &cx, T *base, T v)
    {
-      base[((long)cx.di(R) * cx.nv + cx.di(C)) * cx.f_es] = v;
+      if constexpr (FAST)
+         base[R * TR::total_dofs() + C] = v;
+      else
+         base[((long)cx.di(R) * cx.nv + cx.di(C)) * cx.f_es] = v;
    }
    template <int K>
    static MH_DEV void children(const CX &cx, const CorPath<T, D + 1> &path, CorUp<T> &acc)
    {
       if constexpr (K < TR::n_children(J))
       {
-         const CorUp<T> r = CorSub<TP, TR::child(J, K), T, CX, D + 1>::run(cx, path);
+         const CorUp<T> r = CorSub<TP, TR::child(J, K), T, CX, D + 1, FAST>::run(cx, path);
          if constexpr (K == 0)
             acc = r;
          else
@@ -1399,7 +1405,11 @@ struct CorSub
       if constexpr (DC > 0)
       {
          constexpr int CUR = TR::ancestor_at_depth(J, DC), PAR = TR::ancestor_at_depth(J, DC - 1);
-         const XF<T> Xb = load_xb<T>(CRef<T, false>{cx.C + CUR * MC_STRIDE});
+         // the ancestor's pose is loaded afresh at every step (laundered pointer): merged across the columns and bodies that climb through
+         // the same ancestor it would stay in 24 SGPRs per tree level for the whole subtree -- 2 000 scalar spills on the humanoid
+         const T *cp = cx.C + CUR * MC_STRIDE;
+         asm volatile("" : "+s"(cp));
+         const XF<T> Xb = load_xb<T>(CRef<T, false>{cp});
          F1 = force_up(TP::type[CUR], path.jx[DC], Xb, F1);
          F2 = force_up(TP::type[CUR], path.jx[DC], Xb, F2);
          F3 = force_up(TP::type[CUR], path.jx[DC], Xb, F3);
@@ -1467,7 +1477,9 @@ struct CorSub
       columns<0>(cx, path, out.I, out.B);
       if constexpr (TP::parent[J] >= 0)
       {
-         const XF<T> Xb = load_xb<T>(c);
+         const T *cp = cx.C + J * MC_STRIDE;
+         asm volatile("" : "+s"(cp));
+         const XF<T> Xb = load_xb<T>(CRef<T, false>{cp});
          rigid_up(TYPE, path.jx[D], Xb, out.I); // :651-661
          fb_up(TYPE, path.jx[D], Xb, out.B);    // :675-683
       }
@@ -1475,14 +1487,14 @@ struct CorSub
       return out;
    }
 };
-template <class TP, typename T, class CX, int K = 0>
+template <class TP, typename T, class CX, bool FAST, int K = 0>
 MH_DEV void coriolis_roots(const CX &cx)
 {
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       CorPath<T, 0> empty;
-      (void)CorSub<TP, Tree<TP>::child(-1, K), T, CX, 0>::run(cx, empty);
-      coriolis_roots<TP, T, CX, K + 1>(cx);
+      (void)CorSub<TP, Tree<TP>::child(-1, K), T, CX, 0, FAST>::run(cx, empty);
+      coriolis_roots<TP, T, CX, FAST, K + 1>(cx);
    }
 }
 
@@ -2141,7 +2153,7 @@ __global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg
 
 // Mass + Coriolis matrix, one wave per 64 configurations, direct stores: A.out = H, A.outb = C, both [B][nv][nv] with per-configuration /
 // per-entry strides f_bs / f_es and zero-filled by the caller (only entries of related joints are written).
-template <class TP, typename T, bool IDENT>
+template <class TP, typename T, bool IDENT, bool AOS>
 __global__ void __launch_bounds__(64) spec_coriolis_kernel(Args<T> A)
 {
    using CX = Ctx<T, false, IDENT, WholeStore<TP, ST_GLOBAL_KIND>>;
@@ -2154,9 +2166,12 @@ __global__ void __launch_bounds__(64) spec_coriolis_kernel(Args<T> A)
       cx.frow = nullptr;
       cx.orow = A.out + cfg * A.f_bs;
       cx.orow2 = A.outb + cfg * A.f_bs;
-      cx.nv = A.m.nv;
+      int nv = A.m.nv;
+      long es = A.f_es;
+      asm volatile("" : "+s"(nv), "+s"(es)); // per configuration: keeps the entry offsets from being hoisted out of the loop
+      cx.nv = nv, cx.f_es = es;
       cx.wave = 0;
-      coriolis_roots<TP, T, CX>(cx);
+      coriolis_roots<TP, T, CX, IDENT && AOS>(cx);
    }
 }
 
