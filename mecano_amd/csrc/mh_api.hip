@@ -107,6 +107,7 @@ struct SpecLib
    int (*crba_split_usable)(void) = nullptr;
    int (*launch_crba_split)(const void *args, int groups, int lanes_per_group, void *stream) = nullptr;
    int (*launch_coriolis)(int flags, const void *args, int grid, void *stream) = nullptr;
+   int (*launch_centroidal)(int flags, const void *args, int grid, void *stream) = nullptr;
 };
 enum : int
 {
@@ -617,6 +618,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.crba_split_usable = (decltype(s.crba_split_usable))dlsym(h, "mh_spec_crba_split_usable");
    s.launch_crba_split = (decltype(s.launch_crba_split))dlsym(h, "mh_spec_launch_crba_split");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
+   s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
    bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
    for (int e = 0; ok && e < m->n; e++)
       ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];
@@ -724,6 +726,19 @@ mh_status centroidal_impl(mh_model_t model, int64_t B, const T *q, const T *qd, 
    const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
    const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
    HIP_TRY(hipMemsetAsync(A_out, 0, (size_t)B * 6 * model->nv * sizeof(T), stream)); // columns no considered joint owns stay zero
+   if constexpr (sizeof(T) == 8)
+   {
+      if (model->spec.launch_centroidal && model->use_spec)
+      {
+         const long waves = (B + 63) / 64;
+         const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * 4));
+         const int rc = model->spec.launch_centroidal(model->ident_maps ? SPEC_IDENT : 0, &A, grid, (void *)stream);
+         if (rc == 0)
+            return MH_OK;
+         if (rc != (int)hipErrorNotSupported)
+            return fail(MH_ERR_HIP, "specialised centroidal kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+      }
+   }
    { if (ldsc) hipLaunchKernelGGL((mh::centroidal_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::centroidal_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
    HIP_TRY(hipGetLastError());
    return MH_OK;

@@ -300,6 +300,25 @@ int mh_spec_launch_coriolis(int flags, const void *args, int grid, void *stream)
    return (int)hipGetLastError();
 #endif
 }
+// centroidal momentum matrix (+ convective term when args->b is not NULL) (fp64): one wave per 64 configurations, A zero-filled by the caller
+int mh_spec_launch_centroidal(int flags, const void *args, int grid, void *stream)
+{
+#ifdef MH_SPEC_MINIMAL
+   return (int)hipErrorNotSupported;
+#else
+   const mh::CentArgs<double> &A = *(const mh::CentArgs<double> *)args;
+   const bool id = flags & F_IDENT, wb = A.b != nullptr;
+   if (id && wb)
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, true, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   else if (id)
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, true, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   else if (wb)
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, false, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   else
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, false, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+   return (int)hipGetLastError();
+#endif
+}
 // tree-split CRBA: identity maps, AoS, packed image + limb exchange in LDS
 long mh_spec_crba_split_lds_bytes(void)
 { // lane-major image (odd pitch) + limb exchange + entry -> slot table

@@ -1498,6 +1498,132 @@ MH_DEV void coriolis_roots(const CX &cx)
    }
 }
 
+// ============================================================================================ centroidal momentum
+// Centroidal momentum matrix and convective term as one depth-first recursion (CompositeRigidBodyMassMatrixCalculator.java:801-839; the
+// arithmetic of centroidal_kernel in mh_kernels.h, see there): on the way down the body velocities and Coriolis accelerations (WITH_B),
+// on the way up composite inertias and wrenches; column k of A is Ic S_k climbed through the ancestors' transforms (CrbaPath) to the root
+// body frame and re-expressed in the centroidal frame.
+template <typename T>
+struct CentUp
+{
+   RI<T> I;
+   SV<T> f;
+};
+template <typename T, class BASE>
+struct CentCtx : BASE
+{
+   XF<T> xf;  // centroidal frame -> root body frame
+   T *arow;   // this configuration's A: entry (k, col) at (k * nv + col) * a_es
+   long a_es;
+};
+template <class TP, int J, typename T, class CX, int D, bool WITH_B>
+struct CentSub
+{
+   using TR = Tree<TP>;
+   template <int K>
+   static MH_DEV void children(const CX &cx, const CrbaPath<T, D + 1> &path, const SV<T> &v, const SV<T> &a, CentUp<T> &acc)
+   {
+      if constexpr (K < TR::n_children(J))
+      {
+         const CentUp<T> r = CentSub<TP, TR::child(J, K), T, CX, D + 1, WITH_B>::run(cx, path, v, a);
+         if constexpr (K == 0)
+            acc = r;
+         else
+         {
+            add(acc.I, r.I);
+            acc.f = acc.f + r.f;
+         }
+         children<K + 1>(cx, path, v, a, acc);
+      }
+   }
+   // from the frame after the ancestor at depth DC up to the root body frame
+   template <int DC>
+   static MH_DEV SV<T> to_root(const CX &cx, const CrbaPath<T, D + 1> &path, SV<T> F)
+   {
+      constexpr int CUR = TR::ancestor_at_depth(J, DC);
+      const T *cp = cx.C + CUR * MC_STRIDE;
+      asm volatile("" : "+s"(cp)); // reloaded per step (see CorSub::climb)
+      F = force_up(TP::type[CUR], path.jx[DC], load_xb<T>(CRef<T, false>{cp}), F);
+      if constexpr (DC > 0)
+         return to_root<DC - 1>(cx, path, F);
+      else
+         return F;
+   }
+   template <int K>
+   static MH_DEV void columns(const CX &cx, const CrbaPath<T, D + 1> &path, const RI<T> &Ic)
+   {
+      constexpr int TYPE = TP::type[J], DO = TR::dof_ofs(J);
+      if constexpr (K < TR::ndof(J))
+      {
+         const SV<T> F = to_root<D>(cx, path, mul(Ic, unit_twist<T>(TYPE, K))); // :663-667, 783-792, 805
+         // root body frame -> centroidal frame: f' = R^T f ; n' = R^T (n - p x f)
+         const V3<T> fl = tmul(cx.xf.R, F.l), fa = tmul(cx.xf.R, F.a - cross(cx.xf.p, F.l));
+         const long col = cx.di(DO + K), nv = cx.nv, es = cx.a_es;
+         cx.arow[(0 * nv + col) * es] = fa.x, cx.arow[(1 * nv + col) * es] = fa.y, cx.arow[(2 * nv + col) * es] = fa.z;
+         cx.arow[(3 * nv + col) * es] = fl.x, cx.arow[(4 * nv + col) * es] = fl.y, cx.arow[(5 * nv + col) * es] = fl.z;
+         columns<K + 1>(cx, path, Ic);
+      }
+   }
+   static MH_DEV CentUp<T> run(const CX &cx, const CrbaPath<T, D> &up, const SV<T> &vp, const SV<T> &ap)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J], CO = TR::cfg_ofs(J), DO = TR::dof_ofs(J);
+      constexpr bool LEAF = TR::n_children(J) == 0;
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      CrbaPath<T, D + 1> path;
+#pragma unroll
+      for (int d = 0; d < D; d++)
+         path.jx[d] = up.jx[d];
+      path.jx[D] = spec_joint<TYPE, CO, CX, T>(cx);
+      const V3<T> Z{T(0), T(0), T(0)};
+      SV<T> v{Z, Z}, a{Z, Z};
+      CentUp<T> out;
+      out.I = load_inertia<T>(c);
+      out.f = SV<T>{Z, Z};
+      if constexpr (WITH_B)
+      {
+         const XF<T> Xb = load_xb<T>(c);
+         const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+         v = motion_down(TYPE, path.jx[D], Xb, vp) + vJ;
+         a = motion_down(TYPE, path.jx[D], Xb, ap) + crm(v, vJ);  // :826-831
+         out.f = mul(out.I, a) + crf(v, mul(out.I, v));           // :833
+      }
+      CentUp<T> acc;
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+         children<0>(cx, path, v, a, acc);
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+      {
+         add(out.I, acc.I);
+         out.f = out.f + acc.f;
+      }
+      columns<0>(cx, path, out.I);
+      {
+         const T *cp = cx.C + J * MC_STRIDE;
+         asm volatile("" : "+s"(cp));
+         const XF<T> Xb = load_xb<T>(CRef<T, false>{cp});
+         rigid_up(TYPE, path.jx[D], Xb, out.I);
+         out.f = force_up(TYPE, path.jx[D], Xb, out.f);
+      }
+      MH_BODY_FENCE();
+      return out;
+   }
+};
+template <class TP, typename T, class CX, bool WITH_B, int K = 0>
+MH_DEV void centroidal_roots(const CX &cx, CentUp<T> &total)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      const V3<T> Z{T(0), T(0), T(0)};
+      CrbaPath<T, 0> empty;
+      const CentUp<T> r = CentSub<TP, Tree<TP>::child(-1, K), T, CX, 0, WITH_B>::run(cx, empty, SV<T>{Z, Z}, SV<T>{Z, Z});
+      add(total.I, r.I);
+      total.f = total.f + r.f;
+      centroidal_roots<TP, T, CX, WITH_B, K + 1>(cx, total);
+   }
+}
+
 // ============================================================================================ kernels
 // Coalesced copy of the wave's rows of q, qd and qdd|tau (contiguous blocks of the AoS matrices) into LDS.  ALL loads are
 // issued before the first LDS write, so the whole staging costs one memory round trip (about a microsecond) instead of one
@@ -2172,6 +2298,70 @@ __global__ void __launch_bounds__(64) spec_coriolis_kernel(Args<T> A)
       cx.nv = nv, cx.f_es = es;
       cx.wave = 0;
       coriolis_roots<TP, T, CX, IDENT && AOS>(cx);
+   }
+}
+
+// Centroidal momentum matrix / convective term / centre of mass, one wave per 64 configurations, direct stores (A zero-filled by the
+// caller: columns no considered joint owns stay zero).
+template <class TP, typename T, bool IDENT, bool WITH_B>
+__global__ void __launch_bounds__(64) spec_centroidal_kernel(CentArgs<T> A)
+{
+   using BASE = Ctx<T, false, IDENT, WholeStore<TP, ST_GLOBAL_KIND>>;
+   using CX = CentCtx<T, BASE>;
+   const long lane = (long)blockIdx.x * 64 + threadIdx.x, nlanes = (long)gridDim.x * 64;
+   warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   const V3<T> Z{T(0), T(0), T(0)};
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      CX cx;
+      const void *pc = A.m.consts;
+      const int *pd = A.m.dof_map, *pq = A.m.cfg_map, *pm = A.m.meta;
+      int nv = A.m.nv;
+      long es = A.a_es;
+      asm volatile("" : "+s"(pc), "+s"(pd), "+s"(pq), "+s"(pm), "+s"(nv), "+s"(es));
+      cx.C = (const T *)pc;
+      cx.dof_map = as_const(pd), cx.cfg_map = as_const(pq), cx.meta = as_const(pm);
+      cx.qrow = A.q + cfg * A.q_bs;
+      cx.qdrow = WITH_B ? A.qd + cfg * A.v_bs : nullptr;
+      cx.in3row = nullptr, cx.frow = nullptr, cx.orow = nullptr, cx.orow2 = nullptr;
+      cx.q_es = A.q_es, cx.v_es = A.v_es, cx.f_es = 0;
+      cx.a0l = Z;
+      cx.coriolis = 1, cx.accel = 0;
+      cx.nv = nv, cx.wave = 0;
+      cx.xf.R = M3<T>{A.fR[0], A.fR[1], A.fR[2], A.fR[3], A.fR[4], A.fR[5], A.fR[6], A.fR[7], A.fR[8]};
+      cx.xf.p = V3<T>{A.fp[0], A.fp[1], A.fp[2]};
+      cx.arow = A.A + cfg * A.a_bs;
+      cx.a_es = es;
+      CentUp<T> total;
+      total.I = RI<T>{T(0), Z, S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)}};
+      total.f = SV<T>{Z, Z};
+      centroidal_roots<TP, T, CX, WITH_B>(cx, total);
+      // the frame's origin: centre of mass of the considered bodies, in frame coordinates (CenterOfMassCalculator.java:70-91)
+      V3<T> shift{T(0), T(0), T(0)};
+      if (A.at_com)
+      {
+         shift = tmul(cx.xf.R, (T(1) / total.I.m) * total.I.h - cx.xf.p);
+         T *Am = cx.arow;
+         for (int col = 0; col < nv; col++)
+         { // moving the origin by `shift`: n' = n - shift x f
+            const V3<T> fl{Am[(3L * nv + col) * es], Am[(4L * nv + col) * es], Am[(5L * nv + col) * es]};
+            const V3<T> d = cross(shift, fl);
+            Am[(0L * nv + col) * es] -= d.x, Am[(1L * nv + col) * es] -= d.y, Am[(2L * nv + col) * es] -= d.z;
+         }
+      }
+      if (A.com)
+      {
+         T *crow = A.com + cfg * A.c_bs;
+         crow[0] = shift.x, crow[A.c_es] = shift.y, crow[2 * A.c_es] = shift.z;
+      }
+      if constexpr (WITH_B)
+      {
+         const V3<T> fl = tmul(cx.xf.R, total.f.l);
+         const V3<T> fa = tmul(cx.xf.R, total.f.a - cross(cx.xf.p, total.f.l)) - cross(shift, fl);
+         T *brow = A.b + cfg * A.b_bs;
+         brow[0] = fa.x, brow[A.b_es] = fa.y, brow[2 * A.b_es] = fa.z;
+         brow[3 * A.b_es] = fl.x, brow[4 * A.b_es] = fl.y, brow[5 * A.b_es] = fl.z;
+      }
    }
 }
 

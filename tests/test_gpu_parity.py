@@ -944,6 +944,20 @@ def test_specialised_coriolis_kernel_variants(torch_cuda, shape):
             os.environ.pop("MH_DISABLE_SPEC", None)
         assert (Hg - H).abs().max().item() <= 1e-11 * max(1.0, H.abs().max().item())
         assert (Cg - C).abs().max().item() <= 1e-11 * max(1.0, C.abs().max().item())
+        # the specialised centroidal kernel: fixed frame and centre-of-mass frame, with and without the convective term, SoA
+        Rf = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        Rf *= np.sign(np.linalg.det(Rf))
+        frame = np.concatenate([Rf.ravel(), rng.uniform(-1, 1, 3)])
+        for fr, at_com in ((None, False), (frame, True)):
+            A, b, com = hm.centroidal(tq, tqd, fr, at_com)
+            rA, rb, rcom = om.centroidal(q[idx], qd[idx], fr, at_com)
+            close(A.cpu().numpy()[idx], rA), close(com.cpu().numpy()[idx], rcom)
+            assert np.abs(b.cpu().numpy()[idx] - rb).max() <= TOL * max(1.0, np.abs(rA).max(), np.abs(rb).max())
+            As, bs, cs = hm.centroidal(tq.t().contiguous(), tqd.t().contiguous(), fr, at_com, _lib.LAYOUT_SOA)
+            assert torch.equal(As.t().reshape(B, 6, d.nv), A) and torch.equal(bs.t(), b) and torch.equal(cs.t(), com)
+        A0, b0, _ = hm.centroidal(tq)
+        assert b0 is None
+        close(A0.cpu().numpy()[idx], om.centroidal(q[idx])[0])
     # permuted index maps: same topology (same code object), rows of every matrix in another order
     perm_v, perm_q = rng.permutation(d.nv).astype(np.int32), rng.permutation(d.nq).astype(np.int32)
     d2 = sys_.toModelDesc()
@@ -958,6 +972,10 @@ def test_specialised_coriolis_kernel_variants(torch_cuda, shape):
     H2, C2 = hm2.crba_coriolis(dev(torch, q2), dev(torch, qd2))
     rH, rC = om.crba_coriolis(q, qd)
     close(H2.cpu().numpy()[:, perm_v][:, :, perm_v], rH), close(C2.cpu().numpy()[:, perm_v][:, :, perm_v], rC)
+    A2, b2, _ = hm2.centroidal(dev(torch, q2), dev(torch, qd2), None, True)
+    rA, rb, _ = om.centroidal(q, qd, None, True)
+    close(A2.cpu().numpy()[:, :, perm_v], rA)
+    assert np.abs(b2.cpu().numpy() - rb).max() <= TOL * max(1.0, np.abs(rA).max(), np.abs(rb).max())
 
 
 def test_native_library_is_the_one_loaded(torch_cuda):

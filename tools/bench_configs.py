@@ -51,8 +51,8 @@ def main():
         report(f"C3 humanoid RNEA fp64 [{hm.kernel_variant}]", B, timeit(lambda: hm.rnea(q, qd, qdd, g), stream), 8 * (nq + 3 * nv))
         report(f"C3 humanoid CRBA fp64", B, timeit(lambda: hm.crba(q), stream, iters=10), 8 * (nq + nv * nv))
         report(f"C4 humanoid ABA fp64", B, timeit(lambda: hm.aba(q, qd, tau, g), stream), 8 * (nq + 3 * nv))
-        report(f"N3 humanoid mass + Coriolis matrix fp64 (generic)", B, timeit(lambda: hm.crba_coriolis(q, qd), stream, iters=5), 8 * (nq + nv + 2 * nv * nv))
-        report(f"N3 humanoid centroidal A, b at CoM fp64 (generic)", B, timeit(lambda: hm.centroidal(q, qd, None, True), stream, iters=5), 8 * (nq + nv + 6 * nv + 9))
+        report(f"N3 humanoid mass + Coriolis matrix fp64 (specialised)", B, timeit(lambda: hm.crba_coriolis(q, qd), stream, iters=5), 8 * (nq + nv + 2 * nv * nv))
+        report(f"N3 humanoid centroidal A, b at CoM fp64 (specialised)", B, timeit(lambda: hm.centroidal(q, qd, None, True), stream, iters=5), 8 * (nq + nv + 6 * nv + 9))
     # ---- C5: random 128-body tree, mixed joints, fp32, per-GPU shard of B = 1M over 8 GPUs
     tree = MultiBodySystem.toMultiBodySystemInput(rt.nextJointTree(np.random.default_rng(128), 128, ("revolute", "prismatic", "sixdof"))[0].getPredecessor())
     hm = HipModel(tree.toModelDesc())
