@@ -13,7 +13,7 @@ from mecano_amd.engine import HipModel, HipTimer
 from mecano_amd.multibody import MultiBodySystem
 
 
-def timeit(fn, stream, iters=20, warm=3):
+def timeit(fn, stream, iters=20, warm=10):
     for _ in range(warm):
         fn()
     t = HipTimer()
