@@ -112,10 +112,14 @@ def registered_models():
     return {"humanoid30": humanoid, "arm7": arm7, "quadruped18": quadruped, "torso13": torso, "centaur20": centaur}
 
 
-def build_all(force: bool = False, verbose: bool = False):
+def build_all(force: bool = False, verbose: bool = False, jobs: int = 4):
+    """The library first (the topology keys come from its host-side planner), then the code objects of the registered shapes side by
+    side: they are independent hipcc runs, the humanoid's alone takes minutes."""
+    from concurrent.futures import ThreadPoolExecutor
     out = [build_lib(force, verbose)]
-    for name, desc in registered_models().items():
-        out.append(build_spec(desc, force, verbose))
+    models = list(registered_models().values())
+    with ThreadPoolExecutor(max_workers=max(1, min(jobs, len(models)))) as pool:
+        out += list(pool.map(lambda desc: build_spec(desc, force, verbose), models))
     return out
 
 
