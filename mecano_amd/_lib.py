@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmecano_hip.so")
@@ -45,10 +46,21 @@ class MecanoHipError(RuntimeError):
 
 
 _lib = None
+_load_lock = threading.Lock()
 
 
 def load():
-    """Returns the loaded library; raises ImportError when it has not been built (python -m mecano_amd.build)."""
+    """Returns the loaded library; raises ImportError when it has not been built (python -m mecano_amd.build).  Thread-safe: the order
+    "torch first, then the library" below must not be raced (a second thread that sees a half-imported torch in sys.modules would load
+    the library against the system HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _load_lock:
+        return _load_locked()
+
+
+def _load_locked():
     global _lib
     if _lib is not None:
         return _lib
@@ -59,12 +71,10 @@ def load():
     # the GPU (whichever initialises second reports "no ROCm-capable device"), so when torch is importable it is imported FIRST: the
     # library's libamdhip64.so.7 dependency then binds to the copy torch already loaded and the process holds a single runtime.
     # Hosts without torch (the Java / C++ side of the C-ABI) simply get the system runtime.
-    import sys
-    if "torch" not in sys.modules:
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+    try:
+        import torch  # noqa: F401  (a plain import: waits for an import that another thread has in flight)
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.mh_abi_version.restype = I32

@@ -117,6 +117,8 @@ def build_all(force: bool = False, verbose: bool = False, jobs: int = 4):
     side: they are independent hipcc runs, the humanoid's alone takes minutes."""
     from concurrent.futures import ThreadPoolExecutor
     out = [build_lib(force, verbose)]
+    from . import _lib
+    _lib.load()  # once, on this thread, before the workers ask the library for topology keys
     models = list(registered_models().values())
     with ThreadPoolExecutor(max_workers=max(1, min(jobs, len(models)))) as pool:
         out += list(pool.map(lambda desc: build_spec(desc, force, verbose), models))
