@@ -207,7 +207,8 @@ mh_status mh_aba_locked_f64(mh_model_t model, int64_t B, const double *q, const 
  * Same as mh_rnea_f64 / mh_aba_f64, plus for the successor body of every listed joint its spatial acceleration and / or twist relative
  * to the inertial frame, expressed in the body-fixed frame: body_acc_out, body_twist_out [B][n_joints][6] (angular, linear), laid
  * out like f_ext; either may be NULL.  As in the reference the acceleration carries the root acceleration -g, and the RNEA switches
- * apply (consider_coriolis = 0: velocity terms dropped and twists reported as zero).  Runs the run-time-topology kernels.
+ * apply (consider_coriolis = 0: velocity terms dropped and twists reported as zero).  Models with a tree-split code object, identity
+ * index maps and AoS matrices run variants of the tree-split kernels that write them as well; every other case the run-time-topology kernels.
  */
 mh_status mh_rnea_bodies_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
                              const double *f_ext, const mh_options *opts, double *tau_out, double *body_acc_out, double *body_twist_out);

@@ -76,6 +76,15 @@ def _load_locked():
     except ImportError:
         pass
     lib = ctypes.CDLL(LIB_PATH)
+    try:  # two HIP runtimes in the process: say so now rather than as a puzzling "no device" later
+        with open("/proc/self/maps") as maps:
+            runtimes = sorted({line.split()[-1] for line in maps if "libamdhip64" in line})
+        if len(runtimes) > 1:
+            import warnings
+            warnings.warn("two HIP runtimes are loaded (" + ", ".join(runtimes) + "): only the one that initialises first will see the GPU. "
+                          "Import torch before anything loads libmecano_hip.so, or run without torch.", RuntimeWarning)
+    except OSError:
+        pass
     P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.mh_abi_version.restype = I32
     lib.mh_last_error.restype = ctypes.c_char_p

@@ -113,7 +113,8 @@ enum : int
 {
    SPEC_IO_LDS = 1,
    SPEC_IDENT = 2,
-   SPEC_ST_LDS = 4
+   SPEC_ST_LDS = 4,
+   SPEC_BODIES = 16
 };
 
 struct mh_model
@@ -290,6 +291,19 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    { // per-body outputs: run-time-topology kernels (the model's joint source modes must all be effort sources)
       if (model->n_locked > 0)
          return fail(MH_ERR_INVALID_ARGUMENT, "per-body outputs are not available while joints are acceleration sources");
+      if (sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
+      { // the tree-split kernels write them too (identity maps, rows staged in LDS); other plans: the run-time-topology kernels below
+         const int sf = split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa);
+         if ((sf & SPEC_IDENT) && (sf & SPEC_IO_LDS))
+         {
+            const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
+            const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, sf | SPEC_BODIES, &A, (int)groups, (void *)stream);
+            if (rc == 0)
+               return MH_OK;
+            if (rc != (int)hipErrorNotSupported)
+               return fail(MH_ERR_HIP, "tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+         }
+      }
       if (algo == ALGO_RNEA)
          { if (ldsc) hipLaunchKernelGGL((mh::rnea_kernel<T, true, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::rnea_kernel<T, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A); }
       else

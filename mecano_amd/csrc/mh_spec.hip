@@ -37,7 +37,8 @@ enum : int
 {
    F_IO_LDS = 1, // state rows staged in LDS (AoS layout only)
    F_IDENT = 2,  // identity index maps
-   F_ST_LDS = 4  // ABA hand-over store in LDS
+   F_ST_LDS = 4, // ABA hand-over store in LDS
+   F_BODIES = 16 // tree-split RNEA / ABA that also write the per-body accelerations / twists (identity maps + LDS rows only)
 };
 
 long lds_bytes(int algo, int flags, int nq, int nv)
@@ -192,6 +193,25 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    const bool id = flags & F_IDENT, io = flags & F_IO_LDS;
    hipStream_t s = (hipStream_t)stream;
+   if (flags & F_BODIES)
+   {
+#ifdef MH_SPEC_MINIMAL
+      return (int)hipErrorNotSupported;
+#else
+      if constexpr (SPL::usable())
+      {
+         if (id && io && (algo == 0 || algo == 1))
+         {
+            static size_t attr0 = 0, attr1 = 0;
+            const size_t lds = (size_t)split_lds_bytes(algo, F_IO_LDS, A.m.nq, A.m.nv);
+            if (algo == 0)
+               return (int)launch_lds(&mh::spec_split_kernel<TP, double, 0, true, true, true>, A, groups, lds, attr0, s);
+            return (int)launch_lds(&mh::spec_split_kernel<TP, double, 1, true, true, true>, A, groups, lds, attr1, s);
+         }
+      }
+      return (int)hipErrorNotSupported;
+#endif
+   }
    if (id && io)
       return (int)go_split_algo<true, true>(algo, A, groups, s);
 #ifdef MH_SPEC_MINIMAL // experiment builds (tools/): only the variant bench.py runs, seconds instead of minutes to compile

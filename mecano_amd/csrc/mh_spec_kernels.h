@@ -513,9 +513,13 @@ struct LaneStore
 
 // Everything one lane needs to walk the tree.  IO_LDS: state rows staged in LDS.  IDENT: the index maps are the identity
 // (Mecano's default JointMatrixIndexProvider over joints in depth-first order), so every row index is a compile-time constant.
-template <typename T, bool IO_LDS, bool IDENT, class SP>
+template <typename T, bool IO_LDS, bool IDENT, class SP, bool BODIES = false>
 struct Ctx
 {
+   // BODIES: the kernel also writes every successor body's spatial acceleration / twist (RigidBodyAccelerationProvider; SURVEY.md
+   // section 8f N2) -- a property of the context TYPE, so that the kernels without it stay instruction for instruction what they were
+   static constexpr bool bodies = BODIES;
+   T *bacc, *btw; // this configuration's rows of the two per-body outputs (either may be NULL), entry stride f_es
    const T *C; // per-joint constants [N][MC_STRIDE], global memory, wave-uniform addresses -> scalar loads
    ciptr dof_map, cfg_map, meta;
    const T *qrow, *qdrow, *in3row, *frow;
@@ -635,6 +639,21 @@ MH_DEV void spec_write(const CX &cx, SV<T> w)
    }
 }
 
+// per-body outputs of body J (canonical after-joint frame -> Mecano's body-fixed frame, row MI_EXT of the caller's joint listing)
+template <int J, class CX, typename T>
+MH_DEV void spec_body_outputs(const CX &cx, const SV<T> &acc, const SV<T> &twist)
+{
+   if constexpr (CX::bodies)
+   {
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      const int ext = cx.meta[J * MI_STRIDE + MI_EXT];
+      if (cx.bacc)
+         store_body_motion<T>(c, cx.bacc, cx.f_es, ext, acc);
+      if (cx.btw)
+         store_body_motion<T>(c, cx.btw, cx.f_es, ext, twist);
+   }
+}
+
 // ============================================================================================ RNEA
 // Returns the wrench the subtree rooted at joint J exerts on its parent, expressed in the parent's frame
 // (InverseDynamicsCalculator.java:873-966 as one depth-first recursion).
@@ -698,6 +717,7 @@ struct RneaSub
       const SV<T> a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
       if (!cx.coriolis)
          v = SV<T>{Z, Z};
+      spec_body_outputs<J, CX, T>(cx, a, v);
       SV<T> f = mul(I, a) + crf(v, mul(I, v));
       if (cx.frow)
          f = f - load_fext<T>(c, cx.frow, cx.f_es, cx.meta[J * MI_STRIDE + MI_EXT]);
@@ -751,6 +771,7 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
       v = SV<T>{Z, Z};
    if constexpr (FK >= 0 && Split<TP>::f_limb(J) == FK)
    {
+      spec_body_outputs<J, CX, T>(cx, a, v);
       const RI<T> I = load_inertia<T>(c);
       SV<T> f = mul(I, a) + crf(v, mul(I, v));
       if (cx.frow)
@@ -1078,6 +1099,9 @@ struct AbaOut
             spec_write<TYPE, DO, CX, T>(cx, x - a);
          a = x;
       }
+      if constexpr (CX::bodies)
+         if (MODE == 0 || cx.wave == 0)
+            spec_body_outputs<J, CX, T>(cx, a, v);
       MH_BODY_FENCE();
       if constexpr (!LEAF)
          children<0>(cx, v, a);
@@ -1678,6 +1702,8 @@ MH_DEV void fill_ctx(CX &cx, const Args<T> &A, long cfg)
    cx.in3row = A.in3 + cfg * A.v_bs;
    cx.frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
    cx.orow = A.out + cfg * A.v_bs;
+   cx.bacc = A.body_acc ? A.body_acc + cfg * A.f_bs : nullptr;
+   cx.btw = A.body_twist ? A.body_twist + cfg * A.f_bs : nullptr;
    cx.q_es = A.q_es, cx.v_es = A.v_es, cx.f_es = A.f_es;
    cx.a0l = V3<T>{-A.gx, -A.gy, -A.gz};
    cx.coriolis = A.coriolis, cx.accel = A.accel;
@@ -1958,11 +1984,11 @@ MH_DEV void integrate_rows(int wave, lds_ptr<T> q, lds_ptr<T> v, lds_ptr<T> a, T
 
 // One workgroup's share of a batch.  ALGO: 0 = RNEA, 1 = ABA.  IO_LDS: the 64 rows of q, qd, qdd|tau are staged once in LDS
 // by all 256 threads (the four waves share them) and the results leave through LDS as one coalesced copy.
-template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS>
+template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS, bool BODIES = false>
 MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> lds)
 {
    using S = Split<TP>;
-   using CX = Ctx<T, IO_LDS, IDENT, SplitStore<TP>>;
+   using CX = Ctx<T, IO_LDS, IDENT, SplitStore<TP>, BODIES>;
    constexpr int XW = ALGO == 0 ? 6 : 27;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
@@ -2067,11 +2093,11 @@ __global__ void __launch_bounds__(256) spec_fused_split_kernel(Args<T> A)
       split_group<TP, T, 1, IDENT, IO_LDS>(A2, blockIdx.x - half, half, (lds_ptr<T>)lds_raw);
    }
 }
-template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS>
+template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS, bool BODIES = false>
 __global__ void __launch_bounds__(256) spec_split_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
-   split_group<TP, T, ALGO, IDENT, IO_LDS>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
+   split_group<TP, T, ALGO, IDENT, IO_LDS, BODIES>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
 }
 
 // CRBA, direct stores: H [B][nv][nv] (or [nv*nv][B]) must be zero-filled by the caller; only entries of related joints are

@@ -978,6 +978,36 @@ def test_specialised_coriolis_kernel_variants(torch_cuda, shape):
     assert np.abs(b2.cpu().numpy() - rb).max() <= TOL * max(1.0, np.abs(rA).max(), np.abs(rb).max())
 
 
+@pytest.mark.parametrize("shape", ["humanoid", "torso", "centaur", "quadruped"])
+def test_per_body_outputs_from_the_tree_split_kernels(torch_cuda, shape):
+    """RigidBodyAccelerationProvider outputs from the tree-split RNEA / ABA (identity maps, AoS: the BODIES variants
+    of spec_split_kernel) against the oracle, with and without external wrenches, ragged and full batches; the efforts / accelerations
+    that come with them equal the plain calls' to rounding (a different instantiation of the same templates)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(("bodies" + shape).encode()))
+    sys_ = {"humanoid": rt.nextHumanoid, "torso": rt.nextFixedBaseTorso, "centaur": rt.nextCentaur, "quadruped": rt.nextQuadruped}[shape](rng)
+    d = sys_.toModelDesc()
+    hm, om = HipModel(d), OracleModel(d)
+    g = (0.1, 0.2, -9.81)
+    for B in (1, 70, 4096):
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6)) if B == 70 else None
+        idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 60)), [B - 1]]))
+        fi = None if fext is None else fext[idx]
+        tq, tqd, tqdd, ttau, tf = dev(torch, q), dev(torch, qd), dev(torch, qdd), dev(torch, tau), dev(torch, fext)
+        t, acc, tw = hm.rnea_bodies(tq, tqd, tqdd, g, tf)
+        r_t, r_acc, r_tw = om.rnea_bodies(q[idx], qd[idx], qdd[idx], g, fi)
+        close(t.cpu().numpy()[idx], r_t), close(acc.cpu().numpy()[idx], r_acc), close(tw.cpu().numpy()[idx], r_tw)
+        assert (t - hm.rnea(tq, tqd, tqdd, g, tf)).abs().max().item() <= 1e-12 * max(1.0, t.abs().max().item())  # another instantiation: rounding only
+        a, acc2, tw2 = hm.aba_bodies(tq, tqd, ttau, g, tf)
+        r_a, r_acc2, r_tw2 = om.aba_bodies(q[idx], qd[idx], tau[idx], g, fi)
+        close(a.cpu().numpy()[idx], r_a), close(acc2.cpu().numpy()[idx], r_acc2, 1e-9), close(tw2.cpu().numpy()[idx], r_tw2)
+        assert (a - hm.aba(tq, tqd, ttau, g, tf)).abs().max().item() <= 1e-11 * max(1.0, a.abs().max().item())
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
