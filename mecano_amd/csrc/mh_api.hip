@@ -1088,7 +1088,22 @@ mh_status mh_reserve(mh_model_t m, int64_t max_batch)
    mh_status st = check_common(m, max_batch, nullptr);
    if (st != MH_OK)
       return st;
-   return ensure_workspace(m, max_batch, sizeof(double));
+   st = ensure_workspace(m, max_batch, sizeof(double));
+   if (st != MH_OK)
+      return st;
+   // the whole-tree specialised ABA keeps its hand-over store in the same workspace (more slots than the run-time-topology plan of a
+   // chain), and big AoS batches of wide matrices go through transposed scratch copies: reserve both, so that compute calls allocate nothing
+   if (m->spec.aba_slots)
+   {
+      const Launch L = plan_launch(m, max_batch);
+      st = ensure_bytes(m->ws, (size_t)std::max(m->n_slots, m->spec.aba_slots()) * (size_t)L.lanes * sizeof(double));
+      if (st != MH_OK)
+         return st;
+   }
+   const bool transposes = m->use_transpose >= 0 ? m->use_transpose != 0 : (max_batch >= 8192 && m->nq + m->nv >= 64);
+   if (transposes)
+      st = ensure_bytes(m->tr, (size_t)max_batch * ((size_t)m->nq + 3 * (size_t)m->nv) * sizeof(double));
+   return st;
 }
 
 mh_status mh_rnea_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],

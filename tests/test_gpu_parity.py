@@ -1008,6 +1008,34 @@ def test_per_body_outputs_from_the_tree_split_kernels(torch_cuda, shape):
         assert (a - hm.aba(tq, tqd, ttau, g, tf)).abs().max().item() <= 1e-11 * max(1.0, a.abs().max().item())
 
 
+def test_coriolis_centroidal_argument_errors_and_empty_batches(torch_cuda):
+    """Status codes of the N3 entry points: an empty batch is MH_OK with NULL pointers, NULL outputs / a convective term without
+    velocities / an unknown frame mode are MH_ERR_INVALID_ARGUMENT, and mh_reserve covers the calls (no allocation afterwards is not
+    observable here, the call just has to succeed)."""
+    torch = torch_cuda
+    import ctypes
+    from mecano_amd import random_tools as rt
+    from mecano_amd import _lib
+    from mecano_amd.engine import HipModel
+    lib = _lib.load()
+    sys_ = rt.nextHumanoid(np.random.default_rng(3))
+    hm = HipModel(sys_.toModelDesc())
+    hm.reserve(20000)
+    assert lib.mh_crba_coriolis_f64(hm._h, 0, None, None, None, None, None) == 0
+    assert lib.mh_centroidal_f64(hm._h, 0, None, None, None, 0, None, None, None, None) == 0
+    q, qd, _, _ = (dev(torch, x) for x in rt.nextState(np.random.default_rng(4), sys_, 8))
+    A = torch.empty((8, 6, hm.nv), dtype=torch.float64, device="cuda")
+    b = torch.empty((8, 6), dtype=torch.float64, device="cuda")
+    H = torch.empty((8, hm.nv, hm.nv), dtype=torch.float64, device="cuda")
+    assert lib.mh_crba_coriolis_f64(hm._h, 8, q.data_ptr(), qd.data_ptr(), None, H.data_ptr(), None) == 1
+    assert b"NULL" in lib.mh_last_error()
+    assert lib.mh_centroidal_f64(hm._h, 8, q.data_ptr(), None, None, 0, None, A.data_ptr(), b.data_ptr(), None) == 1  # b needs qd
+    assert lib.mh_centroidal_f64(hm._h, 8, q.data_ptr(), qd.data_ptr(), None, 7, None, A.data_ptr(), b.data_ptr(), None) == 1  # frame mode
+    assert lib.mh_centroidal_f64(hm._h, 8, q.data_ptr(), None, None, 0, None, A.data_ptr(), None, None) == 0  # A alone: fine
+    assert lib.mh_crba_coriolis_f64(hm._h, -1, q.data_ptr(), qd.data_ptr(), None, H.data_ptr(), H.data_ptr()) == 2  # negative batch
+    torch.cuda.synchronize()
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
