@@ -220,7 +220,9 @@ mh_status mh_aba_bodies_f64(mh_model_t model, int64_t B, const double *q, const 
  *      algorithms/CompositeRigidBodyMassMatrixCalculator.java:271-274, 344-365, 604-630, 669-768; algorithms/FactorizedBodyInertia.java) ----
  * H_out and C_out [B][nv][nv] row-major (MH_LAYOUT_SOA: [nv*nv][B]):  tau = H qdd + C qd + G.  C is the reference's matrix entry for entry
  * (the factorisation B = v x* I of the body-level Coriolis terms: C qd = RNEA(q, qd, qdd = 0, g = 0), dH/dt = C + C^T); entries of
- * unrelated joints are zero.  Device pointers, asynchronous on opts->stream.  Runs the run-time-topology kernel.
+ * unrelated joints are zero.  Device pointers, asynchronous on opts->stream.  fp64 models with a specialised code object run its
+ * compile-time recursion, everything else the run-time-topology kernel.  For big batches MH_LAYOUT_SOA outputs are 3x faster to produce
+ * (coalesced stores) than the AoS matrices.
  */
 mh_status mh_crba_coriolis_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const mh_options *opts, double *H_out,
                                double *C_out);
