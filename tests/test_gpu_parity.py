@@ -100,6 +100,22 @@ def test_lagrangian_known_answers(torch_cuda, path):
     close(hm.aba(q, qd, tau, d["gravity"]), qdd, 1e-11)
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "n3_*.json"))))
+def test_coriolis_centroidal_golden_vectors(torch_cuda, path):
+    """Committed Coriolis / centroidal known answers (tests/golden/make_n3_fixtures.py), host-pointer entry points."""
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import ModelDesc
+    d = json.load(open(path))
+    md = ModelDesc(d["n_joints"], d["nq"], d["nv"], *[np.array(d["desc"][k]) for k in (
+        "parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices")])
+    hm = HipModel(md)
+    q, qd = np.array(d["q"]), np.array(d["qd"])
+    _, C = hm.crba_coriolis(q, qd)
+    A, b, com = hm.centroidal(q, qd, np.array(d["frame"]), True)
+    close(C, np.array(d["C"]), 1e-11), close(A, np.array(d["A_com"]), 1e-11), close(com, np.array(d["com"]), 1e-12)
+    assert np.abs(b - np.array(d["b_com"])).max() <= 1e-11 * max(1.0, np.abs(np.array(d["A_com"])).max())
+
+
 def test_config2_seven_dof_arm_b1024(torch_cuda):
     """BASELINE.json configs[1]: 7-DoF serial arm, batched RNEA fp64, batch 1024."""
     torch = torch_cuda

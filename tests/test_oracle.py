@@ -460,3 +460,24 @@ def test_centroidal_momentum_rate_is_the_root_joint_wrench():
             n_root = R @ n_ + np.cross(p, f_root)
             expected = np.concatenate([n_root, f_root])
             assert np.abs(rate[k] - expected).max(initial=0.0) <= 1e-10 * max(1.0, np.abs(expected).max(initial=0.0))
+
+
+def _n3_case(path):
+    from mecano_amd.multibody import ModelDesc
+    d = json.load(open(path))
+    md = ModelDesc(d["n_joints"], d["nq"], d["nv"], *[np.array(d["desc"][k]) for k in (
+        "parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices")])
+    return md, d
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "n3_*.json"))))
+def test_coriolis_centroidal_golden_vectors(path):
+    """Committed Coriolis / centroidal known answers (tests/golden/make_n3_fixtures.py: dense body-Jacobian forms, self-generated)."""
+    md, d = _n3_case(path)
+    om = OracleModel(md)
+    q, qd = np.array(d["q"]), np.array(d["qd"])
+    _, C = om.crba_coriolis(q, qd)
+    A, b, com = om.centroidal(q, qd, np.array(d["frame"]), True)
+    for got, key in ((C, "C"), (A, "A_com"), (b, "b_com"), (com, "com")):
+        ref = np.array(d[key])
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), key
