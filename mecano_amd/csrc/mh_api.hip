@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -864,6 +865,35 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
          Q[e] = m3_identity();
    }
 
+   // The frame after a 1-DoF joint may still turn about and slide along its own axis (both commute with the joint's motion).  That freedom
+   // is spent on the joint's FIRST child (engine order: the next joint): origin and x axis are chosen so that the child's origin lies on the
+   // x axis, p_b(child) = (a, 0, 0) -- two of the three translation components of that child's pose are structural zeros, which the
+   // specialised kernels fold at compile time (Tree<TP>::p_aligned; the run-time-topology kernels just multiply by 0.0).  O[e] = origin of
+   // the canonical frame of joint e in Mecano's after-joint frame (on the axis); children first, because a child's own slide moves its origin.
+   std::vector<std::array<double, 3>> O(n, std::array<double, 3>{0.0, 0.0, 0.0});
+   std::vector<char> aligned(n, 0);
+   for (int e = n - 2; e >= 0; e--)
+   {
+      const int i = order[e], t = d->joint_type[i], ic = order[e + 1];
+      if ((t != MH_JOINT_REVOLUTE && t != MH_JOINT_PRISMATIC) || d->parent[ic] != i)
+         continue;
+      M3d Rbc;
+      std::memcpy(Rbc.m, d->X_before + 12 * ic, sizeof Rbc.m);
+      double w0[3], w[3];
+      m3_mulv(Rbc, O[e + 1].data(), w0);
+      for (int k = 0; k < 3; k++)
+         w0[k] += d->X_before[12 * ic + 9 + k];
+      m3_mulv(m3_T(Q[e]), w0, w);
+      const double delta = w[2], rho = std::hypot(w[0], w[1]);
+      const double cphi = rho > 1.0e-12 ? w[0] / rho : 1.0, sphi = rho > 1.0e-12 ? w[1] / rho : 0.0;
+      const double slide[3] = {0.0, 0.0, delta};
+      m3_mulv(Q[e], slide, O[e].data());
+      M3d Rz = m3_identity();
+      Rz.m[0] = cphi, Rz.m[1] = -sphi, Rz.m[3] = sphi, Rz.m[4] = cphi;
+      Q[e] = m3_mul(Q[e], Rz);
+      aligned[e + 1] = 1;
+   }
+
    mh_model *m = new mh_model();
    m->n = n, m->nq = d->nq, m->nv = d->nv;
    m->meta.assign((size_t)n * mh::MI_STRIDE, 0);
@@ -936,8 +966,13 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       M3d Rb;
       std::memcpy(Rb.m, d->X_before + 12 * i, sizeof Rb.m);
       const M3d Rb2 = m3_mul(m3_mul(m3_T(Qp), Rb), Q[e]);
-      double pb2[3];
-      m3_mulv(m3_T(Qp), d->X_before + 12 * i + 9, pb2);
+      double pb2[3], pb0[3];
+      m3_mulv(Rb, O[e].data(), pb0); // the canonical origin of this joint, then relative to the parent's canonical origin
+      for (int k = 0; k < 3; k++)
+         pb0[k] += d->X_before[12 * i + 9 + k] - (pe < 0 ? 0.0 : O[pe][k]);
+      m3_mulv(m3_T(Qp), pb0, pb2);
+      if (aligned[e])
+         pb2[1] = 0.0, pb2[2] = 0.0; // (a, 0, 0) by construction: what is left is rounding
       for (int k = 0; k < 9; k++)
          c[mh::MC_RB + k] = Rb2.m[k];
       for (int k = 0; k < 3; k++)
@@ -946,8 +981,10 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       M3d Rc;
       std::memcpy(Rc.m, d->X_com + 12 * i, sizeof Rc.m);
       const M3d Rf = m3_mul(m3_T(Q[e]), Rc);
-      double pf[3];
-      m3_mulv(m3_T(Q[e]), d->X_com + 12 * i + 9, pf);
+      double pf[3], pf0[3];
+      for (int k = 0; k < 3; k++)
+         pf0[k] = d->X_com[12 * i + 9 + k] - O[e][k];
+      m3_mulv(m3_T(Q[e]), pf0, pf);
       for (int k = 0; k < 9; k++)
          c[mh::MC_RF + k] = Rf.m[k];
       for (int k = 0; k < 3; k++)

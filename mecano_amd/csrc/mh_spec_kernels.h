@@ -76,6 +76,12 @@ struct Tree
          s += aba_slots_of(i);
       return s;
    }
+   // The frame after a 1-DoF joint may slide along and turn about its own axis without changing the joint; mh_model_create uses that
+   // freedom so that the origin of the joint's FIRST child (engine order: the next joint) lies on its x axis: p_b = (a, 0, 0) exactly.
+   static constexpr bool p_aligned(int j)
+   {
+      return j > 0 && TP::parent[j] == j - 1 && (TP::type[j - 1] == JT_REVOLUTE || TP::type[j - 1] == JT_PRISMATIC);
+   }
    static constexpr int n_children(int j)
    {
       int c = 0;
@@ -455,6 +461,18 @@ struct Split
 template <typename T>
 using lds_ptr = T __attribute__((address_space(3))) *;
 
+// pose of joint J in its parent's frame; for a first child of a 1-DoF joint the y and z components of the position are structural zeros
+// (Tree<TP>::p_aligned): literal here, so that every product with them folds away (-fno-signed-zeros -ffinite-math-only) and the two
+// scalar loads are never issued
+template <class TP, int J, typename T, class CR>
+MH_DEV XF<T> load_xb_j(const CR &c)
+{
+   XF<T> X = load_xb<T>(c);
+   if constexpr (Tree<TP>::p_aligned(J))
+      X.p.y = T(0), X.p.z = T(0);
+   return X;
+}
+
 // Per-lane store for values that must survive from ABA's inward sweep to its outward sweep.  Where slot k of body J lives is
 // a compile-time decision of the store policy SP:
 //   LDS       LDS, slot-major, 64 lanes per slot: "ds_write/read_b64 base offset:imm", no per-slot address register
@@ -708,7 +726,7 @@ struct RneaSub
       const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
       const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
-      const XF<T> Xb = load_xb<T>(c);
+      const XF<T> Xb = load_xb_j<TP, J, T>(c);
       const RI<T> I = load_inertia<T>(c);
       MH_BODY_FENCE(); // everything the body reads is requested before its arithmetic starts (see JQ)
       const JX<T> jx = spec_joint_from<TYPE, T>(jq);
@@ -729,7 +747,7 @@ struct RneaSub
       // SGPR file and turns every use into a v_readlane); the pointer is laundered so that the reload is not merged away
       const T *c2p = cx.C + J * MC_STRIDE;
       asm volatile("" : "+s"(c2p));
-      const SV<T> up = force_up(TYPE, jx, load_xb<T>(CRef<T, false>{c2p}), f);
+      const SV<T> up = force_up(TYPE, jx, load_xb_j<TP, J, T>(CRef<T, false>{c2p}), f);
       MH_BODY_FENCE();
       return up;
    }
@@ -762,7 +780,7 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
    const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
    const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
    const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
-   const XF<T> Xb = load_xb<T>(c);
+   const XF<T> Xb = load_xb_j<TP, J, T>(c);
    MH_BODY_FENCE();
    const JX<T> jx = spec_joint_from<TYPE, T>(jq);
    v = motion_down(TYPE, jx, Xb, vp) + vJ;
@@ -818,7 +836,7 @@ struct RneaTrunkUp
       spec_write<TYPE, DO, CX, T>(cx, f);
       SV<T> up = f;
       if constexpr (TP::parent[J] >= 0)
-         up = force_up(TYPE, jx, load_xb<T>(CRef<T, false>{cx.C + J * MC_STRIDE}), f);
+         up = force_up(TYPE, jx, load_xb_j<TP, J, T>(CRef<T, false>{cx.C + J * MC_STRIDE}), f);
       MH_BODY_FENCE();
       return up;
    }
@@ -846,7 +864,7 @@ MH_DEV SV<T> trunk_v(const CX &cx)
    const CRef<T, false> c{cx.C + J * MC_STRIDE};
    const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
    const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
-   const XF<T> Xb = load_xb<T>(c);
+   const XF<T> Xb = load_xb_j<TP, J, T>(c);
    MH_BODY_FENCE();
    const JX<T> jx = spec_joint_from<TYPE, T>(jq);
    const SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
@@ -941,7 +959,7 @@ struct AbaIn
       const CRef<T, false> c{cx.C + J * MC_STRIDE};
       const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
-      const XF<T> Xb0 = load_xb<T>(c);
+      const XF<T> Xb0 = load_xb_j<TP, J, T>(c);
       MH_BODY_FENCE();
       const JX<T> jx = spec_joint_from<TYPE, T>(jq);
       SV<T> v = motion_down(TYPE, jx, Xb0, vp) + vJ;
@@ -960,7 +978,7 @@ struct AbaIn
          // unaffected; re-forming it from the still-live parent velocity is exact and removes 6 long live ranges.)
          SV<T> vJ2 = vJ;
          asm volatile("" : "+v"(vJ2.a.x), "+v"(vJ2.a.y), "+v"(vJ2.a.z), "+v"(vJ2.l.x), "+v"(vJ2.l.y), "+v"(vJ2.l.z));
-         v = motion_down(TYPE, jx, load_xb<T>(c), vp) + vJ2;
+         v = motion_down(TYPE, jx, load_xb_j<TP, J, T>(c), vp) + vJ2;
       }
       const RI<T> I = load_inertia<T>(c);
       ABI<T> IA = abi_from_rigid(I);
@@ -1005,7 +1023,7 @@ struct AbaIn
             else
                rank1_down(IA, ua, ul, dinv);
             const SV<T> pa = pA + mul(IA, crm(v, vJ)) + SV<T>{ud * ua, ud * ul};
-            const XF<T> Xb = load_xb<T>(c);
+            const XF<T> Xb = load_xb_j<TP, J, T>(c);
             if constexpr (TYPE == JT_REVOLUTE)
             {
                out.p = pa;
@@ -1026,11 +1044,11 @@ struct AbaIn
          cx.st.template put<J, 0>(x.a.x), cx.st.template put<J, 1>(x.a.y), cx.st.template put<J, 2>(x.a.z);
          cx.st.template put<J, 3>(x.l.x), cx.st.template put<J, 4>(x.l.y), cx.st.template put<J, 5>(x.l.z);
          if constexpr (HAS_PARENT)
-            out.p = force_up(TYPE, jx, load_xb<T>(c), tau); // Ia = 0, pa = tau
+            out.p = force_up(TYPE, jx, load_xb_j<TP, J, T>(c), tau); // Ia = 0, pa = tau
       }
       else if constexpr (HAS_PARENT)
       { // fixed joint
-         const XF<T> Xb = load_xb<T>(c);
+         const XF<T> Xb = load_xb_j<TP, J, T>(c);
          abi_up(TYPE, jx, Xb, IA);
          out.I = IA;
          out.p = force_up(TYPE, jx, Xb, pA);
@@ -1075,7 +1093,7 @@ struct AbaOut
       else
          jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
-      const XF<T> Xb = load_xb<T>(c);
+      const XF<T> Xb = load_xb_j<TP, J, T>(c);
       MH_BODY_FENCE();
       if constexpr (TYPE != JT_REVOLUTE)
          jx = spec_joint_from<TYPE, T>(jq);
@@ -1257,7 +1275,7 @@ struct CrbaSub
       {
          constexpr int CUR = TR::ancestor_at_depth(J, DC), PAR = TR::ancestor_at_depth(J, DC - 1);
          const CRef<T, false> c{cx.C + CUR * MC_STRIDE};
-         F = force_up(TP::type[CUR], path.jx[DC], load_xb<T>(c), F);
+         F = force_up(TP::type[CUR], path.jx[DC], load_xb_j<TP, CUR, T>(c), F);
          write_ancestor<PAR, COL>(cx, F);
          climb<DC - 1, COL>(cx, path, F);
       }
@@ -1308,7 +1326,7 @@ struct CrbaSub
          add(Ic, acc);
       columns<0>(cx, path, Ic);
       if constexpr (TP::parent[J] >= 0)
-         rigid_up(TYPE, path.jx[D], load_xb<T>(c), Ic); // :651-661
+         rigid_up(TYPE, path.jx[D], load_xb_j<TP, J, T>(c), Ic); // :651-661
       MH_BODY_FENCE();
       return Ic;
    }
@@ -1433,7 +1451,7 @@ struct CorSub
          // the same ancestor it would stay in 24 SGPRs per tree level for the whole subtree -- 2 000 scalar spills on the humanoid
          const T *cp = cx.C + CUR * MC_STRIDE;
          asm volatile("" : "+s"(cp));
-         const XF<T> Xb = load_xb<T>(CRef<T, false>{cp});
+         const XF<T> Xb = load_xb_j<TP, CUR, T>(CRef<T, false>{cp});
          F1 = force_up(TP::type[CUR], path.jx[DC], Xb, F1);
          F2 = force_up(TP::type[CUR], path.jx[DC], Xb, F2);
          F3 = force_up(TP::type[CUR], path.jx[DC], Xb, F3);
@@ -1484,7 +1502,7 @@ struct CorSub
       SV<T> vp{Z, Z};
       if constexpr (D > 0)
          vp = up.v[D - 1];
-      path.v[D] = motion_down(TYPE, path.jx[D], load_xb<T>(c), vp) + spec_vec<TYPE, DO, 0, CX, T>(cx, true);
+      path.v[D] = motion_down(TYPE, path.jx[D], load_xb_j<TP, J, T>(c), vp) + spec_vec<TYPE, DO, 0, CX, T>(cx, true);
       CorUp<T> acc;
       MH_BODY_FENCE();
       if constexpr (!LEAF)
@@ -1503,7 +1521,7 @@ struct CorSub
       {
          const T *cp = cx.C + J * MC_STRIDE;
          asm volatile("" : "+s"(cp));
-         const XF<T> Xb = load_xb<T>(CRef<T, false>{cp});
+         const XF<T> Xb = load_xb_j<TP, J, T>(CRef<T, false>{cp});
          rigid_up(TYPE, path.jx[D], Xb, out.I); // :651-661
          fb_up(TYPE, path.jx[D], Xb, out.B);    // :675-683
       }
@@ -1567,7 +1585,7 @@ struct CentSub
       constexpr int CUR = TR::ancestor_at_depth(J, DC);
       const T *cp = cx.C + CUR * MC_STRIDE;
       asm volatile("" : "+s"(cp)); // reloaded per step (see CorSub::climb)
-      F = force_up(TP::type[CUR], path.jx[DC], load_xb<T>(CRef<T, false>{cp}), F);
+      F = force_up(TP::type[CUR], path.jx[DC], load_xb_j<TP, CUR, T>(CRef<T, false>{cp}), F);
       if constexpr (DC > 0)
          return to_root<DC - 1>(cx, path, F);
       else
@@ -1606,7 +1624,7 @@ struct CentSub
       out.f = SV<T>{Z, Z};
       if constexpr (WITH_B)
       {
-         const XF<T> Xb = load_xb<T>(c);
+         const XF<T> Xb = load_xb_j<TP, J, T>(c);
          const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, true);
          v = motion_down(TYPE, path.jx[D], Xb, vp) + vJ;
          a = motion_down(TYPE, path.jx[D], Xb, ap) + crm(v, vJ);  // :826-831
@@ -1626,7 +1644,7 @@ struct CentSub
       {
          const T *cp = cx.C + J * MC_STRIDE;
          asm volatile("" : "+s"(cp));
-         const XF<T> Xb = load_xb<T>(CRef<T, false>{cp});
+         const XF<T> Xb = load_xb_j<TP, J, T>(CRef<T, false>{cp});
          rigid_up(TYPE, path.jx[D], Xb, out.I);
          out.f = force_up(TYPE, path.jx[D], Xb, out.f);
       }
