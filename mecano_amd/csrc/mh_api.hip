@@ -115,7 +115,8 @@ enum : int
    SPEC_IO_LDS = 1,
    SPEC_IDENT = 2,
    SPEC_ST_LDS = 4,
-   SPEC_BODIES = 16
+   SPEC_BODIES = 16,
+   SPEC_OCC3 = 32
 };
 
 struct mh_model
@@ -321,15 +322,20 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    }
    if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
    {
-      const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
-      const int sf = split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa);
+      int sf = split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa);
+      // device-filling RNEA batches without LDS rows (SoA): the build with a 168-register budget keeps three workgroups per CU busy
+      // (124 -> 112 us at B = 262144); smaller batches are faster on the plain build
+      const bool occ3 = algo == ALGO_RNEA && !(sf & SPEC_IO_LDS) && (sf & SPEC_IDENT) && (B + 63) / 64 > (long)model->cu_count * 2;
+      if (occ3)
+         sf |= SPEC_OCC3;
+      const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * (occ3 ? 3 : 2));
       if (algo == ALGO_ABA && q_next && (sf & SPEC_IDENT) && (sf & SPEC_IO_LDS))
       { // fused simulation step: the kernel integrates the rows it holds in LDS and writes the new state too
          A.dt = (T)step_dt, A.q_next = q_next, A.qd_next = qd_next;
          if (stepped)
             *stepped = true;
       }
-      const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa), &A, (int)groups, (void *)stream);
+      const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, sf, &A, (int)groups, (void *)stream);
       if (rc != 0)
          return fail(MH_ERR_HIP, "tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
       return MH_OK;

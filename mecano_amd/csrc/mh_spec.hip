@@ -8,6 +8,7 @@
 #include "mh_spec_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #ifndef MH_TOPO_N
 #error "MH_TOPO_N / MH_TOPO_PARENTS / MH_TOPO_TYPES must be defined"
@@ -38,7 +39,8 @@ enum : int
    F_IO_LDS = 1, // state rows staged in LDS (AoS layout only)
    F_IDENT = 2,  // identity index maps
    F_ST_LDS = 4, // ABA hand-over store in LDS
-   F_BODIES = 16 // tree-split RNEA / ABA that also write the per-body accelerations / twists (identity maps + LDS rows only)
+   F_BODIES = 16, // tree-split RNEA / ABA that also write the per-body accelerations / twists (identity maps + LDS rows only)
+   F_OCC3 = 32    // tree-split RNEA without LDS rows (SoA): the build with a three-waves-per-SIMD register budget (device-filling batches)
 };
 
 long lds_bytes(int algo, int flags, int nq, int nv)
@@ -158,12 +160,19 @@ hipError_t go_fused_split(const mh::Args<double> &A, int groups, hipStream_t str
    else
       return hipErrorNotSupported;
 }
+bool g_want_occ3 = false; // set by mh_spec_launch_split for the call in flight (F_OCC3)
 template <int ALGO, bool ID, bool IO>
 hipError_t go_split(const mh::Args<double> &A, int groups, hipStream_t stream)
 {
    if constexpr (SPL::usable())
    {
       static size_t attr_bytes = 0;
+      if constexpr (ALGO == 0 && ID && !IO)
+      {
+         if (g_want_occ3)
+            return launch_lds(&mh::spec_split_kernel_occ3<TP, double, ALGO, ID, IO>, A, groups,
+                              (size_t)split_lds_bytes(ALGO, 0, A.m.nq, A.m.nv), attr_bytes, stream);
+      }
       return launch_lds(&mh::spec_split_kernel<TP, double, ALGO, ID, IO>, A, groups,
                         (size_t)split_lds_bytes(ALGO, IO ? F_IO_LDS : 0, A.m.nq, A.m.nv), attr_bytes, stream);
    }
@@ -193,6 +202,7 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    const bool id = flags & F_IDENT, io = flags & F_IO_LDS;
    hipStream_t s = (hipStream_t)stream;
+   g_want_occ3 = (flags & F_OCC3) != 0;
    if (flags & F_BODIES)
    {
 #ifdef MH_SPEC_MINIMAL

@@ -2118,6 +2118,16 @@ __global__ void __launch_bounds__(256) spec_split_kernel(Args<T> A)
    split_group<TP, T, ALGO, IDENT, IO_LDS, BODIES>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
 }
 
+// The same with a register budget for three waves per SIMD (168 VGPRs): the tree-split RNEA without LDS rows (SoA matrices, read
+// directly and coalesced) needs 31 KB of LDS per workgroup, so five workgroups would fit a CU -- the 190 registers of the plain build hold
+// it at two.
+template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS>
+__global__ void __launch_bounds__(256, 3) spec_split_kernel_occ3(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   split_group<TP, T, ALGO, IDENT, IO_LDS, false>(A, blockIdx.x, gridDim.x, (lds_ptr<T>)lds_raw);
+}
+
 // CRBA, direct stores: H [B][nv][nv] (or [nv*nv][B]) must be zero-filled by the caller; only entries of related joints are
 // written.  Used when the index maps are not the identity.
 template <class TP, typename T, bool IDENT>

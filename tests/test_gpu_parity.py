@@ -1052,6 +1052,28 @@ def test_coriolis_centroidal_argument_errors_and_empty_batches(torch_cuda):
     torch.cuda.synchronize()
 
 
+def test_device_filling_soa_rnea_uses_the_three_wave_build(torch_cuda):
+    """Above 2 workgroups per CU (B > 32768 on 256 CUs) the tree-split RNEA on SoA matrices runs the build with a register budget for three
+    waves per SIMD (spec_split_kernel_occ3): oracle on a sample, the AoS result (plain build) to rounding, ragged batch size."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd import _lib
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    d = sys_.toModelDesc()
+    hm, om = HipModel(d), OracleModel(d)
+    B = 33000 + 77
+    q, qd, qdd, _ = rt.nextState(np.random.default_rng(5), sys_, B)
+    g = (0.0, 0.0, -9.81)
+    tq, tqd, tqdd = dev(torch, q), dev(torch, qd), dev(torch, qdd)
+    t_soa = hm.rnea(tq.t().contiguous(), tqd.t().contiguous(), tqdd.t().contiguous(), g, layout=_lib.LAYOUT_SOA).t()
+    t_aos = hm.rnea(tq, tqd, tqdd, g)
+    assert (t_soa - t_aos).abs().max().item() <= 1e-11 * max(1.0, t_aos.abs().max().item())
+    idx = np.unique(np.concatenate([np.arange(0, B, 331), [B - 1]]))
+    close(t_soa.cpu().numpy()[idx], om.rnea(q[idx], qd[idx], qdd[idx], g))
+
+
 def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
