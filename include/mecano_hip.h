@@ -39,6 +39,10 @@
  *     JointMatrixIndexProvider contract
  *     (multiBodySystem/interfaces/JointMatrixIndexProvider.java:71-123).
  *
+ * Threading: like the reference's calculators (one per thread), a model handle is to be used by one host thread at a time -- compute
+ * calls share its device workspace and scratch buffers.  Create one handle per thread (models are a few KB) or serialise the calls;
+ * different handles are independent.  Calls are asynchronous on opts->stream.
+ *
  * No function throws or aborts; every entry point returns an mh_status and
  * mh_last_error() gives a thread-local message.  The library never falls back
  * to a CPU implementation: without a usable HIP device every compute call
