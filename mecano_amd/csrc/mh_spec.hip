@@ -160,16 +160,15 @@ hipError_t go_fused_split(const mh::Args<double> &A, int groups, hipStream_t str
    else
       return hipErrorNotSupported;
 }
-bool g_want_occ3 = false; // set by mh_spec_launch_split for the call in flight (F_OCC3)
 template <int ALGO, bool ID, bool IO>
-hipError_t go_split(const mh::Args<double> &A, int groups, hipStream_t stream)
+hipError_t go_split(const mh::Args<double> &A, int groups, hipStream_t stream, bool occ3 = false)
 {
    if constexpr (SPL::usable())
    {
       static size_t attr_bytes = 0;
       if constexpr (ALGO == 0 && ID && !IO)
       {
-         if (g_want_occ3)
+         if (occ3)
             return launch_lds(&mh::spec_split_kernel_occ3<TP, double, ALGO, ID, IO>, A, groups,
                               (size_t)split_lds_bytes(ALGO, 0, A.m.nq, A.m.nv), attr_bytes, stream);
       }
@@ -180,12 +179,12 @@ hipError_t go_split(const mh::Args<double> &A, int groups, hipStream_t stream)
       return hipErrorNotSupported;
 }
 template <bool ID, bool IO>
-hipError_t go_split_algo(int algo, const mh::Args<double> &A, int groups, hipStream_t s)
+hipError_t go_split_algo(int algo, const mh::Args<double> &A, int groups, hipStream_t s, bool occ3)
 {
    if (algo == 2)
       return go_fused_split<ID, IO>(A, groups, s);
    if (algo == 0)
-      return go_split<0, ID, IO>(A, groups, s);
+      return go_split<0, ID, IO>(A, groups, s, occ3);
    if (algo == 1)
       return go_split<1, ID, IO>(A, groups, s);
    return hipErrorNotSupported;
@@ -202,7 +201,7 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
    const bool id = flags & F_IDENT, io = flags & F_IO_LDS;
    hipStream_t s = (hipStream_t)stream;
-   g_want_occ3 = (flags & F_OCC3) != 0;
+   const bool occ3 = (flags & F_OCC3) != 0;
    if (flags & F_BODIES)
    {
 #ifdef MH_SPEC_MINIMAL
@@ -223,15 +222,15 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
 #endif
    }
    if (id && io)
-      return (int)go_split_algo<true, true>(algo, A, groups, s);
+      return (int)go_split_algo<true, true>(algo, A, groups, s, occ3);
 #ifdef MH_SPEC_MINIMAL // experiment builds (tools/): only the variant bench.py runs, seconds instead of minutes to compile
    return (int)hipErrorNotSupported;
 #else
    if (id)
-      return (int)go_split_algo<true, false>(algo, A, groups, s);
+      return (int)go_split_algo<true, false>(algo, A, groups, s, occ3);
    if (io)
-      return (int)go_split_algo<false, true>(algo, A, groups, s);
-   return (int)go_split_algo<false, false>(algo, A, groups, s);
+      return (int)go_split_algo<false, true>(algo, A, groups, s, occ3);
+   return (int)go_split_algo<false, false>(algo, A, groups, s, occ3);
 #endif
 }
 // the tree-split plan of this topology, for tests and documentation: out[0] = usable, [1] = staged trunk, [2] = limbs, [3] = sub-trunks,
