@@ -45,6 +45,10 @@ def _load():
         lib.mo_rnea_bodies.argtypes = [P, ctypes.c_long, P, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P, P]
         lib.mo_aba_bodies.argtypes = [P, ctypes.c_long, P, P, P, P, P, P, P, P]
         lib.mo_aba_bodies.restype = ctypes.c_int
+        lib.mo_rnea_wrenches.argtypes = [P, ctypes.c_long, P, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P]
+        lib.mo_rnea_wrenches.restype = None
+        lib.mo_relative_acceleration.argtypes = [P, ctypes.c_long, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, P]
+        lib.mo_relative_acceleration.restype = None
         lib.mo_crba_coriolis.argtypes = [P, ctypes.c_long, P, P, P, P]
         lib.mo_crba_coriolis.restype = None
         lib.mo_centroidal.argtypes = [P, ctypes.c_long, P, P, P, ctypes.c_int, P, P, P]
@@ -129,6 +133,29 @@ class OracleModel:
         if rc:
             raise ArithmeticError("oracle ABA: joint-space inertia block not positive definite")
         return qdd, acc, tw
+
+    def rnea_wrenches(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None, consider_coriolis=True, consider_accelerations=True):
+        """RNEA plus InverseDynamicsCalculator.getComputedJointWrench of every joint: (tau, joint_wrench [B, n, 6]) in the frames after
+        the joints.  With qdd = ABA(tau) this is ForwardDynamicsCalculator.getJointWrench."""
+        q, qd, qdd, f_ext = _c(q), _c(qd), _c(qdd), _c(f_ext)
+        B = q.shape[0]
+        g = np.asarray(gravity, dtype=np.float64)
+        tau, w = np.zeros((B, self.nv)), np.zeros((B, self.n, 6))
+        _load().mo_rnea_wrenches(self._h, B, _p(q), _p(qd), _p(qdd), _p(g), _p(f_ext), int(consider_coriolis), int(consider_accelerations),
+                                 _p(tau), _p(w))
+        return tau, w
+
+    def relative_acceleration(self, q, qd, qdd, base, body, gravity=(0.0, 0.0, -9.81), consider_coriolis=True, consider_accelerations=True):
+        """RigidBodyAccelerationProvider.getRelativeAcceleration for pairs of listed joints' successor bodies (-1 = the root body):
+        [B, n_pairs, 6], expressed in the body's body-fixed frame."""
+        q, qd, qdd = _c(q), _c(qd), _c(qdd)
+        base, body = _c(base, np.int32), _c(body, np.int32)
+        B = q.shape[0]
+        g = np.asarray(gravity, dtype=np.float64)
+        out = np.zeros((B, len(base), 6))
+        _load().mo_relative_acceleration(self._h, B, _p(q), _p(qd), _p(qdd), _p(g), int(consider_coriolis), int(consider_accelerations),
+                                         len(base), _p(base), _p(body), _p(out))
+        return out
 
     def integrate(self, dt, q, qd, qdd):
         """MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration: returns (q', qd', qdd')."""

@@ -119,7 +119,7 @@ class Model:
         return self.dof_idx[self.dof_ofs[i]:self.dof_ofs[i + 1]]
 
 
-def rnea(m: Model, q, qd, qdd, g, fext=None):
+def rnea(m: Model, q, qd, qdd, g, fext=None, return_wrenches=False):
     n = m.n
     v = [None] * n
     a = [None] * n
@@ -148,6 +148,8 @@ def rnea(m: Model, q, qd, qdd, g, fext=None):
         p = m.parent[i]
         if p >= 0:
             f[p] = f[p] + Xup[i].T @ f[i]
+    if return_wrenches:
+        return tau, np.array(f)  # wrench every joint transmits, after-joint frames
     return tau
 
 
@@ -273,3 +275,28 @@ def centroidal_dense(m: Model, q, qd, frame=None, at_com=False):
         A += Xf @ to_root @ m.I[k] @ J[k]
         b += Xf @ to_root @ (m.I[k] @ (Jd[k] @ qd) + crf(v[k]) @ (m.I[k] @ v[k]))
     return A, b, origin
+
+
+def relative_acceleration_dense(m: Model, q, qd, qdd, g, base, body):
+    """Acceleration of body `body` relative to body `base` (indices of listed joints, -1 = the root body), expressed in the body-fixed
+    frame of `body`, in the reference's convention (component-wise derivative of the relative twist expressed in the moving body frame),
+    from the dense body Jacobians: with Featherstone's spatial accelerations a_i = J_i qdd + Jd_i qd + X0_i a0 (true derivatives, which
+    subtract like vectors),  A_rel = a_2 - X_{1->2} a_1 + v_2 x (X_{1->2} v_1).  Independent of the cross-product recipe the C oracle
+    restates from SpatialAccelerationBasics.changeFrame."""
+    v, J, Jd, X0 = _body_jacobians(m, q, qd)
+    a0 = np.concatenate([np.zeros(3), -np.asarray(g, dtype=float)])
+    n = m.n
+    Xc = np.asarray(m.d.X_com).reshape(n, 12)
+
+    def quantities(i):
+        if i < 0:
+            return np.eye(6), np.zeros(6), a0
+        return X0[i], v[i], J[i] @ qdd + Jd[i] @ qd + X0[i] @ a0
+
+    X1, v1, a1 = quantities(base)
+    X2, v2, a2 = quantities(body)
+    X12 = X2 @ np.linalg.inv(X1)  # frame of base -> frame of body (after-joint frames)
+    rel = a2 - X12 @ a1 + crm(v2) @ (X12 @ v1)
+    if body < 0:
+        return rel
+    return np.linalg.inv(plucker_motion(Xc[body, :9].reshape(3, 3), Xc[body, 9:])) @ rel  # after-joint -> body-fixed frame

@@ -342,10 +342,11 @@ static void kinematics(const mo_model *m, const double *qrow, const double *qdro
 /* ------------------------------------------------------------------ Newton-Euler of one body
  * spatial/interfaces/SpatialInertiaReadOnly.java:229-296 with tools/MecanoTools.java:571-598,728-752 (CoM at the origin)
  * or :632-702,785-822 (offset CoM).  acc / tw may be NULL exactly like the Java arguments. */
+static _Thread_local int unit_force_general_wrench = 0; /* unit tests only: take the general branch whatever |c| is */
 static void dynamic_wrench(const double J[9], double mass, const double c[3], const double *acc, const double *tw, double out[6])
 {
    double n[3] = {0, 0, 0}, f[3] = {0, 0, 0};
-   if (v3_dot(c, c) < COM_OFFSET_ZERO_EPSILON)
+   if (!unit_force_general_wrench && v3_dot(c, c) < COM_OFFSET_ZERO_EPSILON)
    {
       if (tw)
       {
@@ -432,6 +433,8 @@ static void dynamic_wrench(const double J[9], double mass, const double c[3], co
  * frame on request) and the twist (frames/MovingReferenceFrame.java:279-311) of every successor body, both relative to the inertial
  * frame and expressed in the body-fixed frame, 6 numbers (angular, linear) per listed joint */
 static _Thread_local double *tap_acc = NULL, *tap_twist = NULL;
+/* per-joint wrench (InverseDynamicsCalculator.getComputedJointWrench, :578-585): what passTwo leaves in jointWrench, frame after the joint */
+static _Thread_local double *tap_wrench = NULL;
 
 static void rnea_one(const mo_model *m, const double *q, const double *qd, const double *qdd, const double g[3], const double *fext,
                      int coriolis, int accel, double *tau)
@@ -517,6 +520,9 @@ static void rnea_one(const mo_model *m, const double *q, const double *qd, const
             wrench[p][k] += w[k];
       }
    }
+   if (tap_wrench)
+      for (int i = 0; i < m->n; i++)
+         memcpy(tap_wrench + 6 * i, wrench[i], 6 * sizeof(double));
 }
 
 /* ================================================================== articulated-body inertia as (A, L, C) blocks
@@ -1566,4 +1572,174 @@ int mo_aba_bodies(void *h, long B, const double *q, const double *qd, const doub
    }
    tap_acc = tap_twist = NULL;
    return rc;
+}
+
+/* RNEA plus the 6-D wrench every joint transmits (moment, force), expressed in the frame after the joint:
+ * InverseDynamicsCalculator.getComputedJointWrench (:578-585; passTwo :930-959 leaves it there).  ForwardDynamicsCalculator.getJointWrench
+ * (:642-650, lazily evaluated by :1330-1363) is the same Newton-Euler sweep run on the accelerations forward dynamics computed, i.e. this
+ * function called with qdd = ABA(tau) -- the reference's own test compares the two (ForwardDynamicsCalculatorTest.java:884-901). */
+void mo_rnea_wrenches(void *h, long B, const double *q, const double *qd, const double *qdd, const double *g, const double *fext, int coriolis,
+                      int accel, double *tau, double *joint_wrench)
+{
+   const mo_model *m = (const mo_model *)h;
+   for (long b = 0; b < B; b++)
+   {
+      tap_wrench = joint_wrench ? joint_wrench + b * 6 * m->n : NULL;
+      rnea_one(m, q + b * m->nq, qd + b * m->nv, qdd ? qdd + b * m->nv : NULL, g, fext ? fext + b * 6 * m->n : NULL, coriolis, accel && qdd,
+               tau + b * m->nv);
+   }
+   tap_wrench = NULL;
+}
+
+/* RigidBodyAccelerationProvider.getRelativeAcceleration(base, body) (algorithms/interfaces/RigidBodyAccelerationProvider.java:199-235) on the
+ * accelerations RNEA's first pass computes: acceleration of body's body-fixed frame with respect to base's, expressed in body's.
+ * base[k] / body[k] index the listed joints (their successor bodies); -1 = the root body (pose identity, no twist, acceleration = the
+ * root acceleration -g).  out [B][n_pairs][6].  The base's acceleration is re-expressed in the body's frame with the velocity-dependent
+ * terms of SpatialAccelerationBasics.changeFrame(desiredFrame, deltaTwist, bodyTwist) (non-flipped branch, :192-200: the twist of the base
+ * frame relative to the body frame and the base's own twist, both in the base frame) when velocities are considered. */
+void mo_relative_acceleration(void *h, long B, const double *q, const double *qd, const double *qdd, const double *g, int coriolis, int accel,
+                              int n_pairs, const int *base, const int *body, double *out)
+{
+   const mo_model *m = (const mo_model *)h;
+   static _Thread_local mo_kin K;
+   static _Thread_local double acc[MO_MAX_JOINTS][6], tw[MO_MAX_JOINTS][6];
+   double *tau = (double *)malloc(sizeof(double) * (size_t)(m->nv > 0 ? m->nv : 1));
+   const double a_root[6] = {0, 0, 0, -g[0], -g[1], -g[2]}, zero6[6] = {0};
+   xf_t W_world, T;
+   xf_identity(&W_world);
+   for (long b = 0; b < B; b++)
+   {
+      tap_acc = &acc[0][0], tap_twist = &tw[0][0];
+      rnea_one(m, q + b * m->nq, qd + b * m->nv, qdd ? qdd + b * m->nv : NULL, g, NULL, coriolis, accel && qdd, tau);
+      tap_acc = tap_twist = NULL;
+      kinematics(m, q + b * m->nq, qd + b * m->nv, &K);
+      for (int k = 0; k < n_pairs; k++)
+      {
+         const int b1 = base[k], b2 = body[k];
+         const xf_t *W1 = b1 < 0 ? &W_world : &K.W_body[b1], *W2 = b2 < 0 ? &W_world : &K.W_body[b2];
+         const double *t1 = b1 < 0 ? zero6 : tw[b1], *t2 = b2 < 0 ? zero6 : tw[b2];
+         double a1[6], a1in2[6];
+         memcpy(a1, b1 < 0 ? a_root : acc[b1], sizeof a1);
+         if (coriolis)
+         {
+            double t2in1[6], d[6], c1[3], c2[3], c3[3];
+            xf_between(W2, W1, &T);
+            xf_motion(&T, t2, t2in1);
+            for (int c = 0; c < 6; c++)
+               d[c] = t1[c] - t2in1[c]; /* baseFrame.getTwistRelativeToOther(bodyFrame): :217 */
+            v3_cross(d + 3, t1, c1);    /* v_delta x w_base   */
+            v3_cross(d, t1 + 3, c2);    /* w_delta x v_base   */
+            v3_cross(d, t1, c3);        /* w_delta x w_base   */
+            for (int c = 0; c < 3; c++)
+               a1[3 + c] += c1[c] + c2[c], a1[c] += c3[c];
+         }
+         xf_between(W1, W2, &T);
+         xf_motion(&T, a1, a1in2);
+         const double *a2 = b2 < 0 ? a_root : acc[b2];
+         for (int c = 0; c < 6; c++)
+            out[((size_t)b * n_pairs + k) * 6 + c] = a2[c] - a1in2[c]; /* :228 */
+      }
+   }
+   free(tau);
+}
+
+/* ================================================================== unit-level entry points
+ * The building blocks above, exported one by one so that tests/test_oracle_units.py can restate the reference's own unit tests on
+ * them (the only pins this environment allows):
+ *   test/.../algorithms/ArticulatedBodyInertiaTest.java:25-130   ABI applyTransform == SpatialInertia applyTransform on rigid inertias
+ *   test/.../spatial/SpatialInertiaBasicsTest.java:76-98,129-157,216-340   co-energy, fast == general wrench, frame invariances
+ *   test/.../tools/MecanoToolsTest.java:218-460,618-694          parallel-axis translation, dynamic force / moment, co-energy
+ * X[12] = R row-major then p, as everywhere in this file. */
+static void xf_load(const double X[12], xf_t *T)
+{
+   memcpy(T->R, X, 9 * sizeof(double));
+   memcpy(T->p, X + 9, 3 * sizeof(double));
+}
+void mo_unit_dynamic_wrench(const double J[9], double mass, const double c[3], const double *acc, const double *tw, int force_general,
+                            double out[6])
+{
+   unit_force_general_wrench = force_general;
+   dynamic_wrench(J, mass, c, acc, tw, out);
+   unit_force_general_wrench = 0;
+}
+/* SpatialInertiaBasics.applyTransform / applyInverseTransform (spatial/interfaces/SpatialInertiaBasics.java:222-269) */
+void mo_unit_rigid_apply_transform(const double X[12], int inverse, double J[9], double *mass, double c[3])
+{
+   xf_t T, Ti;
+   rigid_t I;
+   xf_load(X, &T);
+   if (inverse)
+   {
+      xf_inv(&T, &Ti);
+      T = Ti;
+   }
+   memcpy(I.J, J, sizeof I.J);
+   I.m = *mass;
+   memcpy(I.c, c, sizeof I.c);
+   rigid_apply_transform(&T, &I);
+   memcpy(J, I.J, sizeof I.J);
+   *mass = I.m;
+   memcpy(c, I.c, sizeof I.c);
+}
+/* ArticulatedBodyInertia.applyTransform / applyInverseTransform (algorithms/ArticulatedBodyInertia.java:359-402) */
+void mo_unit_abi_apply_transform(const double X[12], int inverse, double A[9], double L[9], double C[9])
+{
+   xf_t T, Ti;
+   abi_t I;
+   xf_load(X, &T);
+   if (inverse)
+   {
+      xf_inv(&T, &Ti);
+      T = Ti;
+   }
+   memcpy(I.A, A, sizeof I.A), memcpy(I.L, L, sizeof I.L), memcpy(I.C, C, sizeof I.C);
+   abi_apply_transform(&T, &I);
+   memcpy(A, I.A, sizeof I.A), memcpy(L, I.L, sizeof I.L), memcpy(C, I.C, sizeof I.C);
+}
+/* ArticulatedBodyInertia.setIncludingFrame(SpatialInertia) (:176-186) and both dense 6x6 forms (SpatialInertiaReadOnly.java:394-415) */
+void mo_unit_abi_from_rigid(const double J[9], double mass, const double c[3], double A[9], double L[9], double C[9])
+{
+   abi_t I;
+   abi_from_rigid(J, mass, c, &I);
+   memcpy(A, I.A, sizeof I.A), memcpy(L, I.L, sizeof I.L), memcpy(C, I.C, sizeof I.C);
+}
+void mo_unit_abi_to_dense(const double A[9], const double L[9], const double C[9], double M[36])
+{
+   abi_t I;
+   memcpy(I.A, A, sizeof I.A), memcpy(I.L, L, sizeof I.L), memcpy(I.C, C, sizeof I.C);
+   abi_to_dense(&I, M);
+}
+void mo_unit_rigid_mulv(const double J[9], double mass, const double c[3], const double x[6], double out[6])
+{
+   rigid_t I;
+   memcpy(I.J, J, sizeof I.J);
+   I.m = mass;
+   memcpy(I.c, c, sizeof I.c);
+   rigid_mulv(&I, x, out);
+}
+void mo_unit_motion_transform(const double X[12], int inverse, const double in[6], double out[6])
+{
+   xf_t T;
+   xf_load(X, &T);
+   if (inverse)
+      xf_motion_inv(&T, in, out);
+   else
+      xf_motion(&T, in, out);
+}
+void mo_unit_force_transform(const double X[12], const double in[6], double out[6])
+{
+   xf_t T;
+   xf_load(X, &T);
+   xf_force(&T, in, out);
+}
+/* tools/MecanoTools.java:844-890: T = 1/2 (m v.v + 2 m w.(c x v) + w.J w) */
+double mo_unit_kinetic_coenergy(const double J[9], double mass, const double c[3], const double tw[6])
+{
+   double cxv[3], Jw[3];
+   double energy = mass * v3_dot(tw + 3, tw + 3);
+   v3_cross(c, tw + 3, cxv);
+   energy += 2.0 * mass * v3_dot(tw, cxv);
+   m3_mulv(J, tw, Jw);
+   energy += v3_dot(tw, Jw);
+   return 0.5 * energy;
 }

@@ -25,3 +25,17 @@ def hip_lib():
         if not os.path.exists(build.LIB):
             raise
     return _lib.load()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The achieved parity errors of the run (tests/helpers.py: PARITY_LOG), for the record under profiles/."""
+    try:
+        import json
+        from helpers import PARITY_LOG
+        if PARITY_LOG:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "parity_errors.json"), "w") as f:
+                json.dump({"exitstatus": int(exitstatus), "tests": PARITY_LOG}, f, indent=1, sort_keys=True)
+    except Exception:
+        pass

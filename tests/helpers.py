@@ -1,4 +1,6 @@
-"""Shared builders for the tests."""
+"""Shared builders for the tests, and the log of achieved parity errors (written to gpurun_out/parity_errors.json at session end)."""
+import os
+
 import numpy as np
 
 from mecano_amd import random_tools as rt
@@ -23,3 +25,29 @@ def build_lump_pair(weld):
     j2 = rt.nextRevoluteJoint(r, "j2", b1)
     rt.nextRigidBody(r, "b2", j2)
     return root, k0
+
+
+# ---- achieved errors per test: {test id: {"max_err": worst |actual - ref| seen, "bound": the bound it was held to, "checks": n}}
+PARITY_LOG = {}
+
+
+def record_parity(err, bound, label=None):
+    name = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split(" (")[0]
+    if label:
+        name += " :: " + label
+    e = PARITY_LOG.setdefault(name, {"max_err": 0.0, "bound": float(bound), "checks": 0})
+    e["max_err"] = max(e["max_err"], float(err))
+    e["bound"] = max(e["bound"], float(bound))
+    e["checks"] += 1
+
+
+def close(actual, ref, tol=1.0e-10, absolute=False, label=None):
+    """|actual - ref|_inf <= tol * max(1, |ref|_inf), or <= tol outright with absolute=True (the north star's "within 1e-10" on
+    BASELINE.json's fp64 configurations).  Every check lands in PARITY_LOG."""
+    actual, ref = np.asarray(actual), np.asarray(ref)
+    assert actual.shape == ref.shape, (actual.shape, ref.shape)
+    err = float(np.abs(actual - ref).max()) if ref.size else 0.0
+    bound = tol if absolute else tol * max(1.0, float(np.abs(ref).max()) if ref.size else 0.0)
+    record_parity(err, bound, label)
+    assert err <= bound, f"max err {err:.3e} > {bound:.3e}"
+    return err

@@ -1,0 +1,265 @@
+"""The reference's known answers and unit-level invariants, through the C-ABI on the GPU.
+
+tests/test_oracle_units.py and tests/test_oracle.py restate them on the CPU oracle; here the HIP path has to meet the same closed forms
+by itself (no oracle in the loop where a closed form exists), so that the device primitives -- (A, L, C) congruences, rigid-inertia
+shifts, twist propagation, Newton-Euler wrench, planar / spherical joint maps, integrator -- are pinned the way the reference pins its
+own (paths relative to /root/reference/src/test/java/us/ihmc/mecano/).  fp32 entry points are compared with the fp64 oracle.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import close, record_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(hip_lib):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def dev(torch, x, dtype=None):
+    return torch.tensor(np.ascontiguousarray(x), device="cuda", dtype=dtype or torch.float64)
+
+
+def system_of(joints):
+    from mecano_amd.multibody import MultiBodySystem
+    return MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor())
+
+
+def test_planar_joint_ballistic_on_the_device(torch_cuda):
+    """tools/MultiBodySystemStateIntegratorTest.java:433-498 (testPlanarJointBallistic, EPSILON 1e-12): 1000 steps of mh_aba_f64 +
+    mh_integrate_f64 on a unit ball on a PlanarJoint land on the closed-form parabola."""
+    torch = torch_cuda
+    from mecano_amd.engine import HipModel
+    from test_oracle import _free_object, planar_ballistic_check
+    hm = HipModel(_free_object("planar").toModelDesc())
+    rng = np.random.default_rng(4366346)
+
+    def aba(q, qd, g):
+        return hm.aba(dev(torch, q), dev(torch, qd), dev(torch, np.zeros_like(qd)), (0.0, 0.0, g)).cpu().numpy()
+
+    def integrate(dt, q, qd, qdd):
+        return [t.cpu().numpy() for t in hm.integrate(dt, dev(torch, q), dev(torch, qd), dev(torch, qdd), return_acceleration=True)]
+
+    for it in range(2):
+        worst = planar_ballistic_check(aba, integrate, rng, B=64, steps=1000, checks=(0, 1, 499, 999))
+        record_parity(worst, 1e-12, "planar ballistic closed form")
+        assert worst <= 1e-12, worst
+
+
+@pytest.mark.parametrize("kind", ["planar", "spherical"])
+def test_planar_and_spherical_steps_against_finite_differences(torch_cuda, kind):
+    """tools/MultiBodySystemStateIntegratorTest.java:273-431, 505-575 on the device: zero velocity and acceleration leave the state
+    alone; the pose difference over dt reproduces the velocity (first order in dt); a free spinning unit ball has zero angular
+    acceleration and keeps its velocity."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from test_oracle import _free_object, _quat_R
+    sys_ = _free_object(kind)
+    hm = HipModel(sys_.toModelDesc())
+    rng = np.random.default_rng(5464576)
+    B = 32
+    step = lambda dt, q, v, a: [t.cpu().numpy() for t in hm.integrate(dt, dev(torch, q), dev(torch, v), dev(torch, a), return_acceleration=True)]
+    for it in range(4):
+        dt = float(rng.uniform(1.0e-5, 1.0e-3))
+        q, qd, _, _ = rt.nextState(rng, sys_, B)
+        z = np.zeros((B, 3))
+        qn, vn, an = step(dt, q, z, z)
+        assert np.abs(qn - q).max() <= 1e-12 and not vn.any() and not an.any()
+        if kind == "planar":
+            v = np.column_stack([np.zeros(B), rng.uniform(-10, 10, B), rng.uniform(-10, 10, B)])
+            qn, vn, an = step(dt, q, v, z)
+            c, s = np.cos(q[:, 0]), np.sin(q[:, 0])
+            dx, dz = (qn[:, 1] - q[:, 1]) / dt, (qn[:, 2] - q[:, 2]) / dt
+            fd = np.column_stack([c * dx - s * dz, s * dx + c * dz])
+            assert np.abs(fd - v[:, 1:]).max() <= 1e-8 and np.abs(vn - v).max() <= 1e-12 and np.abs(an).max() <= 1e-12
+            assert np.abs(qn[:, 0] - q[:, 0]).max() <= 1e-12
+        else:
+            qdd = hm.aba(dev(torch, q), dev(torch, qd), dev(torch, z), (0.0, 0.0, 0.0)).cpu().numpy()
+            assert np.abs(qdd).max() <= 1e-12  # unit ball: w x J w = 0
+            qn, vn, an = step(dt, q, qd, qdd)
+            for b in range(4):
+                dR = _quat_R(q[b]).T @ _quat_R(qn[b])
+                w_fd = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / (2.0 * dt)
+                assert np.abs(w_fd - qd[b]).max() <= 20 * dt
+            assert np.abs(vn - qd).max() <= 1e-12 and np.abs(np.linalg.norm(qn, axis=1) - 1.0).max() <= 1e-12
+
+
+def _floating_with_welded_bodies(rng, n_fixed):
+    """A SixDoF root body carrying a chain of n_fixed bodies on FixedJoints with random poses and random inertias."""
+    from mecano_amd import random_tools as rt
+    from mecano_amd.multibody import RigidBody
+    root = RigidBody("root")
+    j = rt.nextSixDoFJoint(rng, "floating", root)
+    b = rt.nextRigidBody(rng, "base", j)
+    for k in range(n_fixed):
+        b = rt.nextRigidBody(rng, f"welded{k}", rt.nextFixedJoint(rng, f"weld{k}", b))
+    return system_of([j])
+
+
+def test_articulated_inertia_transform_equals_rigid_inertia_transform_on_the_device(torch_cuda):
+    """algorithms/ArticulatedBodyInertiaTest.java:25-60 restated on device code.  On a floating body that carries two bodies through
+    two FixedJoints with random poses ("apply two random transforms"), forward dynamics hands the (A, L, C) blocks up through the
+    articulated-inertia congruence (rotate, then translate) and inverts the 6x6 it arrives at; the mass-matrix kernel hands (m, m c, I)
+    up through the rigid-inertia shift.  Both 6x6 matrices describe the same rigid assembly: H(q) ABA(tau = e_k; qd = 0, g = 0) = e_k."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    rng = np.random.default_rng(2552)
+    worst = 0.0
+    for it in range(12):
+        sys_ = _floating_with_welded_bodies(rng, 2)
+        hm = HipModel(sys_.toModelDesc())
+        B = 6
+        q, _, _, _ = rt.nextState(rng, sys_, 1)
+        q = np.repeat(q, B, axis=0)
+        tau = np.eye(6)
+        z = np.zeros((B, 6))
+        X = hm.aba(dev(torch, q), dev(torch, z), dev(torch, tau), (0.0, 0.0, 0.0)).cpu().numpy()  # rows: IA^-1 e_k
+        H = hm.crba(dev(torch, q)).cpu().numpy()[0]
+        assert np.array_equal(H, H.T)
+        worst = max(worst, np.abs(X @ H - np.eye(6)).max() / np.linalg.cond(H))
+    record_parity(worst, 1e-12, "|IA^-1 H - 1| / cond(H)")
+    assert worst <= 1e-12, worst
+
+
+def test_kinetic_coenergy_is_frame_invariant_on_the_device(torch_cuda):
+    """spatial/SpatialInertiaBasicsTest.java:76-98, 216-248 and tools/MecanoToolsTest.java:618-655 on device code: the kinetic co-energy
+    1/2 qd^T H qd (composite inertias shifted and rotated down to every ancestor's frame by the mass-matrix kernel) equals the sum over
+    bodies of 1/2 tw^T I tw with the body twists the RNEA kernel propagates, each evaluated in the body's own frame from the description's
+    (J, m, c) with the reference's formula (tools/MecanoTools.java:844-890)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    rng = np.random.default_rng(334523)
+    kinds = [("revolute", "prismatic"), ("revolute", "prismatic", "sixdof", "fixed"), ("planar", "spherical", "revolute")]
+    for it in range(9):
+        joints = rt.nextJointTree(rng, int(rng.integers(2, 30)), kinds[it % 3])
+        sys_ = system_of(joints)
+        d = sys_.toModelDesc()
+        hm = HipModel(d)
+        B = 17
+        q, qd, qdd, _ = rt.nextState(rng, sys_, B)
+        H = hm.crba(dev(torch, q)).cpu().numpy()
+        _, _, tw = hm.rnea_bodies(dev(torch, q), dev(torch, qd), dev(torch, qdd), (0.0, 0.0, 0.0))
+        tw = tw.cpu().numpy()
+        T_H = 0.5 * np.einsum("bi,bij,bj->b", qd, H, qd)
+        J, m, c = np.asarray(d.inertia_J).reshape(-1, 3, 3), np.asarray(d.inertia_mass), np.asarray(d.inertia_com).reshape(-1, 3)
+        w, v = tw[:, :, :3], tw[:, :, 3:]
+        T_b = 0.5 * (m[None] * np.einsum("bni,bni->bn", v, v) + 2.0 * m[None] * np.einsum("bni,bni->bn", w, np.cross(c[None], v))
+                     + np.einsum("bni,nij,bnj->bn", w, J, w)).sum(axis=1)
+        close(T_H, T_b, 1e-11, label="kinetic co-energy")
+
+
+def test_offset_centre_of_mass_equals_the_same_body_described_about_its_centre_of_mass(torch_cuda):
+    """tools/MecanoToolsTest.java:292-460 / spatial/SpatialInertiaBasicsTest.java:129-157 (general Newton-Euler expressions == the fast
+    ones) at system level: every body described (i) with its centre of mass offset c in the body-fixed frame, inertia about that frame's
+    origin (the reference's general branch; the oracle takes it) and (ii) with the body-fixed frame moved onto the centre of mass, c = 0
+    (fast branch).  Same physical system: RNEA, ABA and CRBA agree between the two descriptions on the device, and (i) matches the oracle."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import ModelDesc
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(3453)
+    tilde = lambda v: np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+    for it in range(6):
+        joints = rt.nextJointTree(rng, int(rng.integers(2, 25)), ("revolute", "prismatic", "sixdof") if it % 2 else ("revolute", "prismatic"))
+        sys_ = system_of(joints)
+        d = sys_.toModelDesc()
+        n = d.n_joints
+        c = rng.uniform(-0.5, 0.5, (n, 3))
+        Jc = np.asarray(d.inertia_J).reshape(n, 3, 3)  # taken as the inertia about the centre of mass
+        m = np.asarray(d.inertia_mass)
+        Xc = np.asarray(d.X_com).reshape(n, 12)
+        # (i) same body-fixed frames, CoM at c there: J about the frame origin = Jc - m c~ c~
+        J_i = np.stack([Jc[k] - m[k] * tilde(c[k]) @ tilde(c[k]) for k in range(n)])
+        d_i = ModelDesc(n, d.nq, d.nv, d.parent, d.joint_type, d.axis, d.X_before, d.X_com, J_i.reshape(-1), m, c.reshape(-1), d.dof_indices,
+                        d.cfg_indices)
+        # (ii) body-fixed frames moved onto the CoM: p' = p + R c, c = 0, J = Jc
+        X_ii = Xc.copy()
+        for k in range(n):
+            X_ii[k, 9:] += Xc[k, :9].reshape(3, 3) @ c[k]
+        d_ii = ModelDesc(n, d.nq, d.nv, d.parent, d.joint_type, d.axis, d.X_before, X_ii.reshape(-1), Jc.reshape(-1), m, np.zeros(3 * n),
+                         d.dof_indices, d.cfg_indices)
+        h_i, h_ii, om = HipModel(d_i), HipModel(d_ii), OracleModel(d_i)
+        B = 33
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        g = (0.1, -0.2, -9.81)
+        tq, tqd, tqdd, ttau = (dev(torch, x) for x in (q, qd, qdd, tau))
+        t_i, t_ii = hm_np(h_i.rnea(tq, tqd, tqdd, g)), hm_np(h_ii.rnea(tq, tqd, tqdd, g))
+        close(t_i, t_ii, 1e-11, label="rnea general == fast")
+        close(t_i, om.rnea(q, qd, qdd, g), 1e-10, label="rnea general == oracle general")
+        a_i = hm_np(h_i.aba(tq, tqd, ttau, g))
+        close(a_i, hm_np(h_ii.aba(tq, tqd, ttau, g)), 1e-8 if it % 2 else 1e-9, label="aba general == fast")
+        close(a_i, om.aba(q, qd, tau, g), 1e-8 if it % 2 else 1e-9, label="aba general == oracle general")
+        close(hm_np(h_i.crba(tq)), hm_np(h_ii.crba(tq)), 1e-11, label="crba general == fast")
+
+
+def hm_np(t):
+    return t.cpu().numpy()
+
+
+FAMILIES = {
+    "prismatic_tree": ("prismatic",), "revolute_chain": ("revolute",), "revolute_tree": ("revolute",), "onedof_tree": ("revolute", "prismatic"),
+    "floating_onedof_tree": ("revolute", "prismatic"), "mixed_tree": ("revolute", "prismatic", "sixdof", "fixed"),
+    "all_kinds_tree": ("revolute", "prismatic", "sixdof", "fixed", "planar", "spherical"),
+}
+
+
+@pytest.mark.parametrize("family", sorted(FAMILIES))
+def test_fp32_entry_points_against_the_fp64_oracle(torch_cuda, family):
+    """mh_rnea_f32 / mh_aba_f32 / mh_crba_f32 on the reference's random families (ForwardDynamicsCalculatorTest.java:42-280), against
+    the fp64 oracle.  u = 2^-24.  RNEA and CRBA are forward computations along paths of at most n bodies: |err| <= 64 n u max|ref|
+    (CRBA 16 n u).  ABA: backward error in tau-space <= 64 n u (|tau| + |bias|), forward error <= 16 n u cond_inf(H) per configuration
+    (cond from the oracle's H)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(("f32" + family).encode()))
+    u32, f32 = 2.0 ** -24, torch.float32
+    for it in range(4):
+        n = int(rng.integers(1, 41))
+        if family == "revolute_chain":
+            joints = rt.nextJointChain(rng, n, FAMILIES[family])
+        elif family.startswith("floating"):
+            joints = rt.nextFloatingChain(rng, n, FAMILIES[family], tree=True)
+        else:
+            joints = rt.nextJointTree(rng, n, FAMILIES[family])
+        sys_ = system_of(joints)
+        d = sys_.toModelDesc()
+        nb = d.n_joints
+        hm, om = HipModel(d), OracleModel(d)
+        B = int(rng.integers(1, 150))
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        g = (0.0, 0.0, -9.81)
+        fext = rng.uniform(-1, 1, (B, nb, 6)) if it % 2 else None
+        tf = None if fext is None else dev(torch, fext, f32)
+        t32 = hm.rnea(dev(torch, q, f32), dev(torch, qd, f32), dev(torch, qdd, f32), g, tf).cpu().numpy()
+        assert t32.dtype == np.float32
+        close(t32.astype(np.float64), om.rnea(q, qd, qdd, g, fext), 64 * nb * u32, label="rnea_f32")
+        H_ref = om.crba(q)
+        H32 = hm.crba(dev(torch, q, f32)).cpu().numpy()
+        assert H32.dtype == np.float32
+        close(H32.astype(np.float64), H_ref, 16 * nb * u32, label="crba_f32")
+        assert np.array_equal(H32 == 0, H_ref == 0)
+        if d.nv == 0:
+            continue
+        a32 = hm.aba(dev(torch, q, f32), dev(torch, qd, f32), dev(torch, tau, f32), g, tf).cpu().numpy().astype(np.float64)
+        a_ref = om.aba(q, qd, tau, g, fext)
+        bias = om.rnea(q, qd, np.zeros_like(qdd), g, fext)
+        scale = np.abs(tau).max() + np.abs(bias).max()
+        berr = np.abs(om.rnea(q, qd, a32, g, fext) - tau).max()
+        record_parity(berr, 64 * nb * u32 * scale, "aba_f32 backward error")
+        assert berr <= 64 * nb * u32 * scale, (berr, scale)
+        conds = np.array([np.linalg.cond(H_ref[k], np.inf) for k in range(B)])
+        ferr = np.abs(a32 - a_ref).max(axis=1) / np.maximum(1.0, np.abs(a_ref).max(axis=1))
+        record_parity(float((ferr / (conds * u32)).max()), 16.0 * nb, "aba_f32 forward error / (cond_inf(H) u)")
+        assert (ferr <= 16 * nb * u32 * conds).all(), (ferr.max(), conds.max())
