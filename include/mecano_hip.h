@@ -39,9 +39,10 @@
  *     JointMatrixIndexProvider contract
  *     (multiBodySystem/interfaces/JointMatrixIndexProvider.java:71-123).
  *
- * Threading: like the reference's calculators (one per thread), a model handle is to be used by one host thread at a time -- compute
- * calls share its device workspace and scratch buffers.  Create one handle per thread (models are a few KB) or serialise the calls;
- * different handles are independent.  Calls are asynchronous on opts->stream.
+ * Threading: like the reference's calculators (one per thread), a model handle is to be used by one host thread at a time AND on one
+ * stream at a time -- compute calls share its device workspace and scratch buffers, so two calls on the same handle issued on different
+ * streams would race on them (also from a single host thread).  Create one handle per thread / stream (models are a few KB) or serialise
+ * the calls (an event wait between streams); different handles are independent.  Calls are asynchronous on opts->stream.
  *
  * No function throws or aborts; every entry point returns an mh_status and
  * mh_last_error() gives a thread-local message.  The library never falls back
@@ -58,7 +59,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 1
+#define MH_ABI_VERSION 2
 
 /* ---- status codes (the Java shim maps them back to Mecano's exception types) ---- */
 typedef enum mh_status
@@ -134,6 +135,9 @@ typedef struct mh_model *mh_model_t;
 
 /* ---- library / device ---- */
 int32_t mh_abi_version(void);
+/* what a topology-specialised code object (libmecano_hip_topo_<key>.so) must report from its mh_spec_abi() to be accepted by this
+ * library build: a hash over the argument structs, record strides and the canonical-frame convention the two share */
+uint64_t mh_spec_abi_stamp(void);
 const char *mh_last_error(void);           /* thread-local, never NULL */
 mh_status mh_device_count(int32_t *count); /* 0 devices is MH_OK with *count = 0 */
 mh_status mh_set_device(int32_t device);   /* device used by subsequent calls of this thread */
@@ -145,7 +149,9 @@ void mh_model_destroy(mh_model_t model);
 int32_t mh_model_nq(mh_model_t model);
 int32_t mh_model_nv(mh_model_t model);
 int32_t mh_model_n_joints(mh_model_t model);
-/* name of the kernel variant compute calls will use for this model ("generic", "topo:<hash>") */
+/* name of the kernel variant compute calls will use for this model: "topo:<key>" when the topology-specialised code object
+ * libmecano_hip_topo_<key>.so was found, matches this library build (ABI stamp) and passed the create-time self-check against the
+ * run-time-topology kernels; "generic" otherwise, followed by the reason in parentheses when a code object was found but refused */
 const char *mh_model_kernel_variant(mh_model_t model);
 
 /*
@@ -218,6 +224,33 @@ mh_status mh_rnea_bodies_f64(mh_model_t model, int64_t B, const double *q, const
                              const double *f_ext, const mh_options *opts, double *tau_out, double *body_acc_out, double *body_twist_out);
 mh_status mh_aba_bodies_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
                             const double *f_ext, const mh_options *opts, double *qdd_out, double *body_acc_out, double *body_twist_out);
+
+/*
+ * ---- per-joint wrenches (InverseDynamicsCalculator.getComputedJointWrench, InverseDynamicsCalculator.java:578-585, 930-959;
+ *      ForwardDynamicsCalculator.getJointWrench, ForwardDynamicsCalculator.java:642-650, 1330-1363) ----
+ * Same as mh_rnea_f64 / mh_aba_f64, plus for every listed joint the full 6-D wrench (moment, force) it transmits to its successor body,
+ * before projection onto the motion subspace, expressed in the joint's frame after the joint: joint_wrench_out [B][n_joints][6], laid
+ * out like f_ext.  tau = S^T wrench.  The forward-dynamics form evaluates, like the reference, a Newton-Euler sweep over the accelerations
+ * it has just computed (a second launch on the same stream); it needs every joint to be an effort source.  Run-time-topology kernels.
+ */
+mh_status mh_rnea_joint_wrenches_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                                     const double *f_ext, const mh_options *opts, double *tau_out, double *joint_wrench_out);
+mh_status mh_aba_joint_wrenches_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
+                                    const double *f_ext, const mh_options *opts, double *qdd_out, double *joint_wrench_out);
+
+/*
+ * ---- relative accelerations (RigidBodyAccelerationProvider.getRelativeAcceleration(base, body),
+ *      algorithms/interfaces/RigidBodyAccelerationProvider.java:66, 199-235) ----
+ * For n_pairs pairs of bodies: the spatial acceleration of body's body-fixed frame with respect to base's, expressed in body's, from the
+ * per-body outputs of a previous mh_rnea_bodies_f64 / mh_aba_bodies_f64 call on the same configurations (body_acc, body_twist: DEVICE
+ * pointers, [B][n_joints][6]).  base_joints / body_joints are HOST arrays of n_pairs indices into the model's joint list (the successor
+ * body of that joint); -1 names the root body, whose acceleration is the root acceleration -g (gravity[3], HOST pointer).
+ * opts->consider_coriolis = 0 mirrors a provider that ignores velocities (areVelocitiesConsidered() == false: plain change of frame,
+ * body_twist may be NULL).  out [B][n_pairs][6] (MH_LAYOUT_SOA: [n_pairs*6][B]), DEVICE pointer.
+ */
+mh_status mh_relative_acceleration_f64(mh_model_t model, int64_t B, const double *q, const double *body_acc, const double *body_twist,
+                                       const double gravity[3], int32_t n_pairs, const int32_t *base_joints, const int32_t *body_joints,
+                                       const mh_options *opts, double *out);
 
 /*
  * ---- Coriolis matrix (CompositeRigidBodyMassMatrixCalculator.setEnableCoriolisMatrixCalculation(true) + getMassMatrix / getCoriolisMatrix,

@@ -17,9 +17,9 @@ LAYOUT_AOS, LAYOUT_SOA = 0, 1
 
 # every symbol include/mecano_hip.h declares (tests/test_abi.py checks the library exports each one)
 ABI_SYMBOLS = [
-    "mh_abi_version", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
+    "mh_abi_version", "mh_spec_abi_stamp", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
     "mh_topology_key", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64",
-    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
+    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_rnea_joint_wrenches_f64", "mh_aba_joint_wrenches_f64", "mh_relative_acceleration_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
     "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
 ]
 
@@ -87,6 +87,7 @@ def _load_locked():
         pass
     P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.mh_abi_version.restype = I32
+    lib.mh_spec_abi_stamp.restype = ctypes.c_uint64
     lib.mh_last_error.restype = ctypes.c_char_p
     lib.mh_device_count.argtypes = [ctypes.POINTER(I32)]
     lib.mh_set_device.argtypes = [I32]
@@ -114,6 +115,9 @@ def _load_locked():
     lib.mh_aba_locked_f64.argtypes = [P, I64, P, P, P, P, P, P, opt, P, P]
     for f in ("mh_rnea_bodies_f64", "mh_aba_bodies_f64"):
         getattr(lib, f).argtypes = [P, I64, P, P, P, P, P, opt, P, P, P]
+    for f in ("mh_rnea_joint_wrenches_f64", "mh_aba_joint_wrenches_f64"):
+        getattr(lib, f).argtypes = [P, I64, P, P, P, P, P, opt, P, P]
+    lib.mh_relative_acceleration_f64.argtypes = [P, I64, P, P, P, P, I32, P, P, opt, P]
     for f in ("mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_crba_coriolis_f64_host"):
         getattr(lib, f).argtypes = [P, I64, P, P, opt, P, P]
     for f in ("mh_centroidal_f64", "mh_centroidal_f32", "mh_centroidal_f64_host"):

@@ -26,7 +26,15 @@ SPEC_SOURCE = os.path.join(CSRC, "mh_spec.hip")
 SPEC_HEADERS = HEADERS + [os.path.join(CSRC, "mh_spec_kernels.h")]
 # -fno-signed-zeros -ffinite-math-only: lets the compiler drop the multiplications by the structural zeros of the canonical
 # joint frames (S = e_z); no reassociation is enabled, products and sums keep their written order.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only"]
+# -fno-slp-vectorize: hipcc 7.2 packs adjacent fp32 operations into v_pk_* instructions; in crba_kernel<float> that came with a wrong
+# component select for the first row of a multi-DoF joint's diagonal block (tools/diag_f32_crba2.py, DESIGN.md open issues), and packed
+# fp32 VALU is no faster on gfx950 anyway.  fp64 code is unaffected (there are no packed fp64 instructions).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize"]
+
+
+# deepest root-to-leaf path (in joints) a topology-specialised code object is built for: the humanoid is 9 deep; a 30-joint chain needs
+# the whole register file plus ~600 spilled VGPRs for forward dynamics (mh_spec.hip: kWholeTreeMaxBodies)
+MAX_SPEC_DEPTH = 16
 
 
 def hipcc() -> str:
@@ -87,6 +95,13 @@ def build_spec(desc, force: bool = False, verbose: bool = False) -> str:
     key, parents, kinds = topology_of(desc)
     if any(int(k) > 3 for k in kinds):
         raise ValueError("specialised code objects cover revolute, prismatic, 6-DoF and fixed joints; planar / spherical joints run on the generic kernels")
+    depth = [0] * len(parents)
+    for j, pj in enumerate(parents):
+        depth[j] = 1 + (depth[int(pj)] if int(pj) >= 0 else 0)
+    if max(depth) > MAX_SPEC_DEPTH:
+        raise ValueError(f"the tree is {max(depth)} joints deep: a compile-time walk keeps the state of every body on a root-to-leaf path in "
+                         f"registers, which stops paying (512 registers plus hundreds of spills, minutes of compile time) beyond "
+                         f"{MAX_SPEC_DEPTH}; such models run on the run-time-topology kernels")
     out = spec_path(key)
     if not force and not _stale(out, [SPEC_SOURCE] + SPEC_HEADERS):
         return out

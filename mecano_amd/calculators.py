@@ -74,9 +74,10 @@ class RigidBodyAccelerationProvider:
     """algorithms/interfaces/RigidBodyAccelerationProvider.java:137-260, batched: the spatial acceleration (and twist) of every
     successor body relative to the inertial frame, expressed in its body-fixed frame, as computed by the last ``compute``."""
 
-    def __init__(self, system: MultiBodySystem):
+    def __init__(self, system: MultiBodySystem, owner=None):
         self._pos = {id(j.getSuccessor()): k for k, j in enumerate(system.getJointsToConsider())}
         self._root = system.getRootBody()
+        self._owner = owner  # the calculator whose last compute() filled this provider (model, q, gravity, switches)
         self.body_acc = None
         self.body_twist = None
 
@@ -90,10 +91,24 @@ class RigidBodyAccelerationProvider:
         k = self._pos.get(id(body))
         return None if k is None or self.body_twist is None else self.body_twist[:, k, :]
 
+    def _index(self, body):
+        if body is self._root:
+            return -1
+        return self._pos.get(id(body))
+
     def getRelativeAcceleration(self, base, body):
-        """Not offered: it needs the transform between the two body frames of every configuration (forward kinematics the engine
-        keeps on the device).  The reference's version is RigidBodyAccelerationProvider.java:171-200."""
-        raise NotImplementedError("relative accelerations are not exported by the HIP engine")
+        """RigidBodyAccelerationProvider.java:66, 199-235: acceleration of ``body`` with respect to ``base``, expressed in the body-fixed
+        frame of ``body``, [B, 6]; ``None`` when the calculator does not consider one of the two (:210-216).  ``base`` / ``body`` may
+        also be sequences of bodies: [B, n_pairs, 6]."""
+        many = isinstance(base, (list, tuple))
+        bases, bodies = (list(base), list(body)) if many else ([base], [body])
+        idx1, idx2 = [self._index(b) for b in bases], [self._index(b) for b in bodies]
+        if any(i is None for i in idx1 + idx2) or self.body_acc is None or self._owner is None:
+            return None
+        o = self._owner
+        out = o.model.relative_acceleration(o._last_q, self.body_acc, self.body_twist, idx1, idx2, o._gravity, o.layout,
+                                            consider_velocities=getattr(o, "_coriolis", True))
+        return out if many else out[:, 0, :]
 
 
 class InverseDynamicsCalculator(_Base):
@@ -102,7 +117,10 @@ class InverseDynamicsCalculator(_Base):
         self._coriolis = True
         self._accel = True
         self._tau = None
-        self._provider = RigidBodyAccelerationProvider(self.input)
+        self._wrenches = None
+        self._last_q = None
+        self._provider = RigidBodyAccelerationProvider(self.input, self)
+        self._joint_pos = {id(j): k for k, j in enumerate(self.input.getJointsToConsider())}
 
     def setConsiderCoriolisAndCentrifugalForces(self, flag: bool):
         self._coriolis = bool(flag)
@@ -110,9 +128,17 @@ class InverseDynamicsCalculator(_Base):
     def setConsiderJointAccelerations(self, flag: bool):
         self._accel = bool(flag)
 
-    def compute(self, q, qd, qdd, bodies: bool = False):
-        """``bodies=True`` also fills the acceleration provider (InverseDynamicsCalculator.java:242-250, 660-663)."""
-        if bodies:
+    def compute(self, q, qd, qdd, bodies: bool = False, wrenches: bool = False):
+        """``bodies=True`` also fills the acceleration provider (InverseDynamicsCalculator.java:242-250, 660-663); ``wrenches=True``
+        keeps the 6-D wrench of every joint for getComputedJointWrench (:578-585)."""
+        self._last_q, self._wrenches = q, None
+        if wrenches:
+            self._tau, self._wrenches = self.model.rnea_joint_wrenches(q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis,
+                                                                       self._accel)
+            if bodies:
+                _, self._provider.body_acc, self._provider.body_twist = self.model.rnea_bodies(
+                    q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis, self._accel)
+        elif bodies:
             self._tau, self._provider.body_acc, self._provider.body_twist = self.model.rnea_bodies(
                 q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis, self._accel)
         else:
@@ -124,6 +150,23 @@ class InverseDynamicsCalculator(_Base):
 
     def getJointTauMatrix(self):
         return self._tau
+
+    def getComputedJointWrench(self, joint):
+        """InverseDynamicsCalculator.java:578-585: [B, 6] (moment, force) in the frame after the joint, ``None`` for a joint this
+        calculator does not consider; needs ``compute(..., wrenches=True)``."""
+        k = joint if isinstance(joint, (int, np.integer)) else self._joint_pos.get(id(joint))
+        if k is None:
+            return None
+        if self._wrenches is None:
+            raise ValueError("call compute(q, qd, qdd, wrenches=True) first")
+        return self._wrenches[:, int(k), :]
+
+    def getComputedJointTau(self, joint):
+        """:587-602: the rows of the joint in the tau matrix"""
+        if id(joint) not in self._joint_pos or self._tau is None:
+            return None
+        rows = self.input.getJointMatrixIndexProvider().getJointDoFIndices(joint)
+        return self._tau[:, rows]
 
 
 class JointSourceMode:
@@ -139,7 +182,9 @@ class ForwardDynamicsCalculator(_Base):
         super().__init__(input, considerIgnoredSubtreesInertia)
         self._qdd = None
         self._tau = None
-        self._provider = RigidBodyAccelerationProvider(self.input)
+        self._wrenches = None
+        self._last_q = None
+        self._provider = RigidBodyAccelerationProvider(self.input, self)
         self._modes = [JointSourceMode.EFFORT_SOURCE] * self.model.n_joints
         self._joint_pos = {id(j): k for k, j in enumerate(self.input.getJointsToConsider())}
 
@@ -167,9 +212,16 @@ class ForwardDynamicsCalculator(_Base):
         """ForwardDynamicsCalculator.java:170-180, 715-718; filled by ``compute(..., bodies=True)``."""
         return self._provider
 
-    def compute(self, q, qd, tau, qdd=None, bodies: bool = False):
+    def compute(self, q, qd, tau, qdd=None, bodies: bool = False, wrenches: bool = False):
         """``compute(q, qd, tau)`` (:475-490) or, with acceleration-source joints, ``compute(q, qd, tau, qdd)`` (:508-520): tau is
-        read for the effort sources, qdd for the acceleration sources."""
+        read for the effort sources, qdd for the acceleration sources.  ``wrenches=True`` keeps the joint wrenches (getJointWrench)."""
+        self._last_q, self._wrenches = q, None
+        if wrenches and not any(m == JointSourceMode.ACCELERATION_SOURCE for m in self._modes):
+            self._qdd, self._wrenches = self.model.aba_joint_wrenches(q, qd, tau, self._gravity, self._f_ext, self.layout)
+            self._tau = tau
+            if bodies:
+                _, self._provider.body_acc, self._provider.body_twist = self.model.aba_bodies(q, qd, tau, self._gravity, self._f_ext, self.layout)
+            return self._qdd
         if any(m == JointSourceMode.ACCELERATION_SOURCE for m in self._modes):
             if qdd is None:
                 raise ValueError("some joints are acceleration sources: their accelerations (qdd) are needed")
@@ -188,6 +240,16 @@ class ForwardDynamicsCalculator(_Base):
     def getJointTauMatrix(self):
         """Efforts of all joints: the inputs for effort sources, the computed ones for acceleration sources (:556-567)."""
         return self._tau
+
+    def getJointWrench(self, joint):
+        """ForwardDynamicsCalculator.java:642-650: the wrench the joint exerts, before projection onto its motion subspace, [B, 6] in
+        the frame after the joint; ``None`` for a joint this calculator does not consider; needs ``compute(..., wrenches=True)``."""
+        k = joint if isinstance(joint, (int, np.integer)) else self._joint_pos.get(id(joint))
+        if k is None:
+            return None
+        if self._wrenches is None:
+            raise ValueError("call compute(q, qd, tau, wrenches=True) first")
+        return self._wrenches[:, int(k), :]
 
 
 class CompositeRigidBodyMassMatrixCalculator(_Base):

@@ -109,6 +109,7 @@ struct SpecLib
    int (*launch_crba_split)(const void *args, int groups, int lanes_per_group, void *stream) = nullptr;
    int (*launch_coriolis)(int flags, const void *args, int grid, void *stream) = nullptr;
    int (*launch_centroidal)(int flags, const void *args, int grid, void *stream) = nullptr;
+   unsigned long long (*abi)(void) = nullptr;
 };
 enum : int
 {
@@ -127,6 +128,7 @@ struct mh_model
    int device = 0;
    int cu_count = 256;
    std::vector<int> meta, dof_map, cfg_map;
+   std::vector<int> engine_of; // caller joint index -> engine index
    std::vector<double> consts;
    int *d_meta = nullptr, *d_dof = nullptr, *d_cfg = nullptr;
    double *d_consts64 = nullptr;
@@ -136,6 +138,10 @@ struct mh_model
    Workspace stage;
    // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices)
    Workspace tr;
+   // scratch of the composite entry points: efforts of the Newton-Euler sweep behind mh_aba_joint_wrenches_f64, pair lists of
+   // mh_relative_acceleration_f64
+   Workspace aux, pairs;
+   std::vector<int> pairs_host;
    int use_transpose = -1; // MH_GENERIC_TRANSPOSE = 0 | 1 overrides the size heuristic
    std::string variant = "generic";
    int use_split = -1;      // MH_SPEC_SPLIT = 0 | 1: never / whenever possible use the tree-split kernels (default: small batches)
@@ -246,7 +252,7 @@ template <typename T>
 mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd, const T *in3, const double gravity[3], const T *fext,
                  const mh_options *opts_in, T *out, const T *locked_in = nullptr, T *locked_out = nullptr, T *body_acc = nullptr,
                  T *body_twist = nullptr, bool bodies = false, double step_dt = 0.0, T *q_next = nullptr, T *qd_next = nullptr,
-                 bool *stepped = nullptr)
+                 bool *stepped = nullptr, T *joint_wrench = nullptr)
 {
    mh_options opts;
    if (opts_in)
@@ -269,12 +275,12 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    const Launch L = plan_launch(model, B);
    hipStream_t stream = (hipStream_t)opts.stream;
 
-   mh::Args<T> A;
+   mh::Args<T> A{};
    A.m = dev_model<T>(model);
    A.B = B;
    A.q = q, A.qd = qd, A.in3 = in3, A.fext = fext, A.out = out;
    A.in3b = nullptr, A.outb = nullptr;
-   A.body_acc = body_acc, A.body_twist = body_twist;
+   A.body_acc = body_acc, A.body_twist = body_twist, A.joint_wrench = joint_wrench;
    A.dt = T(0), A.q_next = nullptr, A.qd_next = nullptr;
    A.ws = (T *)model->ws.ptr;
    A.ws_stride = L.lanes;
@@ -291,9 +297,9 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
 
    if (bodies && algo != ALGO_CRBA)
    { // per-body outputs: run-time-topology kernels (the model's joint source modes must all be effort sources)
-      if (model->n_locked > 0)
-         return fail(MH_ERR_INVALID_ARGUMENT, "per-body outputs are not available while joints are acceleration sources");
-      if (sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
+      if (model->n_locked > 0 && algo == ALGO_ABA)
+         return fail(MH_ERR_INVALID_ARGUMENT, "per-body outputs of forward dynamics are not available while joints are acceleration sources");
+      if (sizeof(T) == 8 && !joint_wrench && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
       { // the tree-split kernels write them too (identity maps, rows staged in LDS); other plans: the run-time-topology kernels below
          const int sf = split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa);
          if ((sf & SPEC_IDENT) && (sf & SPEC_IO_LDS))
@@ -640,11 +646,24 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.launch_crba_split = (decltype(s.launch_crba_split))dlsym(h, "mh_spec_launch_crba_split");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
+   s.abi = (decltype(s.abi))dlsym(h, "mh_spec_abi");
+   // the code object reinterprets the library's argument structs and folds parts of the canonical-frame convention at compile time:
+   // it must have been built from the same headers (a stale or foreign libmecano_hip_topo_<key>.so is refused, visibly)
+   if (!s.abi || s.abi() != mh::spec_abi_stamp())
+   {
+      char note[256];
+      snprintf(note, sizeof note, "generic (code object %s refused: built against another library version, ABI stamp %016llx, this library %016llx)",
+               path.c_str(), s.abi ? s.abi() : 0ull, mh::spec_abi_stamp());
+      m->variant = note;
+      dlclose(h);
+      return;
+   }
    bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
    for (int e = 0; ok && e < m->n; e++)
       ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];
    if (!ok)
    {
+      m->variant = "generic (code object " + path + " refused: it was built for another tree)";
       dlclose(h);
       return;
    }
@@ -807,10 +826,13 @@ mh_status integrate_impl(mh_model_t model, int64_t B, double dt, const T *q, con
 }
 } // namespace
 
+static void self_check_spec(mh_model *m);
+
 // =================================================================================================== C-ABI
 extern "C" {
 
 int32_t mh_abi_version(void) { return MH_ABI_VERSION; }
+uint64_t mh_spec_abi_stamp(void) { return mh::spec_abi_stamp(); }
 const char *mh_last_error(void) { return g_err; }
 
 mh_status mh_device_count(int32_t *count)
@@ -902,6 +924,7 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
 
    mh_model *m = new mh_model();
    m->n = n, m->nq = d->nq, m->nv = d->nv;
+   m->engine_of = engine_of;
    m->meta.assign((size_t)n * mh::MI_STRIDE, 0);
    m->consts.assign((size_t)n * mh::MC_STRIDE, 0.0);
    // index maps re-concatenated in ENGINE order: the offset of a joint in them is then a function of the topology alone
@@ -995,6 +1018,11 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
          c[mh::MC_RF + k] = Rf.m[k];
       for (int k = 0; k < 3; k++)
          c[mh::MC_PF + k] = pf[k];
+      // canonical after-joint -> Mecano's after-joint frame: x = Q x' + O (joint wrench outputs)
+      for (int k = 0; k < 9; k++)
+         c[mh::MC_QA + k] = Q[e].m[k];
+      for (int k = 0; k < 3; k++)
+         c[mh::MC_OA + k] = O[e][k];
       // spatial inertia about the canonical after-joint origin.  J is the rotational inertia about the ORIGIN of the
       // body-fixed frame with the CoM at c_b there (spatial/interfaces/SpatialInertiaReadOnly.java:394-415).
       const double mass = d->inertia_mass[i];
@@ -1084,6 +1112,11 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    try_load_spec(m, P);
    if (!m->use_spec)
       m->variant = "generic";
+   int selfcheck = 1;
+   if (const char *e = getenv("MH_SPEC_SELFCHECK"))
+      selfcheck = atoi(e);
+   if (m->spec.handle && m->use_spec && selfcheck)
+      self_check_spec(m);
    *model_out = m;
    return MH_OK;
 }
@@ -1100,6 +1133,8 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->ws.ptr);
    (void)hipFree(m->stage.ptr);
    (void)hipFree(m->tr.ptr);
+   (void)hipFree(m->aux.ptr);
+   (void)hipFree(m->pairs.ptr);
    if (m->spec.handle)
       dlclose(m->spec.handle);
    delete m;
@@ -1216,6 +1251,81 @@ mh_status mh_aba_bodies_f64(mh_model_t model, int64_t B, const double *q, const 
 {
    return launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, nullptr, nullptr, body_acc_out, body_twist_out, true);
 }
+mh_status mh_rnea_joint_wrenches_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                                     const double *f_ext, const mh_options *opts, double *tau_out, double *joint_wrench_out)
+{
+   if (B > 0 && !joint_wrench_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "joint_wrench_out is NULL");
+   return launch<double>(ALGO_RNEA, model, B, q, qd, qdd, gravity, f_ext, opts, tau_out, nullptr, nullptr, nullptr, nullptr, true, 0.0, nullptr, nullptr,
+                         nullptr, joint_wrench_out);
+}
+mh_status mh_aba_joint_wrenches_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
+                                    const double *f_ext, const mh_options *opts, double *qdd_out, double *joint_wrench_out)
+{
+   if (B > 0 && !joint_wrench_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "joint_wrench_out is NULL");
+   mh_status st = launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+   if (st != MH_OK || B == 0)
+      return st;
+   // ForwardDynamicsCalculator.getJointWrench (ForwardDynamicsCalculator.java:1330-1363) is a Newton-Euler sweep over the accelerations
+   // forward dynamics has just produced: the RNEA kernel with its joint-wrench output, on the same stream; its efforts (= tau up to
+   // rounding) go to scratch
+   st = ensure_bytes(model->aux, (size_t)B * model->nv * sizeof(double));
+   if (st != MH_OK)
+      return st;
+   return launch<double>(ALGO_RNEA, model, B, q, qd, qdd_out, gravity, f_ext, opts, (double *)model->aux.ptr, nullptr, nullptr, nullptr, nullptr, true,
+                         0.0, nullptr, nullptr, nullptr, joint_wrench_out);
+}
+mh_status mh_relative_acceleration_f64(mh_model_t model, int64_t B, const double *q, const double *body_acc, const double *body_twist,
+                                       const double gravity[3], int32_t n_pairs, const int32_t *base_joints, const int32_t *body_joints,
+                                       const mh_options *opts_in, double *out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (n_pairs < 0)
+      return fail(MH_ERR_BAD_DIMENSION, "negative number of pairs %d", n_pairs);
+   if (B == 0 || n_pairs == 0)
+      return MH_OK;
+   if (!q || !body_acc || !gravity || !base_joints || !body_joints || !out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / pair / output pointer");
+   model->pairs_host.resize((size_t)n_pairs * 2);
+   for (int k = 0; k < n_pairs; k++)
+   {
+      const int b1 = base_joints[k], b2 = body_joints[k];
+      if (b1 < -1 || b1 >= model->n || b2 < -1 || b2 >= model->n)
+         return fail(MH_ERR_INVALID_ARGUMENT, "pair %d names joint %d / %d (the model has %d joints; -1 = the root body)", k, b1, b2, model->n);
+      model->pairs_host[2 * k] = b1 < 0 ? -1 : model->engine_of[b1];
+      model->pairs_host[2 * k + 1] = b2 < 0 ? -1 : model->engine_of[b2];
+   }
+   st = ensure_bytes(model->pairs, model->pairs_host.size() * sizeof(int));
+   if (st != MH_OK)
+      return st;
+   hipStream_t stream = (hipStream_t)opts.stream;
+   HIP_TRY(hipMemcpyAsync(model->pairs.ptr, model->pairs_host.data(), model->pairs_host.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+   mh::RelArgs<double> A{};
+   A.m = dev_model<double>(model);
+   A.B = B;
+   A.q = q, A.body_acc = body_acc, A.body_twist = opts.consider_coriolis ? body_twist : nullptr, A.out = out;
+   A.pairs = (const int *)model->pairs.ptr, A.n_pairs = n_pairs;
+   const bool soa = opts.layout == MH_LAYOUT_SOA;
+   A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
+   A.f_bs = soa ? 1 : (long)model->n * 6, A.f_es = soa ? B : 1;
+   A.o_bs = soa ? 1 : (long)n_pairs * 6, A.o_es = soa ? B : 1;
+   A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
+   if (opts.consider_coriolis && !body_twist)
+      return fail(MH_ERR_INVALID_ARGUMENT, "body_twist is NULL but velocities are considered (opts->consider_coriolis)");
+   const int block = 64;
+   const int grid = (int)std::max<long>(1, std::min<long>((B + block - 1) / block, (long)model->cu_count * 8));
+   hipLaunchKernelGGL((mh::relative_acceleration_kernel<double>), dim3(grid), dim3(block), 0, stream, A);
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
 mh_status mh_model_set_joint_source_modes(mh_model_t model, const int32_t *modes)
 {
    if (!model)
@@ -1282,7 +1392,7 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
          return st;
       return mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &opts, qdd_out);
    }
-   mh::Args<double> A;
+   mh::Args<double> A{};
    A.m = dev_model<double>(model);
    A.B = B;
    A.q = q, A.qd = qd, A.in3 = qdd, A.fext = f_ext, A.out = tau_out;
@@ -1459,3 +1569,192 @@ mh_status mh_timer_elapsed_ms(mh_timer_t t, float *ms)
 }
 
 } // extern "C"
+
+// =================================================================================================== create-time self-check
+// A topology-specialised code object is machine-generated straight-line code at the edge of the register file (open issues:
+// one whole-tree ABA build of a 25-body tree returned wrong numbers).  So a freshly loaded object is not trusted: 197 seeded
+// configurations (three full groups of 64 and a ragged one) go through every call the dispatcher can route to it -- RNEA, ABA, the fused
+// pair, the fused simulation step, CRBA, the per-body variants, Coriolis and centroidal quantities, AoS and SoA, with the real CU count
+// (small-batch plans) and with a pretended single CU (device-filling plans: global hand-over store, three-wave RNEA build) -- and through
+// the run-time-topology kernels.  On disagreement the object is dropped and mh_model_kernel_variant says why; the model then runs on the
+// run-time-topology kernels.  MH_SPEC_SELFCHECK=0 skips the check.
+namespace
+{
+struct Lcg
+{
+   unsigned long long s;
+   double u(double lo, double hi)
+   {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      return lo + (hi - lo) * (double)(s >> 11) / 9007199254740992.0;
+   }
+};
+enum CheckCase
+{
+   CK_RNEA,
+   CK_ABA,
+   CK_CRBA,
+   CK_FUSED,
+   CK_STEP,
+   CK_BODIES_RNEA,
+   CK_BODIES_ABA,
+   CK_CORIOLIS,
+   CK_CENTROIDAL,
+   CK_COUNT
+};
+const char *const kCheckNames[CK_COUNT] = {"RNEA", "ABA", "CRBA", "fused RNEA+ABA", "ABA + integration step", "RNEA with per-body outputs",
+                                           "ABA with per-body outputs", "mass + Coriolis matrix", "centroidal momentum"};
+} // namespace
+
+static void self_check_spec(mh_model *m)
+{
+   const int64_t B = 64 * 3 + 5;
+   const size_t nq = m->nq, nv = m->nv, n = m->n;
+   if (nv == 0)
+      return;
+   Lcg rng{0x9E3779B97F4A7C15ull ^ (unsigned long long)n};
+   std::vector<double> q((size_t)B * nq, 0.0), qd((size_t)B * nv), qdd((size_t)B * nv), tau((size_t)B * nv);
+   for (int64_t b = 0; b < B; b++)
+      for (int e = 0; e < m->n; e++)
+      {
+         const int *mi = &m->meta[(size_t)e * mh::MI_STRIDE];
+         const int t = mi[mh::MI_TYPE], *ci = &m->cfg_map[mi[mh::MI_CFG]];
+         double *row = &q[(size_t)b * nq];
+         if (t == MH_JOINT_REVOLUTE)
+            row[ci[0]] = rng.u(-3.14159, 3.14159);
+         else if (t == MH_JOINT_PRISMATIC)
+            row[ci[0]] = rng.u(-1, 1);
+         else if (t == MH_JOINT_SIXDOF || t == MH_JOINT_SPHERICAL)
+         {
+            double qt[4], nrm = 0;
+            for (int k = 0; k < 4; k++)
+               qt[k] = rng.u(-1, 1), nrm += qt[k] * qt[k];
+            nrm = std::sqrt(nrm) + 1e-300;
+            for (int k = 0; k < 4; k++)
+               row[ci[k]] = qt[k] / nrm;
+            for (int k = 4; k < joint_ncfg(t); k++)
+               row[ci[k]] = rng.u(-1, 1);
+         }
+         else if (t == MH_JOINT_PLANAR)
+            row[ci[0]] = rng.u(-3.14159, 3.14159), row[ci[1]] = rng.u(-1, 1), row[ci[2]] = rng.u(-1, 1);
+      }
+   for (size_t k = 0; k < (size_t)B * nv; k++)
+      qd[k] = rng.u(-1, 1), qdd[k] = rng.u(-1, 1), tau[k] = rng.u(-1, 1);
+   auto transposed = [&](const std::vector<double> &a, size_t cols) {
+      std::vector<double> t(a.size());
+      for (int64_t b = 0; b < B; b++)
+         for (size_t c = 0; c < cols; c++)
+            t[c * (size_t)B + (size_t)b] = a[(size_t)b * cols + c];
+      return t;
+   };
+   const size_t out_doubles = (size_t)B * std::max<size_t>({2 * nv * nv, 6 * nv + 9, 2 * nv + 19 * n}) + 64;
+   const size_t in_doubles = (size_t)B * (nq + 3 * nv);
+   double *d_all = nullptr;
+   if (hipMalloc((void **)&d_all, (2 * in_doubles + out_doubles) * sizeof(double)) != hipSuccess)
+      return; // cannot check: keep the object (the allocation failure will surface in the first compute call anyway)
+   double *d_in[2] = {d_all, d_all + in_doubles}, *d_out = d_all + 2 * in_doubles;
+   for (int L = 0; L < 2; L++)
+   {
+      const std::vector<double> *src[4] = {&q, &qd, &qdd, &tau};
+      const size_t cols[4] = {nq, nv, nv, nv};
+      size_t ofs = 0;
+      for (int k = 0; k < 4; k++)
+      {
+         const std::vector<double> t = L == 0 ? *src[k] : transposed(*src[k], cols[k]);
+         (void)hipMemcpy(d_in[L] + ofs, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice);
+         ofs += (size_t)B * cols[k];
+      }
+   }
+   const double gravity[3] = {0.3, -0.2, -9.81};
+   auto run = [&](int what, int L, size_t &used) -> mh_status {
+      mh_options o;
+      mh_options_default(&o);
+      o.layout = L == 0 ? MH_LAYOUT_AOS : MH_LAYOUT_SOA;
+      const double *dq = d_in[L], *dqd = dq + (size_t)B * nq, *dqdd = dqd + (size_t)B * nv, *dtau = dqdd + (size_t)B * nv;
+      double *o1 = d_out, *o2 = o1 + (size_t)B * nv, *o3 = o2 + (size_t)B * std::max(nq, 6 * n);
+      (void)hipMemset(d_out, 0xFF, out_doubles * sizeof(double));
+      switch (what)
+      {
+         case CK_RNEA: used = (size_t)B * nv; return mh_rnea_f64(m, B, dq, dqd, dqdd, gravity, nullptr, &o, o1);
+         case CK_ABA: used = (size_t)B * nv; return mh_aba_f64(m, B, dq, dqd, dtau, gravity, nullptr, &o, o1);
+         case CK_CRBA: used = (size_t)B * nv * nv; return mh_crba_f64(m, B, dq, &o, o1);
+         case CK_FUSED: used = 2 * (size_t)B * nv; return mh_rnea_aba_f64(m, B, dq, dqd, dqdd, dtau, gravity, nullptr, &o, o1, o2);
+         case CK_STEP:
+            used = (size_t)B * (nv + std::max(nq, 6 * n) + nv);
+            return mh_aba_integrate_f64(m, B, 1.0e-3, dq, dqd, dtau, gravity, nullptr, &o, o1, o2, o3);
+         case CK_BODIES_RNEA:
+            used = (size_t)B * (nv + std::max(nq, 6 * n) + 6 * n);
+            return mh_rnea_bodies_f64(m, B, dq, dqd, dqdd, gravity, nullptr, &o, o1, o2, o3);
+         case CK_BODIES_ABA:
+            used = (size_t)B * (nv + std::max(nq, 6 * n) + 6 * n);
+            return mh_aba_bodies_f64(m, B, dq, dqd, dtau, gravity, nullptr, &o, o1, o2, o3);
+         case CK_CORIOLIS: used = 2 * (size_t)B * nv * nv; return mh_crba_coriolis_f64(m, B, dq, dqd, &o, d_out, d_out + (size_t)B * nv * nv);
+         case CK_CENTROIDAL:
+            used = (size_t)B * (6 * nv + 9);
+            return mh_centroidal_f64(m, B, dq, dqd, nullptr, MH_CENTROIDAL_FRAME_AT_COM, &o, d_out, d_out + (size_t)B * 6 * nv,
+                                     d_out + (size_t)B * (6 * nv + 6));
+      }
+      return MH_OK;
+   };
+   const int real_cus = m->cu_count;
+   std::vector<double> ref, got;
+   std::string failure;
+   for (int what = 0; what < CK_COUNT && failure.empty(); what++)
+      for (int L = 0; L < 2 && failure.empty(); L++)
+      {
+         if ((what == CK_FUSED || what == CK_STEP) && L == 1)
+            continue; // AoS-only entry points
+         size_t used = 0;
+         m->use_spec = 0;
+         mh_status st = run(what, L, used);
+         (void)hipDeviceSynchronize();
+         m->use_spec = 1;
+         if (st != MH_OK)
+            continue; // the run-time-topology kernels cannot serve this call either: nothing to compare
+         ref.resize(used);
+         (void)hipMemcpy(ref.data(), d_out, used * sizeof(double), hipMemcpyDeviceToHost);
+         for (int pretend = 0; pretend < 2 && failure.empty(); pretend++)
+         {
+            m->cu_count = pretend ? 1 : real_cus;
+            st = run(what, L, used);
+            const hipError_t sync = hipDeviceSynchronize();
+            m->cu_count = real_cus;
+            char buf[320];
+            if (st != MH_OK || sync != hipSuccess)
+            {
+               snprintf(buf, sizeof buf, "%s (%s, %s plan) failed: %s", kCheckNames[what], L ? "SoA" : "AoS", pretend ? "device-filling" : "small-batch",
+                        st != MH_OK ? g_err : hipGetErrorString(sync));
+               failure = buf;
+               break;
+            }
+            got.resize(used);
+            (void)hipMemcpy(got.data(), d_out, used * sizeof(double), hipMemcpyDeviceToHost);
+            double scale = 1.0, err = 0.0;
+            bool nan_mismatch = false;
+            for (size_t k = 0; k < used; k++)
+            {
+               const bool rn = ref[k] != ref[k], gn = got[k] != got[k];
+               if (rn != gn)
+                  nan_mismatch = true;
+               else if (!rn)
+                  scale = std::max(scale, std::fabs(ref[k])), err = std::max(err, std::fabs(ref[k] - got[k]));
+            }
+            // forward dynamics divides by joint-space inertias: rounding differences between two exact evaluation orders are amplified by
+            // their conditioning (1e-8 is what the parity tests grant ill-conditioned random trees); everything else is held to 1e-10
+            const double tol = (what == CK_ABA || what == CK_FUSED || what == CK_STEP || what == CK_BODIES_ABA) ? 1.0e-8 : 1.0e-10;
+            if (nan_mismatch || !(err <= tol * scale))
+            {
+               snprintf(buf, sizeof buf, "%s (%s, %s plan) differs from the run-time-topology kernels by %.3e (|ref| <= %.3e%s)", kCheckNames[what],
+                        L ? "SoA" : "AoS", pretend ? "device-filling" : "small-batch", err, scale, nan_mismatch ? ", entries left unwritten" : "");
+               failure = buf;
+            }
+         }
+      }
+   (void)hipFree(d_all);
+   if (!failure.empty())
+   {
+      dlclose(m->spec.handle);
+      m->spec = SpecLib{};
+      m->variant = "generic (code object topo:" + m->topo_key + " refused by the create-time self-check: " + failure + ")";
+   }
+}

@@ -15,6 +15,8 @@
 #pragma once
 #include "mh_device.h"
 
+#include <cstddef>
+
 namespace mh
 {
 enum : int
@@ -72,8 +74,13 @@ enum : int
    MC_I = 16,  // 6: rotational inertia about that origin (xx, xy, xz, yy, yz, zz)
    MC_RF = 22, // 9: rotation body-fixed -> canonical after-joint (for external wrenches)
    MC_PF = 31, // 3: position of the body-fixed frame
-   MC_STRIDE = 34
+   MC_QA = 34, // 9: rotation canonical after-joint -> Mecano's after-joint frame (joint wrench outputs)
+   MC_OA = 43, // 3: origin of the canonical after-joint frame in Mecano's after-joint frame
+   MC_STRIDE = 46
 };
+// Version of the canonical-frame construction of mh_model_create (axis -> +z, first child on the x axis, inertia about the joint origin).
+// A topology-specialised code object folds parts of it at compile time (Tree<TP>::p_aligned): it must come from the same convention.
+constexpr int MH_FRAME_CONVENTION = 2;
 
 struct DevModel
 {
@@ -106,6 +113,9 @@ struct Args
    // optional per-body outputs (generic kernels with BODIES): spatial acceleration / twist of every successor body relative to the
    // inertial frame, in its body-fixed frame, [B][n_joints][6] laid out like fext (f_bs, f_es); either may be NULL
    T *body_acc, *body_twist;
+   // optional (rnea_kernel with BODIES): the wrench every joint transmits (moment, force), in Mecano's frame after the joint, laid out like
+   // fext -- InverseDynamicsCalculator.getComputedJointWrench (InverseDynamicsCalculator.java:578-585); may be NULL
+   T *joint_wrench;
    // fused simulation step (tree-split ABA kernel): when q_next is not NULL the new state after one MultiBodySystemStateIntegrator
    // step of size dt is written as well (q_next [B][nq], qd_next [B][nv]; may alias q / qd)
    T dt;
@@ -426,6 +436,20 @@ MH_DEV void store_body_motion(const CR &c, T *row, long f_es, int ext, const SV<
    row[(e + 3) * f_es] = b.l.x, row[(e + 4) * f_es] = b.l.y, row[(e + 5) * f_es] = b.l.z;
 }
 
+// wrench a joint transmits, from the engine's canonical after-joint frame into Mecano's frame after the joint, written to row `ext`
+// (InverseDynamicsCalculator.getComputedJointWrench, InverseDynamicsCalculator.java:578-585: jointWrench is left in frameAfterJoint, :947)
+template <typename T, class CR>
+MH_DEV void store_joint_wrench(const CR &c, T *row, long f_es, int ext, const SV<T> &w)
+{
+   XF<T> X;
+   X.R = M3<T>{c[MC_QA + 0], c[MC_QA + 1], c[MC_QA + 2], c[MC_QA + 3], c[MC_QA + 4], c[MC_QA + 5], c[MC_QA + 6], c[MC_QA + 7], c[MC_QA + 8]};
+   X.p = V3<T>{c[MC_OA + 0], c[MC_OA + 1], c[MC_OA + 2]};
+   const SV<T> b = force_to_parent(X, w);
+   const long e = (long)ext * 6;
+   row[(e + 0) * f_es] = b.a.x, row[(e + 1) * f_es] = b.a.y, row[(e + 2) * f_es] = b.a.z;
+   row[(e + 3) * f_es] = b.l.x, row[(e + 4) * f_es] = b.l.y, row[(e + 5) * f_es] = b.l.z;
+}
+
 template <typename T>
 MH_DEV void stage_consts(const DevModel &m, T *lds)
 {
@@ -545,6 +569,11 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
          SV<T> f = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
          if (have_carry)
             f = f + carry;
+         if constexpr (BODIES)
+         {
+            if (A.joint_wrench)
+               store_joint_wrench<T>(c, A.joint_wrench + cfg * A.f_bs, A.f_es, mi[MI_EXT], f);
+         }
          ciptr di = dof_map + mi[MI_DOF];
          if (type == JT_REVOLUTE)
             trow[di[0] * A.v_es] = f.a.z;
@@ -1719,6 +1748,143 @@ __global__ void __launch_bounds__(256) centroidal_kernel(CentArgs<T> A)
          brow[3 * A.b_es] = fl.x, brow[4 * A.b_es] = fl.y, brow[5 * A.b_es] = fl.z;
       }
    }
+}
+
+// ============================================================================================ relative accelerations
+// RigidBodyAccelerationProvider.getRelativeAcceleration(base, body) (algorithms/interfaces/RigidBodyAccelerationProvider.java:199-235): the
+// acceleration of body's body-fixed frame with respect to base's, expressed in body's, from the per-body accelerations and twists a
+// previous mh_rnea_bodies / mh_aba_bodies call produced (both relative to the inertial frame, in the body-fixed frames).  The base's
+// acceleration is re-expressed in the body's frame with the velocity-dependent terms of SpatialAccelerationBasics.changeFrame(desiredFrame,
+// deltaTwist, bodyTwist) (spatial/interfaces/SpatialAccelerationBasics.java:192-200): lin += v_d x w_b + w_d x v_b, ang += w_d x w_b with
+// (w_d, v_d) the twist of the base frame relative to the body frame and (w_b, v_b) the base's own twist, both in the base frame.
+// lane = configuration; the pose of a body-fixed frame in the root frame is composed on the fly up the tree (no workspace).
+template <typename T>
+struct RelArgs
+{
+   DevModel m;
+   long B;
+   const T *q;
+   const T *body_acc, *body_twist; // [B][n_joints][6] laid out with (f_bs, f_es); body_twist NULL = velocities not considered
+   T *out;                         // [B][n_pairs][6] with (o_bs, o_es)
+   const int *pairs;               // device, [n_pairs][2]: ENGINE indices (base, body), -1 = the root body
+   int n_pairs;
+   long q_bs, q_es, f_bs, f_es, o_bs, o_es;
+   T gx, gy, gz;
+};
+template <typename T>
+MH_DEV XF<T> compose(const XF<T> &a, const XF<T> &b)
+{ // a o b: first b, then a
+   XF<T> o;
+   o.R = M3<T>{a.R.xx * b.R.xx + a.R.xy * b.R.yx + a.R.xz * b.R.zx, a.R.xx * b.R.xy + a.R.xy * b.R.yy + a.R.xz * b.R.zy,
+               a.R.xx * b.R.xz + a.R.xy * b.R.yz + a.R.xz * b.R.zz, a.R.yx * b.R.xx + a.R.yy * b.R.yx + a.R.yz * b.R.zx,
+               a.R.yx * b.R.xy + a.R.yy * b.R.yy + a.R.yz * b.R.zy, a.R.yx * b.R.xz + a.R.yy * b.R.yz + a.R.yz * b.R.zz,
+               a.R.zx * b.R.xx + a.R.zy * b.R.yx + a.R.zz * b.R.zx, a.R.zx * b.R.xy + a.R.zy * b.R.yy + a.R.zz * b.R.zy,
+               a.R.zx * b.R.xz + a.R.zy * b.R.yz + a.R.zz * b.R.zz};
+   o.p = mul(a.R, b.p) + a.p;
+   return o;
+}
+// motion vector child -> parent through X (child -> parent pose): w' = R w ; v' = R v + p x w'
+template <typename T>
+MH_DEV SV<T> motion_to_parent(const XF<T> &X, SV<T> m)
+{
+   SV<T> o;
+   o.a = mul(X.R, m.a);
+   o.l = mul(X.R, m.l) + cross(X.p, o.a);
+   return o;
+}
+// pose of the body-fixed frame of engine body e in the root body frame (identity for e < 0)
+template <typename T>
+MH_DEV XF<T> body_pose_in_root(const DevModel &m, ciptr meta, ciptr cfg_map, const T *CB, const T *qrow, long q_es, int e)
+{
+   XF<T> X{M3<T>{T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}, V3<T>{T(0), T(0), T(0)}};
+   if (e < 0)
+      return X;
+   {
+      const CRef<T, false> c{CB + e * MC_STRIDE};
+      X.R = M3<T>{c[MC_RF + 0], c[MC_RF + 1], c[MC_RF + 2], c[MC_RF + 3], c[MC_RF + 4], c[MC_RF + 5], c[MC_RF + 6], c[MC_RF + 7], c[MC_RF + 8]};
+      X.p = V3<T>{c[MC_PF + 0], c[MC_PF + 1], c[MC_PF + 2]};
+   }
+   for (int j = e; j >= 0;)
+   {
+      ciptr mi = meta + j * MI_STRIDE;
+      const int type = mi[MI_TYPE];
+      const CRef<T, false> c{CB + j * MC_STRIDE};
+      const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, q_es, (T *)nullptr, 0, 0, false);
+      XF<T> XJ;
+      if (general_x(type))
+         XJ = jx.X;
+      else
+      {
+         XJ.R = M3<T>{jx.c, -jx.s, T(0), jx.s, jx.c, T(0), T(0), T(0), T(1)};
+         XJ.p = V3<T>{T(0), T(0), jx.d};
+      }
+      X = compose(load_xb<T>(c), compose(XJ, X));
+      j = mi[MI_PARENT];
+   }
+   return X;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) relative_acceleration_kernel(RelArgs<T> A)
+{
+   const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   const ciptr meta = as_const(m.meta), cfg_map = as_const(m.cfg_map), pairs = as_const(A.pairs);
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   const V3<T> Z{T(0), T(0), T(0)};
+   for (long cfg = (long)blockIdx.x * blockDim.x + threadIdx.x; cfg < A.B; cfg += nlanes)
+   {
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *arow = A.body_acc + cfg * A.f_bs;
+      const T *trow = A.body_twist ? A.body_twist + cfg * A.f_bs : nullptr;
+      T *orow = A.out + cfg * A.o_bs;
+      auto load6 = [&](const T *row, int e) {
+         const long k = (long)meta[e * MI_STRIDE + MI_EXT] * 6;
+         return SV<T>{V3<T>{row[(k + 0) * A.f_es], row[(k + 1) * A.f_es], row[(k + 2) * A.f_es]},
+                      V3<T>{row[(k + 3) * A.f_es], row[(k + 4) * A.f_es], row[(k + 5) * A.f_es]}};
+      };
+      for (int k = 0; k < A.n_pairs; k++)
+      {
+         const int b1 = pairs[2 * k], b2 = pairs[2 * k + 1];
+         const XF<T> X1 = body_pose_in_root<T>(m, meta, cfg_map, CB, qrow, A.q_es, b1);
+         const XF<T> X2 = body_pose_in_root<T>(m, meta, cfg_map, CB, qrow, A.q_es, b2);
+         // pose of frame 1 in frame 2: x_2 = R2^T (R1 x_1 + p1 - p2)
+         XF<T> X12;
+         X12.R = M3<T>{X2.R.xx * X1.R.xx + X2.R.yx * X1.R.yx + X2.R.zx * X1.R.zx, X2.R.xx * X1.R.xy + X2.R.yx * X1.R.yy + X2.R.zx * X1.R.zy,
+                       X2.R.xx * X1.R.xz + X2.R.yx * X1.R.yz + X2.R.zx * X1.R.zz, X2.R.xy * X1.R.xx + X2.R.yy * X1.R.yx + X2.R.zy * X1.R.zx,
+                       X2.R.xy * X1.R.xy + X2.R.yy * X1.R.yy + X2.R.zy * X1.R.zy, X2.R.xy * X1.R.xz + X2.R.yy * X1.R.yz + X2.R.zy * X1.R.zz,
+                       X2.R.xz * X1.R.xx + X2.R.yz * X1.R.yx + X2.R.zz * X1.R.zx, X2.R.xz * X1.R.xy + X2.R.yz * X1.R.yy + X2.R.zz * X1.R.zy,
+                       X2.R.xz * X1.R.xz + X2.R.yz * X1.R.yz + X2.R.zz * X1.R.zz};
+         X12.p = tmul(X2.R, X1.p - X2.p);
+         const SV<T> a_root{Z, V3<T>{-A.gx, -A.gy, -A.gz}};
+         SV<T> a1 = b1 < 0 ? a_root : load6(arow, b1);
+         const SV<T> a2 = b2 < 0 ? a_root : load6(arow, b2);
+         if (trow)
+         {
+            const SV<T> t1 = b1 < 0 ? SV<T>{Z, Z} : load6(trow, b1), t2 = b2 < 0 ? SV<T>{Z, Z} : load6(trow, b2);
+            const SV<T> d = t1 - motion_to_child(X12, t2); // twist of the base frame relative to the body frame, in the base frame (:217)
+            a1.l = a1.l + cross(d.l, t1.a) + cross(d.a, t1.l);
+            a1.a = a1.a + cross(d.a, t1.a);
+         }
+         const SV<T> r = a2 - motion_to_parent(X12, a1); // :228
+         const long o = (long)k * 6;
+         orow[(o + 0) * A.o_es] = r.a.x, orow[(o + 1) * A.o_es] = r.a.y, orow[(o + 2) * A.o_es] = r.a.z;
+         orow[(o + 3) * A.o_es] = r.l.x, orow[(o + 4) * A.o_es] = r.l.y, orow[(o + 5) * A.o_es] = r.l.z;
+      }
+   }
+}
+
+// ---- stamp of everything a topology-specialised code object shares with the library beyond the C-ABI: the argument structs it
+// reinterprets, the strides of the per-joint records, the canonical-frame convention.  mh_model_create refuses a code object whose stamp
+// differs (a stale libmecano_hip_topo_<key>.so would otherwise read a mis-laid-out struct or fold zeros that are not there).
+constexpr unsigned long long spec_abi_stamp()
+{
+   unsigned long long h = 1469598103934665603ull;
+   const unsigned long long parts[] = {sizeof(Args<double>), sizeof(CentArgs<double>), (unsigned long long)MC_STRIDE, (unsigned long long)MI_STRIDE,
+                                       (unsigned long long)MH_FRAME_CONVENTION, (unsigned long long)offsetof(Args<double>, joint_wrench),
+                                       (unsigned long long)offsetof(Args<double>, q_next)};
+   for (unsigned long long v : parts)
+      h = (h ^ v) * 1099511628211ull;
+   return h;
 }
 
 #undef MH_WS

@@ -8,6 +8,7 @@
 #include "mh_spec_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #ifndef MH_TOPO_N
@@ -43,6 +44,28 @@ enum : int
    F_OCC3 = 32    // tree-split RNEA without LDS rows (SoA): the build with a three-waves-per-SIMD register budget (device-filling batches)
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: the "already raised to" cache is kept per device
+// (models may live on different devices of one process, mh_set_device) and is atomic (two host threads with handles of the same topology).
+struct LdsAttr
+{
+   std::atomic<size_t> bytes[16] = {};
+};
+hipError_t ensure_lds_attr(const void *kern, size_t lds, LdsAttr &cache)
+{
+   if (lds <= 64 * 1024)
+      return hipSuccess;
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess)
+      dev = 0;
+   std::atomic<size_t> &have = cache.bytes[dev & 15];
+   if (lds <= have.load(std::memory_order_acquire))
+      return hipSuccess;
+   const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+   if (e == hipSuccess)
+      have.store(lds, std::memory_order_release);
+   return e;
+}
+
 long lds_bytes(int algo, int flags, int nq, int nv)
 {
    long b = 0;
@@ -57,21 +80,24 @@ template <int ALGO, bool IO, bool ID, bool ST>
 hipError_t go(const mh::Args<double> &A, int grid, size_t lds, hipStream_t stream)
 {
    auto kern = &mh::spec_kernel<TP, double, ALGO, IO, ID, ST>;
-   static size_t attr_bytes = 0; // per instantiation
-   if (lds > 64 * 1024 && lds > attr_bytes)
-   {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess)
-         return e;
-      attr_bytes = lds;
-   }
+   static LdsAttr attr; // per instantiation
+   if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
+      return e;
    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, A);
    return hipGetLastError();
 }
 // Whole-tree (one wave per 64 configurations) ABA is built only for trees WITHOUT a tree-split form (chains): where the tree-split
 // kernel exists the dispatcher prefers it at every batch size, and the whole-tree ABA of a 25-body tree needs the full 512-register
 // budget plus 50-130 spills -- the one place where hipcc 7.2 handed back wrong results for some memory plans (open issues).
-constexpr bool kWholeTreeAba = !mh::Split<TP>::usable();
+// Long chains are out as well: a whole-tree walk keeps the down-sweep state of every body on the path alive across the turn-around
+// (18+ values per body), so a 30-body chain needs the full 512 registers plus ~600 spilled VGPRs and ~1000 spilled SGPRs (measured:
+// 10 minutes of compile time, 1.9 KB of scratch per lane) -- the regime of the wrong-result build.  Chains of more than
+// kWholeTreeMaxBodies bodies get no whole-tree kernels at all (RNEA included: 512 registers + 70..400 scalar spills at 30 bodies); they
+// run on the run-time-topology kernels, whose per-lane stack is indexed by tree depth.  Whatever IS built is checked against those
+// kernels when the object is loaded (mh_model_create).
+constexpr int kWholeTreeMaxBodies = 12;
+constexpr bool kWholeTreeAba = !mh::Split<TP>::usable() && TP::N <= kWholeTreeMaxBodies;
+constexpr bool kWholeTreeRnea = mh::Split<TP>::usable() || TP::N <= kWholeTreeMaxBodies;
 template <int ALGO, bool IO, bool ID>
 hipError_t go_st(int flags, const mh::Args<double> &A, int grid, size_t lds, hipStream_t s)
 {
@@ -87,7 +113,12 @@ hipError_t go_st(int flags, const mh::Args<double> &A, int grid, size_t lds, hip
       }
    }
    else
-      return go<ALGO, IO, ID, false>(A, grid, lds, s);
+   {
+      if constexpr (!kWholeTreeRnea)
+         return hipErrorNotSupported;
+      else
+         return go<ALGO, IO, ID, false>(A, grid, lds, s);
+   }
 }
 template <int ALGO>
 hipError_t go_flags(int flags, const mh::Args<double> &A, int grid, size_t lds, hipStream_t s)
@@ -112,14 +143,9 @@ hipError_t go_fused(const mh::Args<double> &A, int waves, hipStream_t stream)
    {
    auto kern = &mh::spec_fused_kernel<TP, double, ID>;
    const size_t lds = (size_t)std::max(lds_bytes(0, F_IO_LDS, A.m.nq, A.m.nv), lds_bytes(1, F_ST_LDS, A.m.nq, A.m.nv));
-   static size_t attr_bytes = 0;
-   if (lds > 64 * 1024 && lds > attr_bytes)
-   {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess)
-         return e;
-      attr_bytes = lds;
-   }
+   static LdsAttr attr;
+   if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
+      return e;
    hipLaunchKernelGGL(kern, dim3(2 * waves), dim3(64), lds, stream, A);
    return hipGetLastError();
    }
@@ -136,15 +162,10 @@ long split_lds_bytes(int algo, int flags, int nq, int nv)
    return b;
 }
 template <class K>
-hipError_t launch_lds(K kern, const mh::Args<double> &A, int grid, size_t lds, size_t &attr_bytes, hipStream_t stream)
+hipError_t launch_lds(K kern, const mh::Args<double> &A, int grid, size_t lds, LdsAttr &attr, hipStream_t stream)
 {
-   if (lds > 64 * 1024 && lds > attr_bytes)
-   {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess)
-         return e;
-      attr_bytes = lds;
-   }
+   if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
+      return e;
    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, A);
    return hipGetLastError();
 }
@@ -153,7 +174,7 @@ hipError_t go_fused_split(const mh::Args<double> &A, int groups, hipStream_t str
 {
    if constexpr (SPL::usable())
    {
-      static size_t attr_bytes = 0;
+      static LdsAttr attr_bytes;
       return launch_lds(&mh::spec_fused_split_kernel<TP, double, ID, IO>, A, 2 * groups,
                         (size_t)split_lds_bytes(2, IO ? F_IO_LDS : 0, A.m.nq, A.m.nv), attr_bytes, stream);
    }
@@ -165,12 +186,12 @@ hipError_t go_split(const mh::Args<double> &A, int groups, hipStream_t stream, b
 {
    if constexpr (SPL::usable())
    {
-      static size_t attr_bytes = 0;
+      static LdsAttr attr_bytes, attr_occ3; // one cache per kernel
       if constexpr (ALGO == 0 && ID && !IO)
       {
          if (occ3)
             return launch_lds(&mh::spec_split_kernel_occ3<TP, double, ALGO, ID, IO>, A, groups,
-                              (size_t)split_lds_bytes(ALGO, 0, A.m.nq, A.m.nv), attr_bytes, stream);
+                              (size_t)split_lds_bytes(ALGO, 0, A.m.nq, A.m.nv), attr_occ3, stream);
       }
       return launch_lds(&mh::spec_split_kernel<TP, double, ALGO, ID, IO>, A, groups,
                         (size_t)split_lds_bytes(ALGO, IO ? F_IO_LDS : 0, A.m.nq, A.m.nv), attr_bytes, stream);
@@ -211,7 +232,7 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
       {
          if (id && io && (algo == 0 || algo == 1))
          {
-            static size_t attr0 = 0, attr1 = 0;
+            static LdsAttr attr0, attr1;
             const size_t lds = (size_t)split_lds_bytes(algo, F_IO_LDS, A.m.nq, A.m.nv);
             if (algo == 0)
                return (int)launch_lds(&mh::spec_split_kernel<TP, double, 0, true, true, true>, A, groups, lds, attr0, s);
@@ -251,6 +272,8 @@ int mh_spec_split_plan(int *out, int cap)
       put(SPL::P.cut_body[w]);
    return n < cap ? n : cap;
 }
+// everything this object shares with libmecano_hip.so beyond its own entry points (argument structs, record strides, frame convention)
+unsigned long long mh_spec_abi(void) { return mh::spec_abi_stamp(); }
 int mh_spec_n(void) { return TP::N; }
 const int *mh_spec_parents(void) { return kParents; }
 const int *mh_spec_types(void) { return kTypes; }
@@ -266,7 +289,9 @@ int mh_spec_supports(int algo, int flags)
    if (algo == 1 && (flags & F_IO_LDS) && (flags & F_ST_LDS))
       return 0;
    if (algo == 1 && !kWholeTreeAba)
-      return 0; // trees with a tree-split form: whole-tree ABA is not built (see kWholeTreeAba)
+      return 0; // trees with a tree-split form, long chains: whole-tree ABA is not built (see kWholeTreeAba)
+   if (algo == 0 && !kWholeTreeRnea)
+      return 0;
    return algo == 0 || algo == 1;
 }
 // dynamic LDS one workgroup (one wave) needs for (algo, flags) with the model's matrix sizes
@@ -295,14 +320,9 @@ int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
    {
       auto kern = &mh::spec_crba_packed_kernel<TP, double>;
       const size_t lds = (size_t)mh_spec_crba_lds_bytes();
-      static size_t attr_bytes = 0;
-      if (lds > 64 * 1024 && lds > attr_bytes)
-      {
-         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-         if (e != hipSuccess)
-            return (int)e;
-         attr_bytes = lds;
-      }
+      static LdsAttr attr;
+      if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
+         return (int)e;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, (hipStream_t)stream, A);
    }
    else if (flags & F_IDENT)
@@ -361,14 +381,9 @@ int mh_spec_launch_crba_split(const void *args, int groups, int lanes_per_group,
       const mh::Args<double> &A = *(const mh::Args<double> *)args;
       auto kern = &mh::spec_crba_split_kernel<TP, double>;
       const size_t lds = (size_t)mh_spec_crba_split_lds_bytes();
-      static size_t attr_bytes = 0;
-      if (lds > 64 * 1024 && lds > attr_bytes)
-      {
-         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-         if (e != hipSuccess)
-            return (int)e;
-         attr_bytes = lds;
-      }
+      static LdsAttr attr;
+      if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
+         return (int)e;
       hipLaunchKernelGGL(kern, dim3(groups), dim3(256), lds, (hipStream_t)stream, A, lanes_per_group);
       return (int)hipGetLastError();
    }

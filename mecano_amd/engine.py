@@ -81,6 +81,14 @@ class HipModel:
             raise _lib.MecanoHipError(2, f"state matrix has {rows} rows per configuration, the system needs {n}")
         return B
 
+    def _check_f_ext(self, f_ext, B, layout):
+        """External wrenches are [B, n_joints, 6] (SoA: [n_joints * 6, B]): a wrong shape would be an out-of-bounds device read."""
+        if f_ext is None:
+            return
+        want = (B, self.n_joints, 6) if layout == _lib.LAYOUT_AOS else (self.n_joints * 6, B)
+        if tuple(f_ext.shape) != want and not (layout == _lib.LAYOUT_AOS and tuple(f_ext.shape) == (B, self.n_joints * 6)):
+            raise _lib.MecanoHipError(2, f"external wrenches have shape {tuple(f_ext.shape)}, expected {want}")
+
     def _run(self, kind, q, qd, x3, gravity, f_ext, layout, consider_coriolis, consider_accelerations):
         lib = _lib.load()
         g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
@@ -99,6 +107,7 @@ class HipModel:
             if kind != "crba":
                 if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
                     raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+            self._check_f_ext(f_ext, B, layout)
             stream = torch.cuda.current_stream(q.device).cuda_stream
             opts = self._options(layout, consider_coriolis, consider_accelerations, stream)
             sfx = "f64" if dt == torch.float64 else "f32"
@@ -124,6 +133,7 @@ class HipModel:
         if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         f = None if f_ext is None else _np(f_ext, np.float64)
+        self._check_f_ext(f, B, layout)
         out = np.empty_like(qd)
         _lib.check(getattr(lib, f"mh_{kind}_f64_host")(self._h, B, q.ctypes.data, qd.ctypes.data, x3.ctypes.data, g,
                                                        None if f is None else f.ctypes.data, ctypes.byref(opts), out.ctypes.data))
@@ -169,6 +179,7 @@ class HipModel:
         B = self._batch(q, self.nq, layout)
         if any(self._batch(x, self.nv, layout) != B for x in (qd, tau, qdd_in)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        self._check_f_ext(f_ext, B, layout)
         g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
         opts = self._options(layout, True, True, torch.cuda.current_stream(q.device).cuda_stream)
         qdd_out, tau_out = torch.empty_like(qd), torch.empty_like(qd)
@@ -188,10 +199,17 @@ class HipModel:
         B = self._batch(q, self.nq, layout)
         if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        self._check_f_ext(f_ext, B, layout)
         g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
         opts = self._options(layout, consider_coriolis, consider_accelerations, torch.cuda.current_stream(q.device).cuda_stream)
         out = torch.empty_like(qd)
         shape = (B, self.n_joints, 6) if layout == _lib.LAYOUT_AOS else (self.n_joints * 6, B)
+        if kind in ("rnea_wrenches", "aba_wrenches"):
+            w = torch.empty(shape, dtype=torch.float64, device=q.device)
+            fn = lib.mh_rnea_joint_wrenches_f64 if kind == "rnea_wrenches" else lib.mh_aba_joint_wrenches_f64
+            _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), x3.data_ptr(), g, f_ext.data_ptr() if f_ext is not None else None,
+                          ctypes.byref(opts), out.data_ptr(), w.data_ptr()))
+            return out, w
         acc, tw = torch.empty(shape, dtype=torch.float64, device=q.device), torch.empty(shape, dtype=torch.float64, device=q.device)
         fn = lib.mh_rnea_bodies_f64 if kind == "rnea" else lib.mh_aba_bodies_f64
         _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), x3.data_ptr(), g, f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts),
@@ -206,6 +224,41 @@ class HipModel:
     def aba_bodies(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS):
         """ABA plus per-body outputs: (qdd, body_acc, body_twist)."""
         return self._bodies("aba", q, qd, tau, gravity, f_ext, layout)
+
+    def rnea_joint_wrenches(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS, consider_coriolis=True,
+                            consider_accelerations=True):
+        """RNEA plus InverseDynamicsCalculator.getComputedJointWrench of every joint: (tau, joint_wrench [B, n_joints, 6]), the
+        wrenches (moment, force) in the frames after the joints."""
+        return self._bodies("rnea_wrenches", q, qd, qdd, gravity, f_ext, layout, consider_coriolis, consider_accelerations)
+
+    def aba_joint_wrenches(self, q, qd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, layout=_lib.LAYOUT_AOS):
+        """ABA plus ForwardDynamicsCalculator.getJointWrench of every joint: (qdd, joint_wrench)."""
+        return self._bodies("aba_wrenches", q, qd, tau, gravity, f_ext, layout)
+
+    def relative_acceleration(self, q, body_acc, body_twist, base_joints, body_joints, gravity=(0.0, 0.0, -9.81), layout=_lib.LAYOUT_AOS,
+                              consider_velocities=True):
+        """RigidBodyAccelerationProvider.getRelativeAcceleration for pairs of bodies (indices of listed joints, -1 = the root body) from
+        the per-body outputs of rnea_bodies / aba_bodies on the same configurations: [B, n_pairs, 6] in the body's body-fixed frame."""
+        import torch
+        lib = _lib.load()
+        tensors = (q, body_acc) + ((body_twist,) if body_twist is not None else ())
+        for t in tensors:
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("relative_acceleration needs contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, layout)
+        for t in tensors[1:]:
+            self._check_f_ext(t, B, layout)
+        base, body = _np(base_joints, np.int32).reshape(-1), _np(body_joints, np.int32).reshape(-1)
+        if base.shape != body.shape:
+            raise _lib.MecanoHipError(2, "base and body index lists differ in length")
+        n_pairs = int(base.shape[0])
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(layout, consider_velocities, True, torch.cuda.current_stream(q.device).cuda_stream)
+        out = torch.empty((B, n_pairs, 6) if layout == _lib.LAYOUT_AOS else (n_pairs * 6, B), dtype=torch.float64, device=q.device)
+        _lib.check(lib.mh_relative_acceleration_f64(self._h, B, q.data_ptr(), body_acc.data_ptr(),
+                                                    body_twist.data_ptr() if body_twist is not None else None, g, n_pairs, base.ctypes.data,
+                                                    body.ctypes.data, ctypes.byref(opts), out.data_ptr()))
+        return out
 
     def integrate(self, dt, q, qd, qdd, layout=_lib.LAYOUT_AOS, out=None, return_acceleration=False):
         """One step of MultiBodySystemStateIntegrator.doubleIntegrateFromAcceleration on device tensors (fp64 / fp32).  ``out`` =
@@ -243,6 +296,7 @@ class HipModel:
         B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
         if self._batch(qd, self.nv, _lib.LAYOUT_AOS) != B or self._batch(tau, self.nv, _lib.LAYOUT_AOS) != B:
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        self._check_f_ext(f_ext, B, _lib.LAYOUT_AOS)
         g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
         opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
         qn, vn = (q, qd) if inplace else (q.clone(), qd.clone())

@@ -139,6 +139,23 @@ def nextFloatingChain(rng, numberOfJoints: int, kinds=("revolute",), tree=False)
     return root.subtreeJointList()
 
 
+def referenceBenchmarkSystems(seed: int = 43, numberOfJoints: int = 30):
+    """The four systems of the reference's own (disabled) RNEA benchmarks, InverseDynamicsCalculatorTest.java:24-158: a 30-joint random
+    1-DoF chain and tree on a fixed base, and the same below a SixDoF root joint; seed 43 each (the reference's seed; the RNG is numpy's,
+    bit compatibility with java.util.Random is not claimed)."""
+    one_dof = ("revolute", "prismatic")
+    out = {}
+    rng = np.random.default_rng(seed)
+    out["chain30"] = MultiBodySystem.toMultiBodySystemInput(nextJointChain(rng, numberOfJoints, one_dof)[0].getPredecessor())
+    rng = np.random.default_rng(seed)
+    out["floating_chain30"] = MultiBodySystem.toMultiBodySystemInput(nextFloatingChain(rng, numberOfJoints, one_dof)[0].getPredecessor())
+    rng = np.random.default_rng(seed)
+    out["tree30"] = MultiBodySystem.toMultiBodySystemInput(nextJointTree(rng, numberOfJoints, one_dof)[0].getPredecessor())
+    rng = np.random.default_rng(seed)
+    out["floating_tree30"] = MultiBodySystem.toMultiBodySystemInput(nextFloatingChain(rng, numberOfJoints, one_dof, tree=True)[0].getPredecessor())
+    return out
+
+
 def nextHumanoid(rng) -> MultiBodySystem:
     """The 30-DoF humanoid of BASELINE.json configs[2..3] / SURVEY.md section 8d: SixDoF pelvis + 24 revolute joints:
     legs 6 x 2, waist/torso 3, arms 4 x 2, neck 1  =>  nv = 30, nq = 31, 25 moving bodies, depth 8 pelvis->hand.
