@@ -1,11 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric: robot-configs/sec (RNEA+ABA), 30-DoF humanoid, batch 4096 per GPU.
 
-One "step" = one pass of the hot path over one batch of synthetic input: RNEA (q, qd, qdd -> tau) and ABA (q, qd, tau_in -> qdd)
-of the same 4096 configurations of the 30-DoF humanoid (SixDoF pelvis + 24 revolute joints) through mh_rnea_aba_f64 -- one fused
-launch at this batch size (--separate: mh_rnea_f64 then mh_aba_f64) -- with inputs resident in HBM before the timed region.  Multi-GPU: one process per GPU, every rank owns its own 4096
-configurations (weak scaling), no collective on the data path; the model is broadcast once over RCCL before timing and
-the outputs are all-gathered once after it (reported separately as gather_ms).
+One "step" = one pass of the hot path over one batch of synthetic input.  Default workload (the metric's, BASELINE.json configs[2] with the
+metric's RNEA+ABA pair): RNEA (q, qd, qdd -> tau) and ABA (q, qd, tau_in -> qdd) of the same 4096 configurations of the 30-DoF humanoid
+(SixDoF pelvis + 24 revolute joints) through mh_rnea_aba_f64 -- one fused launch at this batch size (--separate: mh_rnea_f64 then
+mh_aba_f64) -- with inputs resident in HBM before the timed region.  Multi-GPU: one process per GPU, no collective on the data path; the
+model is broadcast once over RCCL before timing and the outputs are all-gathered once after it (reported separately as gather_ms).
+
+  --config 3   configs[2]: humanoid RNEA + CRBA, fp64, 4096 per GPU                      (weak scaling)
+  --config 4   configs[3]: humanoid ABA, fp64, 262 144 configurations sharded over the GPUs (strong scaling)
+  --config 5   configs[4]: random 128-body tree, RNEA + ABA, fp32, 1 048 576 sharded       (strong scaling)
+  (no flag)    the metric: humanoid RNEA + ABA, fp64, 4096 per GPU                       (weak scaling)
+
+Timing: W warm-up steps, then R >= 5 timed REGIONS of exactly K steps each, every region bracketed by barrier + synchronize on both
+sides; `value` and `ms_per_step` come from the MEDIAN region (max over ranks per region), all regions are listed in `region_ms`.  After
+the timed regions the outputs the last step left in HBM are checked against the CPU oracle on a strided sample (`check`).
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), including
   "roofline":     algorithmic bytes of the dominant kernel / its mean launch duration (HIP events on the launch stream)
@@ -27,24 +36,32 @@ sys.path.insert(0, ROOT)
 BATCH = 4096                 # BASELINE.json metric: batch=4096 (per GPU; weak scaling)
 MODEL_SEED, STATE_SEED = 43, 2342
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
-BYTES_RNEA = 968             # (nq + 2 nv + nv) * 8 with nq = 31, nv = 30   
-BYTES_ABA = 968
+REGIONS = 5
 
 
-def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=10.0):
-    """Oracle (CPU port) on the host cores: RNEA+ABA pairs per second on a bounded sample of the same batch.  One thread per core,
-    each walking its own contiguous slice (the C calls release the GIL; the oracle keeps its scratch thread-local); the
-    single-thread rate is measured first and quoted in `sample`."""
+def cpu_baseline(desc, q, qd, qdd, tau, gravity, jobs, target_s=10.0):
+    """Oracle (CPU port) on the host cores: steps' worth of evaluations per second on a bounded sample of the same batch.  One thread per
+    core, each walking its own passes (the C calls release the GIL; the oracle keeps its scratch thread-local); the single-thread rate is
+    measured first and quoted in `sample`.  `jobs`: which oracle calls make one evaluation ("rnea", "aba", "crba")."""
     import threading
     from oracle.cpu_oracle import OracleModel
     om = OracleModel(desc)
-    n = 256
-    om.rnea(q[:n], qd[:n], qdd[:n], gravity)  # warm
+    q, qd, qdd, tau = (np.asarray(x, dtype=np.float64) for x in (q, qd, qdd, tau))
+
+    def one(lo, hi):
+        if "rnea" in jobs:
+            om.rnea(q[lo:hi], qd[lo:hi], qdd[lo:hi], gravity)
+        if "aba" in jobs:
+            om.aba(q[lo:hi], qd[lo:hi], tau[lo:hi], gravity)
+        if "crba" in jobs:
+            om.crba(q[lo:hi])
+
+    n = min(256, len(q))
+    one(0, n)  # warm
     t0 = time.perf_counter()
     reps1 = 0
     while time.perf_counter() - t0 < 2.0:
-        om.rnea(q[:n], qd[:n], qdd[:n], gravity)
-        om.aba(q[:n], qd[:n], tau[:n], gravity)
+        one(0, n)
         reps1 += 1
     single = reps1 * n / (time.perf_counter() - t0)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -54,15 +71,15 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=10.0):
             cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
     except (OSError, ValueError):
         pass
-    # whole batches per thread, bounded: about target_s seconds of wall clock, at most 1024 batches in total
-    reps = int(max(1, min(1024 // cores + 1, target_s * single / len(q))))
+    # bounded: about target_s seconds of wall clock; every thread walks `per` configurations of the batch `reps` times
+    per = min(len(q), 4096)
+    reps = int(max(1, min(1024 // cores + 1, target_s * single / per)))
     done = [0] * cores
 
     def work(t):
         for _ in range(reps):
-            om.rnea(q, qd, qdd, gravity)
-            om.aba(q, qd, tau, gravity)
-            done[t] += len(q)
+            one(0, per)
+            done[t] += per
 
     threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
     t0 = time.perf_counter()
@@ -73,19 +90,20 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, target_s=10.0):
     dt = time.perf_counter() - t0
     total = sum(done)
     return {"value": total / dt, "unit": "configs/s", "cores": cores, "kind": "port",
-            "sample": f"{total} RNEA+ABA pairs ({reps} passes over the same humanoid batch per thread), oracle/mecano_oracle.c (C restatement, not "
-                      f"Mecano/JVM), {cores} threads, {dt:.1f} s; one thread alone: {single:.0f} configs/s"}
+            "sample": f"{total} evaluations of {'+'.join(jobs)} ({reps} passes over {per} configurations of the same batch per thread), "
+                      f"oracle/mecano_oracle.c (C restatement in fp64, not Mecano/JVM), {cores} threads, {dt:.1f} s; one thread alone: {single:.0f} configs/s"}
 
 
 def measured_traffic(fused_launch, B):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE,
     separate passes, same command; FETCH_SIZE x 2 as calibrated on this access pattern, profiles/r01_pmc_calibration_8B_per_lane.txt);
     only quoted for the configuration they were collected on, else null."""
-    path = os.path.join(ROOT, "profiles", "r01_fused_split_b4096_hbm_pmc.json")
-    if not (fused_launch and B == BATCH and os.path.exists(path)):
-        return None
-    pmc = json.load(open(path))
-    return (pmc.get("FETCH_SIZE_correction", 1.0) * pmc["FETCH_SIZE_KB_per_launch_mean"] + pmc["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0
+    for name in ("r02_fused_split_b4096_hbm_pmc.json", "r01_fused_split_b4096_hbm_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if fused_launch and B == BATCH and os.path.exists(path):
+            pmc = json.load(open(path))
+            return (pmc.get("FETCH_SIZE_correction", 1.0) * pmc["FETCH_SIZE_KB_per_launch_mean"] + pmc["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0
+    return None
 
 
 def main():
@@ -93,132 +111,213 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=BATCH, help="configurations per GPU per step (default: the metric's 4096)")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 3, 4, 5), help="BASELINE.json configuration (1-based); default 0 = the metric")
+    ap.add_argument("--batch", type=int, default=0, help="configurations per step: per GPU for the weak-scaling workloads, in total for --config 4 / 5")
+    ap.add_argument("--regions", type=int, default=REGIONS, help="timed regions of --steps steps each; the median is reported (>= 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate", action="store_true", help="two calls per step (mh_rnea_f64, mh_aba_f64) instead of mh_rnea_aba_f64")
     args = ap.parse_args()
 
+    # the launcher's world must be what was asked for -- checked before anything touches a GPU or a process group
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
     import torch
     import torch.distributed as dist
-    from mecano_amd import build, distributed as mdist, random_tools as rt
+    from mecano_amd import _lib, build, distributed as mdist, random_tools as rt
     from mecano_amd.engine import HipModel, HipTimer
+    from mecano_amd.multibody import MultiBodySystem
 
     rank, world, local_rank = mdist.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert world == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if not os.path.exists(build.LIB):
         build.build_lib()
 
+    # ---- workload
+    cfg = args.config
+    strong = cfg in (4, 5)
+    if cfg == 5:
+        sys_ = MultiBodySystem.toMultiBodySystemInput(rt.nextJointTree(np.random.default_rng(128), 128, ("revolute", "prismatic", "sixdof"))[0].getPredecessor())
+        total = args.batch or 1 << 20
+        tdt, np_dt, dtype, word = torch.float32, np.float32, "f32", 4
+    else:
+        sys_ = rt.nextHumanoid(np.random.default_rng(MODEL_SEED))
+        total = args.batch or (262144 if cfg == 4 else BATCH)
+        tdt, np_dt, dtype, word = torch.float64, np.float64, "f64", 8
     # ---- model: built on rank 0, broadcast over RCCL (north_star: "RCCL broadcast of the model")
-    sys_ = rt.nextHumanoid(np.random.default_rng(MODEL_SEED))
     desc = mdist.broadcast_model_desc(sys_.toModelDesc() if rank == 0 else None, src=0)
     model = HipModel(desc)
-    B = args.batch
+    if strong:
+        lo, hi = mdist.shard_range(total, rank, world)
+        B, B_total = hi - lo, total
+    else:
+        B, B_total = total, total * world
     model.reserve(B)
-    q, qd, qdd, tau_in = rt.nextState(np.random.default_rng(STATE_SEED + rank), sys_, B)
+    # synthetic states (SURVEY.md section 8d distributions): at most 16384 distinct configurations are drawn on the host, bigger batches
+    # tile them on the device (the kernels do not care; drawing 1 M x 362 doubles with numpy would take longer than the benchmark)
+    base = min(B, 16384)
+    q, qd, qdd, tau_in = rt.nextState(np.random.default_rng(STATE_SEED + rank), sys_, base)
     gravity = (0.0, 0.0, -9.81)
-    tq, tqd, tqdd, ttau = (torch.tensor(x, device="cuda") for x in (q, qd, qdd, tau_in))
+    reps = (B + base - 1) // base
+    tq, tqd, tqdd, ttau = (torch.tensor(x, device="cuda", dtype=tdt).repeat(reps, 1)[:B].contiguous() for x in (q, qd, qdd, tau_in))
     stream = torch.cuda.current_stream().cuda_stream
+    nq, nv = desc.nq, desc.nv
+    bytes_rnea = bytes_aba = (nq + 3 * nv) * word  # inputs read once + outputs written once
+    bytes_crba = (nq + nv * nv) * word
 
     # caller-owned output buffers, as the C-ABI prescribes (Mecano's calculators also write into pre-allocated matrices)
     tau, acc = torch.empty_like(tqd), torch.empty_like(tqd)
-    fused_step = model.bind_rnea_aba(tq, tqd, tqdd, ttau, tau, acc, gravity)
+    fused = cfg == 0 and not args.separate
+    fused_step = model.bind_rnea_aba(tq, tqd, tqdd, ttau, tau, acc, gravity) if fused else None
+    jobs = {0: ("rnea", "aba"), 3: ("rnea", "crba"), 4: ("aba",), 5: ("rnea", "aba")}[cfg]
+    outs = {}
+
+    def run(job):
+        if job == "rnea":
+            outs["rnea"] = model.rnea(tq, tqd, tqdd, gravity)
+        elif job == "aba":
+            outs["aba"] = model.aba(tq, tqd, ttau, gravity)
+        else:
+            outs["crba"] = model.crba(tq)
 
     def step():
-        if args.separate:
-            return model.rnea(tq, tqd, tqdd, gravity), model.aba(tq, tqd, ttau, gravity)
-        fused_step()
-        return tau, acc
+        if fused:
+            fused_step()
+        else:
+            for job in jobs:
+                run(job)
 
     for _ in range(args.warmup):
-        tau, acc = step()
-    # ---- timed region: exactly K steps between barrier + synchronize pairs; HIP events on the launch stream around every launch
-    K = args.steps
-    # fused: ONE event pair brackets the K launches of the timed region (per-launch event pairs put ~5 us of markers between
-    # two ~30 us kernels); average launch duration = elapsed / K, gaps included.  --separate: an event pair per launch.
-    t_all = HipTimer()
-    t_a = [HipTimer() for _ in range(K)] if args.separate else []
-    t_b = [HipTimer() for _ in range(K)] if args.separate else []
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    t_all.start(stream)
-    for k in range(K):
-        if args.separate:
-            t_a[k].start(stream)
-            tau = model.rnea(tq, tqd, tqdd, gravity)
-            t_a[k].stop(stream)
-            t_b[k].start(stream)
-            acc = model.aba(tq, tqd, ttau, gravity)
-            t_b[k].stop(stream)
+        step()
+    # ---- timed regions: exactly K steps each between barrier + synchronize pairs; HIP events on the launch stream
+    K, R = args.steps, max(1, args.regions)
+    region_s, kernel_ms = [], {j: [] for j in (("rnea_aba",) if fused else jobs)}
+    for r in range(R):
+        # fused: ONE event pair brackets the K launches of a region (per-launch event pairs put ~5 us of markers between two ~25 us
+        # kernels); average launch duration = elapsed / K, gaps included.  Otherwise one event pair per launch.
+        t_all = HipTimer()
+        per_launch = None if fused else [[HipTimer() for _ in range(K)] for _ in jobs]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_all.start(stream)
+        for k in range(K):
+            if fused:
+                fused_step()
+            else:
+                for i, job in enumerate(jobs):
+                    per_launch[i][k].start(stream)
+                    run(job)
+                    per_launch[i][k].stop(stream)
+        t_all.stop(stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        region_s.append(elapsed)
+        if fused:
+            kernel_ms["rnea_aba"].append(t_all.elapsed_ms() / K if K else 0.0)
         else:
-            fused_step()
-    t_all.stop(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if args.separate:
-        ms_a = float(np.mean([t.elapsed_ms() for t in t_a])) if K else 0.0
-        ms_b = float(np.mean([t.elapsed_ms() for t in t_b])) if K else 0.0
-    else:
-        ms_a, ms_b = (t_all.elapsed_ms() / K if K else 0.0), 0.0
+            for i, job in enumerate(jobs):
+                kernel_ms[job].append(float(np.mean([t.elapsed_ms() for t in per_launch[i]])) if K else 0.0)
+    order = np.argsort(region_s)
+    med = int(order[len(order) // 2])
+    elapsed = region_s[med]
+    kernels_ms = {j: v[med] for j, v in kernel_ms.items()}
 
-    # ---- after the timed region: one all-gather of the outputs over xGMI (north_star: "a final gather")
-    gather_ms = None
+    # ---- after the timed regions: one all-gather of the outputs over xGMI (north_star: "a final gather"), per-rank kernel times
+    gather_ms, per_rank = None, None
     if world > 1:
+        last = acc if fused else outs.get("aba", outs.get("rnea"))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        full = mdist.all_gather_rows(acc, B * world)
+        full = mdist.all_gather_rows(last, B_total)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
-        assert full.shape[0] == B * world
+        assert full.shape[0] == B_total
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "batch": B, "kernels_ms": kernels_ms})
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    fused_launch = (not args.separate) and model.kernel_variant.startswith("topo:") and 2 * ((B + 63) // 64) <= 256
-    if args.separate:  # dominant kernel = the slower of the two launches of a step
-        dom, dom_ms, dom_bytes = ("aba", ms_b, BYTES_ABA) if ms_b >= ms_a else ("rnea", ms_a, BYTES_RNEA)
-        kernels_ms = {"rnea": ms_a, "aba": ms_b}
-    else:              # one launch (fused at this batch size) computing both: 968 + 968 algorithmic bytes per configuration
-        dom, dom_ms, dom_bytes = ("rnea+aba fused" if fused_launch else "rnea+aba (two launches)", ms_a, BYTES_RNEA + BYTES_ABA)
-        kernels_ms = {"rnea_aba": ms_a}
+    # ---- the outputs of the launches that were timed, against the CPU oracle on a strided sample (outside the timed regions)
+    from oracle.cpu_oracle import OracleModel
+    om = OracleModel(desc)
+    idx = np.arange(0, B, max(1, B // 64))[:64]
+    q64, qd64, qdd64, tau64 = (np.asarray(x[idx % base], dtype=np_dt).astype(np.float64) for x in (q, qd, qdd, tau_in))
+    check = {"rows": int(len(idx)), "tol": 1e-10 if word == 8 else None}
+    got = {"rnea": tau if fused else outs.get("rnea"), "aba": acc if fused else outs.get("aba"), "crba": outs.get("crba")}
+    ok = True
+    for job in jobs:
+        ref = {"rnea": lambda: om.rnea(q64, qd64, qdd64, gravity), "aba": lambda: om.aba(q64, qd64, tau64, gravity), "crba": lambda: om.crba(q64)}[job]()
+        err = float(np.abs(got[job][torch.as_tensor(idx, device="cuda")].cpu().numpy().astype(np.float64) - ref).max())
+        scale = max(1.0, float(np.abs(ref).max()))
+        check[f"max_err_{job}"] = err
+        if word == 8:
+            ok = ok and err <= 1e-10 * scale
+        else:  # fp32: forward bound 64 n u max|ref| for RNEA / CRBA; ABA is conditioning-bound (tests/test_gpu_parity.py), reported only
+            check[f"bound_{job}"] = 64 * desc.n_joints * 2.0 ** -24 * scale
+            ok = ok and (job == "aba" or err <= check[f"bound_{job}"]) and np.isfinite(err)
+    check["ok"] = bool(ok)
+
+    fused_launch = fused and model.kernel_variant.startswith("topo:") and 2 * ((B + 63) // 64) <= 256
+    bytes_of = {"rnea": bytes_rnea, "aba": bytes_aba, "crba": bytes_crba, "rnea_aba": bytes_rnea + bytes_aba}
+    if fused:  # one launch computing both: 968 + 968 algorithmic bytes per configuration
+        dom, dom_name = "rnea_aba", ("rnea+aba fused" if fused_launch else "rnea+aba (two launches)")
+    else:      # dominant kernel = the slowest launch of a step
+        dom = max(kernels_ms, key=kernels_ms.get)
+        dom_name = dom
+    dom_ms, dom_bytes = kernels_ms[dom], bytes_of[dom]
     achieved = (dom_bytes * B) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    value = world * B * K / elapsed if elapsed > 0 else 0.0
+    value = B_total * K / elapsed if elapsed > 0 else 0.0
+    names = {0: "robot-configs/sec (RNEA+ABA), 30-DoF humanoid batch=4096", 3: "robot-configs/sec (RNEA+CRBA), 30-DoF humanoid batch=4096",
+             4: "robot-configs/sec (ABA), 30-DoF humanoid batch=262144 sharded", 5: "robot-configs/sec (RNEA+ABA), random 128-body tree fp32 batch=1M sharded"}
+    workloads = {0: "30-DoF humanoid (SixDoF pelvis + 24 revolute), RNEA and ABA of every configuration per step, fp64, AoS [B][n] state",
+                 3: "30-DoF humanoid, RNEA and CRBA (30 x 30 mass matrix) of every configuration per step, fp64, AoS",
+                 4: "30-DoF humanoid, ABA of every configuration per step, fp64, AoS, batch sharded over the GPUs",
+                 5: "random 128-body tree (revolute / prismatic / 6-DoF joints), RNEA and ABA per step, fp32, AoS, batch sharded over the GPUs"}
     line = {
-        "metric": "robot-configs/sec (RNEA+ABA), 30-DoF humanoid batch=4096",
+        "metric": names[cfg],
         "value": value, "unit": "configs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": elapsed / K * 1e3 if K else None, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "30-DoF humanoid (SixDoF pelvis + 24 revolute), RNEA and ABA of every configuration per step, fp64, AoS [B][n] state",
-                   "entry_point": "mh_rnea_f64 + mh_aba_f64" if args.separate else "mh_rnea_aba_f64",
-                   "batch_per_gpu": B, "global_batch": B * world, "nq": desc.nq, "nv": desc.nv, "bodies": desc.n_joints,
+        "ms_per_step": elapsed / K * 1e3 if K else None, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": workloads[cfg],
+                   "entry_point": "mh_rnea_aba_f64" if fused else " + ".join(f"mh_{j}_{dtype}" for j in jobs),
+                   "batch_per_gpu": B, "global_batch": B_total, "nq": nq, "nv": nv, "bodies": desc.n_joints,
                    "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
-                   "model_seed": MODEL_SEED, "state_seed": STATE_SEED},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "model_seed": MODEL_SEED if cfg != 5 else 128, "state_seed": STATE_SEED},
+        "regions": R, "region_ms": [s * 1e3 for s in region_s], "reported_region": "median",
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(fused_launch, B),
                      "bytes_per_config": dom_bytes, "launch_ms": dom_ms},
         "kernels_ms": kernels_ms,
+        "per_rank": per_rank,
+        "rccl_ranks": world if world > 1 else None,
+        "dist_backend": (dist.get_backend() if world > 1 else None),
         "gather_ms": gather_ms,
+        "check": check,
     }
     # CPU baseline beside it: rank 0 at N = 1 only (a reported baseline, not the optimisation target)
-    line["cpu_baseline"] = cpu_baseline(desc, q, qd, qdd, tau_in, gravity) if (world == 1 and not args.no_cpu_baseline) else None
+    line["cpu_baseline"] = cpu_baseline(desc, q, qd, qdd, tau_in, gravity, jobs) if (world == 1 and not args.no_cpu_baseline) else None
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"bench.py: the timed launches' outputs disagree with the oracle: {check}")
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@
 // stream.  No CPU implementation of the algorithms exists in this library: without a HIP device the compute
 // entry points return MH_ERR_NO_DEVICE.
 #include "../../include/mecano_hip.h"
-#include "mh_kernels.h"
+#include "mh_dfs_kernels.h"
 
 #include <dlfcn.h>
 
@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -130,7 +131,12 @@ struct mh_model
    std::vector<int> meta, dof_map, cfg_map;
    std::vector<int> engine_of; // caller joint index -> engine index
    std::vector<double> consts;
-   int *d_meta = nullptr, *d_dof = nullptr, *d_cfg = nullptr;
+   int *d_meta = nullptr, *d_dof = nullptr, *d_cfg = nullptr, *d_prog = nullptr;
+   std::vector<int> prog; // event program of the depth-first kernels
+   int rnea_stack = 0, aba_stack = 0, aba_hand = 0; // per-lane slots: depth stacks, ABA hand-over
+   int use_dfs = 1;       // MH_DFS=0: the sweep kernels of mh_kernels.h serve plain RNEA / ABA calls too (A/B measurements)
+   std::map<const void *, size_t> lds_attr; // dynamic-LDS limit already raised per kernel (the model lives on one device, one host thread at a time)
+   int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
    double *d_consts64 = nullptr;
    float *d_consts32 = nullptr;
    Workspace ws;
@@ -199,6 +205,8 @@ mh::DevModel dev_model(const mh_model *m)
    d.n = m->n, d.nq = m->nq, d.nv = m->nv, d.n_slots = m->n_slots;
    d.meta = m->d_meta, d.dof_map = m->d_dof, d.cfg_map = m->d_cfg;
    d.consts = sizeof(T) == 8 ? (const void *)m->d_consts64 : (const void *)m->d_consts32;
+   d.prog = m->d_prog, d.n_events = (int)m->prog.size();
+   d.rnea_stack = m->rnea_stack, d.aba_stack = m->aba_stack, d.aba_hand = m->aba_hand;
    return d;
 }
 
@@ -248,6 +256,58 @@ enum Algo
    ALGO_CRBA
 };
 
+// Depth-first run-time-topology kernels (mh_dfs_kernels.h): where the per-lane depth stack and ABA's hand-over live, grid, launch.
+//   place 0: everything in LDS          place 1: stack in LDS, hand-over in the global workspace          place 2: both global
+// LDS while at least two waves per CU fit (80 KB per wave) -- or the whole 160 KB when the batch has no more waves than the device has
+// CUs anyway; MH_DFS_PLACE overrides (measurements).
+template <typename T>
+mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipStream_t stream)
+{
+   const long waves = (B + 63) / 64;
+   const long LDS_MAX = 160 * 1024, LDS_TWO = 80 * 1024;
+   const long stack = algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack;
+   const long hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
+   const long b_stack = stack * 64 * (long)sizeof(T), b_all = (stack + hand) * 64 * (long)sizeof(T);
+   auto fits = [&](long bytes) { return bytes <= LDS_TWO || (bytes <= LDS_MAX && waves <= (long)model->cu_count); };
+   int place = fits(b_all) ? 0 : (fits(b_stack) ? 1 : 2);
+   if (model->dfs_place >= 0)
+   {
+      place = std::min(2, model->dfs_place);
+      if (place == 0 && b_all > LDS_MAX)
+         place = 1;
+      if (place == 1 && b_stack > LDS_MAX)
+         place = 2;
+   }
+   if (algo == ALGO_RNEA && place == 1)
+      place = 0; // there is no hand-over: b_all == b_stack
+   const long lds = place == 0 ? b_all : (place == 1 ? b_stack : 0);
+   const long per_cu = lds > 0 ? std::max<long>(1, std::min<long>(8, LDS_MAX / lds)) : (long)model->waves_per_cu;
+   const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * per_cu));
+   const long gslots = place == 0 ? 0 : (place == 1 ? hand : stack + hand);
+   if (gslots > 0)
+   {
+      mh_status st = ensure_bytes(model->ws, (size_t)gslots * (size_t)grid * 64 * sizeof(T));
+      if (st != MH_OK)
+         return st;
+   }
+   A.ws = (T *)model->ws.ptr;
+   A.ws_stride = (long)grid * 64;
+   const void *kern = nullptr;
+   if (algo == ALGO_RNEA)
+      kern = place == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true> : (const void *)&mh::rnea_dfs_kernel<T, false>;
+   else
+      kern = place == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, true>
+                        : (place == 1 ? (const void *)&mh::aba_dfs_kernel<T, true, false> : (const void *)&mh::aba_dfs_kernel<T, false, false>);
+   if (lds > 64 * 1024 && model->lds_attr[kern] < (size_t)lds)
+   {
+      HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      model->lds_attr[kern] = (size_t)lds;
+   }
+   void *args[] = {(void *)&A};
+   HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(64), args, (size_t)lds, stream));
+   return MH_OK;
+}
+
 template <typename T>
 mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd, const T *in3, const double gravity[3], const T *fext,
                  const mh_options *opts_in, T *out, const T *locked_in = nullptr, T *locked_out = nullptr, T *body_acc = nullptr,
@@ -269,9 +329,14 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    if (algo == ALGO_ABA && model->n_locked > 0 && !locked_in)
       return fail(MH_ERR_INVALID_ARGUMENT, "%d joint(s) are acceleration sources: forward dynamics needs their accelerations, use mh_aba_locked_f64",
                   model->n_locked);
-   st = ensure_workspace(model, B, sizeof(T));
-   if (st != MH_OK)
-      return st;
+   // the sweep kernels' per-body workspace (plain RNEA / ABA calls run on the depth-first kernels, which size their own)
+   const bool dfs = model->use_dfs && algo != ALGO_CRBA && !bodies && !(algo == ALGO_ABA && model->n_locked > 0);
+   if (!dfs)
+   {
+      st = ensure_workspace(model, B, sizeof(T));
+      if (st != MH_OK)
+         return st;
+   }
    const Launch L = plan_launch(model, B);
    hipStream_t stream = (hipStream_t)opts.stream;
 
@@ -389,6 +454,8 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       return MH_OK;
       } // else: this (algorithm, memory plan) is not in the code object -- the run-time-topology kernels below serve the call
    }
+   if (dfs)
+      return launch_dfs<T>(algo, model, B, A, stream);
    // Run-time-topology RNEA / ABA on AoS matrices: for big batches of wide matrices go through transposed scratch copies
    // (mh::transpose_kernel).  External wrenches keep their own strides.
    T *t_out = nullptr;
@@ -1047,6 +1114,68 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    }
    m->n_slots = std::max(slots, 1);
 
+   // ---- depth-first kernels: children counts, stack-frame / hand-over offsets, event program (mh_dfs_kernels.h)
+   {
+      std::vector<int> nch(n, 0), ofs_r(n, 0), ofs_a(n, 0);
+      for (int e = 0; e < n; e++)
+         if (P.eparent[e] >= 0)
+            nch[P.eparent[e]]++;
+      int hand = 0;
+      for (int e = 0; e < n; e++)
+      {
+         const int pe = P.eparent[e], t = P.etype[e];
+         ofs_r[e] = pe < 0 ? 0 : ofs_r[pe] + mh::rnea_frame_slots(P.etype[pe], nch[pe]);
+         ofs_a[e] = pe < 0 ? 0 : ofs_a[pe] + mh::aba_frame_slots(P.etype[pe], nch[pe]);
+         m->rnea_stack = std::max(m->rnea_stack, ofs_r[e] + mh::rnea_frame_slots(t, nch[e]));
+         m->aba_stack = std::max(m->aba_stack, ofs_a[e] + mh::aba_frame_slots(t, nch[e]));
+         int *mi = &m->meta[(size_t)e * mh::MI_STRIDE];
+         mi[mh::MI_NCH] = nch[e], mi[mh::MI_DFS_R] = ofs_r[e], mi[mh::MI_DFS_A] = ofs_a[e], mi[mh::MI_HAND] = hand;
+         hand += mh::aba_hand_slots(t, nch[e]);
+      }
+      m->aba_hand = std::max(hand, 1);
+      m->rnea_stack = std::max(m->rnea_stack, 1), m->aba_stack = std::max(m->aba_stack, 6);
+      std::vector<int> path;
+      auto pop = [&]() {
+         const int j = path.back();
+         path.pop_back();
+         int ev = (j << mh::EV_BODY_SHIFT) | mh::EV_POP;
+         if (!m->prog.empty() && m->prog.back() == (j << mh::EV_BODY_SHIFT) + (m->prog.back() & mh::EV_PARENT_REGS))
+            ev |= mh::EV_LEAF; // the previous event is VISIT(j)
+         m->prog.push_back(ev);
+      };
+      for (int e = 0; e < n; e++)
+      {
+         while (!path.empty() && path.back() != P.eparent[e])
+            pop();
+         int ev = e << mh::EV_BODY_SHIFT;
+         if (!m->prog.empty() && P.eparent[e] >= 0 && !(m->prog.back() & mh::EV_POP) && (m->prog.back() >> mh::EV_BODY_SHIFT) == P.eparent[e])
+            ev |= mh::EV_PARENT_REGS;
+         m->prog.push_back(ev);
+         path.push_back(e);
+      }
+      while (!path.empty())
+         pop();
+      std::vector<char> contributed(n, 0);
+      for (size_t i = 0; i < m->prog.size(); i++)
+      {
+         int &ev = m->prog[i];
+         if (!(ev & mh::EV_POP))
+            continue;
+         const int j = ev >> mh::EV_BODY_SHIFT, pe = P.eparent[j];
+         if (pe < 0)
+            continue;
+         const bool last = i + 1 < m->prog.size() && (m->prog[i + 1] & mh::EV_POP) && (m->prog[i + 1] >> mh::EV_BODY_SHIFT) == pe;
+         if (last)
+            ev |= mh::EV_LAST_CHILD;
+         else
+         {
+            if (!contributed[pe])
+               ev |= mh::EV_ACC_FIRST;
+            contributed[pe] = 1;
+         }
+      }
+   }
+
    // ---- device side
    int dev = 0, ndev = 0;
    const hipError_t dc = hipGetDeviceCount(&ndev);
@@ -1077,6 +1206,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       e = up((void **)&m->d_dof, m->dof_map.data(), m->dof_map.size() * sizeof(int));
    if (e == hipSuccess)
       e = up((void **)&m->d_cfg, m->cfg_map.data(), m->cfg_map.size() * sizeof(int));
+   if (e == hipSuccess)
+      e = up((void **)&m->d_prog, m->prog.data(), m->prog.size() * sizeof(int));
    if (e == hipSuccess)
       e = up((void **)&m->d_consts64, m->consts.data(), m->consts.size() * sizeof(double));
    if (e == hipSuccess)
@@ -1109,6 +1240,10 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->waves_per_cu = std::max(1, std::min(32, atoi(e)));
    if (const char *e = getenv("MH_SPEC_ST"))
       m->force_st = atoi(e);
+   if (const char *e = getenv("MH_DFS"))
+      m->use_dfs = atoi(e) != 0;
+   if (const char *e = getenv("MH_DFS_PLACE"))
+      m->dfs_place = atoi(e);
    try_load_spec(m, P);
    if (!m->use_spec)
       m->variant = "generic";
@@ -1128,6 +1263,7 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->d_meta);
    (void)hipFree(m->d_dof);
    (void)hipFree(m->d_cfg);
+   (void)hipFree(m->d_prog);
    (void)hipFree(m->d_consts64);
    (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
@@ -1602,6 +1738,14 @@ enum CheckCase
    CK_CENTROIDAL,
    CK_COUNT
 };
+// fills the check's output buffer with the NaN pattern 0xFF..FF ON THE LAUNCH STREAM: the synchronous hipMemset was observed to be
+// unordered against null-stream kernels of this process (results wiped after the kernel had written them, or never wiped), which showed up
+// as intermittent refusals / acceptances
+__global__ void __launch_bounds__(256) fill_nan_kernel(unsigned long long *p, size_t n)
+{
+   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+      p[i] = ~0ull;
+}
 const char *const kCheckNames[CK_COUNT] = {"RNEA", "ABA", "CRBA", "fused RNEA+ABA", "ABA + integration step", "RNEA with per-body outputs",
                                            "ABA with per-body outputs", "mass + Coriolis matrix", "centroidal momentum"};
 } // namespace
@@ -1672,7 +1816,7 @@ static void self_check_spec(mh_model *m)
       o.layout = L == 0 ? MH_LAYOUT_AOS : MH_LAYOUT_SOA;
       const double *dq = d_in[L], *dqd = dq + (size_t)B * nq, *dqdd = dqd + (size_t)B * nv, *dtau = dqdd + (size_t)B * nv;
       double *o1 = d_out, *o2 = o1 + (size_t)B * nv, *o3 = o2 + (size_t)B * std::max(nq, 6 * n);
-      (void)hipMemset(d_out, 0xFF, out_doubles * sizeof(double));
+      hipLaunchKernelGGL(fill_nan_kernel, dim3(64), dim3(256), 0, (hipStream_t) nullptr, (unsigned long long *)d_out, out_doubles);
       switch (what)
       {
          case CK_RNEA: used = (size_t)B * nv; return mh_rnea_f64(m, B, dq, dqd, dqdd, gravity, nullptr, &o, o1);
@@ -1731,11 +1875,17 @@ static void self_check_spec(mh_model *m)
             (void)hipMemcpy(got.data(), d_out, used * sizeof(double), hipMemcpyDeviceToHost);
             double scale = 1.0, err = 0.0;
             bool nan_mismatch = false;
+            size_t first_bad = 0;
+            bool bad_is_unwritten = false;
             for (size_t k = 0; k < used; k++)
             {
                const bool rn = ref[k] != ref[k], gn = got[k] != got[k];
                if (rn != gn)
+               {
+                  if (!nan_mismatch)
+                     first_bad = k, bad_is_unwritten = gn;
                   nan_mismatch = true;
+               }
                else if (!rn)
                   scale = std::max(scale, std::fabs(ref[k])), err = std::max(err, std::fabs(ref[k] - got[k]));
             }
@@ -1744,8 +1894,12 @@ static void self_check_spec(mh_model *m)
             const double tol = (what == CK_ABA || what == CK_FUSED || what == CK_STEP || what == CK_BODIES_ABA) ? 1.0e-8 : 1.0e-10;
             if (nan_mismatch || !(err <= tol * scale))
             {
+               char where[96] = "";
+               if (nan_mismatch)
+                  snprintf(where, sizeof where, ", output word %zu %s", first_bad,
+                           bad_is_unwritten ? "left unwritten" : "written although the run-time-topology kernels do not write it");
                snprintf(buf, sizeof buf, "%s (%s, %s plan) differs from the run-time-topology kernels by %.3e (|ref| <= %.3e%s)", kCheckNames[what],
-                        L ? "SoA" : "AoS", pretend ? "device-filling" : "small-batch", err, scale, nan_mismatch ? ", entries left unwritten" : "");
+                        L ? "SoA" : "AoS", pretend ? "device-filling" : "small-batch", err, scale, where);
                failure = buf;
             }
          }

@@ -54,7 +54,12 @@ enum : int
    MI_SLOT_C = 9,   // 6 slots: ABA bias acceleration
    MI_SLOT_IA = 10, // 21 slots: ABA articulated inertia / CRBA composite inertia accumulator
    MI_SLOT_LK = 11, // 27 slots (6-DoF joints only): articulated inertia + bias wrench of an ACCELERATION_SOURCE joint
-   MI_STRIDE = 12
+   // depth-first kernels (mh_dfs_kernels.h)
+   MI_NCH = 12,     // number of children
+   MI_DFS_R = 13,   // offset of the body's frame in the RNEA depth stack (non-leaf bodies)
+   MI_DFS_A = 14,   // ... in the ABA depth stack
+   MI_HAND = 15,    // offset of the body's record in ABA's inward -> outward hand-over
+   MI_STRIDE = 16
 };
 enum : int
 {
@@ -89,6 +94,9 @@ struct DevModel
    const int *dof_map; // concatenated getJointDoFIndices
    const int *cfg_map; // concatenated getJointConfigurationIndices
    const void *consts; // [n][MC_STRIDE] of T
+   // depth-first kernels: event program (2 n words) and per-lane slot counts
+   const int *prog;
+   int n_events, rnea_stack, aba_stack, aba_hand;
 };
 
 template <typename T>

@@ -1099,3 +1099,53 @@ def test_native_library_is_the_one_loaded(torch_cuda):
     """The GPU tests must run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
     assert "libmecano_hip.so" in maps
+
+
+@pytest.mark.parametrize("place", [0, 1, 2])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_depth_first_kernels_in_every_memory_placement(torch_cuda, monkeypatch, place, dtype):
+    """The run-time-topology RNEA / ABA kernels (mh_dfs_kernels.h) with the per-lane depth stack and ABA's hand-over forced into LDS /
+    LDS + global workspace / global workspace (MH_DFS_PLACE), on trees with every joint kind, several roots, deep chains and wide fans,
+    against the oracle; and bit for bit the same numbers in all placements and both layouts (same arithmetic, different memory)."""
+    torch = torch_cuda
+    from mecano_amd import _lib
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import MultiBodySystem, RigidBody
+    from oracle.cpu_oracle import OracleModel
+    monkeypatch.setenv("MH_DISABLE_SPEC", "1")
+    rng = np.random.default_rng(5150)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    kinds_all = ("revolute", "prismatic", "sixdof", "fixed", "planar", "spherical")
+    systems = [system_of(rt.nextJointTree(rng, 40, kinds_all)), system_of(rt.nextJointChain(rng, 35, ("revolute", "prismatic"))),
+               system_of(rt.nextFloatingChain(rng, 24, ("revolute",), tree=True)), rt.nextHumanoid(rng)]
+    root = RigidBody("root")  # a forest: three subtrees on the root body, one of them a single leaf
+    rt.nextJointTree(rng, 9, ("revolute", "prismatic"), rootBody=root, prefix="a")
+    rt.nextJointChain(rng, 1, ("prismatic",), rootBody=root, prefix="b")
+    rt.nextJointTree(rng, 7, kinds_all, rootBody=root, prefix="c")
+    systems.append(MultiBodySystem.toMultiBodySystemInput(root))
+    g = (0.3, -0.2, -9.81)
+    for sys_ in systems:
+        d = sys_.toModelDesc()
+        monkeypatch.setenv("MH_DFS_PLACE", str(place))
+        hm = HipModel(d)
+        monkeypatch.setenv("MH_DFS_PLACE", "0")
+        h0 = HipModel(d)
+        om = OracleModel(d)
+        for B in (1, 67, 1500):
+            q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+            fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
+            tq, tqd, tqdd, ttau, tf = (dev(torch, x, tdt) for x in (q, qd, qdd, tau, fext))
+            t = hm.rnea(tq, tqd, tqdd, g, tf)
+            a = hm.aba(tq, tqd, ttau, g, tf)
+            assert torch.equal(t, h0.rnea(tq, tqd, tqdd, g, tf)) and torch.equal(a, h0.aba(tq, tqd, ttau, g, tf))
+            T = lambda x: x.reshape(B, -1).t().contiguous()
+            assert torch.equal(hm.rnea(T(tq), T(tqd), T(tqdd), g, T(tf), layout=_lib.LAYOUT_SOA).t(), t)
+            assert torch.equal(hm.aba(T(tq), T(tqd), T(ttau), g, T(tf), layout=_lib.LAYOUT_SOA).t(), a)
+            if dtype == "f64" and B <= 67:
+                close(t.cpu().numpy(), om.rnea(q, qd, qdd, g, fext), 1e-10, label="rnea")
+                close(a.cpu().numpy(), om.aba(q, qd, tau, g, fext), 1e-7, label="aba")
+            for cc, ca in ((False, True), (True, False)):
+                if dtype == "f64" and B == 67:
+                    o = hm.rnea(tq, tqd, tqdd, g, tf, consider_coriolis=cc, consider_accelerations=ca)
+                    close(o.cpu().numpy(), om.rnea(q, qd, qdd, g, fext, cc, ca), 1e-10, label="rnea switches")
