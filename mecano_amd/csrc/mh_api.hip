@@ -81,6 +81,16 @@ M3d frame_with_z(const double k[3])
    return M3d{{x[0], y[0], k[0], x[1], y[1], k[1], x[2], y[2], k[2]}};
 }
 
+// NaN tests on raw 64-bit words that never pass through a `double` value: this translation unit is built with -ffinite-math-only, under
+// which x != x folds to false AND double parameters carry nofpclass(nan), so that even a bit test on a double argument may be folded away
+inline bool nan_word(unsigned long long u) { return (u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull && (u & 0x000fffffffffffffull) != 0; }
+inline bool nan_bits(const double &x)
+{
+   unsigned long long u;
+   std::memcpy(&u, (const void *)&x, sizeof u);
+   asm volatile("" : "+r"(u)); // the optimiser must not trace the word back to a floating-point value
+   return nan_word(u);
+}
 int joint_ndof(int t) { return mh::dof_count(t); }
 int joint_ncfg(int t) { return mh::cfg_count(t); }
 
@@ -136,6 +146,8 @@ struct mh_model
    int rnea_stack = 0, aba_stack = 0, aba_hand = 0; // per-lane slots: depth stacks, ABA hand-over
    int use_dfs = 1;       // MH_DFS=0: the sweep kernels of mh_kernels.h serve plain RNEA / ABA calls too (A/B measurements)
    std::map<const void *, size_t> lds_attr; // dynamic-LDS limit already raised per kernel (the model lives on one device, one host thread at a time)
+   double nonleaf_fraction = 1.0; // share of bodies with children: those are the ones that touch the depth stack
+   int use_win = 1;       // MH_DFS_WIN=0: AoS rows are read per lane instead of through LDS windows (A/B measurements)
    int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
    double *d_consts64 = nullptr;
    float *d_consts32 = nullptr;
@@ -258,18 +270,41 @@ enum Algo
 
 // Depth-first run-time-topology kernels (mh_dfs_kernels.h): where the per-lane depth stack and ABA's hand-over live, grid, launch.
 //   place 0: everything in LDS          place 1: stack in LDS, hand-over in the global workspace          place 2: both global
-// LDS while at least two waves per CU fit (80 KB per wave) -- or the whole 160 KB when the batch has no more waves than the device has
-// CUs anyway; MH_DFS_PLACE overrides (measurements).
+// LDS is the faster home per wave, but a big stack caps the resident waves per CU.  Measured (tools/exp_dfs.py, profiles/r02_dfs_*):
+//   RNEA  a wave on the global stack is r = 1 + 3 (non-leaf fraction)(sizeof(T) / 8) times slower (1.4x on the 128-body fp32 tree where
+//         half the bodies are leaves and never touch the stack, 3.4x on the fp64 humanoid), so the global stack wins only when it
+//         saves more than r batch passes: the 128-body tree at B = 131072 (one pass of 8 waves per CU against three of 3) -- 550 vs
+//         1100 us -- but not the humanoid at 262144 (358 vs 534 us);
+//   ABA   needs the whole register file (one wave per SIMD) and 2.5x the stack: LDS only while the batch has no more waves than the
+//         device has CUs (106 vs 116 us at B = 4096), the global workspace beyond (163 vs 243 us at 32768, 980 vs 1830 at 262144).
+// MH_DFS_PLACE overrides (measurements).
 template <typename T>
 mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipStream_t stream)
 {
    const long waves = (B + 63) / 64;
-   const long LDS_MAX = 160 * 1024, LDS_TWO = 80 * 1024;
+   // AoS matrices with identity index maps: rows go through LDS windows (mh::window_refill); their LDS comes on top of the stack's
+   // ... worth it once a row spans many cache lines (a lane's consecutive reads then no longer share a line with anybody: 64 requests per
+   // wave-load); the humanoid's 248-byte rows are L1-friendly as they are
+   // RNEA only: the ABA kernel has no registers left for the 32 in-flight window entries (it drops to one wave per SIMD: 2306 vs 2016 us
+   // measured), and two of its five per-lane streams (tau in post-order, the accelerations it writes) could not use a window anyway
+   const bool win = algo == ALGO_RNEA && A.q_es == 1 && A.v_es == 1 && model->ident_maps && model->use_win && (long)model->nv * (long)sizeof(T) >= 512;
+   const long b_win = win ? (long)(algo == ALGO_RNEA ? 3 : 2) * mh::ROW_WIN * mh::ROW_PITCH * (long)sizeof(T) : 0;
+   const long LDS_MAX = 160 * 1024 - b_win;
    const long stack = algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack;
    const long hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
    const long b_stack = stack * 64 * (long)sizeof(T), b_all = (stack + hand) * 64 * (long)sizeof(T);
-   auto fits = [&](long bytes) { return bytes <= LDS_TWO || (bytes <= LDS_MAX && waves <= (long)model->cu_count); };
-   int place = fits(b_all) ? 0 : (fits(b_stack) ? 1 : 2);
+   const long cus = model->cu_count;
+   int place;
+   if (algo == ALGO_RNEA)
+   {
+      const long per_cu_lds = b_stack > 0 ? std::max<long>(1, std::min<long>(8, LDS_MAX / b_stack)) : 8;
+      const double passes_lds = std::ceil((double)waves / (double)(cus * per_cu_lds));
+      const double passes_glb = std::ceil((double)waves / (double)(cus * model->waves_per_cu));
+      const double r = 1.0 + 3.0 * model->nonleaf_fraction * (double)sizeof(T) / 8.0;
+      place = (b_stack <= LDS_MAX && passes_lds <= passes_glb * r) ? 0 : 2;
+   }
+   else
+      place = waves <= cus ? (b_all <= LDS_MAX ? 0 : (b_stack <= LDS_MAX ? 1 : 2)) : 2;
    if (model->dfs_place >= 0)
    {
       place = std::min(2, model->dfs_place);
@@ -278,10 +313,10 @@ mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipS
       if (place == 1 && b_stack > LDS_MAX)
          place = 2;
    }
-   if (algo == ALGO_RNEA && place == 1)
-      place = 0; // there is no hand-over: b_all == b_stack
-   const long lds = place == 0 ? b_all : (place == 1 ? b_stack : 0);
-   const long per_cu = lds > 0 ? std::max<long>(1, std::min<long>(8, LDS_MAX / lds)) : (long)model->waves_per_cu;
+   if (algo == ALGO_RNEA)
+      place = (place == 2 || b_stack > LDS_MAX) ? 2 : 0; // there is no hand-over: b_all == b_stack
+   const long lds = (place == 0 ? b_all : (place == 1 ? b_stack : 0)) + b_win;
+   const long per_cu = lds > 0 ? std::max<long>(1, std::min<long>(model->waves_per_cu, (160 * 1024) / lds)) : (long)model->waves_per_cu;
    const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * per_cu));
    const long gslots = place == 0 ? 0 : (place == 1 ? hand : stack + hand);
    if (gslots > 0)
@@ -291,13 +326,21 @@ mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipS
          return st;
    }
    A.ws = (T *)model->ws.ptr;
-   A.ws_stride = (long)grid * 64;
+   A.ws_stride = gslots * 64; // per-wave block of the global workspace: [grid][slots][64 lanes] -- the same constant slot stride as in LDS
    const void *kern = nullptr;
    if (algo == ALGO_RNEA)
-      kern = place == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true> : (const void *)&mh::rnea_dfs_kernel<T, false>;
+   {
+      if (win)
+         kern = place == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true, true> : (const void *)&mh::rnea_dfs_kernel<T, false, true>;
+      else
+         kern = place == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true, false> : (const void *)&mh::rnea_dfs_kernel<T, false, false>;
+   }
+   else if (win)
+      kern = place == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, true, true>
+                        : (place == 1 ? (const void *)&mh::aba_dfs_kernel<T, true, false, true> : (const void *)&mh::aba_dfs_kernel<T, false, false, true>);
    else
-      kern = place == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, true>
-                        : (place == 1 ? (const void *)&mh::aba_dfs_kernel<T, true, false> : (const void *)&mh::aba_dfs_kernel<T, false, false>);
+      kern = place == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, true, false>
+                        : (place == 1 ? (const void *)&mh::aba_dfs_kernel<T, true, false, false> : (const void *)&mh::aba_dfs_kernel<T, false, false, false>);
    if (lds > 64 * 1024 && model->lds_attr[kern] < (size_t)lds)
    {
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -866,7 +909,7 @@ mh_status integrate_impl(mh_model_t model, int64_t B, double dt, const T *q, con
       return MH_OK;
    if (!q || !qd || !qdd || !q_out || !qd_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
-   if (!(dt == dt))
+   if (nan_bits(dt))
       return fail(MH_ERR_INVALID_ARGUMENT, "dt is NaN");
    mh::IntArgs<T> A;
    A.m = dev_model<T>(model);
@@ -1131,8 +1174,17 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
          int *mi = &m->meta[(size_t)e * mh::MI_STRIDE];
          mi[mh::MI_NCH] = nch[e], mi[mh::MI_DFS_R] = ofs_r[e], mi[mh::MI_DFS_A] = ofs_a[e], mi[mh::MI_HAND] = hand;
          hand += mh::aba_hand_slots(t, nch[e]);
+         if (pe >= 0)
+         {
+            const int pj = mh::jx_slots(P.etype[pe]);
+            mi[mh::MI_PFR_R] = ofs_r[pe], mi[mh::MI_PVA_R] = ofs_r[pe] + 6 + pj;
+            mi[mh::MI_PFR_A] = ofs_a[pe], mi[mh::MI_PV_A] = ofs_a[pe] + 12 + pj, mi[mh::MI_PACC_A] = ofs_a[pe] + 18 + pj;
+         }
+         if (t == MH_JOINT_REVOLUTE || t == MH_JOINT_PRISMATIC)
+            mi[mh::MI_ROW_Q] = m->cfg_map[mi[mh::MI_CFG]], mi[mh::MI_ROW_V] = m->dof_map[mi[mh::MI_DOF]];
       }
       m->aba_hand = std::max(hand, 1);
+      m->nonleaf_fraction = (double)std::count_if(nch.begin(), nch.end(), [](int c) { return c > 0; }) / (double)n;
       m->rnea_stack = std::max(m->rnea_stack, 1), m->aba_stack = std::max(m->aba_stack, 6);
       std::vector<int> path;
       auto pop = [&]() {
@@ -1244,6 +1296,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_dfs = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_PLACE"))
       m->dfs_place = atoi(e);
+   if (const char *e = getenv("MH_DFS_WIN"))
+      m->use_win = atoi(e) != 0;
    try_load_spec(m, P);
    if (!m->use_spec)
       m->variant = "generic";
@@ -1363,7 +1417,7 @@ mh_status mh_aba_integrate_f64(mh_model_t model, int64_t B, double dt, const dou
 {
    if (B > 0 && (!q_next || !qd_next))
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
-   if (!(dt == dt))
+   if (nan_bits(dt))
       return fail(MH_ERR_INVALID_ARGUMENT, "dt is NaN");
    bool stepped = false;
    mh_status st = launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, nullptr, nullptr, nullptr, nullptr, false, dt, q_next,
@@ -1841,7 +1895,8 @@ static void self_check_spec(mh_model *m)
       return MH_OK;
    };
    const int real_cus = m->cu_count;
-   std::vector<double> ref, got;
+   const bool verbose = getenv("MH_SPEC_SELFCHECK_VERBOSE") != nullptr;
+   std::vector<unsigned long long> ref, got; // raw words: see nan_word
    std::string failure;
    for (int what = 0; what < CK_COUNT && failure.empty(); what++)
       for (int L = 0; L < 2 && failure.empty(); L++)
@@ -1879,7 +1934,8 @@ static void self_check_spec(mh_model *m)
             bool bad_is_unwritten = false;
             for (size_t k = 0; k < used; k++)
             {
-               const bool rn = ref[k] != ref[k], gn = got[k] != got[k];
+               // bit tests, not x != x: this translation unit is built with -ffinite-math-only, under which the compiler folds NaN tests away
+               const bool rn = nan_word(ref[k]), gn = nan_word(got[k]);
                if (rn != gn)
                {
                   if (!nan_mismatch)
@@ -1887,12 +1943,19 @@ static void self_check_spec(mh_model *m)
                   nan_mismatch = true;
                }
                else if (!rn)
-                  scale = std::max(scale, std::fabs(ref[k])), err = std::max(err, std::fabs(ref[k] - got[k]));
+               {
+                  double rv, gv;
+                  std::memcpy(&rv, &ref[k], sizeof rv), std::memcpy(&gv, &got[k], sizeof gv);
+                  scale = std::max(scale, std::fabs(rv)), err = std::max(err, std::fabs(rv - gv));
+               }
             }
             // forward dynamics divides by joint-space inertias: rounding differences between two exact evaluation orders are amplified by
             // their conditioning (1e-8 is what the parity tests grant ill-conditioned random trees); everything else is held to 1e-10
             const double tol = (what == CK_ABA || what == CK_FUSED || what == CK_STEP || what == CK_BODIES_ABA) ? 1.0e-8 : 1.0e-10;
-            if (nan_mismatch || !(err <= tol * scale))
+            if (verbose)
+               fprintf(stderr, "[mh self-check] %-28s %s %-14s  |diff| %.3e  |ref| %.3e  unwritten-mismatch %d (word %zu)\n", kCheckNames[what], L ? "SoA" : "AoS",
+                       pretend ? "device-filling" : "small-batch", err, scale, (int)nan_mismatch, first_bad);
+            if (nan_mismatch || err > tol * scale)
             {
                char where[96] = "";
                if (nan_mismatch)

@@ -122,53 +122,106 @@ struct In
    T q, v, x;
 };
 __host__ __device__ constexpr bool one_dof(int type) { return type == JT_REVOLUTE || type == JT_PRISMATIC; }
-// what: 1 = configuration entry, 2 = velocity entry, 4 = third matrix (qdd | tau)
+// multi-DoF joints: joint transform / S x from entries already read into registers (same arithmetic as joint_from_q / joint_vec)
 template <typename T>
-MH_DEV void fetch_inputs(In<T> &o, int what, int type, ciptr ci, ciptr di, const T *qrow, long q_es, const T *vrow, const T *xrow, long v_es)
+MH_DEV JX<T> joint_of_vals(int type, const T *q)
 {
-   if (!one_dof(type))
-      return;
-   if (what & 1)
-      o.q = qrow[ci[0] * q_es];
-   if (what & 6)
-   {
-      const long r = di[0] * v_es;
-      if (what & 2)
-         o.v = vrow[r];
-      if (what & 4)
-         o.x = xrow[r];
-   }
-}
-// joint transform of one lane: 1-DoF joints from the fetched entry, the others from q (same arithmetic as joint_from_q)
-template <typename T>
-MH_DEV JX<T> joint_of_in(int type, const In<T> &in, ciptr cfg_map, int cfg_ofs, const T *qrow, long q_es)
-{
-   if (!one_dof(type))
-      return joint_from_q<T>(type, cfg_map, cfg_ofs, qrow, q_es, (T *)nullptr, 0, 0, false);
    JX<T> jx;
    jx.c = T(1), jx.s = T(0), jx.d = T(0);
-   if (type == JT_REVOLUTE)
-      sincos_t(in.q, jx.s, jx.c);
-   else
-      jx.d = in.q;
+   if (type == JT_SIXDOF)
+   {
+      jx.X.R = quat_to_R(q[0], q[1], q[2], q[3]);
+      jx.X.p = V3<T>{q[4], q[5], q[6]};
+   }
+   else if (type == JT_SPHERICAL)
+   {
+      jx.X.R = quat_to_R(q[0], q[1], q[2], q[3]);
+      jx.X.p = V3<T>{T(0), T(0), T(0)};
+   }
+   else if (type == JT_PLANAR)
+   { // rotation about y by the pitch, translation (x, 0, z)
+      T sp, cp;
+      sincos_t(q[0], sp, cp);
+      jx.X.R = M3<T>{cp, T(0), sp, T(0), T(1), T(0), -sp, T(0), cp};
+      jx.X.p = V3<T>{q[1], T(0), q[2]};
+   }
    return jx;
 }
-// S x : 1-DoF joints from the fetched entry, the others from the matrix row
 template <typename T>
-MH_DEV SV<T> joint_vec_in(int type, T x1, ciptr dof_map, int dof_ofs, const T *row, long es, bool enabled)
+MH_DEV SV<T> joint_vec_vals(int type, const T *x, bool enabled)
 {
-   if (!one_dof(type))
-      return joint_vec<T>(type, dof_map, dof_ofs, row, es, enabled);
    SV<T> o{V3<T>{T(0), T(0), T(0)}, V3<T>{T(0), T(0), T(0)}};
-   if (enabled)
-   {
-      if (type == JT_REVOLUTE)
-         o.a.z = x1;
-      else
-         o.l.z = x1;
-   }
+   if (!enabled)
+      return o;
+   if (type == JT_SIXDOF)
+      o.a = V3<T>{x[0], x[1], x[2]}, o.l = V3<T>{x[3], x[4], x[5]};
+   else if (type == JT_SPHERICAL)
+      o.a = V3<T>{x[0], x[1], x[2]};
+   else if (type == JT_PLANAR)
+      o.a.y = x[0], o.l.x = x[1], o.l.z = x[2];
    return o;
 }
+
+// ---- AoS rows through LDS windows (WIN).  With [B][n] matrices a lane's entries are n * sizeof(T) bytes away from its neighbour's: every
+// wave-load touches 64 cache lines for 64 useful words, and the 128-body tree makes 1331 such loads per configuration (measured: 1300 us
+// against 550 us on SoA matrices).  The walk consumes a matrix row in engine order, so the wave keeps a WINDOW of ROW_WIN consecutive
+// entries of its 64 rows in LDS, refilled by coalesced loads (two rows x 128 bytes per wave-instruction) and read back transposed
+// (pitch 65: conflict-free both ways).  Needs identity index maps (entry k of engine order is column k); SoA matrices and permuted maps
+// read directly.
+constexpr int ROW_WIN = 16;
+constexpr int ROW_PITCH = 65;
+// One matrix's window.  The NEXT window's entries are already on their way into registers (`pre`, 16 per lane) while the current one is
+// consumed from LDS: when the walk steps past the window, the registers are committed to LDS and the window after that is requested --
+// no exposed memory latency on a sequential walk; a jump (a walk that re-reads, a matrix consumed out of order) refills synchronously.
+template <typename T>
+struct RowWindow
+{
+   T *win;         // LDS, [ROW_WIN][ROW_PITCH]
+   const T *mat;   // AoS matrix [B][n_cols]
+   long n_cols, cfg0, B;
+   int w0, pre_w0; // start of the window in LDS / of the one in flight (-huge: none)
+   T pre[ROW_WIN];
+   MH_DEV void init(T *lds, const T *matrix, long cols, long first_cfg, long batch)
+   {
+      win = lds, mat = matrix, n_cols = cols, cfg0 = first_cfg, B = batch;
+      w0 = pre_w0 = -(1 << 30);
+#pragma unroll
+      for (int i = 0; i < ROW_WIN; i++)
+         pre[i] = T(0);
+   }
+   MH_DEV void request(int start, int tid)
+   { // lane (r, e) = (4 i + tid / 16, tid % 16): four rows x 64 contiguous bytes per wave-instruction
+      pre_w0 = start;
+#pragma unroll
+      for (int i = 0; i < ROW_WIN; i++)
+      {
+         const long cfg = cfg0 + 4 * i + (tid >> 4);
+         const int col = start + (tid & 15);
+         pre[i] = (cfg < B && col < n_cols) ? mat[cfg * n_cols + col] : T(0);
+      }
+   }
+   MH_DEV void commit(int tid)
+   {
+#pragma unroll
+      for (int i = 0; i < ROW_WIN; i++)
+         win[(tid & 15) * ROW_PITCH + 4 * i + (tid >> 4)] = pre[i];
+      w0 = pre_w0;
+      __syncthreads(); // one wave per workgroup: orders all lanes' LDS writes before the transposed reads
+   }
+   MH_DEV T get(int row, int tid)
+   {
+      if ((unsigned)(row - w0) >= (unsigned)ROW_WIN)
+      {
+         if ((unsigned)(row - pre_w0) >= (unsigned)ROW_WIN)
+            request(row, tid); // not the window in flight: fetch the one that starts here
+         commit(tid);
+         if (w0 + ROW_WIN < n_cols)
+            request(w0 + ROW_WIN, tid);
+      }
+      return win[(row - w0) * ROW_PITCH + tid];
+   }
+};
+
 template <typename T>
 MH_DEV void write_joint_rows(int type, ciptr di, T *row, long es, const SV<T> &f)
 { // tau = S^T f : component picks in the canonical joint frames
@@ -188,29 +241,53 @@ MH_DEV void write_joint_rows(int type, ciptr di, T *row, long es, const SV<T> &f
 }
 
 // ============================================================================================ RNEA
-// STK_LDS: the depth stack lives in LDS ([slot][64]), else in the global workspace A.ws ([slot][A.ws_stride]).
-template <typename T, bool STK_LDS>
+// STK_LDS: the depth stack lives in LDS ([slot][64]), else in this wave's block of the global workspace A.ws ([wave][slot][64]).
+// WIN: AoS state rows are read through LDS windows (identity index maps), see window_refill.
+template <typename T, bool STK_LDS, bool WIN>
 __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
    const DevModel &m = A.m;
    const T *CB = (const T *)m.consts;
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map), prog = as_const(m.prog);
-   const long lane = (long)blockIdx.x * 64 + threadIdx.x;
+   const int tid = threadIdx.x;
    const long nlanes = (long)gridDim.x * 64;
    const V3<T> Z{T(0), T(0), T(0)};
+   T *const wq = (T *)lds_raw + (STK_LDS ? (long)m.rnea_stack * 64 : 0), *const wv = wq + ROW_WIN * ROW_PITCH, *const wx = wv + ROW_WIN * ROW_PITCH;
    auto walk = [&](auto st, const long ss) {
-      for (long cfg = lane; cfg < A.B; cfg += nlanes)
+      // wave-uniform loop over groups of 64 configurations: the lanes of a ragged last group repeat its last configuration (no store)
+      for (long cfg0 = (long)blockIdx.x * 64; cfg0 < A.B; cfg0 += nlanes)
       {
+         const bool active = cfg0 + tid < A.B;
+         const long cfg = active ? cfg0 + tid : A.B - 1;
          const T *qrow = A.q + cfg * A.q_bs;
          const T *qdrow = A.qd + cfg * A.v_bs;
          const T *qddrow = A.in3 + cfg * A.v_bs;
          const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
          T *trow = A.out + cfg * A.v_bs;
+         // entry `row` of this lane's configuration / velocity-sized rows (row = engine-order entry = matrix column with identity maps)
+         RowWindow<T> Wq, Wv, Wx;
+         if constexpr (WIN)
+            Wq.init(wq, A.q, m.nq, cfg0, A.B), Wv.init(wv, A.qd, m.nv, cfg0, A.B), Wx.init(wx, A.in3, m.nv, cfg0, A.B);
+         auto getq = [&](int row) -> T {
+            if constexpr (WIN)
+               return Wq.get(row, tid);
+            else
+               return qrow[row * A.q_es];
+         };
+         auto getv = [&](int row, T &vd, T &xd) {
+            if constexpr (WIN)
+               vd = A.coriolis ? Wv.get(row, tid) : T(0), xd = A.accel ? Wx.get(row, tid) : T(0);
+            else
+            {
+               const long r = row * A.v_es;
+               vd = A.coriolis ? qdrow[r] : T(0), xd = A.accel ? qddrow[r] : T(0);
+            }
+         };
          SV<T> v_reg{Z, Z}, a_reg{Z, Z}, f_reg{Z, Z}, carry{Z, Z};
          JX<T> jx_reg;
          jx_reg.c = T(1), jx_reg.s = T(0), jx_reg.d = T(0);
-         In<T> nxt;
+         In<T> nxt{T(0), T(0), T(0)};
          auto prefetch = [&](int e1) { // the inputs event e1 will consume (a VISIT of a 1-DoF joint: q, qd, qdd; a POP: nothing)
             if (e1 >= m.n_events)
                return;
@@ -218,8 +295,11 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
             if (ev1 & EV_POP)
                return;
             ciptr m1 = meta + (ev1 >> EV_BODY_SHIFT) * MI_STRIDE;
-            fetch_inputs<T>(nxt, 1 | (A.coriolis ? 2 : 0) | (A.accel ? 4 : 0), m1[MI_TYPE], cfg_map + m1[MI_CFG], dof_map + m1[MI_DOF], qrow, A.q_es,
-                            qdrow, qddrow, A.v_es);
+            if (one_dof(m1[MI_TYPE]))
+            {
+               nxt.q = getq(m1[MI_ROW_Q]);
+               getv(m1[MI_ROW_V], nxt.v, nxt.x);
+            }
          };
          prefetch(0);
          for (int e = 0; e < m.n_events; e++)
@@ -231,6 +311,25 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
             const CRef<T, false> c{CB + j * MC_STRIDE};
             const XF<T> Xb = load_xb<T>(c);
             const In<T> in = nxt;
+            JX<T> jxm;
+            SV<T> vJm{Z, Z}, aJm{Z, Z};
+            if (!(ev & EV_POP) && !one_dof(type) && type != JT_FIXED)
+            { // a multi-DoF joint reads its entries now, BEFORE the next event's prefetch may move the windows on
+               T mq[7], mv[6], mx[6];
+               const int nc = cfg_count(type), nd = dof_count(type);
+#pragma unroll
+               for (int k = 0; k < 7; k++)
+                  mq[k] = k < nc ? getq(WIN ? mi[MI_CFG] + k : cfg_map[mi[MI_CFG] + k]) : T(0);
+#pragma unroll
+               for (int k = 0; k < 6; k++)
+               {
+                  mv[k] = T(0), mx[k] = T(0);
+                  if (k < nd)
+                     getv(WIN ? mi[MI_DOF] + k : dof_map[mi[MI_DOF] + k], mv[k], mx[k]);
+               }
+               jxm = joint_of_vals<T>(type, mq);
+               vJm = joint_vec_vals<T>(type, mv, A.coriolis != 0), aJm = joint_vec_vals<T>(type, mx, A.accel != 0);
+            }
             prefetch(e + 1);
             if (!(ev & EV_POP))
             { // ---- VISIT: velocity, acceleration, Newton-Euler wrench of the body (InverseDynamicsCalculator.java:873-917)
@@ -243,14 +342,19 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                else if (ev & EV_PARENT_REGS)
                   vp = v_reg, ap = a_reg;
                else
+                  vp = st_load6<T>(st, ss, mi[MI_PVA_R]), ap = st_load6<T>(st, ss, mi[MI_PVA_R] + 6);
+               JX<T> jx;
+               SV<T> vJ{Z, Z}, aJ{Z, Z};
+               jx.c = T(1), jx.s = T(0), jx.d = T(0);
+               if (type == JT_REVOLUTE)
                {
-                  ciptr mp = meta + parent * MI_STRIDE;
-                  const int va = mp[MI_DFS_R] + 6 + jx_slots(mp[MI_TYPE]);
-                  vp = st_load6<T>(st, ss, va), ap = st_load6<T>(st, ss, va + 6);
+                  sincos_t(in.q, jx.s, jx.c);
+                  vJ.a.z = in.v, aJ.a.z = in.x;
                }
-               const JX<T> jx = joint_of_in<T>(type, in, cfg_map, mi[MI_CFG], qrow, A.q_es);
-               const SV<T> vJ = joint_vec_in<T>(type, in.v, dof_map, mi[MI_DOF], qdrow, A.v_es, A.coriolis != 0);
-               const SV<T> aJ = joint_vec_in<T>(type, in.x, dof_map, mi[MI_DOF], qddrow, A.v_es, A.accel != 0);
+               else if (type == JT_PRISMATIC)
+                  jx.d = in.q, vJ.l.z = in.v, aJ.l.z = in.x;
+               else if (type != JT_FIXED)
+                  jx = jxm, vJ = vJm, aJ = aJm;
                SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
                const SV<T> a = motion_down(type, jx, Xb, ap) + aJ + crm(v, vJ);
                if (!A.coriolis)
@@ -279,61 +383,85 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                   f = st_load6<T>(st, ss, fr) + carry;
                   jx = st_load_jx<T>(st, ss, fr + 6, type);
                }
-               write_joint_rows<T>(type, dof_map + mi[MI_DOF], trow, A.v_es, f);
+               if (active)
+                  write_joint_rows<T>(type, dof_map + mi[MI_DOF], trow, A.v_es, f);
                if (parent >= 0)
                {
                   const SV<T> fp = force_up(type, jx, Xb, f);
                   if (ev & EV_LAST_CHILD)
                      carry = fp;
                   else
-                  {
-                     const int pf = meta[parent * MI_STRIDE + MI_DFS_R];
-                     st_store6<T>(st, ss, pf, st_load6<T>(st, ss, pf) + fp);
-                  }
+                     st_store6<T>(st, ss, mi[MI_PFR_R], st_load6<T>(st, ss, mi[MI_PFR_R]) + fp);
                }
             }
          }
       }
    };
+   // both homes of the stack are blocks of [slot][64 lanes]: the slot stride is a compile-time constant, slot offsets fold into immediates
    if constexpr (STK_LDS)
-      walk((T *)lds_raw + threadIdx.x, 64L);
+      walk((T *)lds_raw + tid, 64L);
    else
-      walk(A.ws + lane, A.ws_stride);
+      walk(A.ws + (long)blockIdx.x * A.ws_stride + tid, 64L);
 }
 
 // ============================================================================================ ABA
 // STK_LDS / HND_LDS: where the depth stack and the inward -> outward hand-over live (LDS, stack first; or the global workspace, stack first).
-template <typename T, bool STK_LDS, bool HND_LDS>
+// WIN: the inward sweep reads q and qd of AoS matrices through LDS windows (window_refill); tau (consumed in post-order), the outward
+// sweep's re-reads of q and the accelerations written are per-lane accesses.
+template <typename T, bool STK_LDS, bool HND_LDS, bool WIN>
 __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
    const DevModel &m = A.m;
    const T *CB = (const T *)m.consts;
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map), prog = as_const(m.prog);
-   const long lane = (long)blockIdx.x * 64 + threadIdx.x;
+   const int tid = threadIdx.x;
    const long nlanes = (long)gridDim.x * 64;
    const V3<T> Z{T(0), T(0), T(0)};
+   T *const wq = (T *)lds_raw + ((STK_LDS ? (long)m.aba_stack : 0) + (HND_LDS ? (long)m.aba_hand : 0)) * 64, *const wv = wq + ROW_WIN * ROW_PITCH;
    auto walk = [&](auto st, const long ss, auto hd, const long hs) {
 #define MH_HD(slot) hd[(long)(slot)*hs]
-      for (long cfg = lane; cfg < A.B; cfg += nlanes)
+      for (long cfg0 = (long)blockIdx.x * 64; cfg0 < A.B; cfg0 += nlanes)
       {
+         const bool active = cfg0 + tid < A.B;
+         const long cfg = active ? cfg0 + tid : A.B - 1;
          const T *qrow = A.q + cfg * A.q_bs;
          const T *qdrow = A.qd + cfg * A.v_bs;
          const T *taurow = A.in3 + cfg * A.v_bs;
          const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
          T *orow = A.out + cfg * A.v_bs;
+         RowWindow<T> Wq, Wv;
+         if constexpr (WIN)
+            Wq.init(wq, A.q, m.nq, cfg0, A.B), Wv.init(wv, A.qd, m.nv, cfg0, A.B);
+         auto getq = [&](int row) -> T {
+            if constexpr (WIN)
+               return Wq.get(row, tid);
+            else
+               return qrow[row * A.q_es];
+         };
+         auto getv = [&](int row) -> T {
+            if constexpr (WIN)
+               return Wv.get(row, tid);
+            else
+               return qdrow[row * A.v_es];
+         };
          // ---- inward part: passes one and two (ForwardDynamicsCalculator.java:1085-1254) fused into one depth-first walk
          SV<T> v_reg{Z, Z}, p_reg{Z, Z}, c_reg{Z, Z}, pcarry{Z, Z};
          JX<T> jx_reg;
          jx_reg.c = T(1), jx_reg.s = T(0), jx_reg.d = T(0);
          ABI<T> Icarry = abi_from_rigid(RI<T>{T(0), Z, S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)}});
-         In<T> nxt;
+         In<T> nxt{T(0), T(0), T(0)};
          auto prefetch = [&](int e1) { // the inputs event e1 will consume (1-DoF joints): a VISIT q and qd, a POP the joint's effort
             if (e1 >= m.n_events)
                return;
             const int ev1 = prog[e1];
             ciptr m1 = meta + (ev1 >> EV_BODY_SHIFT) * MI_STRIDE;
-            fetch_inputs<T>(nxt, (ev1 & EV_POP) ? 4 : (1 | 2), m1[MI_TYPE], cfg_map + m1[MI_CFG], dof_map + m1[MI_DOF], qrow, A.q_es, qdrow, taurow, A.v_es);
+            if (!one_dof(m1[MI_TYPE]))
+               return;
+            if (ev1 & EV_POP)
+               nxt.x = taurow[m1[MI_ROW_V] * A.v_es];
+            else
+               nxt.q = getq(m1[MI_ROW_Q]), nxt.v = getv(m1[MI_ROW_V]);
          };
          prefetch(0);
          for (int e = 0; e < m.n_events; e++)
@@ -346,6 +474,21 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             const CRef<T, false> c{CB + j * MC_STRIDE};
             const XF<T> Xb = load_xb<T>(c);
             const In<T> in = nxt;
+            JX<T> jxm;
+            SV<T> vJm{Z, Z};
+            if (!(ev & EV_POP) && !one_dof(type) && type != JT_FIXED)
+            { // a multi-DoF joint reads its entries now, before the next event's prefetch may move the windows on
+               T mq[7], mv[6];
+               const int nc = cfg_count(type), nd = dof_count(type);
+#pragma unroll
+               for (int k = 0; k < 7; k++)
+                  mq[k] = k < nc ? getq(WIN ? mi[MI_CFG] + k : cfg_map[mi[MI_CFG] + k]) : T(0);
+#pragma unroll
+               for (int k = 0; k < 6; k++)
+                  mv[k] = k < nd ? getv(WIN ? mi[MI_DOF] + k : dof_map[mi[MI_DOF] + k]) : T(0);
+               jxm = joint_of_vals<T>(type, mq);
+               vJm = joint_vec_vals<T>(type, mv, true);
+            }
             prefetch(e + 1);
             if (!(ev & EV_POP))
             { // ---- VISIT (:1085-1127): velocity, bias wrench p, bias acceleration c
@@ -355,12 +498,19 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                else if (ev & EV_PARENT_REGS)
                   vp = v_reg;
                else
+                  vp = st_load6<T>(st, ss, mi[MI_PV_A]);
+               JX<T> jx;
+               SV<T> vJ{Z, Z};
+               jx.c = T(1), jx.s = T(0), jx.d = T(0);
+               if (type == JT_REVOLUTE)
                {
-                  ciptr mp = meta + parent * MI_STRIDE;
-                  vp = st_load6<T>(st, ss, mp[MI_DFS_A] + 12 + jx_slots(mp[MI_TYPE]));
+                  sincos_t(in.q, jx.s, jx.c);
+                  vJ.a.z = in.v;
                }
-               const JX<T> jx = joint_of_in<T>(type, in, cfg_map, mi[MI_CFG], qrow, A.q_es);
-               const SV<T> vJ = joint_vec_in<T>(type, in.v, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+               else if (type == JT_PRISMATIC)
+                  jx.d = in.q, vJ.l.z = in.v;
+               else if (type != JT_FIXED)
+                  jx = jxm, vJ = vJm;
                const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
                const RI<T> I = load_inertia<T>(c);
                SV<T> p = crf(v, mul(I, v));
@@ -483,8 +633,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                      Icarry = Ia, pcarry = pp;
                   else
                   {
-                     ciptr mp = meta + parent * MI_STRIDE;
-                     const int acc = mp[MI_DFS_A] + 18 + jx_slots(mp[MI_TYPE]);
+                     const int acc = mi[MI_PACC_A];
                      if (ev & EV_ACC_FIRST)
                         st_store_abi<T>(st, ss, acc, Ia), st_store6<T>(st, ss, acc + 21, pp);
                      else
@@ -505,7 +654,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                return;
             ciptr m1 = meta + j1 * MI_STRIDE;
             if (m1[MI_TYPE] == JT_PRISMATIC)
-               fetch_inputs<T>(nxt, 1, m1[MI_TYPE], cfg_map + m1[MI_CFG], dof_map + m1[MI_DOF], qrow, A.q_es, qdrow, taurow, A.v_es);
+               nxt.q = qrow[m1[MI_ROW_Q] * A.q_es];
          };
          prefetch_q(0);
          for (int j = 0; j < m.n; j++)
@@ -521,12 +670,14 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             else if (parent == j - 1)
                ap = a_reg;
             else
-               ap = st_load6<T>(st, ss, meta[parent * MI_STRIDE + MI_DFS_A]);
+               ap = st_load6<T>(st, ss, mi[MI_PFR_A]);
             JX<T> jx;
             if (type == JT_REVOLUTE)
                jx.c = MH_HD(hf + 8), jx.s = MH_HD(hf + 9), jx.d = T(0);
+            else if (type == JT_PRISMATIC)
+               jx.c = T(1), jx.s = T(0), jx.d = in.q;
             else
-               jx = joint_of_in<T>(type, in, cfg_map, mi[MI_CFG], qrow, A.q_es);
+               jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, (T *)nullptr, 0, 0, false);
             const SV<T> apx = motion_down(type, jx, load_xb<T>(c), ap);
             ciptr di = dof_map + mi[MI_DOF];
             SV<T> a = apx;
@@ -534,7 +685,8 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             {
                const V3<T> ua{MH_HD(hf + 0), MH_HD(hf + 1), MH_HD(hf + 2)}, ul{MH_HD(hf + 3), MH_HD(hf + 4), MH_HD(hf + 5)};
                const T qdd = MH_HD(hf + 6) * (MH_HD(hf + 7) - (dot(ua, apx.a) + dot(ul, apx.l))); // :1280-1282 with u' = u - U.c
-               orow[di[0] * A.v_es] = qdd;
+               if (active)
+                  orow[di[0] * A.v_es] = qdd;
                if (nch >= 1)
                {
                   const int hn = hf + (type == JT_REVOLUTE ? 10 : 8);
@@ -558,7 +710,8 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                r = V3<T>{rr[0], rr[1], rr[2]};
                const S3<T> Di{MH_HD(hf + 18), MH_HD(hf + 19), MH_HD(hf + 20), MH_HD(hf + 21), MH_HD(hf + 22), MH_HD(hf + 23)};
                const V3<T> qdd = mul(Di, r);
-               orow[di[0] * A.v_es] = qdd.x, orow[di[1] * A.v_es] = qdd.y, orow[di[2] * A.v_es] = qdd.z;
+               if (active)
+                  orow[di[0] * A.v_es] = qdd.x, orow[di[1] * A.v_es] = qdd.y, orow[di[2] * A.v_es] = qdd.z;
                if (nch >= 1)
                   a = apx + SV<T>{V3<T>{MH_HD(hf + 27), MH_HD(hf + 28), MH_HD(hf + 29)}, V3<T>{MH_HD(hf + 30), MH_HD(hf + 31), MH_HD(hf + 32)}} + from_comp3(type, qdd);
             }
@@ -566,8 +719,11 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             {
                const SV<T> xc{V3<T>{MH_HD(hf + 0), MH_HD(hf + 1), MH_HD(hf + 2)}, V3<T>{MH_HD(hf + 3), MH_HD(hf + 4), MH_HD(hf + 5)}};
                const SV<T> qdd = xc - apx;
-               orow[di[0] * A.v_es] = qdd.a.x, orow[di[1] * A.v_es] = qdd.a.y, orow[di[2] * A.v_es] = qdd.a.z;
-               orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
+               if (active)
+               {
+                  orow[di[0] * A.v_es] = qdd.a.x, orow[di[1] * A.v_es] = qdd.a.y, orow[di[2] * A.v_es] = qdd.a.z;
+                  orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
+               }
                if (nch >= 1)
                   a = SV<T>{V3<T>{MH_HD(hf + 6), MH_HD(hf + 7), MH_HD(hf + 8)}, V3<T>{MH_HD(hf + 9), MH_HD(hf + 10), MH_HD(hf + 11)}};
             }
@@ -578,14 +734,14 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
       }
 #undef MH_HD
    };
-   T *const lds = (T *)lds_raw + threadIdx.x;
-   T *const glb = A.ws + lane;
+   T *const lds = (T *)lds_raw + tid;
+   T *const glb = A.ws + (long)blockIdx.x * A.ws_stride + tid; // this wave's block of the global workspace, [slot][64 lanes]
    if constexpr (STK_LDS && HND_LDS)
       walk(lds, 64L, lds + (long)m.aba_stack * 64, 64L);
    else if constexpr (STK_LDS)
-      walk(lds, 64L, glb, A.ws_stride);
+      walk(lds, 64L, glb, 64L);
    else
-      walk(glb, A.ws_stride, glb + (long)m.aba_stack * A.ws_stride, A.ws_stride);
+      walk(glb, 64L, glb + (long)m.aba_stack * 64, 64L);
 }
 #undef MH_ST
 } // namespace mh

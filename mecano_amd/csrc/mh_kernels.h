@@ -59,7 +59,14 @@ enum : int
    MI_DFS_R = 13,   // offset of the body's frame in the RNEA depth stack (non-leaf bodies)
    MI_DFS_A = 14,   // ... in the ABA depth stack
    MI_HAND = 15,    // offset of the body's record in ABA's inward -> outward hand-over
-   MI_STRIDE = 16
+   MI_PFR_R = 16,   // the PARENT's frame offset in the RNEA stack / its (v, a) slots -- no dependent load of the parent's record
+   MI_PVA_R = 17,
+   MI_PFR_A = 18,   // the parent's frame offset in the ABA stack, its v slots, its accumulator slots
+   MI_PV_A = 19,
+   MI_PACC_A = 20,
+   MI_ROW_Q = 21,   // 1-DoF joints: the joint's row in configuration matrices / velocity-sized matrices (dof_map / cfg_map resolved)
+   MI_ROW_V = 22,
+   MI_STRIDE = 24
 };
 enum : int
 {

@@ -26,7 +26,7 @@ def timeit(fn, iters=5, warm=3):
 
 
 def model(desc, **env):
-    keys = ("MH_DFS", "MH_DFS_PLACE", "MH_DISABLE_SPEC", "MH_WAVES_PER_CU")
+    keys = ("MH_DFS", "MH_DFS_PLACE", "MH_DISABLE_SPEC", "MH_WAVES_PER_CU", "MH_DFS_WIN")
     for k in keys:
         os.environ.pop(k, None)
     for k, v in env.items():
@@ -48,8 +48,8 @@ f32 = torch.float32
 q, qd, qdd, tau = (dev(x, f32) for x in rt.nextState(np.random.default_rng(1), tree, B5))
 qs, qds, qdds, taus = T(q), T(qd), T(qdd), T(tau)
 by = 4 * (d5.nq + 3 * d5.nv)
-for label, env in (("sweep kernels (round 1)", dict(MH_DFS=0)), ("dfs auto", {}), ("dfs all LDS", dict(MH_DFS_PLACE=0)), ("dfs stack LDS", dict(MH_DFS_PLACE=1)),
-                   ("dfs global", dict(MH_DFS_PLACE=2)), ("dfs global 16 waves/CU", dict(MH_DFS_PLACE=2, MH_WAVES_PER_CU=16))):
+for label, env in (("sweep kernels (round 1)", dict(MH_DFS=0)), ("dfs auto", {}), ("dfs auto, no row windows", dict(MH_DFS_WIN=0)), ("dfs all LDS", dict(MH_DFS_PLACE=0)),
+                   ("dfs global", dict(MH_DFS_PLACE=2)), ("dfs global, no row windows", dict(MH_DFS_PLACE=2, MH_DFS_WIN=0))):
     hm = model(d5, **env)
     row(f"C5 RNEA fp32 AoS  {label}", B5, timeit(lambda: hm.rnea(q, qd, qdd, g)), by)
     row(f"C5 RNEA fp32 SoA  {label}", B5, timeit(lambda: hm.rnea(qs, qds, qdds, g, layout=_lib.LAYOUT_SOA)), by)

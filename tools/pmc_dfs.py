@@ -13,7 +13,7 @@ if which == "hum":
     sys_ = rt.nextHumanoid(np.random.default_rng(43)); B = 4096; dt = torch.float64; layout = _lib.LAYOUT_AOS
 else:
     sys_ = MultiBodySystem.toMultiBodySystemInput(rt.nextJointTree(np.random.default_rng(128), 128, ("revolute", "prismatic", "sixdof"))[0].getPredecessor())
-    B = 131072; dt = torch.float32; layout = _lib.LAYOUT_SOA
+    B = 131072; dt = torch.float32; layout = _lib.LAYOUT_AOS if which == "c5aos" else _lib.LAYOUT_SOA
 hm = HipModel(sys_.toModelDesc())
 st = rt.nextState(np.random.default_rng(2342), sys_, min(B, 8192))
 q, qd, qdd, tau = (torch.tensor(x, device="cuda", dtype=dt).repeat((B + len(x) - 1) // len(x), 1)[:B].contiguous() for x in st)
