@@ -149,7 +149,9 @@ def main():
         total = args.batch or (262144 if cfg == 4 else BATCH)
         tdt, np_dt, dtype, word = torch.float64, np.float64, "f64", 8
     # ---- model: built on rank 0, broadcast over RCCL (north_star: "RCCL broadcast of the model")
-    desc = mdist.broadcast_model_desc(sys_.toModelDesc() if rank == 0 else None, src=0)
+    # the humanoid is the committed model (mecano_amd/models/humanoid30.json = nextHumanoid(default_rng(43)) when it was generated)
+    desc0 = (rt.humanoid30Desc() if cfg != 5 else sys_.toModelDesc()) if rank == 0 else None
+    desc = mdist.broadcast_model_desc(desc0, src=0)
     model = HipModel(desc)
     if strong:
         lo, hi = mdist.shard_range(total, rank, world)

@@ -162,6 +162,15 @@ const char *mh_model_kernel_variant(mh_model_t model);
  */
 mh_status mh_topology_key(const mh_model_desc *desc, char key_out[17], int32_t *parents_out, int32_t *types_out);
 
+/*
+ * Builds the topology-specialised code object of a model (host-only; runs hipcc -- MH_HIPCC, /opt/rocm/bin/hipcc or the PATH -- on the
+ * kernel sources that ship next to the library, csrc/; minutes for a 25-body tree) into out_dir (NULL: next to the library) and returns
+ * its path.  Models created afterwards with the same tree shape and joint kinds load it (after the ABI-stamp check and the create-time
+ * self-check).  Without it -- and for planar / spherical joints or trees deeper than 16 joints -- a model runs on the run-time-topology
+ * kernels (same results; 4-7x slower at small batches).  A host without Python calls this once per robot, e.g. at installation.
+ */
+mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap);
+
 /* Pre-allocate device workspace for batches up to max_batch so that compute calls allocate nothing. */
 mh_status mh_reserve(mh_model_t model, int64_t max_batch);
 
@@ -327,6 +336,19 @@ mh_status mh_rnea_f64_host(mh_model_t model, int64_t B, const double *q, const d
 mh_status mh_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau,
                           const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out);
 mh_status mh_crba_f64_host(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out);
+/* tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) of the same configurations (mh_rnea_aba_f64 per chunk) */
+mh_status mh_rnea_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
+                               const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out);
+/*
+ * AoS batches above 1024 configurations travel in chunks through three streams (copy-in, kernels, copy-out overlap).  The copies
+ * reach PCIe rate only from / to PINNED host memory: let the host keep its state matrices in memory from mh_host_alloc (Panama: wrap the
+ * returned address as a MemorySegment; JNI: NewDirectByteBuffer), or pin existing off-heap buffers once with mh_host_register.
+ * Pageable pointers work too, at the runtime's staged-copy rate.
+ */
+mh_status mh_host_alloc(size_t bytes, void **ptr_out); /* hipHostMalloc */
+mh_status mh_host_free(void *ptr);
+mh_status mh_host_register(void *ptr, size_t bytes);   /* hipHostRegister: pins a range the host already owns */
+mh_status mh_host_unregister(void *ptr);
 
 mh_status mh_crba_coriolis_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const mh_options *opts, double *H_out,
                                     double *C_out);

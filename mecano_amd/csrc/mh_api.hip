@@ -154,6 +154,10 @@ struct mh_model
    Workspace ws;
    // staging buffers of the *_host entry points
    Workspace stage;
+   // pipelined host path: copy-in / compute / copy-out streams and per-slot events of a ring of three device chunk slots
+   hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
+   hipEvent_t ev_in[3] = {}, ev_run[3] = {}, ev_out[3] = {};
+   int host_chunk = 0; // MH_HOST_CHUNK: configurations per chunk of the host-pointer pipeline (0 = choose)
    // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices)
    Workspace tr;
    // scratch of the composite entry points: efforts of the Newton-Euler sweep behind mh_aba_joint_wrenches_f64, pair lists of
@@ -578,9 +582,33 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    return MH_OK;
 }
 
-// host-pointer front end: stage through one device buffer, run, copy back, synchronise
-mh_status launch_host(Algo algo, mh_model_t model, int64_t B, const double *q, const double *qd, const double *in3, const double gravity[3],
-                      const double *fext, const mh_options *opts_in, double *out)
+// Host-pointer front end (what a JNI / Panama shim with heap or off-heap arrays calls).  The batch is cut into chunks of rows that travel
+// through a ring of three device slots on three streams: copy-in of chunk k+1, kernels of chunk k and copy-out of chunk k-1 overlap
+// (PCIe is full duplex), kernels stay on ONE stream (they share the model's workspace).  The copies run at PCIe rate when the caller's
+// matrices are pinned -- allocated with mh_host_alloc or registered with mh_host_register -- and at the runtime's staged rate otherwise.
+// Returns when every output chunk has landed.  kind: ALGO_RNEA / ALGO_ABA / ALGO_CRBA, or PAIR: in3 = qdd, in4 = tau, out = tau_out,
+// out2 = qdd_out (mh_rnea_aba_f64 per chunk).
+enum
+{
+   HOST_PAIR = 100
+};
+mh_status host_pipeline_init(mh_model *m)
+{
+   if (m->hs_in)
+      return MH_OK;
+   HIP_TRY(hipStreamCreateWithFlags(&m->hs_in, hipStreamNonBlocking));
+   HIP_TRY(hipStreamCreateWithFlags(&m->hs_run, hipStreamNonBlocking));
+   HIP_TRY(hipStreamCreateWithFlags(&m->hs_out, hipStreamNonBlocking));
+   for (int k = 0; k < 3; k++)
+   {
+      HIP_TRY(hipEventCreateWithFlags(&m->ev_in[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&m->ev_run[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&m->ev_out[k], hipEventDisableTiming));
+   }
+   return MH_OK;
+}
+mh_status launch_host(int kind, mh_model_t model, int64_t B, const double *q, const double *qd, const double *in3, const double *in4,
+                      const double gravity[3], const double *fext, const mh_options *opts_in, double *out, double *out2)
 {
    mh_options opts;
    if (opts_in)
@@ -592,30 +620,76 @@ mh_status launch_host(Algo algo, mh_model_t model, int64_t B, const double *q, c
       return st;
    if (B == 0)
       return MH_OK;
-   if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
+   const bool crba = kind == ALGO_CRBA, pair = kind == HOST_PAIR;
+   if (!q || !out || (!crba && (!qd || !in3 || !gravity)) || (pair && (!in4 || !out2)))
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   st = host_pipeline_init(model);
+   if (st != MH_OK)
+      return st;
+   if (opts.stream)
+      HIP_TRY(hipStreamSynchronize((hipStream_t)opts.stream)); // work the caller queued before this (synchronous) call
    const size_t nq = model->nq, nv = model->nv, nj = model->n;
-   const size_t s_q = (size_t)B * nq, s_v = (size_t)B * nv, s_f = fext ? (size_t)B * nj * 6 : 0;
-   const size_t s_out = algo == ALGO_CRBA ? (size_t)B * nv * nv : s_v;
-   const size_t total = (s_q + 2 * s_v + s_f + s_out) * sizeof(double);
-   st = ensure_bytes(model->stage, total);
+   const bool soa = opts.layout == MH_LAYOUT_SOA;
+   // rows per chunk: SoA matrices are not cut (a chunk of configurations is not contiguous there); AoS: about an eighth of the batch,
+   // 4096 .. 16384 configurations, whole waves
+   // (measured, tools/host_path.py: a chunk costs ~60-80 us of copy / event calls, so a 4096-configuration batch is faster whole: 0.39 ms in
+   // four chunks against 0.2 ms in one; from 16384 configurations on the overlap wins)
+   int64_t chunk = B;
+   if (!soa && model->host_chunk > 0 && B > model->host_chunk)
+      chunk = std::max<int64_t>(64, ((int64_t)model->host_chunk + 63) / 64 * 64);
+   else if (!soa && model->host_chunk == 0 && B >= 16384)
+      chunk = std::max<int64_t>(4096, std::min<int64_t>(16384, (B / 8 + 63) / 64 * 64));
+   const size_t c_q = (size_t)chunk * nq, c_v = (size_t)chunk * nv, c_f = fext ? (size_t)chunk * nj * 6 : 0;
+   const size_t c_out = crba ? (size_t)chunk * nv * nv : c_v;
+   const size_t slot = c_q + (crba ? 0 : 2 * c_v) + (pair ? c_v : 0) + c_f + c_out + (pair ? c_v : 0);
+   const int64_t n_chunks = (B + chunk - 1) / chunk;
+   const int ring = n_chunks > 1 ? 3 : 1;
+   st = ensure_bytes(model->stage, slot * ring * sizeof(double));
    if (st != MH_OK)
       return st;
-   hipStream_t stream = (hipStream_t)opts.stream;
-   double *d_q = (double *)model->stage.ptr, *d_qd = d_q + s_q, *d_in3 = d_qd + s_v, *d_f = d_in3 + s_v, *d_out = d_f + s_f;
-   HIP_TRY(hipMemcpyAsync(d_q, q, s_q * sizeof(double), hipMemcpyHostToDevice, stream));
-   if (algo != ALGO_CRBA)
+   mh_options o = opts;
+   o.stream = (void *)model->hs_run;
+   for (int64_t k = 0; k < n_chunks; k++)
    {
-      HIP_TRY(hipMemcpyAsync(d_qd, qd, s_v * sizeof(double), hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipMemcpyAsync(d_in3, in3, s_v * sizeof(double), hipMemcpyHostToDevice, stream));
-      if (fext)
-         HIP_TRY(hipMemcpyAsync(d_f, fext, s_f * sizeof(double), hipMemcpyHostToDevice, stream));
+      const int s = (int)(k % ring);
+      const int64_t r0 = k * chunk, rows = std::min<int64_t>(chunk, B - r0);
+      double *d_q = (double *)model->stage.ptr + slot * s, *d_qd = d_q + c_q, *d_in3 = d_qd + (crba ? 0 : c_v), *d_in4 = d_in3 + (crba ? 0 : c_v);
+      double *d_f = d_in4 + (pair ? c_v : 0), *d_out = d_f + c_f, *d_out2 = d_out + c_out;
+      if (k >= ring)
+         HIP_TRY(hipStreamWaitEvent(model->hs_in, model->ev_run[s], 0)); // the kernels of the slot's previous tenant have read their inputs
+      const size_t b_q = (size_t)rows * nq * sizeof(double), b_v = (size_t)rows * nv * sizeof(double);
+      HIP_TRY(hipMemcpyAsync(d_q, q + (size_t)r0 * nq, b_q, hipMemcpyHostToDevice, model->hs_in));
+      if (!crba)
+      {
+         HIP_TRY(hipMemcpyAsync(d_qd, qd + (size_t)r0 * nv, b_v, hipMemcpyHostToDevice, model->hs_in));
+         HIP_TRY(hipMemcpyAsync(d_in3, in3 + (size_t)r0 * nv, b_v, hipMemcpyHostToDevice, model->hs_in));
+         if (pair)
+            HIP_TRY(hipMemcpyAsync(d_in4, in4 + (size_t)r0 * nv, b_v, hipMemcpyHostToDevice, model->hs_in));
+         if (fext)
+            HIP_TRY(hipMemcpyAsync(d_f, fext + (size_t)r0 * nj * 6, (size_t)rows * nj * 6 * sizeof(double), hipMemcpyHostToDevice, model->hs_in));
+      }
+      HIP_TRY(hipEventRecord(model->ev_in[s], model->hs_in));
+      HIP_TRY(hipStreamWaitEvent(model->hs_run, model->ev_in[s], 0));
+      if (k >= ring)
+         HIP_TRY(hipStreamWaitEvent(model->hs_run, model->ev_out[s], 0)); // ... and their outputs have left the slot
+      if (pair)
+         st = mh_rnea_aba_f64(model, rows, d_q, d_qd, d_in3, d_in4, gravity, fext ? d_f : nullptr, &o, d_out, d_out2);
+      else
+         st = launch<double>((Algo)kind, model, rows, d_q, d_qd, d_in3, gravity, fext ? d_f : nullptr, &o, d_out);
+      if (st != MH_OK)
+      {
+         (void)hipDeviceSynchronize();
+         return st;
+      }
+      HIP_TRY(hipEventRecord(model->ev_run[s], model->hs_run));
+      HIP_TRY(hipStreamWaitEvent(model->hs_out, model->ev_run[s], 0));
+      const size_t b_o = crba ? (size_t)rows * nv * nv * sizeof(double) : b_v;
+      HIP_TRY(hipMemcpyAsync(out + (size_t)r0 * (crba ? nv * nv : nv), d_out, b_o, hipMemcpyDeviceToHost, model->hs_out));
+      if (pair)
+         HIP_TRY(hipMemcpyAsync(out2 + (size_t)r0 * nv, d_out2, b_v, hipMemcpyDeviceToHost, model->hs_out));
+      HIP_TRY(hipEventRecord(model->ev_out[s], model->hs_out));
    }
-   st = launch<double>(algo, model, B, d_q, d_qd, d_in3, gravity, fext ? d_f : nullptr, &opts, d_out);
-   if (st != MH_OK)
-      return st;
-   HIP_TRY(hipMemcpyAsync(out, d_out, s_out * sizeof(double), hipMemcpyDeviceToHost, stream));
-   HIP_TRY(hipStreamSynchronize(stream));
+   HIP_TRY(hipStreamSynchronize(model->hs_out));
    return MH_OK;
 }
 } // namespace
@@ -1298,6 +1372,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->dfs_place = atoi(e);
    if (const char *e = getenv("MH_DFS_WIN"))
       m->use_win = atoi(e) != 0;
+   if (const char *e = getenv("MH_HOST_CHUNK"))
+      m->host_chunk = std::max(0, atoi(e));
    try_load_spec(m, P);
    if (!m->use_spec)
       m->variant = "generic";
@@ -1322,6 +1398,21 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
    (void)hipFree(m->stage.ptr);
+   for (int k = 0; k < 3; k++)
+   {
+      if (m->ev_in[k])
+         (void)hipEventDestroy(m->ev_in[k]);
+      if (m->ev_run[k])
+         (void)hipEventDestroy(m->ev_run[k]);
+      if (m->ev_out[k])
+         (void)hipEventDestroy(m->ev_out[k]);
+   }
+   if (m->hs_in)
+      (void)hipStreamDestroy(m->hs_in);
+   if (m->hs_run)
+      (void)hipStreamDestroy(m->hs_run);
+   if (m->hs_out)
+      (void)hipStreamDestroy(m->hs_out);
    (void)hipFree(m->tr.ptr);
    (void)hipFree(m->aux.ptr);
    (void)hipFree(m->pairs.ptr);
@@ -1350,6 +1441,68 @@ int32_t mh_model_nq(mh_model_t m) { return m ? m->nq : -1; }
 int32_t mh_model_nv(mh_model_t m) { return m ? m->nv : -1; }
 int32_t mh_model_n_joints(mh_model_t m) { return m ? m->n : -1; }
 const char *mh_model_kernel_variant(mh_model_t m) { return m ? m->variant.c_str() : ""; }
+
+// Builds the topology-specialised code object of a model with hipcc (what mecano_amd/build.py does), for hosts without Python.
+mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap)
+{
+   Plan P;
+   mh_status st = plan_model(desc, P);
+   if (st != MH_OK)
+      return st;
+   const int n = desc->n_joints;
+   std::vector<int> depth(n, 0);
+   int deepest = 0;
+   for (int e = 0; e < n; e++)
+   {
+      if (P.etype[e] > MH_JOINT_FIXED)
+         return fail(MH_ERR_UNSUPPORTED_JOINT, "specialised code objects cover revolute, prismatic, 6-DoF and fixed joints; planar / spherical joints run on the run-time-topology kernels");
+      depth[e] = 1 + (P.eparent[e] >= 0 ? depth[P.eparent[e]] : 0);
+      deepest = std::max(deepest, depth[e]);
+   }
+   if (deepest > 16)
+      return fail(MH_ERR_BAD_TOPOLOGY, "the tree is %d joints deep: a compile-time walk stops paying beyond 16 (512 registers plus hundreds of spills); such models run on the run-time-topology kernels", deepest);
+   Dl_info info;
+   if (!dladdr((const void *)&mh_build_code_object, &info) || !info.dli_fname)
+      return fail(MH_ERR_INVALID_ARGUMENT, "cannot locate libmecano_hip.so");
+   std::string dir(info.dli_fname);
+   const size_t slash = dir.find_last_of('/');
+   dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+   const std::string src = dir + "/csrc/mh_spec.hip";
+   if (FILE *f = fopen(src.c_str(), "r"))
+      fclose(f);
+   else
+      return fail(MH_ERR_INVALID_ARGUMENT, "%s not found: the kernel sources must sit next to the library (csrc/)", src.c_str());
+   const char *hipcc = getenv("MH_HIPCC");
+   std::string cc = hipcc ? hipcc : "";
+   if (cc.empty())
+   {
+      if (FILE *f = fopen("/opt/rocm/bin/hipcc", "r"))
+      {
+         fclose(f);
+         cc = "/opt/rocm/bin/hipcc";
+      }
+      else
+         cc = "hipcc";
+   }
+   std::string parents, kinds;
+   for (int e = 0; e < n; e++)
+   {
+      parents += (e ? "," : "") + std::to_string(P.eparent[e]);
+      kinds += (e ? "," : "") + std::to_string(P.etype[e]);
+   }
+   const std::string out = std::string(out_dir ? out_dir : dir.c_str()) + "/libmecano_hip_topo_" + P.key + ".so";
+   const char *extra = getenv("MH_HIPCC_FLAGS"); // appended to the compiler flags (e.g. -DMH_SPEC_MINIMAL: only the tree-split kernels bench.py runs)
+   const std::string cmd = cc + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-signed-zeros -ffinite-math-only -fno-slp-vectorize "
+                           + std::string(extra ? extra : "") + " -DMH_TOPO_N="
+                           + std::to_string(n) + " \"-DMH_TOPO_PARENTS=" + parents + "\" \"-DMH_TOPO_TYPES=" + kinds + "\" -o \"" + out + ".tmp\" \"" + src
+                           + "\" && mv \"" + out + ".tmp\" \"" + out + "\"";
+   const int rc = system(cmd.c_str());
+   if (rc != 0)
+      return fail(MH_ERR_HIP, "building the code object failed (exit status %d): %s", rc, cmd.c_str());
+   if (path_out && path_cap)
+      snprintf(path_out, path_cap, "%s", out.c_str());
+   return MH_OK;
+}
 
 mh_status mh_reserve(mh_model_t m, int64_t max_batch)
 {
@@ -1630,16 +1783,48 @@ mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_opti
 mh_status mh_rnea_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
                            const double *f_ext, const mh_options *opts, double *tau_out)
 {
-   return launch_host(ALGO_RNEA, model, B, q, qd, qdd, gravity, f_ext, opts, tau_out);
+   return launch_host(ALGO_RNEA, model, B, q, qd, qdd, nullptr, gravity, f_ext, opts, tau_out, nullptr);
 }
 mh_status mh_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
                           const double *f_ext, const mh_options *opts, double *qdd_out)
 {
-   return launch_host(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+   return launch_host(ALGO_ABA, model, B, q, qd, tau, nullptr, gravity, f_ext, opts, qdd_out, nullptr);
+}
+mh_status mh_rnea_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
+                               const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out)
+{
+   return launch_host(HOST_PAIR, model, B, q, qd, qdd, tau, gravity, f_ext, opts, tau_out, qdd_out);
+}
+mh_status mh_host_alloc(size_t bytes, void **ptr_out)
+{
+   if (!ptr_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "ptr_out is NULL");
+   *ptr_out = nullptr;
+   HIP_TRY(hipHostMalloc(ptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+   return MH_OK;
+}
+mh_status mh_host_free(void *ptr)
+{
+   if (ptr)
+      HIP_TRY(hipHostFree(ptr));
+   return MH_OK;
+}
+mh_status mh_host_register(void *ptr, size_t bytes)
+{
+   if (!ptr || !bytes)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL pointer / empty range");
+   HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+   return MH_OK;
+}
+mh_status mh_host_unregister(void *ptr)
+{
+   if (ptr)
+      HIP_TRY(hipHostUnregister(ptr));
+   return MH_OK;
 }
 mh_status mh_crba_f64_host(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
 {
-   return launch_host(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+   return launch_host(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, nullptr, opts, H_out, nullptr);
 }
 
 // ---- HIP-event timer

@@ -117,9 +117,13 @@ MH_DEV V3<T> rotzT(T c, T s, V3<T> v)
 template <typename T>
 MH_DEV SV<T> motion_to_child(const XF<T> &X, SV<T> m)
 {
+   // every component is ONE flat sum of products, so that it contracts into a multiply followed by an unbroken chain of FMAs (a sum of two
+   // separately parenthesised product sums costs an extra add per component: 13 % of the fp64 instructions of the ABA kernel were such adds)
    SV<T> o;
    o.a = tmul(X.R, m.a);
-   o.l = tmul(X.R, m.l + cross(m.a, X.p));
+   const V3<T> &p = X.p;
+   const T tx = m.a.y * p.z - m.a.z * p.y + m.l.x, ty = m.a.z * p.x - m.a.x * p.z + m.l.y, tz = m.a.x * p.y - m.a.y * p.x + m.l.z;
+   o.l = tmul(X.R, V3<T>{tx, ty, tz});
    return o;
 }
 // ---- force vectors child -> parent:  f' = R f ; n' = R n + p x f'      (spatial/interfaces/FixedFrameSpatialForceBasics.java:249-259)
@@ -127,8 +131,12 @@ template <typename T>
 MH_DEV SV<T> force_to_parent(const XF<T> &X, SV<T> w)
 {
    SV<T> o;
-   o.l = mul(X.R, w.l);
-   o.a = mul(X.R, w.a) + cross(X.p, o.l);
+   const M3<T> &R = X.R;
+   const V3<T> &p = X.p;
+   o.l = mul(R, w.l);
+   o.a.x = R.xx * w.a.x + R.xy * w.a.y + R.xz * w.a.z + p.y * o.l.z - p.z * o.l.y;
+   o.a.y = R.yx * w.a.x + R.yy * w.a.y + R.yz * w.a.z + p.z * o.l.x - p.x * o.l.z;
+   o.a.z = R.zx * w.a.x + R.zy * w.a.y + R.zz * w.a.z + p.x * o.l.y - p.y * o.l.x;
    return o;
 }
 
@@ -137,8 +145,14 @@ template <typename T>
 MH_DEV SV<T> mul(const RI<T> &I, SV<T> v)
 {
    SV<T> o;
-   o.a = mul(I.I, v.a) + cross(I.h, v.l);
-   o.l = I.m * v.l - cross(I.h, v.a);
+   const S3<T> &J = I.I;
+   const V3<T> &h = I.h;
+   o.a.x = J.xx * v.a.x + J.xy * v.a.y + J.xz * v.a.z + h.y * v.l.z - h.z * v.l.y;
+   o.a.y = J.xy * v.a.x + J.yy * v.a.y + J.yz * v.a.z + h.z * v.l.x - h.x * v.l.z;
+   o.a.z = J.xz * v.a.x + J.yz * v.a.y + J.zz * v.a.z + h.x * v.l.y - h.y * v.l.x;
+   o.l.x = I.m * v.l.x - h.y * v.a.z + h.z * v.a.y;
+   o.l.y = I.m * v.l.y - h.z * v.a.x + h.x * v.a.z;
+   o.l.z = I.m * v.l.z - h.x * v.a.y + h.y * v.a.x;
    return o;
 }
 // v x* f  (spatial force cross product): [w x n + v x f ; w x f]
@@ -146,7 +160,9 @@ template <typename T>
 MH_DEV SV<T> crf(SV<T> v, SV<T> f)
 {
    SV<T> o;
-   o.a = cross(v.a, f.a) + cross(v.l, f.l);
+   o.a.x = v.a.y * f.a.z - v.a.z * f.a.y + v.l.y * f.l.z - v.l.z * f.l.y;
+   o.a.y = v.a.z * f.a.x - v.a.x * f.a.z + v.l.z * f.l.x - v.l.x * f.l.z;
+   o.a.z = v.a.x * f.a.y - v.a.y * f.a.x + v.l.x * f.l.y - v.l.y * f.l.x;
    o.l = cross(v.a, f.l);
    return o;
 }
@@ -156,7 +172,9 @@ MH_DEV SV<T> crm(SV<T> v, SV<T> m)
 {
    SV<T> o;
    o.a = cross(v.a, m.a);
-   o.l = cross(v.a, m.l) + cross(v.l, m.a);
+   o.l.x = v.a.y * m.l.z - v.a.z * m.l.y + v.l.y * m.a.z - v.l.z * m.a.y;
+   o.l.y = v.a.z * m.l.x - v.a.x * m.l.z + v.l.z * m.a.x - v.l.x * m.a.z;
+   o.l.z = v.a.x * m.l.y - v.a.y * m.l.x + v.l.x * m.a.y - v.l.y * m.a.x;
    return o;
 }
 template <typename T>
@@ -261,18 +279,13 @@ MH_DEV void translate(ABI<T> &I, V3<T> p)
    N.zx = C.zx - p.y * L.xx + p.x * L.xy, N.zy = C.zy - p.y * L.xy + p.x * L.yy, N.zz = C.zz - p.y * L.xz + p.x * L.yz;
    // M1 = P C^T : (M1)_ij = sum_k P_ik C_jk ;  M2 = P N^T ;  A' = A + M1 + M2^T  (symmetric)
    // row x of P = (0, -pz, py), row y = (pz, 0, -px), row z = (-py, px, 0)
-   T m1xx = -p.z * C.xy + p.y * C.xz, m1xy = -p.z * C.yy + p.y * C.yz, m1xz = -p.z * C.zy + p.y * C.zz;
-   T m1yy = p.z * C.yx - p.x * C.yz, m1yz = p.z * C.zx - p.x * C.zz;
-   T m1zz = -p.y * C.zx + p.x * C.zy;
-   T m2xx = -p.z * N.xy + p.y * N.xz;
-   T m2yx = p.z * N.xx - p.x * N.xz, m2yy = p.z * N.yx - p.x * N.yz;
-   T m2zx = -p.y * N.xx + p.x * N.xy, m2zy = -p.y * N.yx + p.x * N.yy, m2zz = -p.y * N.zx + p.x * N.zy;
-   I.A.xx += m1xx + m2xx;
-   I.A.xy += m1xy + m2yx;
-   I.A.xz += m1xz + m2zx;
-   I.A.yy += m1yy + m2yy;
-   I.A.yz += m1yz + m2zy;
-   I.A.zz += m1zz + m2zz;
+   // each entry one flat sum: A_ij + (M1)_ij + (M2)_ji as a single FMA chain
+   I.A.xx = I.A.xx - p.z * C.xy + p.y * C.xz - p.z * N.xy + p.y * N.xz;
+   I.A.xy = I.A.xy - p.z * C.yy + p.y * C.yz + p.z * N.xx - p.x * N.xz;
+   I.A.xz = I.A.xz - p.z * C.zy + p.y * C.zz - p.y * N.xx + p.x * N.xy;
+   I.A.yy = I.A.yy + p.z * C.yx - p.x * C.yz + p.z * N.yx - p.x * N.yz;
+   I.A.yz = I.A.yz + p.z * C.zx - p.x * C.zz - p.y * N.yx + p.x * N.yy;
+   I.A.zz = I.A.zz - p.y * C.zx + p.x * C.zy - p.y * N.zx + p.x * N.zy;
    I.C = N;
 }
 // ---- slide along z by d (prismatic joint): same as translate(I, {0,0,d})
@@ -300,8 +313,14 @@ template <typename T>
 MH_DEV SV<T> mul(const ABI<T> &I, SV<T> v)
 {
    SV<T> o;
-   o.a = mul(I.A, v.a) + mul(I.C, v.l);
-   o.l = tmul(I.C, v.a) + mul(I.L, v.l);
+   const S3<T> &A = I.A, &L = I.L;
+   const M3<T> &C = I.C;
+   o.a.x = A.xx * v.a.x + A.xy * v.a.y + A.xz * v.a.z + C.xx * v.l.x + C.xy * v.l.y + C.xz * v.l.z;
+   o.a.y = A.xy * v.a.x + A.yy * v.a.y + A.yz * v.a.z + C.yx * v.l.x + C.yy * v.l.y + C.yz * v.l.z;
+   o.a.z = A.xz * v.a.x + A.yz * v.a.y + A.zz * v.a.z + C.zx * v.l.x + C.zy * v.l.y + C.zz * v.l.z;
+   o.l.x = C.xx * v.a.x + C.yx * v.a.y + C.zx * v.a.z + L.xx * v.l.x + L.xy * v.l.y + L.xz * v.l.z;
+   o.l.y = C.xy * v.a.x + C.yy * v.a.y + C.zy * v.a.z + L.xy * v.l.x + L.yy * v.l.y + L.yz * v.l.z;
+   o.l.z = C.xz * v.a.x + C.yz * v.a.y + C.zz * v.a.z + L.xz * v.l.x + L.yz * v.l.y + L.zz * v.l.z;
    return o;
 }
 template <typename T>

@@ -306,10 +306,24 @@ class HipModel:
                                             vn.data_ptr()))
         return qn, vn, qdd
 
-    def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None):
-        """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call (device tensors, fp64, AoS)."""
-        import torch
+    def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, out=None):
+        """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call (fp64, AoS).  Device tensors: mh_rnea_aba_f64; numpy arrays:
+        the pipelined host-pointer entry point mh_rnea_aba_f64_host (``out`` = (tau_out, qdd_out) arrays to write into, e.g. pinned ones)."""
         lib = _lib.load()
+        if not self._is_torch(q):
+            q, qd, qdd, tau = (_np(x, np.float64) for x in (q, qd, qdd, tau))
+            B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
+            if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau)):
+                raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+            f = None if f_ext is None else _np(f_ext, np.float64)
+            self._check_f_ext(f, B, _lib.LAYOUT_AOS)
+            tau_out, qdd_out = out if out is not None else (np.empty_like(qd), np.empty_like(qd))
+            g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+            opts = self._options(_lib.LAYOUT_AOS)
+            _lib.check(lib.mh_rnea_aba_f64_host(self._h, B, q.ctypes.data, qd.ctypes.data, qdd.ctypes.data, tau.ctypes.data, g,
+                                                None if f is None else f.ctypes.data, ctypes.byref(opts), tau_out.ctypes.data, qdd_out.ctypes.data))
+            return tau_out, qdd_out
+        import torch
         for t in (q, qd, qdd, tau) + ((f_ext,) if f_ext is not None else ()):
             if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
                 raise ValueError("rnea_aba needs contiguous float64 tensors on the HIP device")
@@ -425,6 +439,21 @@ class HipModel:
                                                                ctypes.byref(opts), A.data_ptr(), None if b is None else b.data_ptr(),
                                                                com.data_ptr()))
         return A, b, com
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A numpy array in PINNED host memory (mh_host_alloc): the host-pointer entry points copy from / to it at PCIe rate, where pageable
+    arrays go through the runtime's staging copies.  The memory is released when the array (and every view of it) is gone."""
+    import weakref
+    lib = _lib.load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    ptr = ctypes.c_void_p()
+    _lib.check(lib.mh_host_alloc(max(1, n * dt.itemsize), ctypes.byref(ptr)))
+    buf = (ctypes.c_char * max(1, n * dt.itemsize)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    weakref.finalize(buf, lib.mh_host_free, ctypes.c_void_p(ptr.value))
+    return arr
 
 
 class HipTimer:

@@ -139,6 +139,18 @@ def nextFloatingChain(rng, numberOfJoints: int, kinds=("revolute",), tree=False)
     return root.subtreeJointList()
 
 
+def humanoid30Desc():
+    """The committed benchmark model (mecano_amd/models/humanoid30.json): the 30-DoF humanoid of BASELINE.json's metric as a ModelDesc,
+    byte for byte what nextHumanoid(numpy.random.default_rng(43)).toModelDesc() produced when it was generated."""
+    import json
+    import os
+    from .multibody import ModelDesc
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "humanoid30.json")))
+    return ModelDesc(d["n_joints"], d["nq"], d["nv"], np.array(d["parent"], dtype=np.int32), np.array(d["joint_type"], dtype=np.int32),
+                     np.array(d["axis"]), np.array(d["X_before"]), np.array(d["X_com"]), np.array(d["inertia_J"]), np.array(d["inertia_mass"]),
+                     np.array(d["inertia_com"]), np.array(d["dof_indices"], dtype=np.int32), np.array(d["cfg_indices"], dtype=np.int32))
+
+
 def referenceBenchmarkSystems(seed: int = 43, numberOfJoints: int = 30):
     """The four systems of the reference's own (disabled) RNEA benchmarks, InverseDynamicsCalculatorTest.java:24-158: a 30-joint random
     1-DoF chain and tree on a fixed base, and the same below a SixDoF root joint; seed 43 each (the reference's seed; the RNG is numpy's,

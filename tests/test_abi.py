@@ -170,3 +170,42 @@ int main(void)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert out.stdout.startswith("ok ")
+
+
+def test_code_objects_can_be_built_through_the_c_abi(hip_lib, tmp_path, monkeypatch):
+    """mh_build_code_object: a host without Python gets the topology-specialised code object of its robot from the library itself
+    (hipcc cross-compiles here without a GPU); deep chains and planar / spherical joints are refused with a reason."""
+    import ctypes
+    import shutil
+    import numpy as np
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.multibody import MultiBodySystem
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    monkeypatch.setenv("MH_HIPCC_FLAGS", "-DMH_SPEC_MINIMAL")  # seconds instead of minutes: the entry point is under test, not the kernels
+
+    def c_desc(desc):
+        keep, d = [], _lib.MhModelDesc()
+        d.n_joints, d.nq, d.nv = int(desc.n_joints), int(desc.nq), int(desc.nv)
+        for k, dt in (("parent", np.int32), ("joint_type", np.int32), ("dof_indices", np.int32), ("cfg_indices", np.int32), ("axis", np.float64),
+                      ("X_before", np.float64), ("X_com", np.float64), ("inertia_J", np.float64), ("inertia_mass", np.float64), ("inertia_com", np.float64)):
+            a = np.ascontiguousarray(getattr(desc, k), dtype=dt)
+            keep.append(a)
+            setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
+        return d, keep
+
+    rng = np.random.default_rng(3)
+    arm = MultiBodySystem.toMultiBodySystemInput(rt.nextJointChain(rng, 3, ("revolute", "prismatic"))[0].getPredecessor()).toModelDesc()
+    d, keep = c_desc(arm)
+    path = ctypes.create_string_buffer(1024)
+    st = hip_lib.mh_build_code_object(ctypes.byref(d), str(tmp_path).encode(), path, 1024)
+    assert st == 0, hip_lib.mh_last_error()
+    built = path.value.decode()
+    assert os.path.exists(built) and os.path.basename(built).startswith("libmecano_hip_topo_")
+    obj = ctypes.CDLL(built)
+    obj.mh_spec_abi.restype = ctypes.c_uint64
+    assert obj.mh_spec_abi() == hip_lib.mh_spec_abi_stamp() and obj.mh_spec_n() == 3
+    deep, keep2 = c_desc(rt.referenceBenchmarkSystems()["chain30"].toModelDesc())
+    assert hip_lib.mh_build_code_object(ctypes.byref(deep), str(tmp_path).encode(), path, 1024) == 5 and b"joints deep" in hip_lib.mh_last_error()
+    sph, keep3 = c_desc(MultiBodySystem.toMultiBodySystemInput(rt.nextJointTree(rng, 4, ("spherical",))[0].getPredecessor()).toModelDesc())
+    assert hip_lib.mh_build_code_object(ctypes.byref(sph), str(tmp_path).encode(), path, 1024) == 3

@@ -1149,3 +1149,84 @@ def test_depth_first_kernels_in_every_memory_placement(torch_cuda, monkeypatch, 
                 if dtype == "f64" and B == 67:
                     o = hm.rnea(tq, tqd, tqdd, g, tf, consider_coriolis=cc, consider_accelerations=ca)
                     close(o.cpu().numpy(), om.rnea(q, qd, qdd, g, fext, cc, ca), 1e-10, label="rnea switches")
+
+
+def test_host_pointer_pipeline(torch_cuda, monkeypatch):
+    """The host-pointer entry points (what a Java shim calls): batches above 1024 configurations travel in chunks through three streams.
+    Pageable and pinned (mh_host_alloc) matrices, a chunk size that leaves a ragged last chunk and re-uses every ring slot, external
+    wrenches, RNEA / ABA / CRBA / the pair call: bit for bit the device-pointer results."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel, pinned_empty
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(77)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    monkeypatch.setenv("MH_HOST_CHUNK", "1088")
+    hm = HipModel(d)
+    g = (0.1, 0.0, -9.81)
+    for B in (5, 1024, 1025, 7 * 1088 + 333):
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
+        tq, tqd, tqdd, ttau, tf = (dev(torch, x) for x in (q, qd, qdd, tau, fext))
+        ref_t, ref_a, ref_H = hm.rnea(tq, tqd, tqdd, g, tf).cpu().numpy(), hm.aba(tq, tqd, ttau, g, tf).cpu().numpy(), hm.crba(tq).cpu().numpy()
+        for pinned in (False, True):
+            arrs = [q, qd, qdd, tau, fext]
+            if pinned:
+                arrs = []
+                for x in (q, qd, qdd, tau, fext):
+                    a = pinned_empty(x.shape)
+                    a[...] = x
+                    arrs.append(a)
+            hq, hqd, hqdd, htau, hf = arrs
+            assert np.array_equal(hm.rnea(hq, hqd, hqdd, g, hf), ref_t)
+            assert np.array_equal(hm.aba(hq, hqd, htau, g, hf), ref_a)
+            assert np.array_equal(hm.crba(hq), ref_H)
+            t2, a2 = hm.rnea_aba(hq, hqd, hqdd, htau, g, hf)
+            close(t2, ref_t, 1e-12, label="pair tau"), close(a2, ref_a, 1e-11, label="pair qdd")
+    om = OracleModel(d)
+    close(ref_t[:64], om.rnea(q[:64], qd[:64], qdd[:64], g, fext[:64]), 1e-10, label="rnea")
+
+
+def _two_rank_worker(rank, world, port, B, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MECANO_DIST_BACKEND="gloo")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mecano_amd import distributed as mdist, random_tools as rt
+    from mecano_amd.engine import HipModel
+    r, w, _ = mdist.init_from_env()
+    torch.cuda.set_device(0)  # both ranks share the one GPU of the box
+    desc = mdist.broadcast_model_desc(rt.humanoid30Desc() if rank == 0 else None, src=0)
+    hm = HipModel(desc)
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    q, qd, qdd, tau = rt.nextState(np.random.default_rng(7), sys_, B)  # the same full batch on every rank
+    lo, hi = mdist.shard_range(B, rank, world)
+    d = lambda x: torch.tensor(x[lo:hi], device="cuda")
+    g = (0.0, 0.0, -9.81)
+    t_loc, a_loc = hm.rnea_aba(d(q), d(qd), d(qdd), d(tau), g)
+    t_all, a_all = mdist.all_gather_rows(t_loc, B), mdist.all_gather_rows(a_loc, B)
+    if rank == 0:
+        full = lambda x: torch.tensor(x, device="cuda")
+        t_ref, a_ref = hm.rnea_aba(full(q), full(qd), full(qdd), full(tau), g)
+        assert torch.equal(t_all, t_ref) and torch.equal(a_all, a_ref)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").close()
+
+
+@pytest.mark.parametrize("B", [8192, 4099])
+def test_two_ranks_sharing_one_gpu_reproduce_the_single_rank_result(torch_cuda, tmp_path, B):
+    """The N > 1 path through the HIP kernels: two processes (gloo as the transport, MECANO_DIST_BACKEND) share the box's one GPU, the
+    model is broadcast from rank 0, each rank computes its contiguous shard (equal and ragged shards), the all-gathered outputs equal the
+    single-rank result bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")

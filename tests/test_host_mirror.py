@@ -140,3 +140,12 @@ def test_tree_split_plans_of_the_registered_code_objects():
         else:
             assert all(l[2] == l[3] for l in limbs)
         print(name, "staged" if staged else "plain", limbs, cuts)
+
+
+def test_committed_humanoid_model_is_what_the_generator_produces():
+    """mecano_amd/models/humanoid30.json (the benchmark model) against nextHumanoid(default_rng(43)): identical."""
+    from mecano_amd import random_tools as rt
+    a, b = rt.humanoid30Desc(), rt.nextHumanoid(np.random.default_rng(43)).toModelDesc()
+    assert (a.n_joints, a.nq, a.nv) == (b.n_joints, b.nq, b.nv) == (25, 31, 30)
+    for f in ("parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices"):
+        assert np.array_equal(np.asarray(getattr(a, f)).reshape(-1), np.asarray(getattr(b, f)).reshape(-1)), f
