@@ -75,7 +75,8 @@ typedef enum mh_status
    MH_ERR_HIP = 8,                /* a HIP runtime call failed (message has the HIP error)     */
    MH_ERR_OUT_OF_MEMORY = 9,
    MH_ERR_NOT_RESERVED = 10,      /* batch larger than mh_reserve()d while allocation is forbidden */
-   MH_ERR_SINGULAR = 11           /* reserved */
+   MH_ERR_SINGULAR = 11           /* reserved: the device path does not test joint-space inertias for definiteness -- like the reference's
+                                     unguarded 1/D (ForwardDynamicsCalculator.java:1183) a singular block shows as inf / nan in qdd */
 } mh_status;
 
 /* ---- joint kinds ---- */
@@ -325,6 +326,13 @@ mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *
 mh_status mh_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau,
                      const double gravity[3], const float *f_ext, const mh_options *opts, float *qdd_out);
 mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_options *opts, float *H_out);
+/* fp32 forms of the per-body outputs and of forward dynamics with acceleration-source joints (run-time-topology kernels) */
+mh_status mh_rnea_bodies_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
+                             const float *f_ext, const mh_options *opts, float *tau_out, float *body_acc_out, float *body_twist_out);
+mh_status mh_aba_bodies_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau, const double gravity[3],
+                            const float *f_ext, const mh_options *opts, float *qdd_out, float *body_acc_out, float *body_twist_out);
+mh_status mh_aba_locked_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau, const float *qdd_in,
+                            const double gravity[3], const float *f_ext, const mh_options *opts, float *qdd_out, float *tau_out);
 
 /*
  * ---- compute, HOST pointers (what a JNI / Panama shim with heap or off-heap arrays calls) ----
@@ -336,6 +344,11 @@ mh_status mh_rnea_f64_host(mh_model_t model, int64_t B, const double *q, const d
 mh_status mh_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau,
                           const double gravity[3], const double *f_ext, const mh_options *opts, double *qdd_out);
 mh_status mh_crba_f64_host(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out);
+mh_status mh_rnea_f32_host(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
+                           const float *f_ext, const mh_options *opts, float *tau_out);
+mh_status mh_aba_f32_host(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau, const double gravity[3],
+                          const float *f_ext, const mh_options *opts, float *qdd_out);
+mh_status mh_crba_f32_host(mh_model_t model, int64_t B, const float *q, const mh_options *opts, float *H_out);
 /* tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) of the same configurations (mh_rnea_aba_f64 per chunk) */
 mh_status mh_rnea_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
                                const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out);

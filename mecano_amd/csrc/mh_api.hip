@@ -607,8 +607,9 @@ mh_status host_pipeline_init(mh_model *m)
    }
    return MH_OK;
 }
-mh_status launch_host(int kind, mh_model_t model, int64_t B, const double *q, const double *qd, const double *in3, const double *in4,
-                      const double gravity[3], const double *fext, const mh_options *opts_in, double *out, double *out2)
+template <typename T>
+mh_status launch_host(int kind, mh_model_t model, int64_t B, const T *q, const T *qd, const T *in3, const T *in4, const double gravity[3],
+                      const T *fext, const mh_options *opts_in, T *out, T *out2)
 {
    mh_options opts;
    if (opts_in)
@@ -644,7 +645,7 @@ mh_status launch_host(int kind, mh_model_t model, int64_t B, const double *q, co
    const size_t slot = c_q + (crba ? 0 : 2 * c_v) + (pair ? c_v : 0) + c_f + c_out + (pair ? c_v : 0);
    const int64_t n_chunks = (B + chunk - 1) / chunk;
    const int ring = n_chunks > 1 ? 3 : 1;
-   st = ensure_bytes(model->stage, slot * ring * sizeof(double));
+   st = ensure_bytes(model->stage, slot * ring * sizeof(T));
    if (st != MH_OK)
       return st;
    mh_options o = opts;
@@ -653,11 +654,11 @@ mh_status launch_host(int kind, mh_model_t model, int64_t B, const double *q, co
    {
       const int s = (int)(k % ring);
       const int64_t r0 = k * chunk, rows = std::min<int64_t>(chunk, B - r0);
-      double *d_q = (double *)model->stage.ptr + slot * s, *d_qd = d_q + c_q, *d_in3 = d_qd + (crba ? 0 : c_v), *d_in4 = d_in3 + (crba ? 0 : c_v);
-      double *d_f = d_in4 + (pair ? c_v : 0), *d_out = d_f + c_f, *d_out2 = d_out + c_out;
+      T *d_q = (T *)model->stage.ptr + slot * s, *d_qd = d_q + c_q, *d_in3 = d_qd + (crba ? 0 : c_v), *d_in4 = d_in3 + (crba ? 0 : c_v);
+      T *d_f = d_in4 + (pair ? c_v : 0), *d_out = d_f + c_f, *d_out2 = d_out + c_out;
       if (k >= ring)
          HIP_TRY(hipStreamWaitEvent(model->hs_in, model->ev_run[s], 0)); // the kernels of the slot's previous tenant have read their inputs
-      const size_t b_q = (size_t)rows * nq * sizeof(double), b_v = (size_t)rows * nv * sizeof(double);
+      const size_t b_q = (size_t)rows * nq * sizeof(T), b_v = (size_t)rows * nv * sizeof(T);
       HIP_TRY(hipMemcpyAsync(d_q, q + (size_t)r0 * nq, b_q, hipMemcpyHostToDevice, model->hs_in));
       if (!crba)
       {
@@ -666,16 +667,21 @@ mh_status launch_host(int kind, mh_model_t model, int64_t B, const double *q, co
          if (pair)
             HIP_TRY(hipMemcpyAsync(d_in4, in4 + (size_t)r0 * nv, b_v, hipMemcpyHostToDevice, model->hs_in));
          if (fext)
-            HIP_TRY(hipMemcpyAsync(d_f, fext + (size_t)r0 * nj * 6, (size_t)rows * nj * 6 * sizeof(double), hipMemcpyHostToDevice, model->hs_in));
+            HIP_TRY(hipMemcpyAsync(d_f, fext + (size_t)r0 * nj * 6, (size_t)rows * nj * 6 * sizeof(T), hipMemcpyHostToDevice, model->hs_in));
       }
       HIP_TRY(hipEventRecord(model->ev_in[s], model->hs_in));
       HIP_TRY(hipStreamWaitEvent(model->hs_run, model->ev_in[s], 0));
       if (k >= ring)
          HIP_TRY(hipStreamWaitEvent(model->hs_run, model->ev_out[s], 0)); // ... and their outputs have left the slot
-      if (pair)
-         st = mh_rnea_aba_f64(model, rows, d_q, d_qd, d_in3, d_in4, gravity, fext ? d_f : nullptr, &o, d_out, d_out2);
+      if constexpr (sizeof(T) == 8)
+      {
+         if (pair)
+            st = mh_rnea_aba_f64(model, rows, d_q, d_qd, d_in3, d_in4, gravity, fext ? d_f : nullptr, &o, d_out, d_out2);
+         else
+            st = launch<T>((Algo)kind, model, rows, d_q, d_qd, d_in3, gravity, fext ? d_f : nullptr, &o, d_out);
+      }
       else
-         st = launch<double>((Algo)kind, model, rows, d_q, d_qd, d_in3, gravity, fext ? d_f : nullptr, &o, d_out);
+         st = launch<T>((Algo)kind, model, rows, d_q, d_qd, d_in3, gravity, fext ? d_f : nullptr, &o, d_out);
       if (st != MH_OK)
       {
          (void)hipDeviceSynchronize();
@@ -683,7 +689,7 @@ mh_status launch_host(int kind, mh_model_t model, int64_t B, const double *q, co
       }
       HIP_TRY(hipEventRecord(model->ev_run[s], model->hs_run));
       HIP_TRY(hipStreamWaitEvent(model->hs_out, model->ev_run[s], 0));
-      const size_t b_o = crba ? (size_t)rows * nv * nv * sizeof(double) : b_v;
+      const size_t b_o = crba ? (size_t)rows * nv * nv * sizeof(T) : b_v;
       HIP_TRY(hipMemcpyAsync(out + (size_t)r0 * (crba ? nv * nv : nv), d_out, b_o, hipMemcpyDeviceToHost, model->hs_out));
       if (pair)
          HIP_TRY(hipMemcpyAsync(out2 + (size_t)r0 * nv, d_out2, b_v, hipMemcpyDeviceToHost, model->hs_out));
@@ -1783,17 +1789,57 @@ mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_opti
 mh_status mh_rnea_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
                            const double *f_ext, const mh_options *opts, double *tau_out)
 {
-   return launch_host(ALGO_RNEA, model, B, q, qd, qdd, nullptr, gravity, f_ext, opts, tau_out, nullptr);
+   return launch_host<double>(ALGO_RNEA, model, B, q, qd, qdd, nullptr, gravity, f_ext, opts, tau_out, nullptr);
 }
 mh_status mh_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *tau, const double gravity[3],
                           const double *f_ext, const mh_options *opts, double *qdd_out)
 {
-   return launch_host(ALGO_ABA, model, B, q, qd, tau, nullptr, gravity, f_ext, opts, qdd_out, nullptr);
+   return launch_host<double>(ALGO_ABA, model, B, q, qd, tau, nullptr, gravity, f_ext, opts, qdd_out, nullptr);
 }
 mh_status mh_rnea_aba_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
                                const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out)
 {
-   return launch_host(HOST_PAIR, model, B, q, qd, qdd, tau, gravity, f_ext, opts, tau_out, qdd_out);
+   return launch_host<double>(HOST_PAIR, model, B, q, qd, qdd, tau, gravity, f_ext, opts, tau_out, qdd_out);
+}
+mh_status mh_rnea_f32_host(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
+                           const float *f_ext, const mh_options *opts, float *tau_out)
+{
+   return launch_host<float>(ALGO_RNEA, model, B, q, qd, qdd, nullptr, gravity, f_ext, opts, tau_out, nullptr);
+}
+mh_status mh_aba_f32_host(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau, const double gravity[3],
+                          const float *f_ext, const mh_options *opts, float *qdd_out)
+{
+   return launch_host<float>(ALGO_ABA, model, B, q, qd, tau, nullptr, gravity, f_ext, opts, qdd_out, nullptr);
+}
+mh_status mh_crba_f32_host(mh_model_t model, int64_t B, const float *q, const mh_options *opts, float *H_out)
+{
+   return launch_host<float>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, nullptr, opts, H_out, nullptr);
+}
+mh_status mh_rnea_bodies_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
+                             const float *f_ext, const mh_options *opts, float *tau_out, float *body_acc_out, float *body_twist_out)
+{
+   return launch<float>(ALGO_RNEA, model, B, q, qd, qdd, gravity, f_ext, opts, tau_out, nullptr, nullptr, body_acc_out, body_twist_out, true);
+}
+mh_status mh_aba_bodies_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau, const double gravity[3],
+                            const float *f_ext, const mh_options *opts, float *qdd_out, float *body_acc_out, float *body_twist_out)
+{
+   return launch<float>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, nullptr, nullptr, body_acc_out, body_twist_out, true);
+}
+mh_status mh_aba_locked_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau, const float *qdd_in,
+                            const double gravity[3], const float *f_ext, const mh_options *opts, float *qdd_out, float *tau_out)
+{
+   if (!model)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model is NULL");
+   if (model->n_locked == 0)
+   {
+      mh_status st = launch<float>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+      if (st == MH_OK && tau_out && tau_out != tau && B > 0)
+         HIP_TRY(hipMemcpyAsync(tau_out, tau, (size_t)B * model->nv * sizeof(float), hipMemcpyDeviceToDevice, opts ? (hipStream_t)opts->stream : nullptr));
+      return st;
+   }
+   if (B > 0 && !qdd_in)
+      return fail(MH_ERR_INVALID_ARGUMENT, "qdd_in is NULL but %d joint(s) are acceleration sources", model->n_locked);
+   return launch<float>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, qdd_in, tau_out);
 }
 mh_status mh_host_alloc(size_t bytes, void **ptr_out)
 {
@@ -1824,7 +1870,7 @@ mh_status mh_host_unregister(void *ptr)
 }
 mh_status mh_crba_f64_host(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
 {
-   return launch_host(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, nullptr, opts, H_out, nullptr);
+   return launch_host<double>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, nullptr, opts, H_out, nullptr);
 }
 
 // ---- HIP-event timer

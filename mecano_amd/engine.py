@@ -121,22 +121,24 @@ class HipModel:
                 _lib.check(getattr(lib, f"mh_{kind}_{sfx}")(self._h, B, q.data_ptr(), qd.data_ptr(), x3.data_ptr(), g, fp, ctypes.byref(opts),
                                                             out.data_ptr()))
             return out
-        # numpy: host-pointer entry points (fp64)
-        q = _np(q, np.float64)
+        # numpy: host-pointer entry points (fp64; float32 arrays go to the fp32 ones)
+        ndt = np.float32 if getattr(q, "dtype", None) == np.float32 else np.float64
+        sfx = "f32" if ndt == np.float32 else "f64"
+        q = _np(q, ndt)
         B = self._batch(q, self.nq, layout)
         opts = self._options(layout, consider_coriolis, consider_accelerations, None)
         if kind == "crba":
-            out = np.empty((B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B))
-            _lib.check(lib.mh_crba_f64_host(self._h, B, q.ctypes.data, ctypes.byref(opts), out.ctypes.data))
+            out = np.empty((B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B), dtype=ndt)
+            _lib.check(getattr(lib, f"mh_crba_{sfx}_host")(self._h, B, q.ctypes.data, ctypes.byref(opts), out.ctypes.data))
             return out
-        qd, x3 = _np(qd, np.float64), _np(x3, np.float64)
+        qd, x3 = _np(qd, ndt), _np(x3, ndt)
         if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
-        f = None if f_ext is None else _np(f_ext, np.float64)
+        f = None if f_ext is None else _np(f_ext, ndt)
         self._check_f_ext(f, B, layout)
         out = np.empty_like(qd)
-        _lib.check(getattr(lib, f"mh_{kind}_f64_host")(self._h, B, q.ctypes.data, qd.ctypes.data, x3.ctypes.data, g,
-                                                       None if f is None else f.ctypes.data, ctypes.byref(opts), out.ctypes.data))
+        _lib.check(getattr(lib, f"mh_{kind}_{sfx}_host")(self._h, B, q.ctypes.data, qd.ctypes.data, x3.ctypes.data, g,
+                                                        None if f is None else f.ctypes.data, ctypes.byref(opts), out.ctypes.data))
         return out
 
     # ------------------------------------------------------------------ the three hot-path calls
@@ -173,9 +175,12 @@ class HipModel:
             dev = torch.device("cuda", torch.cuda.current_device())
             q, qd, tau, qdd_in = [torch.from_numpy(_np(x, np.float64)).to(dev) for x in (q, qd, tau, qdd_in)]
             f_ext = None if f_ext is None else torch.from_numpy(_np(f_ext, np.float64)).to(dev)
+        dt = q.dtype
+        if dt not in (torch.float64, torch.float32):
+            raise TypeError("state tensors must be float64 or float32")
         for t in (q, qd, tau, qdd_in) + ((f_ext,) if f_ext is not None else ()):
-            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
-                raise ValueError("aba_locked needs contiguous float64 tensors on the HIP device")
+            if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise ValueError("aba_locked needs contiguous tensors of one dtype on the HIP device")
         B = self._batch(q, self.nq, layout)
         if any(self._batch(x, self.nv, layout) != B for x in (qd, tau, qdd_in)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
@@ -183,7 +188,8 @@ class HipModel:
         g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
         opts = self._options(layout, True, True, torch.cuda.current_stream(q.device).cuda_stream)
         qdd_out, tau_out = torch.empty_like(qd), torch.empty_like(qd)
-        _lib.check(lib.mh_aba_locked_f64(self._h, B, q.data_ptr(), qd.data_ptr(), tau.data_ptr(), qdd_in.data_ptr(), g,
+        fn = lib.mh_aba_locked_f64 if dt == torch.float64 else lib.mh_aba_locked_f32
+        _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), tau.data_ptr(), qdd_in.data_ptr(), g,
                                          f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts), qdd_out.data_ptr(),
                                          tau_out.data_ptr()))
         if host:
@@ -193,9 +199,12 @@ class HipModel:
     def _bodies(self, kind, q, qd, x3, gravity, f_ext, layout, consider_coriolis=True, consider_accelerations=True):
         import torch
         lib = _lib.load()
+        dt = q.dtype
+        if dt not in (torch.float64, torch.float32) or (dt == torch.float32 and kind not in ("rnea", "aba")):
+            raise TypeError("per-body outputs take float64 or float32 tensors, joint wrenches float64")
         for t in (q, qd, x3) + ((f_ext,) if f_ext is not None else ()):
-            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
-                raise ValueError("per-body outputs need contiguous float64 tensors on the HIP device")
+            if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise ValueError("per-body outputs need contiguous tensors of one dtype on the HIP device")
         B = self._batch(q, self.nq, layout)
         if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
@@ -205,13 +214,14 @@ class HipModel:
         out = torch.empty_like(qd)
         shape = (B, self.n_joints, 6) if layout == _lib.LAYOUT_AOS else (self.n_joints * 6, B)
         if kind in ("rnea_wrenches", "aba_wrenches"):
-            w = torch.empty(shape, dtype=torch.float64, device=q.device)
+            w = torch.empty(shape, dtype=dt, device=q.device)
             fn = lib.mh_rnea_joint_wrenches_f64 if kind == "rnea_wrenches" else lib.mh_aba_joint_wrenches_f64
             _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), x3.data_ptr(), g, f_ext.data_ptr() if f_ext is not None else None,
                           ctypes.byref(opts), out.data_ptr(), w.data_ptr()))
             return out, w
-        acc, tw = torch.empty(shape, dtype=torch.float64, device=q.device), torch.empty(shape, dtype=torch.float64, device=q.device)
-        fn = lib.mh_rnea_bodies_f64 if kind == "rnea" else lib.mh_aba_bodies_f64
+        acc, tw = torch.empty(shape, dtype=dt, device=q.device), torch.empty(shape, dtype=dt, device=q.device)
+        sfx = "f64" if dt == torch.float64 else "f32"
+        fn = getattr(lib, f"mh_rnea_bodies_{sfx}" if kind == "rnea" else f"mh_aba_bodies_{sfx}")
         _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), x3.data_ptr(), g, f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts),
                       out.data_ptr(), acc.data_ptr(), tw.data_ptr()))
         return out, acc, tw

@@ -351,3 +351,43 @@ def test_joint_wrenches_and_relative_accelerations(torch_cuda, family):
     assert root_rel is not None and root_rel.shape == (40, 6)
     from mecano_amd.multibody import RigidBody
     assert idc.getAccelerationProvider().getRelativeAcceleration(RigidBody("stranger"), bodies[0]) is None
+
+
+def test_fp32_forms_of_the_wider_entry_points(torch_cuda):
+    """mh_rnea_bodies_f32 / mh_aba_bodies_f32 / mh_aba_locked_f32 and the fp32 host-pointer entry points against their fp64 twins
+    (forward bounds ~ n u max|ref| with u = 2^-24; forward dynamics by its backward error, see test_fp32_entry_points_against_the_fp64_oracle)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    rng = np.random.default_rng(3232)
+    sys_ = system_of(rt.nextFloatingChain(rng, 14, ("revolute", "prismatic"), tree=True))
+    d = sys_.toModelDesc()
+    hm = HipModel(d)
+    B, u32, nb = 300, 2.0 ** -24, d.n_joints
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    g = (0.0, 0.0, -9.81)
+    f32 = torch.float32
+    d64 = [dev(torch, x) for x in (q, qd, qdd, tau)]
+    d32 = [dev(torch, x, f32) for x in (q, qd, qdd, tau)]
+    t64, acc64, tw64 = hm.rnea_bodies(d64[0], d64[1], d64[2], g)
+    t32, acc32, tw32 = hm.rnea_bodies(d32[0], d32[1], d32[2], g)
+    assert t32.dtype == f32 and acc32.dtype == f32
+    for a, b, name in ((t32, t64, "tau"), (acc32, acc64, "body acc"), (tw32, tw64, "body twist")):
+        close(a.double().cpu().numpy(), b.cpu().numpy(), 64 * nb * u32, label="rnea_bodies_f32 " + name)
+    a64, bacc64, _ = hm.aba_bodies(d64[0], d64[1], t64, g)
+    a32, bacc32, _ = hm.aba_bodies(d32[0], d32[1], t32, g)
+    back = hm.rnea(d64[0], d64[1], a32.double().contiguous(), g)  # fp64 inverse dynamics of the fp32 answer
+    close(back.cpu().numpy(), t64.cpu().numpy(), 256 * nb * u32, label="aba_bodies_f32 backward error")
+    modes = [1 if k % 3 == 1 else 0 for k in range(nb)]
+    hm.set_joint_source_modes(modes)
+    ql64, tl64 = hm.aba_locked(d64[0], d64[1], t64, d64[2], g)
+    ql32, tl32 = hm.aba_locked(d32[0], d32[1], t32, d32[2], g)
+    hm.set_joint_source_modes(None)
+    assert ql32.dtype == f32
+    back = hm.rnea(d64[0], d64[1], ql32.double().contiguous(), g)
+    close(back.cpu().numpy(), tl64.cpu().numpy(), 256 * nb * u32, label="aba_locked_f32 backward error")
+    # fp32 host-pointer entry points = the fp32 device-pointer ones, bit for bit
+    h32 = [x.astype(np.float32) for x in (q, qd, qdd, tau)]
+    assert np.array_equal(hm.rnea(h32[0], h32[1], h32[2], g), hm.rnea(d32[0], d32[1], d32[2], g).cpu().numpy())
+    assert np.array_equal(hm.aba(h32[0], h32[1], h32[3], g), hm.aba(d32[0], d32[1], d32[3], g).cpu().numpy())
+    assert np.array_equal(hm.crba(h32[0]), hm.crba(d32[0]).cpu().numpy())
