@@ -53,6 +53,31 @@ int main(void)
              back[b][1] - qdd[b][1]);
       err = fmax(err, fmax(fabs(back[b][0] - qdd[b][0]), fabs(back[b][1] - qdd[b][1])));
    }
+   /* a simulation loop that never leaves the device (what a Java host does with mh_device_alloc: no HIP binding of its own needed):
+    * state uploaded once, 200 steps of forward dynamics + integration, state downloaded once */
+   {
+      double *d_q, *d_qd, *d_tau, *d_qdd, zero[B][2] = {{0}}, q1[B][2], qd1[B][2];
+      if (mh_device_alloc(sizeof q, (void **)&d_q) || mh_device_alloc(sizeof q, (void **)&d_qd) || mh_device_alloc(sizeof q, (void **)&d_tau)
+          || mh_device_alloc(sizeof q, (void **)&d_qdd) || mh_copy_to_device(d_q, q, sizeof q, NULL) || mh_copy_to_device(d_qd, qd, sizeof q, NULL)
+          || mh_copy_to_device(d_tau, zero, sizeof q, NULL))
+      {
+         printf("device memory helpers failed: %s\n", mh_last_error());
+         return 1;
+      }
+      for (int step = 0; step < 200; step++)
+         if (mh_aba_integrate_f64(model, B, 1.0e-3, d_q, d_qd, d_tau, g, NULL, NULL, d_qdd, d_q, d_qd) != MH_OK)
+         {
+            printf("step failed: %s\n", mh_last_error());
+            return 1;
+         }
+      if (mh_copy_to_host(q1, d_q, sizeof q, NULL) || mh_copy_to_host(qd1, d_qd, sizeof q, NULL) || mh_stream_synchronize(NULL))
+         return 1;
+      /* configuration 0 starts at rest with gravity along the revolute axis and across the slide: it must stay at rest */
+      printf("after 0.2 s on the device: q[0] = (% .3e, % .3e), q[1] = (% .6f, % .6f)\n", q1[0][0], q1[0][1], q1[1][0], q1[1][1]);
+      if (fabs(q1[0][0]) > 1e-12 || fabs(q1[0][1]) > 1e-12 || !(q1[1][0] == q1[1][0]))
+         return 1;
+      mh_device_free(d_q), mh_device_free(d_qd), mh_device_free(d_tau), mh_device_free(d_qdd);
+   }
    /* gravity acts along the revolute axis and across the slide: at rest no effort is needed */
    printf("kernel variant: %s, round-trip error %.1e\n", mh_model_kernel_variant(model), err);
    mh_model_destroy(model);

@@ -368,6 +368,19 @@ mh_status mh_crba_coriolis_f64_host(mh_model_t model, int64_t B, const double *q
 mh_status mh_centroidal_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double frame[12], int32_t frame_mode,
                                  const mh_options *opts, double *A_out, double *b_out, double *com_out);
 
+/*
+ * ---- device memory for hosts without a HIP binding of their own ----
+ * A Java shim keeps its state matrices on the device with these and calls the DEVICE-pointer entry points: a simulation loop
+ * (mh_aba_integrate_f64 per step) then never crosses PCIe.  Copies are asynchronous on `stream` (NULL = the null stream); pageable
+ * host memory is staged by the runtime, pinned memory (mh_host_alloc) is read / written in place -- keep it alive until
+ * mh_stream_synchronize returns.
+ */
+mh_status mh_device_alloc(size_t bytes, void **ptr_out);
+mh_status mh_device_free(void *ptr);
+mh_status mh_copy_to_device(void *dst_device, const void *src_host, size_t bytes, void *stream);
+mh_status mh_copy_to_host(void *dst_host, const void *src_device, size_t bytes, void *stream);
+mh_status mh_stream_synchronize(void *stream);
+
 /* ---- measurement helper: HIP-event timing of launches on a stream (bench.py, §8d timing protocol) ---- */
 typedef struct mh_timer *mh_timer_t;
 mh_status mh_timer_create(mh_timer_t *timer_out);

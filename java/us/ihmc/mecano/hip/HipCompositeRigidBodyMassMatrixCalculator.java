@@ -27,8 +27,14 @@ public class HipCompositeRigidBodyMassMatrixCalculator implements AutoCloseable
 
    public HipCompositeRigidBodyMassMatrixCalculator(MultiBodySystemReadOnly input)
    {
+      this(input, true);
+   }
+
+   /** CompositeRigidBodyMassMatrixCalculator(MultiBodySystemReadOnly, ReferenceFrame, boolean considerIgnoredSubtreesInertia) (java:177-200). */
+   public HipCompositeRigidBodyMassMatrixCalculator(MultiBodySystemReadOnly input, boolean considerIgnoredSubtreesInertia)
+   {
       this.input = input;
-      model = new HipMultiBodyModel(input);
+      model = new HipMultiBodyModel(input, considerIgnoredSubtreesInertia);
    }
 
    /** CompositeRigidBodyMassMatrixCalculator.setEnableCoriolisMatrixCalculation (java:271-274). */
@@ -60,26 +66,18 @@ public class HipCompositeRigidBodyMassMatrixCalculator implements AutoCloseable
          if (enableCoriolisMatrixCalculation)
          {
             MemorySegment C = arena.allocate(JAVA_DOUBLE, (long) B * nv * nv);
-            MecanoHipNative.check((int) MecanoHipNative.CRBA_CORIOLIS_HOST.invokeExact(model.handle, (long) B, qSeg, qdSeg, MemorySegment.NULL, H, C));
+            MecanoHipNative.invoke(() -> (int) MecanoHipNative.CRBA_CORIOLIS_HOST.invokeExact(model.handle, (long) B, qSeg, qdSeg, MemorySegment.NULL, H, C));
             MemorySegment.copy(C, JAVA_DOUBLE, 0, coriolisMatrix.data, 0, B * nv * nv);
          }
          else
-            MecanoHipNative.check((int) MecanoHipNative.CRBA_HOST.invokeExact(model.handle, (long) B, qSeg, MemorySegment.NULL, H));
+            MecanoHipNative.invoke(() -> (int) MecanoHipNative.CRBA_HOST.invokeExact(model.handle, (long) B, qSeg, MemorySegment.NULL, H));
          MemorySegment.copy(H, JAVA_DOUBLE, 0, massMatrix.data, 0, B * nv * nv);
          MemorySegment A = arena.allocate(JAVA_DOUBLE, (long) B * 6 * nv), b = arena.allocate(JAVA_DOUBLE, (long) B * 6);
-         MecanoHipNative.check((int) MecanoHipNative.CENTROIDAL_HOST.invokeExact(model.handle, (long) B, qSeg, qdSeg, MemorySegment.NULL,
-                                                                                centroidalFrameAtCenterOfMass ? 1 : 0, MemorySegment.NULL, A, b,
-                                                                                MemorySegment.NULL));
+         int frameMode = centroidalFrameAtCenterOfMass ? 1 : 0;
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.CENTROIDAL_HOST.invokeExact(model.handle, (long) B, qSeg, qdSeg, MemorySegment.NULL, frameMode,
+                                                                                       MemorySegment.NULL, A, b, MemorySegment.NULL));
          MemorySegment.copy(A, JAVA_DOUBLE, 0, centroidalMomentumMatrix.data, 0, B * 6 * nv);
          MemorySegment.copy(b, JAVA_DOUBLE, 0, centroidalConvectiveTermMatrix.data, 0, B * 6);
-      }
-      catch (RuntimeException | Error e)
-      {
-         throw e;
-      }
-      catch (Throwable t)
-      {
-         throw new IllegalStateException(t);
       }
    }
 

@@ -1,0 +1,129 @@
+package us.ihmc.mecano.hip;
+
+import java.lang.foreign.Arena;
+import java.lang.foreign.MemorySegment;
+
+import org.ejml.data.DMatrixRMaj;
+
+import static java.lang.foreign.ValueLayout.ADDRESS;
+import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
+
+/**
+ * State of B configurations RESIDENT ON THE DEVICE: q (B x nq), qd, qdd, tau (B x nv), optional external wrenches (B x 6 n) and the
+ * per-body / per-joint outputs (B x 6 n).  The calculators' device-side calls read and write these buffers, so a simulation loop
+ * (forward dynamics + integration per step, mh_aba_integrate_f64) or a controller that chains inverse dynamics, mass matrix and forward
+ * dynamics never crosses PCIe between calls; upload(...) / download(...) move a matrix when the host wants to see it.
+ * Row b of every matrix is the column vector Mecano's MultiBodySystemTools.extractJointsState produces for configuration b.
+ */
+public final class HipDeviceBatch implements AutoCloseable
+{
+   final HipMultiBodyModel model;
+   final int batchSize;
+   final MemorySegment q, qd, qdd, tau, fExt, bodyAcceleration, bodyTwist, jointWrench, pairOutput;
+
+   public HipDeviceBatch(HipMultiBodyModel model, int batchSize)
+   {
+      this.model = model;
+      this.batchSize = batchSize;
+      long B = batchSize;
+      q = allocate(B * model.nq);
+      qd = allocate(B * model.nv);
+      qdd = allocate(B * model.nv);
+      tau = allocate(B * model.nv);
+      fExt = allocate(B * 6 * model.numberOfJoints);
+      bodyAcceleration = allocate(B * 6 * model.numberOfJoints);
+      bodyTwist = allocate(B * 6 * model.numberOfJoints);
+      jointWrench = allocate(B * 6 * model.numberOfJoints);
+      pairOutput = allocate(B * 6); // one (base, body) pair of mh_relative_acceleration_f64
+      MecanoHipNative.invoke(() -> (int) MecanoHipNative.RESERVE.invokeExact(model.handle, (long) batchSize));
+   }
+
+   private static MemorySegment allocate(long doubles)
+   {
+      try (Arena arena = Arena.ofConfined())
+      {
+         MemorySegment out = arena.allocate(ADDRESS);
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.DEVICE_ALLOC.invokeExact(Math.max(1L, doubles) * Double.BYTES, out));
+         return out.get(ADDRESS, 0);
+      }
+   }
+
+   /** host matrix (rows = configurations) -> device buffer */
+   public void upload(DMatrixRMaj matrix, MemorySegment deviceBuffer)
+   {
+      try (Arena arena = Arena.ofConfined())
+      {
+         MemorySegment host = arena.allocateFrom(JAVA_DOUBLE, matrix.data);
+         long bytes = (long) matrix.getNumElements() * Double.BYTES;
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.COPY_TO_DEVICE.invokeExact(deviceBuffer, host, bytes, MemorySegment.NULL));
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.STREAM_SYNCHRONIZE.invokeExact(MemorySegment.NULL));
+      }
+   }
+
+   /** device buffer -> host matrix (reshaped to rows x columns) */
+   public void download(MemorySegment deviceBuffer, int rows, int columns, DMatrixRMaj matrixToPack)
+   {
+      matrixToPack.reshape(rows, columns);
+      try (Arena arena = Arena.ofConfined())
+      {
+         long count = (long) rows * columns;
+         MemorySegment host = arena.allocate(JAVA_DOUBLE, Math.max(1L, count));
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.COPY_TO_HOST.invokeExact(host, deviceBuffer, count * Double.BYTES, MemorySegment.NULL));
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.STREAM_SYNCHRONIZE.invokeExact(MemorySegment.NULL));
+         MemorySegment.copy(host, JAVA_DOUBLE, 0, matrixToPack.data, 0, (int) count);
+      }
+   }
+
+   public void setConfiguration(DMatrixRMaj q)
+   {
+      upload(q, this.q);
+   }
+
+   public void setVelocity(DMatrixRMaj qd)
+   {
+      upload(qd, this.qd);
+   }
+
+   public void setAcceleration(DMatrixRMaj qdd)
+   {
+      upload(qdd, this.qdd);
+   }
+
+   public void setEffort(DMatrixRMaj tau)
+   {
+      upload(tau, this.tau);
+   }
+
+   /** B x 6 n: (moment, force) on the successor body of every listed joint, in that body's frame. */
+   public void setExternalWrenches(DMatrixRMaj wrenches)
+   {
+      upload(wrenches, fExt);
+   }
+
+   public void getConfiguration(DMatrixRMaj qToPack)
+   {
+      download(q, batchSize, model.nq, qToPack);
+   }
+
+   public void getVelocity(DMatrixRMaj qdToPack)
+   {
+      download(qd, batchSize, model.nv, qdToPack);
+   }
+
+   public void getAcceleration(DMatrixRMaj qddToPack)
+   {
+      download(qdd, batchSize, model.nv, qddToPack);
+   }
+
+   public void getEffort(DMatrixRMaj tauToPack)
+   {
+      download(tau, batchSize, model.nv, tauToPack);
+   }
+
+   @Override
+   public void close()
+   {
+      for (MemorySegment buffer : new MemorySegment[] {q, qd, qdd, tau, fExt, bodyAcceleration, bodyTwist, jointWrench, pairOutput})
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.DEVICE_FREE.invokeExact(buffer));
+   }
+}

@@ -13,11 +13,15 @@ import us.ihmc.mecano.multiBodySystem.interfaces.JointMatrixIndexProvider;
 import us.ihmc.mecano.multiBodySystem.interfaces.JointReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.MultiBodySystemReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.OneDoFJointReadOnly;
+import us.ihmc.mecano.multiBodySystem.interfaces.PlanarJointReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.PrismaticJointReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.RevoluteJointReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.RigidBodyReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.SixDoFJointReadOnly;
+import us.ihmc.mecano.multiBodySystem.interfaces.SphericalJointReadOnly;
+import us.ihmc.mecano.spatial.SpatialInertia;
 import us.ihmc.mecano.spatial.interfaces.SpatialInertiaReadOnly;
+import us.ihmc.mecano.tools.MultiBodySystemTools;
 
 import static java.lang.foreign.ValueLayout.ADDRESS;
 import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
@@ -26,7 +30,10 @@ import static java.lang.foreign.ValueLayout.JAVA_INT;
 /**
  * Flattens a MultiBodySystemReadOnly into mh_model_desc -- the model-extraction recipe of MultiBodySystemFactories.java:401-470, 782-868
  * (SURVEY.md appendix B) -- and owns the device-side model handle.  Joints are listed in
- * input.getJointMatrixIndexProvider().getIndexedJointsInOrder(); joints to ignore are simply not listed.
+ * input.getJointMatrixIndexProvider().getIndexedJointsInOrder(); joints to ignore are not listed, and with
+ * considerIgnoredSubtreesInertia the inertia of every ignored subtree is lumped into the body it hangs from, with Mecano's own code and at
+ * the configuration the system is in when the model is built -- exactly what InverseDynamicsCalculator.java:226-236, 832-860 does
+ * (MultiBodySystemTools.computeSubtreeInertia, changeFrame(bodyFixedFrame), SpatialInertia.add).
  */
 public final class HipMultiBodyModel implements AutoCloseable
 {
@@ -39,11 +46,18 @@ public final class HipMultiBodyModel implements AutoCloseable
 
    final MemorySegment handle;
    final int numberOfJoints, nq, nv;
+   final List<? extends JointReadOnly> jointList;
 
    public HipMultiBodyModel(MultiBodySystemReadOnly input)
    {
+      this(input, true);
+   }
+
+   public HipMultiBodyModel(MultiBodySystemReadOnly input, boolean considerIgnoredSubtreesInertia)
+   {
       JointMatrixIndexProvider provider = input.getJointMatrixIndexProvider();
       List<? extends JointReadOnly> joints = provider.getIndexedJointsInOrder();
+      jointList = joints;
       int n = joints.size();
       int[] parent = new int[n], type = new int[n];
       double[] axis = new double[3 * n], xBefore = new double[12 * n], xCom = new double[12 * n], J = new double[9 * n], mass = new double[n],
@@ -62,6 +76,10 @@ public final class HipMultiBodyModel implements AutoCloseable
             type[i] = 2;
          else if (joint instanceof FixedJointReadOnly)
             type[i] = 3;
+         else if (joint instanceof PlanarJointReadOnly)
+            type[i] = 4; // q = (pitch, x, z), qd = (w_y, v_x, v_z): PlanarJointReadOnly.java:17-72
+         else if (joint instanceof SphericalJointReadOnly)
+            type[i] = 5; // q = quaternion (x, y, z, s), qd = angular velocity: SphericalJointReadOnly.java:18-104
          else
             throw new UnsupportedOperationException("Joint kind not supported by the HIP engine: " + joint.getClass().getSimpleName());
          if (joint.isLoopClosure())
@@ -79,6 +97,25 @@ public final class HipMultiBodyModel implements AutoCloseable
          RigidBodyReadOnly body = joint.getSuccessor();
          pack(body.getBodyFixedFrame().getTransformToParent(), xCom, 12 * i);
          SpatialInertiaReadOnly inertia = body.getInertia();
+         if (considerIgnoredSubtreesInertia)
+         { // InverseDynamicsCalculator.java:839-855: ignored children of this body, summed in its body-fixed frame
+            SpatialInertia lumped = null;
+            for (JointReadOnly childJoint : body.getChildrenJoints())
+            {
+               if (!input.getJointsToIgnore().contains(childJoint))
+                  continue;
+               SpatialInertia subtreeInertia = MultiBodySystemTools.computeSubtreeInertia(childJoint);
+               subtreeInertia.changeFrame(body.getBodyFixedFrame());
+               if (lumped == null)
+               {
+                  lumped = new SpatialInertia(body.getBodyFixedFrame(), body.getBodyFixedFrame());
+                  lumped.setIncludingFrame(body.getInertia());
+               }
+               lumped.add(subtreeInertia);
+            }
+            if (lumped != null)
+               inertia = lumped;
+         }
          for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++)
                J[9 * i + 3 * r + c] = inertia.getMomentOfInertia().getElement(r, c);
@@ -144,6 +181,35 @@ public final class HipMultiBodyModel implements AutoCloseable
       array[start + 9] = transform.getTranslationX();
       array[start + 10] = transform.getTranslationY();
       array[start + 11] = transform.getTranslationZ();
+   }
+
+   /** "topo:<key>" when a topology-specialised code object serves this model, "generic" (+ the reason) otherwise. */
+   public String kernelVariant()
+   {
+      try
+      {
+         return ((MemorySegment) MecanoHipNative.MODEL_KERNEL_VARIANT.invokeExact(handle)).reinterpret(1024).getString(0);
+      }
+      catch (Throwable t)
+      {
+         throw new IllegalStateException(t);
+      }
+   }
+
+   /** JointSourceMode of every listed joint (0 = EFFORT_SOURCE, 1 = ACCELERATION_SOURCE); null resets (ForwardDynamicsCalculator.java:400-444). */
+   public void setJointSourceModes(int[] modes)
+   {
+      try (Arena arena = Arena.ofConfined())
+      {
+         MemorySegment seg = modes == null ? MemorySegment.NULL : arena.allocateFrom(JAVA_INT, modes);
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.SET_JOINT_SOURCE_MODES.invokeExact(handle, seg));
+      }
+   }
+
+   /** Position of a joint in the model's joint list (row block of the per-body / per-joint outputs), -1 for a joint that is not listed. */
+   public int indexOf(JointReadOnly joint)
+   {
+      return jointList.indexOf(joint);
    }
 
    @Override

@@ -3,18 +3,23 @@ package us.ihmc.mecano.hip;
 import java.lang.foreign.Arena;
 import java.lang.foreign.FunctionDescriptor;
 import java.lang.foreign.Linker;
+import java.lang.foreign.MemoryLayout;
 import java.lang.foreign.MemorySegment;
+import java.lang.foreign.StructLayout;
 import java.lang.foreign.SymbolLookup;
 import java.lang.invoke.MethodHandle;
 
 import static java.lang.foreign.ValueLayout.ADDRESS;
+import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
 import static java.lang.foreign.ValueLayout.JAVA_INT;
 import static java.lang.foreign.ValueLayout.JAVA_LONG;
 
 /**
- * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h.  NOT compiled in this repository's image (no JVM there);
- * it is the reference-side stub a Mecano maintainer adds.  One downcall handle per C entry point; every entry point returns an
- * mh_status int which {@link #check(int)} maps back to the exception types Mecano itself throws.
+ * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h, ABI version 2.  NOT compiled in this repository's image (no JVM
+ * there); it is the reference-side stub a Mecano maintainer adds.  One downcall handle per C entry point the shim classes use; every
+ * entry point returns an mh_status int which {@link #check(int)} maps back to the exception types Mecano itself throws.
+ * <p>
+ * Pointer arguments named "host" are heap / off-heap memory of the JVM; "device" pointers come from {@link #DEVICE_ALLOC}.
  */
 public final class MecanoHipNative
 {
@@ -26,27 +31,90 @@ public final class MecanoHipNative
       return LINKER.downcallHandle(LIB.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), descriptor);
    }
 
+   private static FunctionDescriptor status(MemoryLayout... arguments)
+   {
+      return FunctionDescriptor.of(JAVA_INT, arguments);
+   }
+
+   /** struct mh_options { int32 consider_coriolis, consider_accelerations, layout, reserved0; void *stream; } */
+   static final StructLayout OPTIONS = MemoryLayout.structLayout(JAVA_INT.withName("consider_coriolis"), JAVA_INT.withName("consider_accelerations"),
+                                                                JAVA_INT.withName("layout"), JAVA_INT.withName("reserved0"), ADDRESS.withName("stream"));
+
+   static final MethodHandle ABI_VERSION = handle("mh_abi_version", FunctionDescriptor.of(JAVA_INT));
    static final MethodHandle LAST_ERROR = handle("mh_last_error", FunctionDescriptor.of(ADDRESS));
-   static final MethodHandle MODEL_CREATE = handle("mh_model_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
+   static final MethodHandle MODEL_CREATE = handle("mh_model_create", status(ADDRESS, ADDRESS));
    static final MethodHandle MODEL_DESTROY = handle("mh_model_destroy", FunctionDescriptor.ofVoid(ADDRESS));
-   static final MethodHandle RESERVE = handle("mh_reserve", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG));
-   /* (model, B, q, qd, qdd|tau, gravity[3], f_ext|NULL, opts|NULL, out) -- host pointers: copies in, launches, copies out, synchronises */
-   private static final FunctionDescriptor DYNAMICS = FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS,
-                                                                            ADDRESS);
+   static final MethodHandle MODEL_KERNEL_VARIANT = handle("mh_model_kernel_variant", FunctionDescriptor.of(ADDRESS, ADDRESS));
+   /** (desc, out_dir|NULL, path_out, path_cap): runs hipcc on the kernel sources next to the library; minutes; once per robot. */
+   static final MethodHandle BUILD_CODE_OBJECT = handle("mh_build_code_object", status(ADDRESS, ADDRESS, ADDRESS, JAVA_LONG));
+   static final MethodHandle RESERVE = handle("mh_reserve", status(ADDRESS, JAVA_LONG));
+   static final MethodHandle SET_JOINT_SOURCE_MODES = handle("mh_model_set_joint_source_modes", status(ADDRESS, ADDRESS));
+
+   /* (model, B, q, qd, qdd|tau, gravity[3] (host), f_ext|NULL, opts|NULL, out) */
+   private static final FunctionDescriptor DYNAMICS = status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS);
+   /* (model, B, q, qd, qdd|tau, gravity, f_ext|NULL, opts|NULL, out, out2, out3): bodies (tau|qdd, body_acc, body_twist) */
+   private static final FunctionDescriptor DYNAMICS_3 = status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS,
+                                                               ADDRESS);
+   /* (model, B, q, qd, qdd|tau, gravity, f_ext|NULL, opts|NULL, out, joint_wrench_out) */
+   private static final FunctionDescriptor DYNAMICS_2 = status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS);
+   /* (model, B, q, qd, qdd, tau, gravity, f_ext|NULL, opts|NULL, tau_out, qdd_out) */
+   private static final FunctionDescriptor PAIR = status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS);
+
+   // ---- host-pointer entry points: copy in (chunked, three streams), launch, copy out, synchronise
    static final MethodHandle RNEA_HOST = handle("mh_rnea_f64_host", DYNAMICS);
    static final MethodHandle ABA_HOST = handle("mh_aba_f64_host", DYNAMICS);
-   static final MethodHandle CRBA_HOST = handle("mh_crba_f64_host", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS));
+   static final MethodHandle RNEA_ABA_HOST = handle("mh_rnea_aba_f64_host", PAIR);
+   static final MethodHandle CRBA_HOST = handle("mh_crba_f64_host", status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS));
    /** CompositeRigidBodyMassMatrixCalculator with setEnableCoriolisMatrixCalculation(true): (model, B, q, qd, opts, H_out, C_out). */
-   static final MethodHandle CRBA_CORIOLIS_HOST = handle("mh_crba_coriolis_f64_host",
-                                                         FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+   static final MethodHandle CRBA_CORIOLIS_HOST = handle("mh_crba_coriolis_f64_host", status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
    /**
     * getCentroidalMomentumMatrix / getCentroidalConvectiveTermMatrix: (model, B, q, qd, frame[12] or NULL, frame_mode, opts, A_out, b_out,
     * com_out); frame = centroidalMomentumFrame.getTransformToDesiredFrame(rootBody.getBodyFixedFrame()) as R row-major + p, frame_mode 1
     * for a CenterOfMassReferenceFrame under it.
     */
-   static final MethodHandle CENTROIDAL_HOST = handle("mh_centroidal_f64_host", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS,
-                                                                                                       ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS,
-                                                                                                       ADDRESS));
+   static final MethodHandle CENTROIDAL_HOST = handle("mh_centroidal_f64_host", status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, ADDRESS,
+                                                                                       ADDRESS, ADDRESS, ADDRESS));
+
+   // ---- device-pointer entry points (asynchronous on opts->stream): what HipDeviceBatch drives
+   static final MethodHandle RNEA = handle("mh_rnea_f64", DYNAMICS);
+   static final MethodHandle ABA = handle("mh_aba_f64", DYNAMICS);
+   static final MethodHandle RNEA_ABA = handle("mh_rnea_aba_f64", PAIR);
+   /** (model, B, q, qd, tau, qdd_in, gravity, f_ext, opts, qdd_out, tau_out) */
+   static final MethodHandle ABA_LOCKED = handle("mh_aba_locked_f64", PAIR);
+   static final MethodHandle RNEA_BODIES = handle("mh_rnea_bodies_f64", DYNAMICS_3);
+   static final MethodHandle ABA_BODIES = handle("mh_aba_bodies_f64", DYNAMICS_3);
+   static final MethodHandle RNEA_JOINT_WRENCHES = handle("mh_rnea_joint_wrenches_f64", DYNAMICS_2);
+   static final MethodHandle ABA_JOINT_WRENCHES = handle("mh_aba_joint_wrenches_f64", DYNAMICS_2);
+   /** (model, B, q, body_acc, body_twist|NULL, gravity, n_pairs, base_joints (host int[]), body_joints (host int[]), opts, out) */
+   static final MethodHandle RELATIVE_ACCELERATION = handle("mh_relative_acceleration_f64", status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS,
+                                                                                                   JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+   /** (model, B, dt, q, qd, qdd, opts, q_out, qd_out, qdd_out|NULL) */
+   static final MethodHandle INTEGRATE = handle("mh_integrate_f64", status(ADDRESS, JAVA_LONG, JAVA_DOUBLE, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS,
+                                                                           ADDRESS));
+   /** one simulation step: (model, B, dt, q, qd, tau, gravity, f_ext, opts, qdd_out, q_next, qd_next); q_next / qd_next may alias q / qd */
+   static final MethodHandle ABA_INTEGRATE = handle("mh_aba_integrate_f64", status(ADDRESS, JAVA_LONG, JAVA_DOUBLE, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS,
+                                                                                   ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+
+   // ---- memory: pinned host memory for PCIe-rate copies, device memory for state that stays resident
+   static final MethodHandle HOST_ALLOC = handle("mh_host_alloc", status(JAVA_LONG, ADDRESS));
+   static final MethodHandle HOST_FREE = handle("mh_host_free", status(ADDRESS));
+   static final MethodHandle DEVICE_ALLOC = handle("mh_device_alloc", status(JAVA_LONG, ADDRESS));
+   static final MethodHandle DEVICE_FREE = handle("mh_device_free", status(ADDRESS));
+   static final MethodHandle COPY_TO_DEVICE = handle("mh_copy_to_device", status(ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
+   static final MethodHandle COPY_TO_HOST = handle("mh_copy_to_host", status(ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
+   static final MethodHandle STREAM_SYNCHRONIZE = handle("mh_stream_synchronize", status(ADDRESS));
+
+   /** An mh_options in `arena`: the calculators' switches, AoS layout (rows = configurations), the null stream. */
+   static MemorySegment options(Arena arena, boolean considerCoriolis, boolean considerAccelerations)
+   {
+      MemorySegment options = arena.allocate(OPTIONS);
+      options.set(JAVA_INT, 0, considerCoriolis ? 1 : 0);
+      options.set(JAVA_INT, 4, considerAccelerations ? 1 : 0);
+      options.set(JAVA_INT, 8, 0);
+      options.set(JAVA_INT, 12, 0);
+      options.set(ADDRESS, 16, MemorySegment.NULL);
+      return options;
+   }
 
    /** mh_status -> the exception Mecano's own calculators would have thrown (SURVEY.md section 8b, "Errors"). */
    static void check(int status)
@@ -78,6 +146,30 @@ public final class MecanoHipNative
          default: // MH_ERR_NO_DEVICE, MH_ERR_HIP, ...
             throw new IllegalStateException(message);
       }
+   }
+
+   /** Runs a downcall that returns an mh_status and converts checked Throwables (MethodHandle.invoke) into unchecked ones. */
+   interface Call
+   {
+      int run() throws Throwable;
+   }
+
+   static void invoke(Call call)
+   {
+      int status;
+      try
+      {
+         status = call.run();
+      }
+      catch (RuntimeException | Error e)
+      {
+         throw e;
+      }
+      catch (Throwable t)
+      {
+         throw new IllegalStateException(t);
+      }
+      check(status);
    }
 
    private MecanoHipNative()

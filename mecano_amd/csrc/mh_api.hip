@@ -1841,6 +1841,40 @@ mh_status mh_aba_locked_f32(mh_model_t model, int64_t B, const float *q, const f
       return fail(MH_ERR_INVALID_ARGUMENT, "qdd_in is NULL but %d joint(s) are acceleration sources", model->n_locked);
    return launch<float>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, qdd_in, tau_out);
 }
+// ---- device memory for hosts without a HIP binding of their own (a Java shim keeps simulation state resident between steps with these)
+mh_status mh_device_alloc(size_t bytes, void **ptr_out)
+{
+   if (!ptr_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "ptr_out is NULL");
+   *ptr_out = nullptr;
+   HIP_TRY(hipMalloc(ptr_out, bytes ? bytes : 1));
+   return MH_OK;
+}
+mh_status mh_device_free(void *ptr)
+{
+   if (ptr)
+      HIP_TRY(hipFree(ptr));
+   return MH_OK;
+}
+mh_status mh_copy_to_device(void *dst_device, const void *src_host, size_t bytes, void *stream)
+{
+   if (bytes && (!dst_device || !src_host))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL pointer");
+   HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+   return MH_OK;
+}
+mh_status mh_copy_to_host(void *dst_host, const void *src_device, size_t bytes, void *stream)
+{
+   if (bytes && (!dst_host || !src_device))
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL pointer");
+   HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+   return MH_OK;
+}
+mh_status mh_stream_synchronize(void *stream)
+{
+   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+   return MH_OK;
+}
 mh_status mh_host_alloc(size_t bytes, void **ptr_out)
 {
    if (!ptr_out)
