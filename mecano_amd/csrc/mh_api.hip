@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -147,8 +149,19 @@ struct mh_model
    int use_dfs = 1;       // MH_DFS=0: the sweep kernels of mh_kernels.h serve plain RNEA / ABA calls too (A/B measurements)
    std::map<const void *, size_t> lds_attr; // dynamic-LDS limit already raised per kernel (the model lives on one device, one host thread at a time)
    double nonleaf_fraction = 1.0; // share of bodies with children: those are the ones that touch the depth stack
+   // depth-first kernels: frame homes for a given LDS budget (slots per wave), one copy of the body records per (algorithm, budget) on
+   // the device; built on first use (dfs_plan), dropped when the records change (joint source modes)
+   struct DfsPlan
+   {
+      int algo, budget, lds_slots, glb_slots, glb_frames;
+      int *d_meta;
+   };
+   std::deque<DfsPlan> dfs_plans; // references stay valid across push_back
+   std::mutex dfs_mutex;
    int use_win = 1;       // MH_DFS_WIN=0: AoS rows are read per lane instead of through LDS windows (A/B measurements)
    int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
+   int dfs_budget = -1;   // MH_DFS_BUDGET: cap of the stack's LDS budget in slots per wave (measurements)
+   int dfs_aba64 = 0;     // MH_DFS_ABA64=1: fp64 forward dynamics on the depth-first kernel too (measurements)
    double *d_consts64 = nullptr;
    float *d_consts32 = nullptr;
    Workspace ws;
@@ -272,79 +285,152 @@ enum Algo
    ALGO_CRBA
 };
 
-// Depth-first run-time-topology kernels (mh_dfs_kernels.h): where the per-lane depth stack and ABA's hand-over live, grid, launch.
-//   place 0: everything in LDS          place 1: stack in LDS, hand-over in the global workspace          place 2: both global
-// LDS is the faster home per wave, but a big stack caps the resident waves per CU.  Measured (tools/exp_dfs.py, profiles/r02_dfs_*):
-//   RNEA  a wave on the global stack is r = 1 + 3 (non-leaf fraction)(sizeof(T) / 8) times slower (1.4x on the 128-body fp32 tree where
-//         half the bodies are leaves and never touch the stack, 3.4x on the fp64 humanoid), so the global stack wins only when it
-//         saves more than r batch passes: the 128-body tree at B = 131072 (one pass of 8 waves per CU against three of 3) -- 550 vs
-//         1100 us -- but not the humanoid at 262144 (358 vs 534 us);
-//   ABA   needs the whole register file (one wave per SIMD) and 2.5x the stack: LDS only while the batch has no more waves than the
-//         device has CUs (106 vs 116 us at B = 4096), the global workspace beyond (163 vs 243 us at 32768, 980 vs 1830 at 262144).
-// MH_DFS_PLACE overrides (measurements).
+// Depth-first run-time-topology kernels (mh_dfs_kernels.h): homes of the stack frames, where ABA's hand-over lives, grid, launch.
+//
+// Frame homes.  A frame (non-leaf bodies only) is written when its body is visited and read when the body is popped, plus one
+// read-modify-write per child that is not the last: stack traffic is proportional to the number of non-leaf bodies, and most of those
+// sit near the leaves.  On an all-global stack the 128-body tree of BASELINE.json's configs[4] moved 5.3x (RNEA) and 17.7x (ABA) its
+// algorithmic bytes through HBM at 4.2 / 5.7 TB/s (profiles/r02_config5_dfs_hbm_pmc.json): the kernels were bound by their own
+// workspace.  An all-LDS stack needs 37 KB (RNEA) / 100+ KB (ABA) per wave there, i.e. 1-4 waves per CU, and loses more than it saves.
+// So LDS is given a BUDGET per wave (what is left of 160 KB at the occupancy the launch wants) and filled from the leaves upwards: a
+// frame is placed in LDS if it fits on top of the deepest LDS path below it.  The live frames of a walk are one root-to-leaf path, so
+// every path keeps its LDS sum within the budget; the frames that do not fit -- few, near the root -- go to the wave's global block,
+// whose offsets count global-homed ancestors only.
+const mh_model::DfsPlan *dfs_plan(mh_model *m, int algo, int budget)
+{
+   std::lock_guard<std::mutex> lock(m->dfs_mutex);
+   for (const mh_model::DfsPlan &p : m->dfs_plans)
+      if (p.algo == algo && p.budget == budget)
+         return &p;
+   const int n = m->n;
+   std::vector<int> meta = m->meta, frame(n), below(n, 0), lofs(n, 0), gofs(n, 0);
+   std::vector<char> home(n, 0);
+   auto MI = [&](int e, int k) -> int & { return meta[(size_t)e * mh::MI_STRIDE + k]; };
+   for (int e = 0; e < n; e++)
+      frame[e] = algo == 0 ? mh::rnea_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH)) : mh::aba_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH));
+   for (int e = n - 1; e >= 0; e--)
+   { // engine order is depth-first: children come after their parent
+      int need = below[e];
+      if (frame[e] > 0 && below[e] + frame[e] <= budget)
+         home[e] = 1, need += frame[e];
+      const int pe = MI(e, mh::MI_PARENT);
+      if (pe >= 0)
+         below[pe] = std::max(below[pe], need);
+   }
+   mh_model::DfsPlan plan{algo, budget, 0, 0, 0, nullptr};
+   for (int e = 0; e < n; e++)
+   {
+      const int pe = MI(e, mh::MI_PARENT);
+      if (pe >= 0)
+         lofs[e] = lofs[pe] + (home[pe] ? frame[pe] : 0), gofs[e] = gofs[pe] + (home[pe] ? 0 : frame[pe]);
+      if (home[e])
+         plan.lds_slots = std::max(plan.lds_slots, lofs[e] + frame[e]);
+      else if (frame[e] > 0)
+         plan.glb_slots = std::max(plan.glb_slots, gofs[e] + frame[e]), plan.glb_frames++;
+   }
+   auto code = [&](int e) { return home[e] ? (lofs[e] | mh::DFS_LDS) : gofs[e]; };
+   for (int e = 0; e < n; e++)
+   {
+      const int pe = MI(e, mh::MI_PARENT);
+      const int pj = pe >= 0 ? mh::jx_slots(MI(pe, mh::MI_TYPE)) : 0;
+      if (algo == 0)
+      {
+         MI(e, mh::MI_DFS_R) = code(e);
+         if (pe >= 0)
+            MI(e, mh::MI_PFR_R) = code(pe), MI(e, mh::MI_PVA_R) = code(pe) + 6 + pj;
+      }
+      else
+      {
+         MI(e, mh::MI_DFS_A) = code(e);
+         if (pe >= 0)
+            MI(e, mh::MI_PFR_A) = code(pe), MI(e, mh::MI_PV_A) = code(pe) + 12 + pj, MI(e, mh::MI_PACC_A) = code(pe) + 18 + pj;
+      }
+   }
+   plan.glb_slots = std::max(plan.glb_slots, 6);
+   if (hipMalloc((void **)&plan.d_meta, meta.size() * sizeof(int)) != hipSuccess)
+      return nullptr;
+   if (hipMemcpy(plan.d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+   {
+      (void)hipFree(plan.d_meta);
+      return nullptr;
+   }
+   m->dfs_plans.push_back(plan);
+   return &m->dfs_plans.back();
+}
+void dfs_plans_drop(mh_model *m)
+{
+   std::lock_guard<std::mutex> lock(m->dfs_mutex);
+   for (mh_model::DfsPlan &p : m->dfs_plans)
+      (void)hipFree(p.d_meta);
+   m->dfs_plans.clear();
+}
+
+// Launch policy.  Occupancy first: the grid wants min(resident cap, waves of the batch) waves, spread over the CUs; the LDS a wave may
+// use is 160 KB divided by the waves per CU that follow from it (ABA in fp64 holds the whole register file: 4 waves per CU at most).
+// Out of that come the row windows (RNEA on AoS matrices), ABA's hand-over if all of it fits (small models at one wave per CU: measured
+// 106 vs 116 us on the humanoid at B = 4096), and the rest is the stack's budget.  MH_DFS_PLACE = 0 | 1 | 2 forces an all-LDS stack
+// with the hand-over in LDS / an all-LDS stack / an all-global stack (measurements, tests); MH_DFS_BUDGET=<slots> the budget itself.
 template <typename T>
 mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipStream_t stream)
 {
    const long waves = (B + 63) / 64;
-   // AoS matrices with identity index maps: rows go through LDS windows (mh::window_refill); their LDS comes on top of the stack's
-   // ... worth it once a row spans many cache lines (a lane's consecutive reads then no longer share a line with anybody: 64 requests per
-   // wave-load); the humanoid's 248-byte rows are L1-friendly as they are
-   // RNEA only: the ABA kernel has no registers left for the 32 in-flight window entries (it drops to one wave per SIMD: 2306 vs 2016 us
-   // measured), and two of its five per-lane streams (tau in post-order, the accelerations it writes) could not use a window anyway
    const bool win = algo == ALGO_RNEA && A.q_es == 1 && A.v_es == 1 && model->ident_maps && model->use_win && (long)model->nv * (long)sizeof(T) >= 512;
-   const long b_win = win ? (long)(algo == ALGO_RNEA ? 3 : 2) * mh::ROW_WIN * mh::ROW_PITCH * (long)sizeof(T) : 0;
-   const long LDS_MAX = 160 * 1024 - b_win;
-   const long stack = algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack;
-   const long hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
-   const long b_stack = stack * 64 * (long)sizeof(T), b_all = (stack + hand) * 64 * (long)sizeof(T);
+   const long b_win = win ? 3L * mh::ROW_WIN * mh::ROW_PITCH * (long)sizeof(T) : 0;
+   const long slot_bytes = 64 * (long)sizeof(T);
    const long cus = model->cu_count;
-   int place;
-   if (algo == ALGO_RNEA)
-   {
-      const long per_cu_lds = b_stack > 0 ? std::max<long>(1, std::min<long>(8, LDS_MAX / b_stack)) : 8;
-      const double passes_lds = std::ceil((double)waves / (double)(cus * per_cu_lds));
-      const double passes_glb = std::ceil((double)waves / (double)(cus * model->waves_per_cu));
-      const double r = 1.0 + 3.0 * model->nonleaf_fraction * (double)sizeof(T) / 8.0;
-      place = (b_stack <= LDS_MAX && passes_lds <= passes_glb * r) ? 0 : 2;
+   const long reg_cap = (algo == ALGO_ABA && sizeof(T) == 8) ? 4 : model->waves_per_cu; // resident waves per CU the registers allow
+   long per_cu = std::max<long>(1, std::min<long>(std::min<long>(model->waves_per_cu, reg_cap), (waves + cus - 1) / cus));
+   const long full_stack = algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack;
+   const long hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
+   bool hand_lds = false;
+   long budget;
+   if (model->dfs_place >= 0)
+   { // forced placements: give the stack what it needs and let the occupancy follow
+      budget = model->dfs_place == 2 ? 0 : full_stack;
+      hand_lds = model->dfs_place == 0 && algo == ALGO_ABA && (full_stack + hand) * slot_bytes + b_win <= 160 * 1024;
+      if (budget * slot_bytes + b_win > 160 * 1024)
+         budget = (160 * 1024 - b_win) / slot_bytes;
    }
    else
-      place = waves <= cus ? (b_all <= LDS_MAX ? 0 : (b_stack <= LDS_MAX ? 1 : 2)) : 2;
-   if (model->dfs_place >= 0)
    {
-      place = std::min(2, model->dfs_place);
-      if (place == 0 && b_all > LDS_MAX)
-         place = 1;
-      if (place == 1 && b_stack > LDS_MAX)
-         place = 2;
+      const long avail = 160 * 1024 / per_cu - b_win;
+      hand_lds = algo == ALGO_ABA && (full_stack + hand) * slot_bytes <= avail;
+      budget = std::max<long>(0, std::min<long>(full_stack, (avail - (hand_lds ? hand * slot_bytes : 0)) / slot_bytes));
+      if (model->dfs_budget >= 0)
+         budget = std::min<long>(model->dfs_budget, budget);
    }
-   if (algo == ALGO_RNEA)
-      place = (place == 2 || b_stack > LDS_MAX) ? 2 : 0; // there is no hand-over: b_all == b_stack
-   const long lds = (place == 0 ? b_all : (place == 1 ? b_stack : 0)) + b_win;
-   const long per_cu = lds > 0 ? std::max<long>(1, std::min<long>(model->waves_per_cu, (160 * 1024) / lds)) : (long)model->waves_per_cu;
-   const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * per_cu));
-   const long gslots = place == 0 ? 0 : (place == 1 ? hand : stack + hand);
-   if (gslots > 0)
-   {
-      mh_status st = ensure_bytes(model->ws, (size_t)gslots * (size_t)grid * 64 * sizeof(T));
-      if (st != MH_OK)
-         return st;
-   }
+   const mh_model::DfsPlan *plan = dfs_plan(model, algo == ALGO_RNEA ? 0 : 1, (int)budget);
+   if (!plan)
+      return fail(MH_ERR_HIP, "depth-first kernels: the body records of the frame plan could not be uploaded");
+   const long lds = (plan->lds_slots + (hand_lds ? hand : 0)) * slot_bytes + b_win;
+   if (lds > 0)
+      per_cu = std::max<long>(1, std::min<long>(per_cu, (160 * 1024) / lds));
+   const int grid = (int)std::max<long>(1, std::min(waves, cus * per_cu));
+   const long gslots = (hand_lds ? 0 : hand) + plan->glb_slots;
+   mh_status st = ensure_bytes(model->ws, (size_t)gslots * (size_t)grid * 64 * sizeof(T));
+   if (st != MH_OK)
+      return st;
    A.ws = (T *)model->ws.ptr;
    A.ws_stride = gslots * 64; // per-wave block of the global workspace: [grid][slots][64 lanes] -- the same constant slot stride as in LDS
+   A.m.meta = plan->d_meta;
+   if (algo == ALGO_RNEA)
+      A.m.rnea_stack = plan->lds_slots;
+   else
+      A.m.aba_stack = plan->lds_slots;
+   // every frame in LDS / every frame global: builds without the per-group branch
+   const int mode = plan->glb_frames == 0 ? 0 : (plan->lds_slots == 0 ? 1 : 2);
    const void *kern = nullptr;
    if (algo == ALGO_RNEA)
    {
       if (win)
-         kern = place == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true, true> : (const void *)&mh::rnea_dfs_kernel<T, false, true>;
+         kern = mode == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true, 0> : (mode == 1 ? (const void *)&mh::rnea_dfs_kernel<T, true, 1> : (const void *)&mh::rnea_dfs_kernel<T, true, 2>);
       else
-         kern = place == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true, false> : (const void *)&mh::rnea_dfs_kernel<T, false, false>;
+         kern = mode == 0 ? (const void *)&mh::rnea_dfs_kernel<T, false, 0> : (mode == 1 ? (const void *)&mh::rnea_dfs_kernel<T, false, 1> : (const void *)&mh::rnea_dfs_kernel<T, false, 2>);
    }
-   else if (win)
-      kern = place == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, true, true>
-                        : (place == 1 ? (const void *)&mh::aba_dfs_kernel<T, true, false, true> : (const void *)&mh::aba_dfs_kernel<T, false, false, true>);
+   else if (hand_lds)
+      kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, false, 0> : (const void *)&mh::aba_dfs_kernel<T, true, false, 2>;
    else
-      kern = place == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, true, false>
-                        : (place == 1 ? (const void *)&mh::aba_dfs_kernel<T, true, false, false> : (const void *)&mh::aba_dfs_kernel<T, false, false, false>);
+      kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, false, false, 0> : (mode == 1 ? (const void *)&mh::aba_dfs_kernel<T, false, false, 1> : (const void *)&mh::aba_dfs_kernel<T, false, false, 2>);
    if (lds > 64 * 1024 && model->lds_attr[kern] < (size_t)lds)
    {
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -377,7 +463,11 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       return fail(MH_ERR_INVALID_ARGUMENT, "%d joint(s) are acceleration sources: forward dynamics needs their accelerations, use mh_aba_locked_f64",
                   model->n_locked);
    // the sweep kernels' per-body workspace (plain RNEA / ABA calls run on the depth-first kernels, which size their own)
-   const bool dfs = model->use_dfs && algo != ALGO_CRBA && !bodies && !(algo == ALGO_ABA && model->n_locked > 0);
+   // fp64 ABA stays on the sweep kernel: the depth-first walk fuses passes one and two, which in fp64 costs the whole register file plus
+   // scratch (512 registers + 320 B against 310 and none) -- measured slower at every batch size on every 25..30-body model (humanoid
+   // 112 vs 128 us at B = 4096, 1.04 vs 1.30 ms at 262144; profiles/r02_dfs_kernels_rates.txt).  In fp32 it fits and wins (config 5).
+   const bool dfs_aba = sizeof(T) == 4 || model->dfs_place >= 0 || model->dfs_aba64;
+   const bool dfs = model->use_dfs && algo != ALGO_CRBA && !bodies && !(algo == ALGO_ABA && (model->n_locked > 0 || !dfs_aba));
    if (!dfs)
    {
       st = ensure_workspace(model, B, sizeof(T));
@@ -1374,6 +1464,10 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->force_st = atoi(e);
    if (const char *e = getenv("MH_DFS"))
       m->use_dfs = atoi(e) != 0;
+   if (const char *e = getenv("MH_DFS_ABA64"))
+      m->dfs_aba64 = atoi(e) != 0;
+   if (const char *e = getenv("MH_DFS_BUDGET"))
+      m->dfs_budget = std::max(0, atoi(e));
    if (const char *e = getenv("MH_DFS_PLACE"))
       m->dfs_place = atoi(e);
    if (const char *e = getenv("MH_DFS_WIN"))
@@ -1396,6 +1490,7 @@ void mh_model_destroy(mh_model_t m)
 {
    if (!m)
       return;
+   dfs_plans_drop(m);
    (void)hipFree(m->d_meta);
    (void)hipFree(m->d_dof);
    (void)hipFree(m->d_cfg);
@@ -1695,6 +1790,7 @@ mh_status mh_model_set_joint_source_modes(mh_model_t model, const int32_t *modes
    }
    HIP_TRY(hipDeviceSynchronize());
    HIP_TRY(hipMemcpy(model->d_meta, model->meta.data(), model->meta.size() * sizeof(int), hipMemcpyHostToDevice));
+   dfs_plans_drop(model); // copies of the records
    model->n_locked = n_locked;
    return MH_OK;
 }

@@ -11,8 +11,13 @@
 //     say where the operands are: in registers (the previous event left them there: a chain never touches memory) or in the stack
 //     frame of the body / its parent;
 //   * stack frames exist for non-leaf bodies only; their offsets are a function of the tree (sum of the ancestors' frame sizes), so the
-//     stack a lane needs is (deepest path) x (frame), not (bodies) x (record): 146 slots instead of ~2500 on the 128-body tree.  It lives
-//     in LDS (slot-major, [slot][64 lanes]: conflict-free) when a few waves per CU fit, else in a global slot-major workspace;
+//     stack a lane needs is (deepest path) x (frame), not (bodies) x (record): 146 slots instead of ~2500 on the 128-body tree.  Every
+//     frame has a HOME chosen by the host (mh_api.hip: dfs_plan): LDS (slot-major, [slot][64 lanes]: conflict-free) or this wave's block
+//     of a global slot-major workspace.  A slot number in the body's record carries its home (DFS_LDS bit).  The host fills LDS from the
+//     leaves upwards: a frame goes to LDS when it still fits on top of the deepest LDS path below it, so with a budget of 20 KB per wave
+//     (8 waves per CU) the many small subtrees near the leaves -- most of the frames, hence most of the traffic -- never leave the CU,
+//     and only the few bodies near the root use the global stack.  Measured on the 128-body tree the all-global stack moved 5 (RNEA) and
+//     18 (ABA) times the algorithmic bytes through HBM at 4-6 TB/s: those kernels were bound by their own workspace;
 //   * RNEA needs nothing else.  ABA's inward sweep (passes one and two fused into the walk) hands U, 1/D, u' = u - U.c (and cos, sin, c
 //     for bodies with children) per body to the outward sweep: 8..16 values per body instead of 30+, in LDS for small models, in the
 //     global workspace otherwise.
@@ -52,63 +57,116 @@ __host__ __device__ constexpr int aba_hand_slots(int type, int n_children)
    return own + ((n_children > 0 && type != JT_FIXED) ? 6 : 0);
 }
 
-#define MH_ST(slot) st[(long)(slot)*ss]
-template <typename T, class P>
-MH_DEV void st_store6(P st, long ss, int slot, const SV<T> &v)
+// ---- the per-lane depth stack: slot codes carry the frame's home
+enum : int
 {
-   MH_ST(slot + 0) = v.a.x, MH_ST(slot + 1) = v.a.y, MH_ST(slot + 2) = v.a.z, MH_ST(slot + 3) = v.l.x, MH_ST(slot + 4) = v.l.y, MH_ST(slot + 5) = v.l.z;
-}
-template <typename T, class P>
-MH_DEV SV<T> st_load6(P st, long ss, int slot)
+   DFS_LDS = 1 << 20,      // slot code: the frame lives in LDS (else in the wave's block of the global workspace)
+   DFS_SLOT = DFS_LDS - 1
+};
+template <typename T>
+using dfs_lds_ptr = T __attribute__((address_space(3))) *;
+// MODE: 0 = every frame in LDS, 1 = every frame in the global block (no branch in either), 2 = per frame, as the slot code says
+template <typename T, int MODE>
+struct DStack
+{ // [slot][64 lanes] blocks, this lane's column.  The two homes are pointers of different address spaces on purpose: with two generic
+  // pointers the compiler merges the branches of a group into flat_load / flat_store through a selected pointer
+   static constexpr int mode = MODE;
+   dfs_lds_ptr<T> lds;
+   T *glb;
+};
+// one wave-uniform branch per GROUP of accesses (the code is a scalar): ds_* on one side, global_* on the other, never flat
+#define MH_ST_GROUP(code, ...)                               \
+   if (SK::mode == 0 || (SK::mode == 2 && ((code)&DFS_LDS))) \
+   {                                                         \
+      const dfs_lds_ptr<T> sp = S.lds + ((code)&DFS_SLOT) * 64; \
+      __VA_ARGS__                                            \
+   }                                                         \
+   else                                                      \
+   {                                                         \
+      T *const sp = S.glb + (long)(code)*64;                 \
+      __VA_ARGS__                                            \
+   }
+#define MH_SP(k) sp[(k)*64]
+template <typename T, class SK>
+MH_DEV void st_store6(const SK &S, int code, const SV<T> &v)
 {
-   return SV<T>{V3<T>{MH_ST(slot + 0), MH_ST(slot + 1), MH_ST(slot + 2)}, V3<T>{MH_ST(slot + 3), MH_ST(slot + 4), MH_ST(slot + 5)}};
+   MH_ST_GROUP(code, MH_SP(0) = v.a.x; MH_SP(1) = v.a.y; MH_SP(2) = v.a.z; MH_SP(3) = v.l.x; MH_SP(4) = v.l.y; MH_SP(5) = v.l.z;)
 }
-template <typename T, class P>
-MH_DEV void st_store_jx(P st, long ss, int slot, int type, const JX<T> &jx)
+template <typename T, class SK>
+MH_DEV SV<T> st_load6(const SK &S, int code)
+{
+   SV<T> v;
+   MH_ST_GROUP(code, v.a.x = MH_SP(0); v.a.y = MH_SP(1); v.a.z = MH_SP(2); v.l.x = MH_SP(3); v.l.y = MH_SP(4); v.l.z = MH_SP(5);)
+   return v;
+}
+template <typename T, class SK>
+MH_DEV void st_add6(const SK &S, int code, const SV<T> &v)
+{
+   MH_ST_GROUP(code, MH_SP(0) += v.a.x; MH_SP(1) += v.a.y; MH_SP(2) += v.a.z; MH_SP(3) += v.l.x; MH_SP(4) += v.l.y; MH_SP(5) += v.l.z;)
+}
+template <typename T, class SK>
+MH_DEV void st_store_jx(const SK &S, int code, int type, const JX<T> &jx)
 {
    if (type == JT_REVOLUTE)
-      MH_ST(slot) = jx.c, MH_ST(slot + 1) = jx.s;
+   {
+      MH_ST_GROUP(code, MH_SP(0) = jx.c; MH_SP(1) = jx.s;)
+   }
    else if (type == JT_PRISMATIC)
-      MH_ST(slot) = jx.d;
+   {
+      MH_ST_GROUP(code, MH_SP(0) = jx.d;)
+   }
    else if (general_x(type))
    {
-      MH_ST(slot + 0) = jx.X.R.xx, MH_ST(slot + 1) = jx.X.R.xy, MH_ST(slot + 2) = jx.X.R.xz, MH_ST(slot + 3) = jx.X.R.yx, MH_ST(slot + 4) = jx.X.R.yy;
-      MH_ST(slot + 5) = jx.X.R.yz, MH_ST(slot + 6) = jx.X.R.zx, MH_ST(slot + 7) = jx.X.R.zy, MH_ST(slot + 8) = jx.X.R.zz;
-      MH_ST(slot + 9) = jx.X.p.x, MH_ST(slot + 10) = jx.X.p.y, MH_ST(slot + 11) = jx.X.p.z;
+      MH_ST_GROUP(code, MH_SP(0) = jx.X.R.xx; MH_SP(1) = jx.X.R.xy; MH_SP(2) = jx.X.R.xz; MH_SP(3) = jx.X.R.yx; MH_SP(4) = jx.X.R.yy; MH_SP(5) = jx.X.R.yz;
+                  MH_SP(6) = jx.X.R.zx; MH_SP(7) = jx.X.R.zy; MH_SP(8) = jx.X.R.zz; MH_SP(9) = jx.X.p.x; MH_SP(10) = jx.X.p.y; MH_SP(11) = jx.X.p.z;)
    }
 }
-template <typename T, class P>
-MH_DEV JX<T> st_load_jx(P st, long ss, int slot, int type)
+template <typename T, class SK>
+MH_DEV JX<T> st_load_jx(const SK &S, int code, int type)
 {
    JX<T> jx;
    jx.c = T(1), jx.s = T(0), jx.d = T(0);
    if (type == JT_REVOLUTE)
-      jx.c = MH_ST(slot), jx.s = MH_ST(slot + 1);
+   {
+      MH_ST_GROUP(code, jx.c = MH_SP(0); jx.s = MH_SP(1);)
+   }
    else if (type == JT_PRISMATIC)
-      jx.d = MH_ST(slot);
+   {
+      MH_ST_GROUP(code, jx.d = MH_SP(0);)
+   }
    else if (general_x(type))
    {
-      jx.X.R = M3<T>{MH_ST(slot + 0), MH_ST(slot + 1), MH_ST(slot + 2), MH_ST(slot + 3), MH_ST(slot + 4), MH_ST(slot + 5), MH_ST(slot + 6), MH_ST(slot + 7), MH_ST(slot + 8)};
-      jx.X.p = V3<T>{MH_ST(slot + 9), MH_ST(slot + 10), MH_ST(slot + 11)};
+      MH_ST_GROUP(code, jx.X.R = M3<T>{MH_SP(0), MH_SP(1), MH_SP(2), MH_SP(3), MH_SP(4), MH_SP(5), MH_SP(6), MH_SP(7), MH_SP(8)};
+                  jx.X.p = V3<T>{MH_SP(9), MH_SP(10), MH_SP(11)};)
    }
    return jx;
 }
-template <typename T, class P>
-MH_DEV void st_store_abi(P st, long ss, int s, const ABI<T> &I)
+template <typename T, class SK>
+MH_DEV void st_store_abi(const SK &S, int code, const ABI<T> &I)
 {
-   MH_ST(s + 0) = I.A.xx, MH_ST(s + 1) = I.A.xy, MH_ST(s + 2) = I.A.xz, MH_ST(s + 3) = I.A.yy, MH_ST(s + 4) = I.A.yz, MH_ST(s + 5) = I.A.zz;
-   MH_ST(s + 6) = I.L.xx, MH_ST(s + 7) = I.L.xy, MH_ST(s + 8) = I.L.xz, MH_ST(s + 9) = I.L.yy, MH_ST(s + 10) = I.L.yz, MH_ST(s + 11) = I.L.zz;
-   MH_ST(s + 12) = I.C.xx, MH_ST(s + 13) = I.C.xy, MH_ST(s + 14) = I.C.xz, MH_ST(s + 15) = I.C.yx, MH_ST(s + 16) = I.C.yy, MH_ST(s + 17) = I.C.yz;
-   MH_ST(s + 18) = I.C.zx, MH_ST(s + 19) = I.C.zy, MH_ST(s + 20) = I.C.zz;
+   MH_ST_GROUP(code, MH_SP(0) = I.A.xx; MH_SP(1) = I.A.xy; MH_SP(2) = I.A.xz; MH_SP(3) = I.A.yy; MH_SP(4) = I.A.yz; MH_SP(5) = I.A.zz;
+               MH_SP(6) = I.L.xx; MH_SP(7) = I.L.xy; MH_SP(8) = I.L.xz; MH_SP(9) = I.L.yy; MH_SP(10) = I.L.yz; MH_SP(11) = I.L.zz;
+               MH_SP(12) = I.C.xx; MH_SP(13) = I.C.xy; MH_SP(14) = I.C.xz; MH_SP(15) = I.C.yx; MH_SP(16) = I.C.yy; MH_SP(17) = I.C.yz;
+               MH_SP(18) = I.C.zx; MH_SP(19) = I.C.zy; MH_SP(20) = I.C.zz;)
 }
-template <typename T, class P>
-MH_DEV ABI<T> st_load_abi(P st, long ss, int s)
+template <typename T, class SK>
+MH_DEV ABI<T> st_load_abi(const SK &S, int code)
 {
    ABI<T> I;
-   I.A = S3<T>{MH_ST(s + 0), MH_ST(s + 1), MH_ST(s + 2), MH_ST(s + 3), MH_ST(s + 4), MH_ST(s + 5)};
-   I.L = S3<T>{MH_ST(s + 6), MH_ST(s + 7), MH_ST(s + 8), MH_ST(s + 9), MH_ST(s + 10), MH_ST(s + 11)};
-   I.C = M3<T>{MH_ST(s + 12), MH_ST(s + 13), MH_ST(s + 14), MH_ST(s + 15), MH_ST(s + 16), MH_ST(s + 17), MH_ST(s + 18), MH_ST(s + 19), MH_ST(s + 20)};
+   MH_ST_GROUP(code, I.A = S3<T>{MH_SP(0), MH_SP(1), MH_SP(2), MH_SP(3), MH_SP(4), MH_SP(5)};
+               I.L = S3<T>{MH_SP(6), MH_SP(7), MH_SP(8), MH_SP(9), MH_SP(10), MH_SP(11)};
+               I.C = M3<T>{MH_SP(12), MH_SP(13), MH_SP(14), MH_SP(15), MH_SP(16), MH_SP(17), MH_SP(18), MH_SP(19), MH_SP(20)};)
    return I;
+}
+// accumulator of a body with several children: (articulated inertia 21, bias wrench 6) += contribution
+template <typename T, class SK>
+MH_DEV void st_add_abi6(const SK &S, int code, const ABI<T> &I, const SV<T> &p)
+{
+   MH_ST_GROUP(code, MH_SP(0) += I.A.xx; MH_SP(1) += I.A.xy; MH_SP(2) += I.A.xz; MH_SP(3) += I.A.yy; MH_SP(4) += I.A.yz; MH_SP(5) += I.A.zz;
+               MH_SP(6) += I.L.xx; MH_SP(7) += I.L.xy; MH_SP(8) += I.L.xz; MH_SP(9) += I.L.yy; MH_SP(10) += I.L.yz; MH_SP(11) += I.L.zz;
+               MH_SP(12) += I.C.xx; MH_SP(13) += I.C.xy; MH_SP(14) += I.C.xz; MH_SP(15) += I.C.yx; MH_SP(16) += I.C.yy; MH_SP(17) += I.C.yz;
+               MH_SP(18) += I.C.zx; MH_SP(19) += I.C.zy; MH_SP(20) += I.C.zz; MH_SP(21) += p.a.x; MH_SP(22) += p.a.y; MH_SP(23) += p.a.z;
+               MH_SP(24) += p.l.x; MH_SP(25) += p.l.y; MH_SP(26) += p.l.z;)
 }
 
 // ---- inputs of one body, fetched ONE EVENT AHEAD of their use.  The walk is a chain of dependent latencies otherwise -- scalar load of
@@ -241,9 +299,10 @@ MH_DEV void write_joint_rows(int type, ciptr di, T *row, long es, const SV<T> &f
 }
 
 // ============================================================================================ RNEA
-// STK_LDS: the depth stack lives in LDS ([slot][64]), else in this wave's block of the global workspace A.ws ([wave][slot][64]).
+// The depth stack: m.rnea_stack slots of LDS ([slot][64]) + this wave's block of the global workspace A.ws ([wave][slot][64]); the slot
+// codes in the bodies' records say which (DStack).
 // WIN: AoS state rows are read through LDS windows (identity index maps), see window_refill.
-template <typename T, bool STK_LDS, bool WIN>
+template <typename T, bool WIN, int MODE>
 __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -253,8 +312,9 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
    const int tid = threadIdx.x;
    const long nlanes = (long)gridDim.x * 64;
    const V3<T> Z{T(0), T(0), T(0)};
-   T *const wq = (T *)lds_raw + (STK_LDS ? (long)m.rnea_stack * 64 : 0), *const wv = wq + ROW_WIN * ROW_PITCH, *const wx = wv + ROW_WIN * ROW_PITCH;
-   auto walk = [&](auto st, const long ss) {
+   T *const wq = (T *)lds_raw + (long)m.rnea_stack * 64, *const wv = wq + ROW_WIN * ROW_PITCH, *const wx = wv + ROW_WIN * ROW_PITCH;
+   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + (long)blockIdx.x * A.ws_stride + tid};
+   {
       // wave-uniform loop over groups of 64 configurations: the lanes of a ragged last group repeat its last configuration (no store)
       for (long cfg0 = (long)blockIdx.x * 64; cfg0 < A.B; cfg0 += nlanes)
       {
@@ -342,7 +402,7 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                else if (ev & EV_PARENT_REGS)
                   vp = v_reg, ap = a_reg;
                else
-                  vp = st_load6<T>(st, ss, mi[MI_PVA_R]), ap = st_load6<T>(st, ss, mi[MI_PVA_R] + 6);
+                  vp = st_load6<T>(S, mi[MI_PVA_R]), ap = st_load6<T>(S, mi[MI_PVA_R] + 6);
                JX<T> jx;
                SV<T> vJ{Z, Z}, aJ{Z, Z};
                jx.c = T(1), jx.s = T(0), jx.d = T(0);
@@ -365,10 +425,10 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                   f = f - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
                if (nch >= 1)
                { // children follow: park what POP needs
-                  st_store6<T>(st, ss, fr, f);
-                  st_store_jx<T>(st, ss, fr + 6, type, jx);
+                  st_store6<T>(S, fr, f);
+                  st_store_jx<T>(S, fr + 6, type, jx);
                   if (nch >= 2)
-                     st_store6<T>(st, ss, fr + 6 + jx_slots(type), v), st_store6<T>(st, ss, fr + 12 + jx_slots(type), a);
+                     st_store6<T>(S, fr + 6 + jx_slots(type), v), st_store6<T>(S, fr + 12 + jx_slots(type), a);
                }
                v_reg = v, a_reg = a, f_reg = f, jx_reg = jx;
             }
@@ -380,8 +440,8 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                   f = f_reg, jx = jx_reg;
                else
                {
-                  f = st_load6<T>(st, ss, fr) + carry;
-                  jx = st_load_jx<T>(st, ss, fr + 6, type);
+                  f = st_load6<T>(S, fr) + carry;
+                  jx = st_load_jx<T>(S, fr + 6, type);
                }
                if (active)
                   write_joint_rows<T>(type, dof_map + mi[MI_DOF], trow, A.v_es, f);
@@ -391,24 +451,20 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                   if (ev & EV_LAST_CHILD)
                      carry = fp;
                   else
-                     st_store6<T>(st, ss, mi[MI_PFR_R], st_load6<T>(st, ss, mi[MI_PFR_R]) + fp);
+                     st_add6<T>(S, mi[MI_PFR_R], fp);
                }
             }
          }
       }
-   };
-   // both homes of the stack are blocks of [slot][64 lanes]: the slot stride is a compile-time constant, slot offsets fold into immediates
-   if constexpr (STK_LDS)
-      walk((T *)lds_raw + tid, 64L);
-   else
-      walk(A.ws + (long)blockIdx.x * A.ws_stride + tid, 64L);
+   }
 }
 
 // ============================================================================================ ABA
-// STK_LDS / HND_LDS: where the depth stack and the inward -> outward hand-over live (LDS, stack first; or the global workspace, stack first).
+// The depth stack: m.aba_stack slots of LDS + the wave's block of the global workspace (slot codes, DStack).  HND_LDS: the inward ->
+// outward hand-over lives in LDS behind the stack, else at the start of the wave's global block (the global part of the stack follows).
 // WIN: the inward sweep reads q and qd of AoS matrices through LDS windows (window_refill); tau (consumed in post-order), the outward
 // sweep's re-reads of q and the accelerations written are per-lane accesses.
-template <typename T, bool STK_LDS, bool HND_LDS, bool WIN>
+template <typename T, bool HND_LDS, bool WIN, int MODE>
 __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -418,9 +474,11 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
    const int tid = threadIdx.x;
    const long nlanes = (long)gridDim.x * 64;
    const V3<T> Z{T(0), T(0), T(0)};
-   T *const wq = (T *)lds_raw + ((STK_LDS ? (long)m.aba_stack : 0) + (HND_LDS ? (long)m.aba_hand : 0)) * 64, *const wv = wq + ROW_WIN * ROW_PITCH;
-   auto walk = [&](auto st, const long ss, auto hd, const long hs) {
-#define MH_HD(slot) hd[(long)(slot)*hs]
+   T *const wq = (T *)lds_raw + ((long)m.aba_stack + (HND_LDS ? (long)m.aba_hand : 0)) * 64, *const wv = wq + ROW_WIN * ROW_PITCH;
+   T *const glb = A.ws + (long)blockIdx.x * A.ws_stride + tid; // this wave's block of the global workspace, [slot][64 lanes]
+   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, glb + (HND_LDS ? 0 : (long)m.aba_hand * 64)};
+   auto walk = [&](auto hd) {
+#define MH_HD(slot) hd[(long)(slot)*64]
       for (long cfg0 = (long)blockIdx.x * 64; cfg0 < A.B; cfg0 += nlanes)
       {
          const bool active = cfg0 + tid < A.B;
@@ -498,7 +556,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                else if (ev & EV_PARENT_REGS)
                   vp = v_reg;
                else
-                  vp = st_load6<T>(st, ss, mi[MI_PV_A]);
+                  vp = st_load6<T>(S, mi[MI_PV_A]);
                JX<T> jx;
                SV<T> vJ{Z, Z};
                jx.c = T(1), jx.s = T(0), jx.d = T(0);
@@ -519,10 +577,10 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                const SV<T> cj = crm(v, vJ);
                if (nch >= 1)
                {
-                  st_store6<T>(st, ss, fr, p), st_store6<T>(st, ss, fr + 6, cj);
-                  st_store_jx<T>(st, ss, fr + 12, type, jx);
+                  st_store6<T>(S, fr, p), st_store6<T>(S, fr + 6, cj);
+                  st_store_jx<T>(S, fr + 12, type, jx);
                   if (nch >= 2)
-                     st_store6<T>(st, ss, fr + 12 + jxs, v);
+                     st_store6<T>(S, fr + 12 + jxs, v);
                }
                v_reg = v, p_reg = p, c_reg = cj, jx_reg = jx;
             }
@@ -535,13 +593,13 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   pA = p_reg, cj = c_reg, jx = jx_reg;
                else
                {
-                  pA = st_load6<T>(st, ss, fr) + pcarry, cj = st_load6<T>(st, ss, fr + 6);
-                  jx = st_load_jx<T>(st, ss, fr + 12, type);
+                  pA = st_load6<T>(S, fr) + pcarry, cj = st_load6<T>(S, fr + 6);
+                  jx = st_load_jx<T>(S, fr + 12, type);
                   add(IA, Icarry);
                   if (nch >= 2)
                   {
-                     add(IA, st_load_abi<T>(st, ss, fr + 18 + jxs));
-                     pA = pA + st_load6<T>(st, ss, fr + 39 + jxs);
+                     add(IA, st_load_abi<T>(S, fr + 18 + jxs));
+                     pA = pA + st_load6<T>(S, fr + 39 + jxs);
                   }
                }
                ABI<T> Ia = IA;
@@ -635,14 +693,9 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   {
                      const int acc = mi[MI_PACC_A];
                      if (ev & EV_ACC_FIRST)
-                        st_store_abi<T>(st, ss, acc, Ia), st_store6<T>(st, ss, acc + 21, pp);
+                        st_store_abi<T>(S, acc, Ia), st_store6<T>(S, acc + 21, pp);
                      else
-                     {
-                        ABI<T> s = st_load_abi<T>(st, ss, acc);
-                        add(s, Ia);
-                        st_store_abi<T>(st, ss, acc, s);
-                        st_store6<T>(st, ss, acc + 21, st_load6<T>(st, ss, acc + 21) + pp);
-                     }
+                        st_add_abi6<T>(S, acc, Ia, pp);
                   }
                }
             }
@@ -670,7 +723,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             else if (parent == j - 1)
                ap = a_reg;
             else
-               ap = st_load6<T>(st, ss, mi[MI_PFR_A]);
+               ap = st_load6<T>(S, mi[MI_PFR_A]);
             JX<T> jx;
             if (type == JT_REVOLUTE)
                jx.c = MH_HD(hf + 8), jx.s = MH_HD(hf + 9), jx.d = T(0);
@@ -728,20 +781,17 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   a = SV<T>{V3<T>{MH_HD(hf + 6), MH_HD(hf + 7), MH_HD(hf + 8)}, V3<T>{MH_HD(hf + 9), MH_HD(hf + 10), MH_HD(hf + 11)}};
             }
             if (nch >= 2)
-               st_store6<T>(st, ss, fr, a); // later children re-read it
+               st_store6<T>(S, fr, a); // later children re-read it
             a_reg = a;
          }
       }
 #undef MH_HD
    };
-   T *const lds = (T *)lds_raw + tid;
-   T *const glb = A.ws + (long)blockIdx.x * A.ws_stride + tid; // this wave's block of the global workspace, [slot][64 lanes]
-   if constexpr (STK_LDS && HND_LDS)
-      walk(lds, 64L, lds + (long)m.aba_stack * 64, 64L);
-   else if constexpr (STK_LDS)
-      walk(lds, 64L, glb, 64L);
+   if constexpr (HND_LDS)
+      walk((T *)lds_raw + tid + (long)m.aba_stack * 64);
    else
-      walk(glb, 64L, glb + (long)m.aba_stack * 64, 64L);
+      walk(glb);
 }
-#undef MH_ST
+#undef MH_ST_GROUP
+#undef MH_SP
 } // namespace mh

@@ -26,7 +26,7 @@ def timeit(fn, iters=5, warm=3):
 
 
 def model(desc, **env):
-    keys = ("MH_DFS", "MH_DFS_PLACE", "MH_DISABLE_SPEC", "MH_WAVES_PER_CU", "MH_DFS_WIN")
+    keys = ("MH_DFS", "MH_DFS_PLACE", "MH_DISABLE_SPEC", "MH_WAVES_PER_CU", "MH_DFS_WIN", "MH_DFS_BUDGET", "MH_DFS_ABA64")
     for k in keys:
         os.environ.pop(k, None)
     for k, v in env.items():
@@ -48,8 +48,10 @@ f32 = torch.float32
 q, qd, qdd, tau = (dev(x, f32) for x in rt.nextState(np.random.default_rng(1), tree, B5))
 qs, qds, qdds, taus = T(q), T(qd), T(qdd), T(tau)
 by = 4 * (d5.nq + 3 * d5.nv)
-for label, env in (("sweep kernels (round 1)", dict(MH_DFS=0)), ("dfs auto", {}), ("dfs auto, no row windows", dict(MH_DFS_WIN=0)), ("dfs all LDS", dict(MH_DFS_PLACE=0)),
-                   ("dfs global", dict(MH_DFS_PLACE=2)), ("dfs global, no row windows", dict(MH_DFS_PLACE=2, MH_DFS_WIN=0))):
+for label, env in (("sweep kernels (round 1)", dict(MH_DFS=0)), ("dfs auto (frames near the leaves in LDS)", {}), ("dfs auto, no row windows", dict(MH_DFS_WIN=0)),
+                   ("dfs all LDS", dict(MH_DFS_PLACE=0)), ("dfs all global", dict(MH_DFS_PLACE=2)), ("dfs all global, no row windows", dict(MH_DFS_PLACE=2, MH_DFS_WIN=0)),
+                   ("dfs LDS budget 16 slots", dict(MH_DFS_BUDGET=16)), ("dfs LDS budget 32 slots", dict(MH_DFS_BUDGET=32)), ("dfs LDS budget 48 slots", dict(MH_DFS_BUDGET=48)),
+                   ("dfs LDS budget 64 slots, 6 waves per CU", dict(MH_DFS_BUDGET=64, MH_WAVES_PER_CU=6)), ("dfs 4 waves per CU", dict(MH_WAVES_PER_CU=4))):
     hm = model(d5, **env)
     row(f"C5 RNEA fp32 AoS  {label}", B5, timeit(lambda: hm.rnea(q, qd, qdd, g)), by)
     row(f"C5 RNEA fp32 SoA  {label}", B5, timeit(lambda: hm.rnea(qs, qds, qdds, g, layout=_lib.LAYOUT_SOA)), by)
@@ -61,7 +63,7 @@ dh = hum.toModelDesc()
 for B in (4096, 32768, 262144):
     q, qd, qdd, tau = (dev(x) for x in rt.nextState(np.random.default_rng(2342), hum, B))
     by = 8 * (dh.nq + 3 * dh.nv)
-    for label, env in (("specialised", {}), ("sweep kernels", dict(MH_DISABLE_SPEC=1, MH_DFS=0)), ("dfs auto", dict(MH_DISABLE_SPEC=1)),
+    for label, env in (("specialised", {}), ("sweep kernels", dict(MH_DISABLE_SPEC=1, MH_DFS=0)), ("auto (RNEA depth-first, fp64 ABA sweep)", dict(MH_DISABLE_SPEC=1)), ("dfs auto, ABA too", dict(MH_DISABLE_SPEC=1, MH_DFS_ABA64=1)),
                        ("dfs all LDS", dict(MH_DISABLE_SPEC=1, MH_DFS_PLACE=0)), ("dfs stack LDS", dict(MH_DISABLE_SPEC=1, MH_DFS_PLACE=1)),
                        ("dfs global", dict(MH_DISABLE_SPEC=1, MH_DFS_PLACE=2))):
         hm = model(dh, **env)
@@ -75,7 +77,7 @@ for name, sys_ in rt.referenceBenchmarkSystems().items():
     for B in (4096, 262144):
         q, qd, qdd, tau = (dev(x) for x in rt.nextState(np.random.default_rng(2342), sys_, B))
         by = 8 * (d.nq + 3 * d.nv)
-        for label, env in (("sweep kernels", dict(MH_DFS=0)), ("dfs auto", {})):
+        for label, env in (("sweep kernels", dict(MH_DFS=0)), ("auto", {}), ("dfs ABA too", dict(MH_DFS_ABA64=1))):
             hm = model(d, **env)
             row(f"{name} RNEA fp64 {label}", B, timeit(lambda: hm.rnea(q, qd, qdd, g), 10, 3), by)
             row(f"{name} ABA  fp64 {label}", B, timeit(lambda: hm.aba(q, qd, tau, g), 10, 3), by)
