@@ -162,6 +162,7 @@ struct mh_model
    int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
    int dfs_budget = -1;   // MH_DFS_BUDGET: cap of the stack's LDS budget in slots per wave (measurements)
    int dfs_aba64 = 0;     // MH_DFS_ABA64=1: fp64 forward dynamics on the depth-first kernel too (measurements)
+   int dfs_transpose = -1; // MH_DFS_TRANSPOSE = 0 | 1: depth-first kernels on big AoS batches never / always through transposed scratch copies
    double *d_consts64 = nullptr;
    float *d_consts32 = nullptr;
    Workspace ws;
@@ -591,14 +592,15 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       return MH_OK;
       } // else: this (algorithm, memory plan) is not in the code object -- the run-time-topology kernels below serve the call
    }
-   if (dfs)
-      return launch_dfs<T>(algo, model, B, A, stream);
    // Run-time-topology RNEA / ABA on AoS matrices: for big batches of wide matrices go through transposed scratch copies
-   // (mh::transpose_kernel).  External wrenches keep their own strides.
+   // (mh::transpose_kernel).  External wrenches keep their own strides.  The depth-first RNEA reads AoS rows through LDS windows instead
+   // (mh_dfs_kernels.h, RowWindow) unless MH_DFS_TRANSPOSE=1; the depth-first ABA has no registers left for windows and takes the copies.
    T *t_out = nullptr;
    if (algo != ALGO_CRBA && !soa)
    {
-      const bool want = model->use_transpose >= 0 ? model->use_transpose != 0 : (B >= 8192 && model->nq + model->nv >= 64);
+      bool want = model->use_transpose >= 0 ? model->use_transpose != 0 : (B >= 8192 && model->nq + model->nv >= 64);
+      if (dfs && want)
+         want = model->dfs_transpose >= 0 ? model->dfs_transpose != 0 : (algo == ALGO_ABA || !(model->ident_maps && model->use_win));
       if (want)
       {
          const size_t nq = model->nq, nv = model->nv;
@@ -615,6 +617,13 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
          A.q_bs = 1, A.q_es = B, A.v_bs = 1, A.v_es = B;
       }
    }
+   if (dfs)
+   {
+      st = launch_dfs<T>(algo, model, B, A, stream);
+      if (st != MH_OK)
+         return st;
+   }
+   else
    switch (algo)
    {
       case ALGO_RNEA:
@@ -1464,6 +1473,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->force_st = atoi(e);
    if (const char *e = getenv("MH_DFS"))
       m->use_dfs = atoi(e) != 0;
+   if (const char *e = getenv("MH_DFS_TRANSPOSE"))
+      m->dfs_transpose = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_ABA64"))
       m->dfs_aba64 = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_BUDGET"))

@@ -26,7 +26,7 @@ def timeit(fn, iters=5, warm=3):
 
 
 def model(desc, **env):
-    keys = ("MH_DFS", "MH_DFS_PLACE", "MH_DISABLE_SPEC", "MH_WAVES_PER_CU", "MH_DFS_WIN", "MH_DFS_BUDGET", "MH_DFS_ABA64")
+    keys = ("MH_DFS", "MH_DFS_PLACE", "MH_DISABLE_SPEC", "MH_WAVES_PER_CU", "MH_DFS_WIN", "MH_DFS_BUDGET", "MH_DFS_ABA64", "MH_DFS_TRANSPOSE")
     for k in keys:
         os.environ.pop(k, None)
     for k, v in env.items():
@@ -42,6 +42,7 @@ def row(name, B, secs, bytes_per_eval):
 
 
 B5 = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+ONLY5 = len(sys.argv) > 2 and sys.argv[2] == "c5"
 tree = MultiBodySystem.toMultiBodySystemInput(rt.nextJointTree(np.random.default_rng(128), 128, ("revolute", "prismatic", "sixdof"))[0].getPredecessor())
 d5 = tree.toModelDesc()
 f32 = torch.float32
@@ -49,6 +50,7 @@ q, qd, qdd, tau = (dev(x, f32) for x in rt.nextState(np.random.default_rng(1), t
 qs, qds, qdds, taus = T(q), T(qd), T(qdd), T(tau)
 by = 4 * (d5.nq + 3 * d5.nv)
 for label, env in (("sweep kernels (round 1)", dict(MH_DFS=0)), ("dfs auto (frames near the leaves in LDS)", {}), ("dfs auto, no row windows", dict(MH_DFS_WIN=0)),
+                   ("dfs auto, AoS always via transposed copies", dict(MH_DFS_TRANSPOSE=1)), ("dfs auto, AoS never via transposed copies", dict(MH_DFS_TRANSPOSE=0)),
                    ("dfs all LDS", dict(MH_DFS_PLACE=0)), ("dfs all global", dict(MH_DFS_PLACE=2)), ("dfs all global, no row windows", dict(MH_DFS_PLACE=2, MH_DFS_WIN=0)),
                    ("dfs LDS budget 16 slots", dict(MH_DFS_BUDGET=16)), ("dfs LDS budget 32 slots", dict(MH_DFS_BUDGET=32)), ("dfs LDS budget 48 slots", dict(MH_DFS_BUDGET=48)),
                    ("dfs LDS budget 64 slots, 6 waves per CU", dict(MH_DFS_BUDGET=64, MH_WAVES_PER_CU=6)), ("dfs 4 waves per CU", dict(MH_WAVES_PER_CU=4))):
@@ -58,6 +60,8 @@ for label, env in (("sweep kernels (round 1)", dict(MH_DFS=0)), ("dfs auto (fram
     row(f"C5 ABA  fp32 AoS  {label}", B5, timeit(lambda: hm.aba(q, qd, tau, g)), by)
     row(f"C5 ABA  fp32 SoA  {label}", B5, timeit(lambda: hm.aba(qs, qds, taus, g, layout=_lib.LAYOUT_SOA)), by)
 
+if ONLY5:
+    sys.exit(0)
 hum = rt.nextHumanoid(np.random.default_rng(43))
 dh = hum.toModelDesc()
 for B in (4096, 32768, 262144):

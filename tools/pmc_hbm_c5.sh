@@ -3,9 +3,9 @@
 root=$(pwd); out=$root/gpurun_out/pmc_c5hbm; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $out/$c -o pmc --output-format csv -- python3 $root/tools/pmc_dfs.py c5aos > $out/$c.log 2>&1
+  rocprofv3 --pmc $c -d $out/$c -o pmc --output-format csv -- python3 $root/tools/pmc_dfs.py ${LAYOUT:-c5aos} > $out/$c.log 2>&1
 done
-rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 $root/tools/pmc_dfs.py c5aos > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 $root/tools/pmc_dfs.py ${LAYOUT:-c5aos} > $out/trace.log 2>&1
 cd $root
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, json
