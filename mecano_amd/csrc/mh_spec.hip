@@ -96,7 +96,11 @@ hipError_t go(const mh::Args<double> &A, int grid, size_t lds, hipStream_t strea
 // run on the run-time-topology kernels, whose per-lane stack is indexed by tree depth.  Whatever IS built is checked against those
 // kernels when the object is loaded (mh_model_create).
 constexpr int kWholeTreeMaxBodies = 12;
+#ifdef MH_FORCE_WHOLE_TREE_ABA // diagnosis builds only (tools/diag_whole_tree.py): the regime this gate exists to keep out
+constexpr bool kWholeTreeAba = true;
+#else
 constexpr bool kWholeTreeAba = !mh::Split<TP>::usable() && TP::N <= kWholeTreeMaxBodies;
+#endif
 constexpr bool kWholeTreeRnea = mh::Split<TP>::usable() || TP::N <= kWholeTreeMaxBodies;
 template <int ALGO, bool IO, bool ID>
 hipError_t go_st(int flags, const mh::Args<double> &A, int grid, size_t lds, hipStream_t s)
