@@ -172,6 +172,11 @@ struct mh_model
    hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
    hipEvent_t ev_in[3] = {}, ev_run[3] = {}, ev_out[3] = {};
    int host_chunk = 0; // MH_HOST_CHUNK: configurations per chunk of the host-pointer pipeline (0 = choose)
+   // mh_rnea_aba_f64 without a fused kernel, small batches: the two launches run side by side, the ABA on this stream with its own workspace
+   hipStream_t pair_stream = nullptr;
+   hipEvent_t pair_fork = nullptr, pair_join = nullptr;
+   Workspace ws_pair;
+   int use_pair = 1; // MH_DISABLE_PAIR=1: always one after the other
    // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices)
    Workspace tr;
    // scratch of the composite entry points: efforts of the Newton-Euler sweep behind mh_aba_joint_wrenches_f64, pair lists of
@@ -1483,6 +1488,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->dfs_place = atoi(e);
    if (const char *e = getenv("MH_DFS_WIN"))
       m->use_win = atoi(e) != 0;
+   if (getenv("MH_DISABLE_PAIR"))
+      m->use_pair = 0;
    if (const char *e = getenv("MH_HOST_CHUNK"))
       m->host_chunk = std::max(0, atoi(e));
    try_load_spec(m, P);
@@ -1509,6 +1516,13 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->d_consts64);
    (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
+   (void)hipFree(m->ws_pair.ptr);
+   if (m->pair_stream)
+   {
+      (void)hipStreamDestroy(m->pair_stream);
+      (void)hipEventDestroy(m->pair_fork);
+      (void)hipEventDestroy(m->pair_join);
+   }
    (void)hipFree(m->stage.ptr);
    for (int k = 0; k < 3; k++)
    {
@@ -1841,13 +1855,37 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    const bool fusable = model->n_locked == 0 && model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
                         && opts.consider_coriolis && opts.consider_accelerations && 2 * waves <= (long)model->cu_count * model->fused_factor
                         && model->spec.fused_lds_bytes(model->nq, model->nv) <= 160 * 1024;
+   // No fused kernel for this call (no code object, SoA, switches, ...).  While the batch leaves most of the device idle -- the
+   // run-time-topology kernels put one wave per 64 configurations on it -- the two launches run SIDE BY SIDE: the ABA on a stream of the
+   // model's own, forked from and joined back into the caller's stream with events, on a workspace of its own (humanoid without its code
+   // object, B = 4096: 63 + 112 us one after the other, ~115 us together).
+   auto two_calls = [&]() -> mh_status {
+      hipStream_t s = (hipStream_t)opts.stream;
+      if (!model->use_pair || waves > (long)model->cu_count) // measured: pays up to one wave per CU (profiles/r02_generic_pair_side_by_side.txt)
+      {
+         mh_status r = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
+         return r != MH_OK ? r : mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &opts, qdd_out);
+      }
+      if (!model->pair_stream)
+      {
+         HIP_TRY(hipStreamCreateWithFlags(&model->pair_stream, hipStreamNonBlocking));
+         HIP_TRY(hipEventCreateWithFlags(&model->pair_fork, hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&model->pair_join, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(model->pair_fork, s));
+      HIP_TRY(hipStreamWaitEvent(model->pair_stream, model->pair_fork, 0));
+      mh_options ob = opts;
+      ob.stream = (void *)model->pair_stream;
+      std::swap(model->ws, model->ws_pair); // every launch path sizes and reads model->ws
+      const mh_status rb = mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &ob, qdd_out);
+      std::swap(model->ws, model->ws_pair);
+      const mh_status ra = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
+      HIP_TRY(hipEventRecord(model->pair_join, model->pair_stream)); // join even after an error: the caller's stream must not run ahead
+      HIP_TRY(hipStreamWaitEvent(s, model->pair_join, 0));
+      return rb != MH_OK ? rb : ra;
+   };
    if (!fusable)
-   {
-      st = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
-      if (st != MH_OK)
-         return st;
-      return mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &opts, qdd_out);
-   }
+      return two_calls();
    mh::Args<double> A{};
    A.m = dev_model<double>(model);
    A.B = B;
@@ -1867,12 +1905,8 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
       return MH_OK;
    }
    if (!model->spec.supports(1, SPEC_ST_LDS | (model->ident_maps ? SPEC_IDENT : 0)))
-   { // no whole-tree ABA in this code object (trees with a tree-split form) and the tree-split launch was ruled out: two calls
-      st = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
-      if (st != MH_OK)
-         return st;
-      return mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &opts, qdd_out);
-   }
+   // no whole-tree ABA in this code object (trees with a tree-split form) and the tree-split launch was ruled out: two calls
+      return two_calls();
    const int rc = model->spec.launch_fused(model->ident_maps ? SPEC_IDENT : 0, &A, (int)waves, opts.stream);
    if (rc != 0)
       return fail(MH_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
