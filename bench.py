@@ -94,16 +94,50 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, jobs, target_s=10.0):
                       f"oracle/mecano_oracle.c (C restatement in fp64, not Mecano/JVM), {cores} threads, {dt:.1f} s; one thread alone: {single:.0f} configs/s"}
 
 
-def measured_traffic(fused_launch, B):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE,
-    separate passes, same command; FETCH_SIZE x 2 as calibrated on this access pattern, profiles/r01_pmc_calibration_8B_per_lane.txt);
-    only quoted for the configuration they were collected on, else null."""
+def committed_traffic(fused_launch, B):
+    """Fallback for `roofline.traffic`: the rocprofv3 PMC passes committed under profiles/ (same workload, same correction); only quoted
+    for the configuration they were collected on, else null."""
     for name in ("r02_fused_split_b4096_hbm_pmc.json", "r01_fused_split_b4096_hbm_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if fused_launch and B == BATCH and os.path.exists(path):
             pmc = json.load(open(path))
-            return (pmc.get("FETCH_SIZE_correction", 1.0) * pmc["FETCH_SIZE_KB_per_launch_mean"] + pmc["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0
-    return None
+            return (pmc.get("FETCH_SIZE_correction", 1.0) * pmc["FETCH_SIZE_KB_per_launch_mean"] + pmc["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0, "profiles/" + name
+    return None, None
+
+
+def live_traffic(B):
+    """HBM bytes per launch of the dominant kernel, measured for THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, nothing else enabled) run a short form of this very command BEFORE this process touches the GPU; the
+    launches of the benchmark's grid are picked out by kernel name and grid size (the create-time self-check launches the same kernel on
+    197 configurations).  FETCH_SIZE counts half of the bytes read on this access pattern (profiles/r01_pmc_calibration_8B_per_lane.txt),
+    WRITE_SIZE the bytes written.  None when rocprofv3 is missing, when this process already runs under a profiler, or on any failure."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if (not exe or os.environ.get("MH_BENCH_NO_PMC") or os.environ.get("MH_BENCH_PMC_INNER") or "rocprof" in os.environ.get("LD_PRELOAD", "")
+            or any(k.startswith("ROCPROF") for k in os.environ)):
+        return None
+    grid = 2 * ((B + 63) // 64) * 256  # fused tree-split launch: RNEA and ABA workgroups of 256 threads per 64 configurations
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="mh_bench_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", MH_BENCH_PMC_INNER="1")
+            subprocess.run([exe, "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                            "--steps", "20", "--warmup", "5", "--regions", "1", "--no-cpu-baseline", "--batch", str(B)],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "fused_split" in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) == grid:
+                        vals.append(float(r["Counter_Value"]))
+            if len(vals) < 10:
+                return None
+            kb[counter] = sum(vals) / len(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
 
 
 def main():
@@ -122,6 +156,9 @@ def main():
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if env_world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    # roofline.traffic measured for this run (N = 1, the metric's configuration), in child processes, before this one touches the GPU
+    pmc_bytes = live_traffic(args.batch or BATCH) if (args.gpus == 1 and args.config == 0 and not args.separate) else None
 
     import torch
     import torch.distributed as dist
@@ -292,6 +329,10 @@ def main():
                  3: "30-DoF humanoid, RNEA and CRBA (30 x 30 mass matrix) of every configuration per step, fp64, AoS",
                  4: "30-DoF humanoid, ABA of every configuration per step, fp64, AoS, batch sharded over the GPUs",
                  5: "random 128-body tree (revolute / prismatic / 6-DoF joints), RNEA and ABA per step, fp32, AoS, batch sharded over the GPUs"}
+    if pmc_bytes is not None and fused_launch:
+        traffic, traffic_source = pmc_bytes, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, child processes of this run), 2 x FETCH + WRITE"
+    else:
+        traffic, traffic_source = committed_traffic(fused_launch, B)
     line = {
         "metric": names[cfg],
         "value": value, "unit": "configs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -304,7 +345,7 @@ def main():
                    "model_seed": MODEL_SEED if cfg != 5 else 128, "state_seed": STATE_SEED},
         "regions": R, "region_ms": [s * 1e3 for s in region_s], "reported_region": "median",
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(fused_launch, B),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_config": dom_bytes, "launch_ms": dom_ms},
         "kernels_ms": kernels_ms,
         "per_rank": per_rank,

@@ -3,6 +3,7 @@
 # rocprofv3 kernel-trace statistics of the default bench.py run, then the HBM counters in their own passes (never combined with
 # trace flags).  Summaries land in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 tag=${1:-prof}
+export MH_BENCH_NO_PMC=1   # bench.py must not start profiler children of its own from under a profiler
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
