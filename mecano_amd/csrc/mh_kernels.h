@@ -511,8 +511,10 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
-   const long ws_stride = A.ws_stride;
-   T *ws = A.ws + lane;
+   // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
+   // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
    const V3<T> Z{T(0), T(0), T(0)};
 
    for (long cfg = lane; cfg < A.B; cfg += nlanes)
@@ -735,6 +737,9 @@ MH_DEV SV<T> spd6_solve(const ABI<T> &I, SV<T> b)
 // LOCKED: some joints are ACCELERATION_SOURCE (:1237-1253, 1284-1297, 1315-1363).  Mecano's pass four re-runs a Newton-Euler sweep to
 // get the efforts of those joints; here tau = S^T (IA a + pA) is read off the articulated quantities pass two already holds, which is
 // the same wrench (the articulated-body equation of the subtree) without a fourth sweep.
+#ifndef MH_SWEEP_AHEAD
+#define MH_SWEEP_AHEAD 0
+#endif
 template <typename T, bool LDSC, bool LOCKED = false, bool BODIES = false>
 __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
 {
@@ -750,8 +755,10 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
-   const long ws_stride = A.ws_stride;
-   T *ws = A.ws + lane;
+   // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
+   // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
    const V3<T> Z{T(0), T(0), T(0)};
 
    for (long cfg = lane; cfg < A.B; cfg += nlanes)
@@ -762,13 +769,32 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
       T *orow = A.out + cfg * A.v_bs;
 
+      // The per-lane operands of a body are gathered by pre1 / pre2 / pre3 (1-DoF joints: rows resolved in the body's record, no walk
+      // through the index maps); MH_SWEEP_AHEAD = 1 requests them one body ahead.
       // ---- pass one (ForwardDynamicsCalculator.java:1085-1127): velocities, bias wrench p, bias acceleration c
       SV<T> v_prev{Z, Z};
+      T nq_ = T(0), nv_ = T(0);
+      auto pre1 = [&](int j1) {
+         if (j1 < m.n)
+         {
+            ciptr m1 = meta + j1 * MI_STRIDE;
+            const int t1 = m1[MI_TYPE];
+            if (t1 == JT_REVOLUTE || t1 == JT_PRISMATIC)
+               nq_ = qrow[m1[MI_ROW_Q] * A.q_es], nv_ = qdrow[m1[MI_ROW_V] * A.v_es];
+         }
+      };
+      if (MH_SWEEP_AHEAD)
+         pre1(0);
       for (int j = 0; j < m.n; j++)
       {
          ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
          const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         if (!MH_SWEEP_AHEAD)
+            pre1(j);
+         const T q_in = nq_, v_in = nv_;
+         if (MH_SWEEP_AHEAD)
+            pre1(j + 1);
          SV<T> vp;
          if (parent < 0)
             vp = SV<T>{Z, Z};
@@ -777,8 +803,22 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          else
             vp = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
          const XF<T> Xb = load_xb<T>(c);
-         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
-         const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+         JX<T> jx;
+         SV<T> vJ{Z, Z};
+         if (type == JT_REVOLUTE)
+         {
+            jx.d = T(0);
+            sincos_t(q_in, jx.s, jx.c);
+            MH_WS(mi[MI_SLOT_JP]) = jx.c, MH_WS(mi[MI_SLOT_JP] + 1) = jx.s;
+            vJ.a.z = v_in;
+         }
+         else if (type == JT_PRISMATIC)
+            jx.c = T(1), jx.s = T(0), jx.d = q_in, vJ.l.z = v_in;
+         else
+         {
+            jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+            vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+         }
          const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
          if constexpr (BODIES)
          {
@@ -799,13 +839,35 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       ABI<T> Icarry;
       SV<T> pcarry{Z, Z};
       bool have_carry = false;
+      // the next body of this sweep is j - 1: its bias wrench and bias acceleration (pass one wrote them; a body in between only adds to
+      // the slots of a NON-adjacent parent, never to those of j - 1) and its effort
+      SV<T> npA{Z, Z}, ncj{Z, Z};
+      T ntau = T(0);
+      auto pre2 = [&](int j1) {
+         if (j1 >= 0)
+         {
+            ciptr m1 = meta + j1 * MI_STRIDE;
+            const int t1 = m1[MI_TYPE];
+            npA = ws_load6(ws, ws_stride, m1[MI_SLOT_F]);
+            if (t1 == JT_REVOLUTE || t1 == JT_PRISMATIC)
+               ncj = ws_load6(ws, ws_stride, m1[MI_SLOT_C]), ntau = taurow[m1[MI_ROW_V] * A.v_es];
+         }
+      };
+      if (MH_SWEEP_AHEAD)
+         pre2(m.n - 1);
       for (int j = m.n - 1; j >= 0; j--)
       {
          ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
          const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          ABI<T> IA = abi_from_rigid(load_inertia<T>(c));
-         SV<T> pA = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         if (!MH_SWEEP_AHEAD)
+            pre2(j);
+         SV<T> pA = npA;
+         const SV<T> cj_in = ncj;
+         const T tau_in = ntau;
+         if (MH_SWEEP_AHEAD)
+            pre2(j - 1);
          if (have_carry)
          {
             add(IA, Icarry);
@@ -818,6 +880,7 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          ciptr di = dof_map + mi[MI_DOF];
          ABI<T> Ia = IA;
          SV<T> pa = pA;
+         bool handed_up = false;
          if (type == JT_REVOLUTE || type == JT_PRISMATIC)
          {
             V3<T> ua, ul;
@@ -850,16 +913,29 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
             else
             {
             const T dinv = T(1) / D;                          // :1183
-            const T u = taurow[di[0] * A.v_es] - pz;          // :1200-1215
+            const T u = tau_in - pz;                          // :1200-1215
             ws_store6(ws, ws_stride, sf, SV<T>{ua, ul});
             MH_WS(sf + 6) = dinv;
             MH_WS(sf + 7) = u;
             if (parent >= 0)
             {
-               rank1_down(Ia, ua, ul, dinv);                   // :1220-1226
-               const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+               const SV<T> cj = cj_in;
                const T ud = u * dinv;
-               pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
+               if (type == JT_REVOLUTE)
+               { // Ia S = 0: structural zeros, and the hand-up in the same block so that the products with them fold (as in the
+                 // depth-first and the specialised kernels)
+                  rank1_down_revolute(Ia, ua, ul, dinv);       // :1220-1226
+                  pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
+                  JX<T> jx;
+                  jx.c = MH_WS(mi[MI_SLOT_JP]), jx.s = MH_WS(mi[MI_SLOT_JP] + 1), jx.d = T(0);
+                  revolute_up(jx, load_xb<T>(c), Ia, pa);      // :1156-1166; pa is now expressed in the parent's frame
+                  handed_up = true;
+               }
+               else
+               {
+                  rank1_down(Ia, ua, ul, dinv);
+                  pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul};
+               }
             }
             }
          }
@@ -913,15 +989,18 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          }
          if (parent >= 0)
          {
-            const XF<T> Xb = load_xb<T>(c);
-            const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
             SV<T> pp = pa;
-            if (type == JT_REVOLUTE)
-               revolute_up(jx, Xb, Ia, pp);
-            else
+            if (!handed_up)
             {
-               abi_up(type, jx, Xb, Ia); // :1156-1166
-               pp = force_up(type, jx, Xb, pa);
+               const XF<T> Xb = load_xb<T>(c);
+               const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+               if (type == JT_REVOLUTE)
+                  revolute_up(jx, Xb, Ia, pp);
+               else
+               {
+                  abi_up(type, jx, Xb, Ia); // :1156-1166
+                  pp = force_up(type, jx, Xb, pa);
+               }
             }
             if (flags & MF_PARENT_ADJ)
             {
@@ -944,11 +1023,34 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       }
       // ---- pass three (:1259-1310): joint accelerations, root to leaves
       SV<T> a_prev{Z, Z};
+      // next body of this sweep: bias acceleration, and for 1-DoF joints U, (cos, sin) | q -- all final since pass two
+      SV<T> ncj3{Z, Z}, nU{Z, Z};
+      T nc_ = T(1), ns_ = T(0);
+      auto pre3 = [&](int j1) {
+         if (j1 < m.n)
+         {
+            ciptr m1 = meta + j1 * MI_STRIDE;
+            const int t1 = m1[MI_TYPE];
+            ncj3 = ws_load6(ws, ws_stride, m1[MI_SLOT_C]);
+            if (t1 == JT_REVOLUTE)
+               nU = ws_load6(ws, ws_stride, m1[MI_SLOT_F]), nc_ = MH_WS(m1[MI_SLOT_JP]), ns_ = MH_WS(m1[MI_SLOT_JP] + 1);
+            else if (t1 == JT_PRISMATIC)
+               nU = ws_load6(ws, ws_stride, m1[MI_SLOT_F]), nc_ = qrow[m1[MI_ROW_Q] * A.q_es];
+         }
+      };
+      if (MH_SWEEP_AHEAD)
+         pre3(0);
       for (int j = 0; j < m.n; j++)
       {
          ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
          const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         if (!MH_SWEEP_AHEAD)
+            pre3(j);
+         const SV<T> cj3 = ncj3, U_in = nU;
+         const T c_in = nc_, s_in = ns_;
+         if (MH_SWEEP_AHEAD)
+            pre3(j + 1);
          SV<T> ap;
          if (parent < 0)
             ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :259-264
@@ -957,13 +1059,19 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          else
             ap = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
          const XF<T> Xb = load_xb<T>(c);
-         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
-         SV<T> a = motion_down(type, jx, Xb, ap) + ws_load6(ws, ws_stride, mi[MI_SLOT_C]); // :1270-1273
+         JX<T> jx;
+         if (type == JT_REVOLUTE)
+            jx.c = c_in, jx.s = s_in, jx.d = T(0);
+         else if (type == JT_PRISMATIC)
+            jx.c = T(1), jx.s = T(0), jx.d = c_in;
+         else
+            jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         SV<T> a = motion_down(type, jx, Xb, ap) + cj3; // :1270-1273
          const int sf = mi[MI_SLOT_F];
          ciptr di = dof_map + mi[MI_DOF];
          if (type == JT_REVOLUTE || type == JT_PRISMATIC)
          {
-            const SV<T> U = ws_load6(ws, ws_stride, sf);
+            const SV<T> U = U_in;
             T qdd;
             if (LOCKED && (flags & MF_LOCKED))
                qdd = (A.in3b + cfg * A.v_bs)[di[0] * A.v_es]; // :1284-1297
@@ -1271,8 +1379,10 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
-   const long ws_stride = A.ws_stride;
-   T *ws = A.ws + lane;
+   // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
+   // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
    const int nv = m.nv;
 
    for (long cfg = lane; cfg < A.B; cfg += nlanes)
@@ -1445,8 +1555,10 @@ __global__ void __launch_bounds__(256) coriolis_kernel(Args<T> A)
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
-   const long ws_stride = A.ws_stride;
-   T *ws = A.ws + lane;
+   // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
+   // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
    const int nv = m.nv;
    const V3<T> Z{T(0), T(0), T(0)};
 
@@ -1613,8 +1725,10 @@ __global__ void __launch_bounds__(256) centroidal_kernel(CentArgs<T> A)
    const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
-   const long ws_stride = A.ws_stride;
-   T *ws = A.ws + lane;
+   // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
+   // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
    const int nv = m.nv;
    const V3<T> Z{T(0), T(0), T(0)};
    XF<T> Xf; // centroidal frame -> root body frame
