@@ -247,6 +247,11 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
     a_aos = hm.aba(tq, tqd, t_aos, g, tf)
     assert (a_aos - tqdd).abs().max().item() < 1e-5
     assert torch.equal(hm.aba(tq, tqd, ttau, g), hm.aba(T(tq), T(tqd), T(ttau), g, layout=_lib.LAYOUT_SOA).t())
+    # fp32 at that size: the depth-first ABA takes the transposed copies too, the depth-first RNEA reads its AoS rows through LDS windows
+    fq, fqd, fqdd, ftau = (dev(torch, x, f32) for x in (q, qd, qdd, tau))
+    assert torch.equal(hm.aba(fq, fqd, ftau, g), hm.aba(T(fq), T(fqd), T(ftau), g, layout=_lib.LAYOUT_SOA).t())
+    assert torch.equal(hm.rnea(fq, fqd, fqdd, g), hm.rnea(T(fq), T(fqd), T(fqdd), g, layout=_lib.LAYOUT_SOA).t())
+    close(hm.rnea(fq, fqd, fqdd, g).cpu().numpy().astype(np.float64)[idx], om.rnea(q[idx], qd[idx], qdd[idx], g), 64 * d.n_joints * 2.0 ** -24, label="rnea_f32 big batch")
 
 
 def test_layouts_soa_equals_aos(torch_cuda):
@@ -1101,12 +1106,16 @@ def test_native_library_is_the_one_loaded(torch_cuda):
     assert "libmecano_hip.so" in maps
 
 
-@pytest.mark.parametrize("place", [0, 1, 2])
+@pytest.mark.parametrize("place", [{"MH_DFS_PLACE": "0"}, {"MH_DFS_PLACE": "1"}, {"MH_DFS_PLACE": "2"}, {"MH_DFS_BUDGET": "9", "MH_DFS_ABA64": "1"},
+                                   {"MH_DFS_BUDGET": "24", "MH_DFS_ABA64": "1"}, {"MH_DFS_BUDGET": "60", "MH_DFS_ABA64": "1"}],
+                         ids=["all-lds", "stack-lds", "all-global", "budget9", "budget24", "budget60"])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_depth_first_kernels_in_every_memory_placement(torch_cuda, monkeypatch, place, dtype):
     """The run-time-topology RNEA / ABA kernels (mh_dfs_kernels.h) with the per-lane depth stack and ABA's hand-over forced into LDS /
-    LDS + global workspace / global workspace (MH_DFS_PLACE), on trees with every joint kind, several roots, deep chains and wide fans,
-    against the oracle; and bit for bit the same numbers in all placements and both layouts (same arithmetic, different memory)."""
+    LDS + global workspace / global workspace (MH_DFS_PLACE), and with per-frame homes under LDS budgets of 9 / 24 / 60 slots per wave
+    (MH_DFS_BUDGET: frames near the leaves in LDS, the rest in the global block -- the plans big batches of big models get), on trees with
+    every joint kind, several roots, deep chains and wide fans, against the oracle; and bit for bit the same numbers in all placements
+    and both layouts (same arithmetic, different memory)."""
     torch = torch_cuda
     from mecano_amd import _lib
     from mecano_amd import random_tools as rt
@@ -1127,10 +1136,14 @@ def test_depth_first_kernels_in_every_memory_placement(torch_cuda, monkeypatch, 
     g = (0.3, -0.2, -9.81)
     for sys_ in systems:
         d = sys_.toModelDesc()
-        monkeypatch.setenv("MH_DFS_PLACE", str(place))
+        for k, v in place.items():
+            monkeypatch.setenv(k, v)
         hm = HipModel(d)
+        for k in place:
+            monkeypatch.delenv(k)
         monkeypatch.setenv("MH_DFS_PLACE", "0")
         h0 = HipModel(d)
+        monkeypatch.delenv("MH_DFS_PLACE")
         om = OracleModel(d)
         for B in (1, 67, 1500):
             q, qd, qdd, tau = rt.nextState(rng, sys_, B)
