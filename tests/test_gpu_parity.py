@@ -1164,6 +1164,36 @@ def test_depth_first_kernels_in_every_memory_placement(torch_cuda, monkeypatch, 
                     close(o.cpu().numpy(), om.rnea(q, qd, qdd, g, fext, cc, ca), 1e-10, label="rnea switches")
 
 
+def test_pair_call_without_a_code_object_runs_side_by_side(torch_cuda, monkeypatch):
+    """mh_rnea_aba_f64 of a model without a fused kernel launches RNEA and ABA side by side on small batches (the ABA on a stream and a
+    workspace of the model's own, forked from / joined into the caller's stream): the same numbers as two separate calls, on the default and
+    on a non-default stream, call after call without a synchronisation in between, and the oracle's on a sample."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    monkeypatch.setenv("MH_DISABLE_SPEC", "1")
+    rng = np.random.default_rng(99)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    hm, om = HipModel(d), OracleModel(d)
+    assert hm.kernel_variant.startswith("generic")
+    g = (0.0, 0.0, -9.81)
+    for B in (1, 300, 4096, 20000):  # 20000: more waves than CUs, one call after the other
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        tq, tqd, tqdd, ttau = (dev(torch, x) for x in (q, qd, qdd, tau))
+        t_ref, a_ref = hm.rnea(tq, tqd, tqdd, g), hm.aba(tq, tqd, ttau, g)
+        for stream in (None, torch.cuda.Stream()):
+            with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+                outs = [hm.rnea_aba(tq, tqd, tqdd, ttau, g) for _ in range(4)]
+            torch.cuda.synchronize()
+            for t, a in outs:
+                assert torch.equal(t, t_ref) and torch.equal(a, a_ref)
+        if B == 300:
+            close(t_ref.cpu().numpy(), om.rnea(q, qd, qdd, g), 1e-10, label="rnea")
+            close(a_ref.cpu().numpy(), om.aba(q, qd, tau, g), 1e-10, label="aba")
+
+
 def test_host_pointer_pipeline(torch_cuda, monkeypatch):
     """The host-pointer entry points (what a Java shim calls): batches above 1024 configurations travel in chunks through three streams.
     Pageable and pinned (mh_host_alloc) matrices, a chunk size that leaves a ragged last chunk and re-uses every ring slot, external
