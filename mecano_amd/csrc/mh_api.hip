@@ -376,35 +376,52 @@ void dfs_plans_drop(mh_model *m)
 // Out of that come the row windows (RNEA on AoS matrices), ABA's hand-over if all of it fits (small models at one wave per CU: measured
 // 106 vs 116 us on the humanoid at B = 4096), and the rest is the stack's budget.  MH_DFS_PLACE = 0 | 1 | 2 forces an all-LDS stack
 // with the hand-over in LDS / an all-LDS stack / an all-global stack (measurements, tests); MH_DFS_BUDGET=<slots> the budget itself.
+struct DfsChoice
+{
+   long per_cu, budget, hand, b_win, slot_bytes;
+   bool hand_lds;
+};
+DfsChoice dfs_choose(const mh_model *model, Algo algo, size_t elem, int64_t B, bool win)
+{
+   DfsChoice c{};
+   const long waves = (B + 63) / 64;
+   c.b_win = win ? 3L * mh::ROW_WIN * mh::ROW_PITCH * (long)elem : 0;
+   c.slot_bytes = 64 * (long)elem;
+   const long cus = model->cu_count;
+   const long reg_cap = (algo == ALGO_ABA && elem == 8) ? 4 : model->waves_per_cu; // resident waves per CU the registers allow
+   c.per_cu = std::max<long>(1, std::min<long>(std::min<long>(model->waves_per_cu, reg_cap), (waves + cus - 1) / cus));
+   const long full_stack = algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack;
+   c.hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
+   if (model->dfs_place >= 0)
+   { // forced placements: give the stack what it needs and let the occupancy follow
+      c.budget = model->dfs_place == 2 ? 0 : full_stack;
+      c.hand_lds = model->dfs_place == 0 && algo == ALGO_ABA && (full_stack + c.hand) * c.slot_bytes + c.b_win <= 160 * 1024;
+      if (c.budget * c.slot_bytes + c.b_win > 160 * 1024)
+         c.budget = (160 * 1024 - c.b_win) / c.slot_bytes;
+   }
+   else
+   {
+      const long avail = 160 * 1024 / c.per_cu - c.b_win;
+      c.hand_lds = algo == ALGO_ABA && (full_stack + c.hand) * c.slot_bytes <= avail;
+      c.budget = std::max<long>(0, std::min<long>(full_stack, (avail - (c.hand_lds ? c.hand * c.slot_bytes : 0)) / c.slot_bytes));
+      if (model->dfs_budget >= 0)
+         c.budget = std::min<long>(model->dfs_budget, c.budget);
+   }
+   return c;
+}
+bool dfs_windows(const mh_model *model, Algo algo, size_t elem, bool aos)
+{ // AoS matrices with identity index maps and rows that span many cache lines: RNEA reads them through LDS windows (mh_dfs_kernels.h)
+   return algo == ALGO_RNEA && aos && model->ident_maps && model->use_win && (long)model->nv * (long)elem >= 512;
+}
 template <typename T>
 mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipStream_t stream)
 {
    const long waves = (B + 63) / 64;
-   const bool win = algo == ALGO_RNEA && A.q_es == 1 && A.v_es == 1 && model->ident_maps && model->use_win && (long)model->nv * (long)sizeof(T) >= 512;
-   const long b_win = win ? 3L * mh::ROW_WIN * mh::ROW_PITCH * (long)sizeof(T) : 0;
-   const long slot_bytes = 64 * (long)sizeof(T);
-   const long cus = model->cu_count;
-   const long reg_cap = (algo == ALGO_ABA && sizeof(T) == 8) ? 4 : model->waves_per_cu; // resident waves per CU the registers allow
-   long per_cu = std::max<long>(1, std::min<long>(std::min<long>(model->waves_per_cu, reg_cap), (waves + cus - 1) / cus));
-   const long full_stack = algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack;
-   const long hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
-   bool hand_lds = false;
-   long budget;
-   if (model->dfs_place >= 0)
-   { // forced placements: give the stack what it needs and let the occupancy follow
-      budget = model->dfs_place == 2 ? 0 : full_stack;
-      hand_lds = model->dfs_place == 0 && algo == ALGO_ABA && (full_stack + hand) * slot_bytes + b_win <= 160 * 1024;
-      if (budget * slot_bytes + b_win > 160 * 1024)
-         budget = (160 * 1024 - b_win) / slot_bytes;
-   }
-   else
-   {
-      const long avail = 160 * 1024 / per_cu - b_win;
-      hand_lds = algo == ALGO_ABA && (full_stack + hand) * slot_bytes <= avail;
-      budget = std::max<long>(0, std::min<long>(full_stack, (avail - (hand_lds ? hand * slot_bytes : 0)) / slot_bytes));
-      if (model->dfs_budget >= 0)
-         budget = std::min<long>(model->dfs_budget, budget);
-   }
+   const bool win = dfs_windows(model, algo, sizeof(T), A.q_es == 1 && A.v_es == 1);
+   const DfsChoice ch = dfs_choose(model, algo, sizeof(T), B, win);
+   const long b_win = ch.b_win, slot_bytes = ch.slot_bytes, hand = ch.hand, budget = ch.budget, cus = model->cu_count;
+   long per_cu = ch.per_cu;
+   const bool hand_lds = ch.hand_lds;
    const mh_model::DfsPlan *plan = dfs_plan(model, algo == ALGO_RNEA ? 0 : 1, (int)budget);
    if (!plan)
       return fail(MH_ERR_HIP, "depth-first kernels: the body records of the frame plan could not be uploaded");
@@ -1650,6 +1667,29 @@ mh_status mh_reserve(mh_model_t m, int64_t max_batch)
    const bool transposes = m->use_transpose >= 0 ? m->use_transpose != 0 : (max_batch >= 8192 && m->nq + m->nv >= 64);
    if (transposes)
       st = ensure_bytes(m->tr, (size_t)max_batch * ((size_t)m->nq + 3 * (size_t)m->nv) * sizeof(double));
+   if (st != MH_OK)
+      return st;
+   // the depth-first kernels: the frame plans a batch of this size gets (both algorithms, both precisions, both layouts) and the
+   // global blocks behind them; the second workspace of the side-by-side pair call
+   size_t dfs_bytes = 0;
+   for (int a = 0; a < 2 && m->use_dfs; a++)
+      for (size_t elem : {sizeof(double), sizeof(float)})
+         for (int aos = 0; aos < 2; aos++)
+         {
+            const Algo algo = a == 0 ? ALGO_RNEA : ALGO_ABA;
+            const DfsChoice ch = dfs_choose(m, algo, elem, max_batch, dfs_windows(m, algo, elem, aos != 0));
+            const mh_model::DfsPlan *plan = dfs_plan(m, a, (int)ch.budget);
+            if (!plan)
+               return fail(MH_ERR_HIP, "depth-first kernels: the body records of the frame plan could not be uploaded");
+            const long lds = (plan->lds_slots + (ch.hand_lds ? ch.hand : 0)) * ch.slot_bytes + ch.b_win;
+            const long per_cu = lds > 0 ? std::max<long>(1, std::min<long>(ch.per_cu, (160 * 1024) / lds)) : ch.per_cu;
+            const long grid = std::max<long>(1, std::min<long>((max_batch + 63) / 64, (long)m->cu_count * per_cu));
+            dfs_bytes = std::max(dfs_bytes, (size_t)((ch.hand_lds ? 0 : ch.hand) + plan->glb_slots) * (size_t)grid * 64 * elem);
+         }
+   if (dfs_bytes > 0)
+      st = ensure_bytes(m->ws, dfs_bytes);
+   if (st == MH_OK && m->use_pair && (max_batch + 63) / 64 <= (long)m->cu_count)
+      st = ensure_bytes(m->ws_pair, m->ws.bytes);
    return st;
 }
 
