@@ -6,6 +6,7 @@
 // entry points return MH_ERR_NO_DEVICE.
 #include "../../include/mecano_hip.h"
 #include "mh_dfs_kernels.h"
+#include "mh_split_kernels.h"
 
 #include <dlfcn.h>
 
@@ -177,6 +178,16 @@ struct mh_model
    hipEvent_t pair_fork = nullptr, pair_join = nullptr;
    Workspace ws_pair;
    int use_pair = 1; // MH_DISABLE_PAIR=1: always one after the other
+   // run-time tree split (mh_split_kernels.h): plan made at creation, device copies, workspace blocks
+   struct SplitRt
+   {
+      bool usable = false;
+      int n_trunk = 0, n_limbs = 0, slots = 0, est = 0;
+      int n_seg[mh::SPLIT_WAVES] = {};
+      int *d_meta = nullptr, *d_trunk = nullptr, *d_seg = nullptr, *d_xl_ofs = nullptr, *d_xl = nullptr;
+      std::vector<int> meta; // host copy of the adapted records (joint source modes invalidate it)
+   } split_rt;
+   int use_split_rt = -1; // MH_SPLIT_RT = 0 | 1: never / whenever usable (default: small batches)
    // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices)
    Workspace tr;
    // scratch of the composite entry points: efforts of the Newton-Euler sweep behind mh_aba_joint_wrenches_f64, pair lists of
@@ -376,6 +387,219 @@ void dfs_plans_drop(mh_model *m)
 // Out of that come the row windows (RNEA on AoS matrices), ABA's hand-over if all of it fits (small models at one wave per CU: measured
 // 106 vs 116 us on the humanoid at B = 4096), and the rest is the stack's budget.  MH_DFS_PLACE = 0 | 1 | 2 forces an all-LDS stack
 // with the hand-over in LDS / an all-LDS stack / an all-global stack (measurements, tests); MH_DFS_BUDGET=<slots> the budget itself.
+// ---- run-time tree split (mh_split_kernels.h): trunk / limbs / owners from the tree alone, made once per model.
+// Greedy: the limbs start as the trees of the forest; the largest limb is split at its first branching (the chain down to it joins the
+// trunk, the branches become limbs) as long as that shortens the estimated critical path  (trunk bodies) + (bodies of the busiest wave).
+void split_rt_free(mh_model *m)
+{
+   mh_model::SplitRt &S = m->split_rt;
+   (void)hipFree(S.d_meta), (void)hipFree(S.d_trunk), (void)hipFree(S.d_seg), (void)hipFree(S.d_xl_ofs), (void)hipFree(S.d_xl);
+   S.d_meta = S.d_trunk = S.d_seg = S.d_xl_ofs = S.d_xl = nullptr;
+   S.usable = false;
+}
+mh_status split_rt_upload_meta(mh_model *m)
+{ // the adapted body records: the model's with the (body, field, value) patches of the plan applied
+   mh_model::SplitRt &S = m->split_rt;
+   if (!S.usable)
+      return MH_OK;
+   std::vector<int> meta = m->meta;
+   for (size_t k = 0; k + 2 < S.meta.size(); k += 3)
+      meta[(size_t)S.meta[k] * mh::MI_STRIDE + S.meta[k + 1]] = S.meta[k + 2];
+   if (!S.d_meta)
+      HIP_TRY(hipMalloc((void **)&S.d_meta, meta.size() * sizeof(int)));
+   HIP_TRY(hipMemcpy(S.d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+   return MH_OK;
+}
+void split_rt_plan(mh_model *m)
+{
+   mh_model::SplitRt &S = m->split_rt;
+   const int n = m->n, W = mh::SPLIT_WAVES;
+   auto MI = [&](int e, int k) { return m->meta[(size_t)e * mh::MI_STRIDE + k]; };
+   std::vector<std::vector<int>> ch(n);
+   std::vector<int> sz(n, 1), roots;
+   for (int e = n - 1; e >= 0; e--)
+   {
+      const int pe = MI(e, mh::MI_PARENT);
+      if (pe >= 0)
+         sz[pe] += sz[e];
+   }
+   for (int e = 0; e < n; e++)
+   {
+      const int pe = MI(e, mh::MI_PARENT);
+      (pe >= 0 ? ch[pe] : roots).push_back(e);
+   }
+   std::vector<char> trunk(n, 0);
+   std::vector<int> limbs = roots;
+   auto estimate = [&](const std::vector<int> &L, int nt, std::vector<int> *owner) {
+      std::vector<int> order(L.size());
+      for (size_t i = 0; i < L.size(); i++)
+         order[i] = (int)i;
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return sz[L[a]] != sz[L[b]] ? sz[L[a]] > sz[L[b]] : L[a] < L[b]; });
+      int load[mh::SPLIT_WAVES] = {}, cnt[mh::SPLIT_WAVES] = {};
+      if (owner)
+         owner->assign(L.size(), 0);
+      for (int i : order)
+      {
+         int w = 0;
+         for (int k = 1; k < W; k++)
+            if (load[k] < load[w])
+               w = k;
+         load[w] += sz[L[i]], cnt[w]++;
+         if (owner)
+            (*owner)[i] = w;
+      }
+      int mx = 0, mc = 0;
+      for (int k = 0; k < W; k++)
+         mx = std::max(mx, load[k]), mc = std::max(mc, cnt[k]);
+      return mc > mh::SPLIT_MAX_SEG ? 1 << 30 : 2 * nt + mx; // a trunk body is walked by every wave AND folded by one while three wait
+   };
+   int best = estimate(limbs, 0, nullptr), nt = 0;
+   std::vector<int> best_limbs = limbs;
+   std::vector<char> best_trunk = trunk;
+   int best_nt = 0;
+   for (int iter = 0; iter < n; iter++)
+   {
+      int big = -1;
+      for (size_t i = 0; i < limbs.size(); i++)
+         if (big < 0 || sz[limbs[i]] > sz[limbs[big]])
+            big = (int)i;
+      if (big < 0)
+         break;
+      int r = limbs[big], chain = 1;
+      while (ch[r].size() == 1)
+         r = ch[r][0], chain++;
+      if (ch[r].empty())
+         break; // the largest limb is a chain: it cannot be split
+      for (int b = limbs[big];; b = ch[b][0])
+      {
+         trunk[b] = 1;
+         if (b == r)
+            break;
+      }
+      nt += chain;
+      limbs.erase(limbs.begin() + big);
+      for (int c : ch[r])
+         limbs.push_back(c);
+      const int est = estimate(limbs, nt, nullptr);
+      if (est < best)
+         best = est, best_limbs = limbs, best_trunk = trunk, best_nt = nt;
+   }
+   S.usable = false;
+   if (best_limbs.size() < 2 || best > (3 * n) / 4)
+      return; // a chain, or nothing to gain
+   limbs = best_limbs, trunk = best_trunk;
+   std::vector<int> owner;
+   S.est = estimate(limbs, best_nt, &owner);
+   // per wave: limbs in ascending order; exchange records behind the sweep kernels' slots
+   std::vector<int> seg((size_t)W * mh::SPLIT_MAX_SEG * 2, 0), xslot(n, -1), trunk_list;
+   for (int k = 0; k < W; k++)
+      S.n_seg[k] = 0;
+   std::vector<int> by_start(limbs.size());
+   for (size_t i = 0; i < limbs.size(); i++)
+      by_start[i] = (int)i;
+   std::sort(by_start.begin(), by_start.end(), [&](int a, int b) { return limbs[a] < limbs[b]; });
+   int slots = m->n_slots;
+   for (int i : by_start)
+   {
+      const int w = owner[i], r = limbs[i];
+      seg[((size_t)w * mh::SPLIT_MAX_SEG + S.n_seg[w]) * 2] = r, seg[((size_t)w * mh::SPLIT_MAX_SEG + S.n_seg[w]) * 2 + 1] = r + sz[r];
+      S.n_seg[w]++;
+      if (MI(r, mh::MI_PARENT) >= 0)
+         xslot[r] = slots, slots += 27;
+   }
+   for (int e = 0; e < n; e++)
+      if (trunk[e])
+         trunk_list.push_back(e);
+   // adapted records: (body, field, value) triples applied on top of the model's records
+   std::vector<int> nflags(n), nva(n, -1), nia(n, -1);
+   for (int e = 0; e < n; e++)
+      nflags[e] = MI(e, mh::MI_FLAGS);
+   for (int e = 0; e < n; e++)
+   {
+      if (xslot[e] >= 0)
+         nflags[e] &= ~mh::MF_PARENT_ADJ; // a limb root: its parent's state comes from the workspace, its contribution goes to the exchange record
+      if (!trunk[e])
+         continue;
+      bool limb_child = false, nonadj_trunk_child = false;
+      int first_acc = -1;
+      for (int c : ch[e])
+      {
+         if (!trunk[c])
+            limb_child = true;
+         else if (c != e + 1)
+            nonadj_trunk_child = true, first_acc = std::max(first_acc, c);
+      }
+      nflags[e] &= ~(mh::MF_HAS_ACC | mh::MF_STORE_VA);
+      if (nonadj_trunk_child)
+         nflags[e] |= mh::MF_HAS_ACC;
+      if (limb_child || nonadj_trunk_child)
+      {
+         nflags[e] |= mh::MF_STORE_VA;
+         if (!(MI(e, mh::MI_FLAGS) & mh::MF_STORE_VA))
+            nva[e] = slots, slots += 12; // the model's records hold no slots for it
+      }
+      if (nonadj_trunk_child && !(MI(e, mh::MI_FLAGS) & mh::MF_HAS_ACC))
+         nia[e] = slots, slots += 40;
+      for (int c : ch[e])
+         if (trunk[c] && c != e + 1) // first contributor of the trunk-only fold: the highest index
+            nflags[c] = (nflags[c] & ~mh::MF_ACC_FIRST) | (c == first_acc ? mh::MF_ACC_FIRST : 0);
+   }
+   S.meta.clear();
+   auto patch = [&](int e, int field, int value) { S.meta.push_back(e), S.meta.push_back(field), S.meta.push_back(value); };
+   std::vector<int> xl_ofs(trunk_list.size() + 1, 0), xl;
+   for (int e = 0; e < n; e++)
+   {
+      patch(e, mh::MI_HAND, xslot[e]);
+      patch(e, mh::MI_FLAGS, nflags[e]);
+      if (nva[e] >= 0)
+         patch(e, mh::MI_SLOT_VA, nva[e]);
+      if (nia[e] >= 0)
+         patch(e, mh::MI_SLOT_IA, nia[e]);
+   }
+   for (size_t k = 0; k < trunk_list.size(); k++)
+   {
+      for (size_t i = 0; i < limbs.size(); i++)
+         if (MI(limbs[i], mh::MI_PARENT) == trunk_list[k])
+            xl.push_back(xslot[limbs[i]]);
+      xl_ofs[k + 1] = (int)xl.size();
+   }
+   if (xl.empty())
+      xl.push_back(0);
+   if (trunk_list.empty())
+      trunk_list.push_back(0);
+   S.n_trunk = best_nt, S.n_limbs = (int)limbs.size(), S.slots = slots;
+   auto up = [&](int **dst, const std::vector<int> &v) {
+      return hipMalloc((void **)dst, v.size() * sizeof(int)) == hipSuccess && hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+   };
+   S.usable = up(&S.d_trunk, trunk_list) && up(&S.d_seg, seg) && up(&S.d_xl_ofs, xl_ofs) && up(&S.d_xl, xl);
+   if (S.usable && split_rt_upload_meta(m) != MH_OK)
+      S.usable = false;
+   if (!S.usable)
+      split_rt_free(m);
+}
+template <typename T>
+mh_status launch_split_rt(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipStream_t stream)
+{
+   const mh_model::SplitRt &S = model->split_rt;
+   const long groups = (B + 63) / 64;
+   const int grid = (int)std::max<long>(1, std::min<long>(groups, model->cu_count));
+   mh_status st = ensure_bytes(model->ws, (size_t)S.slots * (size_t)grid * 64 * sizeof(T));
+   if (st != MH_OK)
+      return st;
+   A.ws = (T *)model->ws.ptr;
+   mh::SplitDev P{};
+   P.meta = S.d_meta, P.trunk = S.d_trunk, P.seg = S.d_seg, P.xl_ofs = S.d_xl_ofs, P.xl = S.d_xl;
+   P.n_trunk = S.n_trunk, P.slots = S.slots;
+   for (int k = 0; k < mh::SPLIT_WAVES; k++)
+      P.n_seg[k] = S.n_seg[k];
+   if (algo == ALGO_RNEA)
+      hipLaunchKernelGGL((mh::rnea_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
+   else
+      hipLaunchKernelGGL((mh::aba_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
+
 struct DfsChoice
 {
    long per_cu, budget, hand, b_win, slot_bytes;
@@ -614,6 +838,10 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       return MH_OK;
       } // else: this (algorithm, memory plan) is not in the code object -- the run-time-topology kernels below serve the call
    }
+   // Small batches of a model whose tree branches: the tree split over the four waves of a workgroup (mh_split_kernels.h)
+   if (model->split_rt.usable && algo != ALGO_CRBA && !bodies && !joint_wrench && model->n_locked == 0 && !locked_in
+       && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * (model->n >= 64 ? 2 : 1))) // measured: profiles/r02_split_rt_sweep.txt
+      return launch_split_rt<T>(algo, model, B, A, stream);
    // Run-time-topology RNEA / ABA on AoS matrices: for big batches of wide matrices go through transposed scratch copies
    // (mh::transpose_kernel).  External wrenches keep their own strides.  The depth-first RNEA reads AoS rows through LDS windows instead
    // (mh_dfs_kernels.h, RowWindow) unless MH_DFS_TRANSPOSE=1; the depth-first ABA has no registers left for windows and takes the copies.
@@ -1509,9 +1737,20 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_pair = 0;
    if (const char *e = getenv("MH_HOST_CHUNK"))
       m->host_chunk = std::max(0, atoi(e));
+   if (const char *e = getenv("MH_SPLIT_RT"))
+      m->use_split_rt = atoi(e);
+   if (m->use_split_rt != 0)
+      split_rt_plan(m);
    try_load_spec(m, P);
    if (!m->use_spec)
       m->variant = "generic";
+   if (m->split_rt.usable && m->variant.compare(0, 7, "generic") == 0)
+   {
+      char buf[160];
+      snprintf(buf, sizeof buf, "; small batches: run-time tree split over 4 waves (%d trunk bodies + %d limbs, path %d of %d bodies)", m->split_rt.n_trunk,
+               m->split_rt.n_limbs, m->split_rt.est, m->n);
+      m->variant += buf;
+   }
    int selfcheck = 1;
    if (const char *e = getenv("MH_SPEC_SELFCHECK"))
       selfcheck = atoi(e);
@@ -1526,6 +1765,7 @@ void mh_model_destroy(mh_model_t m)
    if (!m)
       return;
    dfs_plans_drop(m);
+   split_rt_free(m);
    (void)hipFree(m->d_meta);
    (void)hipFree(m->d_dof);
    (void)hipFree(m->d_cfg);

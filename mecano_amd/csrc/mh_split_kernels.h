@@ -1,0 +1,432 @@
+// mh_split_kernels.h -- run-time-topology RNEA / ABA with the tree split over the FOUR waves of a workgroup (small batches).
+//
+// A batch of a few thousand configurations puts one wave per 64 configurations on the device: 64 waves on 1024 SIMDs at B = 4096, each
+// walking all n bodies one after the other.  The topology-specialised code objects split the tree over four waves at compile time
+// (mh_spec_kernels.h, Split<TP>); these kernels do the same for ANY model from a plan the host makes when the model is created
+// (mh_api.hip: split_plan): the TRUNK (bodies the split goes through: the root side of every branching that is used) and the LIMBS
+// (whole subtrees hanging off trunk bodies; joints are stored depth-first, so a limb is a contiguous index range), dealt to the waves
+// largest first.
+//
+//   outward sweeps   every wave walks the trunk (redundantly: it needs the trunk's velocities / accelerations for its limbs and would
+//                    idle otherwise; all waves store the same values), then its own limbs;
+//   inward sweep     every wave its own limbs; a limb root hands its contribution (RNEA: wrench, 6; ABA: articulated inertia + bias
+//                    wrench, 27) to an EXCHANGE record in the workgroup's workspace block instead of its parent's slots; barrier; wave 0
+//                    folds the trunk, reading the records of the limbs attached to each trunk body; (ABA) barrier.
+//
+// Same per-body arithmetic, workspace slots and flags as the sweep kernels of mh_kernels.h (rnea_kernel / aba_kernel; the body records
+// are a copy with the flags of the limb roots and trunk bodies adapted); plain calls only (no per-body outputs, no acceleration-source
+// joints).  InverseDynamicsCalculator.java:873-966, ForwardDynamicsCalculator.java:1085-1310.
+#pragma once
+#include "mh_dfs_kernels.h"
+
+#ifndef MH_WS
+#define MH_WS(slot) ws[(long)(slot)*ws_stride]
+#endif
+
+namespace mh
+{
+constexpr int SPLIT_WAVES = 4;
+constexpr int SPLIT_MAX_SEG = 16; // limbs per wave
+struct SplitDev
+{
+   const int *meta;    // [n][MI_STRIDE]: MI_FLAGS adapted, MI_HAND = exchange slot of a limb root (-1 otherwise)
+   const int *trunk;   // trunk bodies, ascending
+   const int *seg;     // [SPLIT_WAVES][SPLIT_MAX_SEG][2]: (first, one past last) body of the wave's limbs, ascending
+   const int *xl_ofs;  // [n_trunk + 1]: per trunk body (position in `trunk`), its attached limbs' exchange slots in xl
+   const int *xl;
+   int n_trunk, slots; // workspace slots of one workgroup block: the sweep kernels' + the exchange records
+   int n_seg[SPLIT_WAVES];
+};
+
+// ============================================================================================ RNEA
+template <typename T>
+__global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
+{
+   const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   const ciptr meta = as_const(P.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
+   const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
+   const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid;
+   const V3<T> Z{T(0), T(0), T(0)};
+   const int n_seg = P.n_seg[wave];
+   const long groups = (A.B + 63) / 64;
+
+   for (long grp = blockIdx.x; grp < groups; grp += gridDim.x)
+   {
+      const long cfg0 = grp * 64 + tid;
+      const bool active = cfg0 < A.B;
+      const long cfg = active ? cfg0 : A.B - 1; // the lanes of a ragged last group repeat its last configuration (no store)
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *qdrow = A.qd + cfg * A.v_bs;
+      const T *qddrow = A.in3 + cfg * A.v_bs;
+      const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
+      T *trow = A.out + cfg * A.v_bs;
+
+      // ---- outward sweep: velocities, accelerations, Newton-Euler wrench (InverseDynamicsCalculator.java:873-917)
+      SV<T> v_prev{Z, Z}, a_prev{Z, Z};
+      auto outward = [&](int j) {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, false> c{CB + j * MC_STRIDE};
+         SV<T> vp, ap;
+         if (parent < 0)
+         {
+            vp = SV<T>{Z, Z};
+            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :343-348
+         }
+         else if (flags & MF_PARENT_ADJ)
+            vp = v_prev, ap = a_prev;
+         else
+         {
+            const int sp = meta[parent * MI_STRIDE + MI_SLOT_VA];
+            vp = ws_load6(ws, ws_stride, sp);
+            ap = ws_load6(ws, ws_stride, sp + 6);
+         }
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, A.coriolis != 0);
+         const SV<T> aJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qddrow, A.v_es, A.accel != 0);
+         SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         const SV<T> a = motion_down(type, jx, Xb, ap) + aJ + crm(v, vJ);
+         if (!A.coriolis)
+            v = SV<T>{Z, Z};
+         const RI<T> I = load_inertia<T>(c);
+         SV<T> f = mul(I, a) + crf(v, mul(I, v));
+         if (frow)
+            f = f - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_F], f);
+         if (flags & MF_STORE_VA)
+         {
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA] + 6, a);
+         }
+         v_prev = v, a_prev = a;
+      };
+      for (int k = 0; k < P.n_trunk; k++)
+         outward(trunk[k]);
+      for (int s = 0; s < n_seg; s++)
+      {
+         const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
+         for (int j = j0; j < j1; j++)
+            outward(j);
+      }
+      // ---- inward sweep (:930-966)
+      SV<T> carry{Z, Z};
+      bool have_carry = false;
+      auto inward = [&](int j, int xk0, int xk1) {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
+         const CRef<T, false> c{CB + j * MC_STRIDE};
+         SV<T> f = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         if (have_carry)
+            f = f + carry;
+         for (int k = xk0; k < xk1; k++) // trunk bodies: what the attached limbs handed up
+            f = f + ws_load6(ws, ws_stride, xl[k]);
+         if (active)
+            write_joint_rows<T>(type, dof_map + mi[MI_DOF], trow, A.v_es, f);
+         have_carry = false;
+         if (parent >= 0)
+         {
+            const XF<T> Xb = load_xb<T>(c);
+            const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+            const SV<T> fp = force_up(type, jx, Xb, f);
+            if (xs >= 0)
+               ws_store6(ws, ws_stride, xs, fp); // a limb root: through the exchange record
+            else if (flags & MF_PARENT_ADJ)
+               carry = fp, have_carry = true;
+            else
+               ws_add6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_F], fp);
+         }
+      };
+      for (int s = n_seg - 1; s >= 0; s--)
+      {
+         const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
+         have_carry = false;
+         for (int j = j1 - 1; j >= j0; j--)
+            inward(j, 0, 0);
+      }
+      __syncthreads(); // the limbs' records are in the workgroup's block
+      if (wave == 0)
+      {
+         have_carry = false;
+         for (int k = P.n_trunk - 1; k >= 0; k--)
+            inward(trunk[k], xl_ofs[k], xl_ofs[k + 1]);
+      }
+      __syncthreads(); // the next group of configurations re-uses the block
+   }
+}
+
+// ============================================================================================ ABA
+template <typename T>
+__global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
+{
+   const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   const ciptr meta = as_const(P.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
+   const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
+   const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid;
+   const V3<T> Z{T(0), T(0), T(0)};
+   const int n_seg = P.n_seg[wave];
+   const long groups = (A.B + 63) / 64;
+
+   for (long grp = blockIdx.x; grp < groups; grp += gridDim.x)
+   {
+      const long cfg0 = grp * 64 + tid;
+      const bool active = cfg0 < A.B;
+      const long cfg = active ? cfg0 : A.B - 1;
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *qdrow = A.qd + cfg * A.v_bs;
+      const T *taurow = A.in3 + cfg * A.v_bs;
+      const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
+      T *orow = A.out + cfg * A.v_bs;
+
+      // ---- pass one (ForwardDynamicsCalculator.java:1085-1127): velocities, bias wrench p, bias acceleration c
+      SV<T> v_prev{Z, Z};
+      auto pass1 = [&](int j) {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, false> c{CB + j * MC_STRIDE};
+         SV<T> vp;
+         if (parent < 0)
+            vp = SV<T>{Z, Z};
+         else if (flags & MF_PARENT_ADJ)
+            vp = v_prev;
+         else
+            vp = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
+         const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         const RI<T> I = load_inertia<T>(c);
+         SV<T> p = crf(v, mul(I, v));
+         if (frow)
+            p = p - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_F], p);
+         ws_store6(ws, ws_stride, mi[MI_SLOT_C], crm(v, vJ));
+         if (flags & MF_STORE_VA)
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
+         v_prev = v;
+      };
+      for (int k = 0; k < P.n_trunk; k++)
+         pass1(trunk[k]);
+      for (int s = 0; s < n_seg; s++)
+      {
+         const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
+         for (int j = j0; j < j1; j++)
+            pass1(j);
+      }
+      // ---- pass two (:1136-1254): articulated inertias and bias wrenches, leaves to root
+      ABI<T> Icarry;
+      SV<T> pcarry{Z, Z};
+      bool have_carry = false;
+      auto pass2 = [&](int j, int xk0, int xk1) {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
+         const CRef<T, false> c{CB + j * MC_STRIDE};
+         ABI<T> IA = abi_from_rigid(load_inertia<T>(c));
+         SV<T> pA = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         if (have_carry)
+         {
+            add(IA, Icarry);
+            pA = pA + pcarry;
+         }
+         if (flags & MF_HAS_ACC)
+            add(IA, ws_load_abi(ws, ws_stride, mi[MI_SLOT_IA])); // (the bias wrenches of those children were added to slot F)
+         for (int k = xk0; k < xk1; k++)
+         { // trunk bodies: articulated inertia and bias wrench of the attached limbs
+            add(IA, ws_load_abi(ws, ws_stride, xl[k]));
+            pA = pA + ws_load6(ws, ws_stride, xl[k] + 21);
+         }
+         have_carry = false;
+         const int sf = mi[MI_SLOT_F];
+         ciptr di = dof_map + mi[MI_DOF];
+         ABI<T> Ia = IA;
+         SV<T> pa = pA;
+         bool handed_up = false;
+         if (type == JT_REVOLUTE || type == JT_PRISMATIC)
+         {
+            V3<T> ua, ul;
+            T D, pz;
+            if (type == JT_REVOLUTE)
+               ua = V3<T>{IA.A.xz, IA.A.yz, IA.A.zz}, ul = V3<T>{IA.C.zx, IA.C.zy, IA.C.zz}, D = IA.A.zz, pz = pA.a.z;
+            else
+               ua = V3<T>{IA.C.xz, IA.C.yz, IA.C.zz}, ul = V3<T>{IA.L.xz, IA.L.yz, IA.L.zz}, D = IA.L.zz, pz = pA.l.z;
+            const T dinv = T(1) / D;                 // :1183
+            const T u = taurow[di[0] * A.v_es] - pz; // :1200-1215
+            ws_store6(ws, ws_stride, sf, SV<T>{ua, ul});
+            MH_WS(sf + 6) = dinv;
+            MH_WS(sf + 7) = u;
+            if (parent >= 0)
+            {
+               const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+               const T ud = u * dinv;
+               if (type == JT_REVOLUTE)
+               {
+                  rank1_down_revolute(Ia, ua, ul, dinv);           // :1220-1226
+                  pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
+                  JX<T> jx;
+                  jx.c = MH_WS(mi[MI_SLOT_JP]), jx.s = MH_WS(mi[MI_SLOT_JP] + 1), jx.d = T(0);
+                  revolute_up(jx, load_xb<T>(c), Ia, pa); // :1156-1166; pa is now expressed in the parent's frame
+                  handed_up = true;
+               }
+               else
+               {
+                  rank1_down(Ia, ua, ul, dinv);
+                  pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul};
+               }
+            }
+         }
+         else if (type == JT_PLANAR || type == JT_SPHERICAL)
+         { // 3-DoF joint: U = IA S (6 x 3), D = S^T U (3 x 3), u = tau - S^T pA   (:1177-1215 with N = 3)
+            const SV<T> U0 = mul(IA, unit_twist<T>(type, 0)), U1 = mul(IA, unit_twist<T>(type, 1)), U2 = mul(IA, unit_twist<T>(type, 2));
+            const V3<T> d0 = comp3(type, U0), d1 = comp3(type, U1), d2 = comp3(type, U2);
+            const S3<T> Di = spd3_inverse(S3<T>{d0.x, d0.y, d0.z, d1.y, d1.z, d2.z});
+            const V3<T> tau3{taurow[di[0] * A.v_es], taurow[di[1] * A.v_es], taurow[di[2] * A.v_es]};
+            const V3<T> u3 = tau3 - comp3(type, pA);
+            const int sl = mi[MI_SLOT_LK];
+            ws_store6(ws, ws_stride, sl, U0), ws_store6(ws, ws_stride, sl + 6, U1), ws_store6(ws, ws_stride, sl + 12, U2);
+            MH_WS(sl + 18) = Di.xx, MH_WS(sl + 19) = Di.xy, MH_WS(sl + 20) = Di.xz, MH_WS(sl + 21) = Di.yy, MH_WS(sl + 22) = Di.yz, MH_WS(sl + 23) = Di.zz;
+            MH_WS(sl + 24) = u3.x, MH_WS(sl + 25) = u3.y, MH_WS(sl + 26) = u3.z;
+            if (parent >= 0)
+            {
+               const SV<T> W0 = Di.xx * U0 + Di.xy * U1 + Di.xz * U2, W1 = Di.xy * U0 + Di.yy * U1 + Di.yz * U2, W2 = Di.xz * U0 + Di.yz * U1 + Di.zz * U2;
+               rank1_pair_down(Ia, W0, U0), rank1_pair_down(Ia, W1, U1), rank1_pair_down(Ia, W2, U2);
+               const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+               pa = pA + mul(Ia, cj) + u3.x * W0 + u3.y * W1 + u3.z * W2;
+            }
+         }
+         else if (type == JT_SIXDOF)
+         { // S = 1_6: pass three needs only x = IA^-1 u; for the parent Ia = 0 and pa = tau
+            const SV<T> tau{V3<T>{taurow[di[0] * A.v_es], taurow[di[1] * A.v_es], taurow[di[2] * A.v_es]},
+                            V3<T>{taurow[di[3] * A.v_es], taurow[di[4] * A.v_es], taurow[di[5] * A.v_es]}};
+            const SV<T> x = spd6_solve(IA, tau - pA);
+            ws_store6(ws, ws_stride, sf, x);
+            if (parent >= 0)
+            {
+               Ia.A = S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)};
+               Ia.L = Ia.A;
+               Ia.C = M3<T>{T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+               pa = tau;
+            }
+         }
+         // fixed joint: the whole articulated body is handed over unchanged (c = 0)
+         if (parent >= 0)
+         {
+            SV<T> pp = pa;
+            if (!handed_up)
+            {
+               const XF<T> Xb = load_xb<T>(c);
+               const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+               abi_up(type, jx, Xb, Ia); // :1156-1166
+               pp = force_up(type, jx, Xb, pa);
+            }
+            if (xs >= 0)
+            { // a limb root: through the exchange record
+               ws_store_abi(ws, ws_stride, xs, Ia);
+               ws_store6(ws, ws_stride, xs + 21, pp);
+            }
+            else if (flags & MF_PARENT_ADJ)
+               Icarry = Ia, pcarry = pp, have_carry = true;
+            else
+            {
+               ciptr pmi = meta + parent * MI_STRIDE;
+               if (flags & MF_ACC_FIRST)
+                  ws_store_abi(ws, ws_stride, pmi[MI_SLOT_IA], Ia);
+               else
+               {
+                  ABI<T> acc = ws_load_abi(ws, ws_stride, pmi[MI_SLOT_IA]);
+                  add(acc, Ia);
+                  ws_store_abi(ws, ws_stride, pmi[MI_SLOT_IA], acc);
+               }
+               ws_add6(ws, ws_stride, pmi[MI_SLOT_F], pp);
+            }
+         }
+      };
+      for (int s = n_seg - 1; s >= 0; s--)
+      {
+         const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
+         have_carry = false;
+         for (int j = j1 - 1; j >= j0; j--)
+            pass2(j, 0, 0);
+      }
+      __syncthreads(); // the limbs' records are in the workgroup's block
+      if (wave == 0)
+      {
+         have_carry = false;
+         for (int k = P.n_trunk - 1; k >= 0; k--)
+            pass2(trunk[k], xl_ofs[k], xl_ofs[k + 1]);
+      }
+      __syncthreads(); // the trunk's U, 1/D, u are in the block
+      // ---- pass three (:1259-1310): joint accelerations, root to leaves
+      SV<T> a_prev{Z, Z};
+      auto pass3 = [&](int j, bool writes) {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, false> c{CB + j * MC_STRIDE};
+         SV<T> ap;
+         if (parent < 0)
+            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :259-264
+         else if (flags & MF_PARENT_ADJ)
+            ap = a_prev;
+         else
+            ap = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         SV<T> a = motion_down(type, jx, Xb, ap) + ws_load6(ws, ws_stride, mi[MI_SLOT_C]); // :1270-1273
+         const int sf = mi[MI_SLOT_F];
+         ciptr di = dof_map + mi[MI_DOF];
+         if (type == JT_REVOLUTE || type == JT_PRISMATIC)
+         {
+            const SV<T> U = ws_load6(ws, ws_stride, sf);
+            const T dinv = MH_WS(sf + 6), u = MH_WS(sf + 7);
+            const T qdd = dinv * (u - (dot(U.a, a.a) + dot(U.l, a.l))); // :1280-1282
+            if (writes)
+               orow[di[0] * A.v_es] = qdd;
+            if (type == JT_REVOLUTE)
+               a.a.z += qdd;
+            else
+               a.l.z += qdd;
+         }
+         else if (type == JT_PLANAR || type == JT_SPHERICAL)
+         {
+            const int sl = mi[MI_SLOT_LK];
+            const SV<T> U0 = ws_load6(ws, ws_stride, sl), U1 = ws_load6(ws, ws_stride, sl + 6), U2 = ws_load6(ws, ws_stride, sl + 12);
+            const S3<T> Di{MH_WS(sl + 18), MH_WS(sl + 19), MH_WS(sl + 20), MH_WS(sl + 21), MH_WS(sl + 22), MH_WS(sl + 23)};
+            const V3<T> r{MH_WS(sl + 24) - (dot(U0.a, a.a) + dot(U0.l, a.l)), MH_WS(sl + 25) - (dot(U1.a, a.a) + dot(U1.l, a.l)),
+                          MH_WS(sl + 26) - (dot(U2.a, a.a) + dot(U2.l, a.l))};
+            const V3<T> qdd = mul(Di, r);
+            if (writes)
+               orow[di[0] * A.v_es] = qdd.x, orow[di[1] * A.v_es] = qdd.y, orow[di[2] * A.v_es] = qdd.z;
+            a = a + from_comp3(type, qdd);
+         }
+         else if (type == JT_SIXDOF)
+         {
+            const SV<T> x = ws_load6(ws, ws_stride, sf);
+            const SV<T> qdd = x - a;
+            if (writes)
+            {
+               orow[di[0] * A.v_es] = qdd.a.x, orow[di[1] * A.v_es] = qdd.a.y, orow[di[2] * A.v_es] = qdd.a.z;
+               orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
+            }
+            a = x;
+         }
+         if (flags & MF_STORE_VA)
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], a);
+         a_prev = a;
+      };
+      for (int k = 0; k < P.n_trunk; k++)
+         pass3(trunk[k], active && wave == 0);
+      for (int s = 0; s < n_seg; s++)
+      {
+         const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
+         for (int j = j0; j < j1; j++)
+            pass3(j, active);
+      }
+      __syncthreads(); // the next group of configurations re-uses the block
+   }
+}
+} // namespace mh

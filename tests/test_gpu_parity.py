@@ -439,7 +439,7 @@ def test_every_specialised_variant(torch_cuda, B):
         finally:
             for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT"):
                 os.environ.pop(k, None)
-        assert "generic" in seen and any(v.startswith("topo:") for v in seen), seen
+        assert any(v.startswith("generic") for v in seen) and any(v.startswith("topo:") for v in seen), seen
 
 
 @pytest.mark.parametrize("B", [1, 15, 64, 100, 4096, 5000])
@@ -777,7 +777,7 @@ def test_planar_and_spherical_joints(torch_cuda, kinds):
         sys_ = system_of(rt.nextJointTree(rng, int(rng.integers(1, 30)), kinds))
         d = sys_.toModelDesc()
         om, hm = OracleModel(d), HipModel(d)
-        assert hm.kernel_variant == "generic"
+        assert hm.kernel_variant.startswith("generic")
         B = int(rng.integers(1, 200))
         q, qd, qdd, tau = rt.nextState(rng, sys_, B)
         g = (0.2, -0.4, -9.81)
@@ -1162,6 +1162,70 @@ def test_depth_first_kernels_in_every_memory_placement(torch_cuda, monkeypatch, 
                 if dtype == "f64" and B == 67:
                     o = hm.rnea(tq, tqd, tqdd, g, tf, consider_coriolis=cc, consider_accelerations=ca)
                     close(o.cpu().numpy(), om.rnea(q, qd, qdd, g, fext, cc, ca), 1e-10, label="rnea switches")
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
+    """mh_split_kernels.h: small batches of models without a code object run with the tree split over the four waves of a workgroup (trunk /
+    limbs / owners planned at model creation).  Forced on (MH_SPLIT_RT=1, also for batches with more groups than CUs: workgroups loop)
+    against forced off (the one-wave run-time-topology kernels) and the oracle: trees with every joint kind, a forest, wide fans, the
+    humanoid; ragged batches, both layouts, external wrenches, the RNEA switches.  Chains have no split and must say so."""
+    torch = torch_cuda
+    from mecano_amd import _lib
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import MultiBodySystem, RigidBody
+    from oracle.cpu_oracle import OracleModel
+    monkeypatch.setenv("MH_DISABLE_SPEC", "1")
+    rng = np.random.default_rng(2718)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    tol = 1e-10 if dtype == "f64" else 2e-3
+    kinds_all = ("revolute", "prismatic", "sixdof", "fixed", "planar", "spherical")
+    systems = [system_of(rt.nextJointTree(rng, 40, kinds_all)), system_of(rt.nextJointTree(rng, 23, ("revolute", "prismatic"))),
+               system_of(rt.nextFloatingChain(rng, 24, ("revolute",), tree=True)), rt.nextHumanoid(rng)]
+    root = RigidBody("root")  # a forest: three subtrees on the root body, one of them a single leaf -- limbs without a trunk
+    rt.nextJointTree(rng, 9, ("revolute", "prismatic"), rootBody=root, prefix="a")
+    rt.nextJointChain(rng, 1, ("prismatic",), rootBody=root, prefix="b")
+    rt.nextJointTree(rng, 12, kinds_all, rootBody=root, prefix="c")
+    systems.append(MultiBodySystem.toMultiBodySystemInput(root))
+    g = (0.3, -0.2, -9.81)
+    n_split = 0
+    for sys_ in systems:
+        d = sys_.toModelDesc()
+        monkeypatch.setenv("MH_SPLIT_RT", "1")
+        on = HipModel(d)
+        monkeypatch.setenv("MH_SPLIT_RT", "0")
+        off = HipModel(d)
+        assert "run-time tree split" not in off.kernel_variant
+        n_split += "run-time tree split" in on.kernel_variant  # (a tree whose split would not shorten the path keeps the one-wave kernels)
+        print(d.n_joints, "joints:", on.kernel_variant)
+        om = OracleModel(d)
+        for B in (1, 67, 300, 20000):
+            q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+            fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
+            tq, tqd, tqdd, ttau, tf = (dev(torch, x, tdt) for x in (q, qd, qdd, tau, fext))
+            t, a = on.rnea(tq, tqd, tqdd, g, tf), on.aba(tq, tqd, ttau, g, tf)
+            t0, a0 = off.rnea(tq, tqd, tqdd, g, tf), off.aba(tq, tqd, ttau, g, tf)
+            scale_t, scale_a = max(1.0, t0.abs().max().item()), max(1.0, a0.abs().max().item())
+            assert (t - t0).abs().max().item() <= (1e-12 if dtype == "f64" else 2e-4) * scale_t
+            assert (a - a0).abs().max().item() <= (1e-9 if dtype == "f64" else 2e-2) * scale_a  # mixed trees: ABA conditioning, cf. the 1e-8 of test_mixed_tree
+            T = lambda x: x.reshape(B, -1).t().contiguous()
+            assert torch.equal(on.rnea(T(tq), T(tqd), T(tqdd), g, T(tf), layout=_lib.LAYOUT_SOA).t(), t)
+            assert torch.equal(on.aba(T(tq), T(tqd), T(ttau), g, T(tf), layout=_lib.LAYOUT_SOA).t(), a)
+            if B <= 67:
+                close(t.cpu().numpy().astype(np.float64), om.rnea(q, qd, qdd, g, fext), tol, label="rnea")
+                close(a.cpu().numpy().astype(np.float64), om.aba(q, qd, tau, g, fext), 1e-7 if dtype == "f64" else 5e-2, label="aba")
+                for cc, ca in ((False, True), (True, False)):
+                    o = on.rnea(tq, tqd, tqdd, g, tf, consider_coriolis=cc, consider_accelerations=ca)
+                    close(o.cpu().numpy().astype(np.float64), om.rnea(q, qd, qdd, g, fext, cc, ca), tol, label="rnea switches")
+    assert n_split >= 3
+    # a chain cannot be split: the plan says so and the calls run on the one-wave kernels
+    chain = system_of(rt.nextJointChain(rng, 12, ("revolute", "prismatic")))
+    monkeypatch.setenv("MH_SPLIT_RT", "1")
+    hc = HipModel(chain.toModelDesc())
+    assert "run-time tree split" not in hc.kernel_variant
+    q, qd, qdd, tau = rt.nextState(rng, chain, 50)
+    close(hc.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), g).cpu().numpy(), OracleModel(chain.toModelDesc()).rnea(q, qd, qdd, g), 1e-10)
 
 
 def test_pair_call_without_a_code_object_runs_side_by_side(torch_cuda, monkeypatch):
