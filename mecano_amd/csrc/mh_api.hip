@@ -428,6 +428,7 @@ void split_rt_plan(mh_model *m)
       const int pe = MI(e, mh::MI_PARENT);
       (pe >= 0 ? ch[pe] : roots).push_back(e);
    }
+   const int trunk_weight = getenv("MH_SPLIT_RT_TRUNK_WEIGHT") ? atoi(getenv("MH_SPLIT_RT_TRUNK_WEIGHT")) : 2; // in half bodies; measured (tools/exp_split_rt_weight.py): 1..3 tie, 4+ splits too little
    std::vector<char> trunk(n, 0);
    std::vector<int> limbs = roots;
    auto estimate = [&](const std::vector<int> &L, int nt, std::vector<int> *owner) {
@@ -451,7 +452,7 @@ void split_rt_plan(mh_model *m)
       int mx = 0, mc = 0;
       for (int k = 0; k < W; k++)
          mx = std::max(mx, load[k]), mc = std::max(mc, cnt[k]);
-      return mc > mh::SPLIT_MAX_SEG ? 1 << 30 : 2 * nt + mx; // a trunk body is walked by every wave AND folded by one while three wait
+      return mc > mh::SPLIT_MAX_SEG ? 1 << 30 : (trunk_weight * nt + 1) / 2 + mx; // a trunk body: light outward steps on every wave + its fold on one while three wait
    };
    int best = estimate(limbs, 0, nullptr), nt = 0;
    std::vector<int> best_limbs = limbs;
