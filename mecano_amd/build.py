@@ -22,6 +22,7 @@ LIB = os.path.join(HERE, "libmecano_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "mh_api.hip")]
 HEADERS = [os.path.join(CSRC, "mh_kernels.h"), os.path.join(CSRC, "mh_device.h"), os.path.join(ROOT, "include", "mecano_hip.h")]
+LIB_HEADERS = HEADERS + [os.path.join(CSRC, "mh_dfs_kernels.h"), os.path.join(CSRC, "mh_split_kernels.h")]  # the library's own kernels
 SPEC_SOURCE = os.path.join(CSRC, "mh_spec.hip")
 SPEC_HEADERS = HEADERS + [os.path.join(CSRC, "mh_spec_kernels.h")]
 # -fno-signed-zeros -ffinite-math-only: lets the compiler drop the multiplications by the structural zeros of the canonical
@@ -52,7 +53,7 @@ def _stale(target, deps) -> bool:
 
 
 def needs_build() -> bool:
-    return _stale(LIB, SOURCES + HEADERS)
+    return _stale(LIB, SOURCES + LIB_HEADERS)
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
