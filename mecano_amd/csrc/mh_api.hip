@@ -182,7 +182,7 @@ struct mh_model
    struct SplitRt
    {
       bool usable = false;
-      int n_trunk = 0, n_limbs = 0, slots = 0, est = 0;
+      int n_trunk = 0, n_limbs = 0, slots = 0, est = 0, total = 0;
       int n_seg[mh::SPLIT_WAVES] = {};
       int *d_meta = nullptr, *d_trunk = nullptr, *d_seg = nullptr, *d_xl_ofs = nullptr, *d_xl = nullptr;
       std::vector<int> meta; // host copy of the adapted records (joint source modes invalidate it)
@@ -416,12 +416,18 @@ void split_rt_plan(mh_model *m)
    const int n = m->n, W = mh::SPLIT_WAVES;
    auto MI = [&](int e, int k) { return m->meta[(size_t)e * mh::MI_STRIDE + k]; };
    std::vector<std::vector<int>> ch(n);
-   std::vector<int> sz(n, 1), roots;
+   std::vector<int> sz(n, 1), cnt(n, 1), roots; // sz: cost of the subtree in tenths of a 1-DoF body step; cnt: bodies in it
+   for (int e = 0; e < n; e++)
+   { // measured on the sweep kernels: a 6-DoF joint (LDL^T solve, general transforms) costs about 2.5 revolute steps, a 3-DoF joint 2
+      const int t = MI(e, mh::MI_TYPE);
+      sz[e] = t == MH_JOINT_SIXDOF ? 25 : ((t == MH_JOINT_PLANAR || t == MH_JOINT_SPHERICAL) ? 20 : (t == MH_JOINT_FIXED ? 4 : 10));
+   }
+   const std::vector<int> own = sz;
    for (int e = n - 1; e >= 0; e--)
    {
       const int pe = MI(e, mh::MI_PARENT);
       if (pe >= 0)
-         sz[pe] += sz[e];
+         sz[pe] += sz[e], cnt[pe] += cnt[e];
    }
    for (int e = 0; e < n; e++)
    {
@@ -454,10 +460,10 @@ void split_rt_plan(mh_model *m)
          mx = std::max(mx, load[k]), mc = std::max(mc, cnt[k]);
       return mc > mh::SPLIT_MAX_SEG ? 1 << 30 : (trunk_weight * nt + 1) / 2 + mx; // a trunk body: light outward steps on every wave + its fold on one while three wait
    };
-   int best = estimate(limbs, 0, nullptr), nt = 0;
+   int best = estimate(limbs, 0, nullptr), nt = 0, ntc = 0; // trunk cost / trunk bodies
    std::vector<int> best_limbs = limbs;
    std::vector<char> best_trunk = trunk;
-   int best_nt = 0;
+   int best_nt = 0, best_ntc = 0;
    for (int iter = 0; iter < n; iter++)
    {
       int big = -1;
@@ -466,27 +472,29 @@ void split_rt_plan(mh_model *m)
             big = (int)i;
       if (big < 0)
          break;
-      int r = limbs[big], chain = 1;
+      int r = limbs[big];
       while (ch[r].size() == 1)
-         r = ch[r][0], chain++;
+         r = ch[r][0];
       if (ch[r].empty())
          break; // the largest limb is a chain: it cannot be split
       for (int b = limbs[big];; b = ch[b][0])
       {
-         trunk[b] = 1;
+         trunk[b] = 1, nt += own[b], ntc++;
          if (b == r)
             break;
       }
-      nt += chain;
       limbs.erase(limbs.begin() + big);
       for (int c : ch[r])
          limbs.push_back(c);
       const int est = estimate(limbs, nt, nullptr);
       if (est < best)
-         best = est, best_limbs = limbs, best_trunk = trunk, best_nt = nt;
+         best = est, best_limbs = limbs, best_trunk = trunk, best_nt = nt, best_ntc = ntc;
    }
+   int sz_total = 0;
+   for (int r0 : roots)
+      sz_total += sz[r0];
    S.usable = false;
-   if (best_limbs.size() < 2 || best > (3 * n) / 4)
+   if (best_limbs.size() < 2 || best > (3 * sz_total) / 4)
       return; // a chain, or nothing to gain
    limbs = best_limbs, trunk = best_trunk;
    std::vector<int> owner;
@@ -503,7 +511,7 @@ void split_rt_plan(mh_model *m)
    for (int i : by_start)
    {
       const int w = owner[i], r = limbs[i];
-      seg[((size_t)w * mh::SPLIT_MAX_SEG + S.n_seg[w]) * 2] = r, seg[((size_t)w * mh::SPLIT_MAX_SEG + S.n_seg[w]) * 2 + 1] = r + sz[r];
+      seg[((size_t)w * mh::SPLIT_MAX_SEG + S.n_seg[w]) * 2] = r, seg[((size_t)w * mh::SPLIT_MAX_SEG + S.n_seg[w]) * 2 + 1] = r + cnt[r];
       S.n_seg[w]++;
       if (MI(r, mh::MI_PARENT) >= 0)
          xslot[r] = slots, slots += 27;
@@ -568,7 +576,7 @@ void split_rt_plan(mh_model *m)
       xl.push_back(0);
    if (trunk_list.empty())
       trunk_list.push_back(0);
-   S.n_trunk = best_nt, S.n_limbs = (int)limbs.size(), S.slots = slots;
+   S.n_trunk = best_ntc, S.n_limbs = (int)limbs.size(), S.slots = slots, S.est = (S.est + 5) / 10, S.total = (sz_total + 5) / 10;
    auto up = [&](int **dst, const std::vector<int> &v) {
       return hipMalloc((void **)dst, v.size() * sizeof(int)) == hipSuccess && hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
    };
@@ -1748,8 +1756,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    if (m->split_rt.usable && m->variant.compare(0, 7, "generic") == 0)
    {
       char buf[160];
-      snprintf(buf, sizeof buf, "; small batches: run-time tree split over 4 waves (%d trunk bodies + %d limbs, path %d of %d bodies)", m->split_rt.n_trunk,
-               m->split_rt.n_limbs, m->split_rt.est, m->n);
+      snprintf(buf, sizeof buf, "; small batches: run-time tree split over 4 waves (%d trunk bodies + %d limbs, path %d of %d body steps)", m->split_rt.n_trunk,
+               m->split_rt.n_limbs, m->split_rt.est, m->split_rt.total);
       m->variant += buf;
    }
    int selfcheck = 1;
