@@ -684,7 +684,8 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                      revolute_up(jx, Xb, Ia, pp);
                   else
                   {
-                     abi_up(type, jx, Xb, Ia); // :1156-1166
+                     if (type != JT_SIXDOF) // (a floating joint transmits no inertia: Ia = 0 stays 0)
+                        abi_up(type, jx, Xb, Ia); // :1156-1166
                      pp = force_up(type, jx, Xb, pa);
                   }
                   if (ev & EV_LAST_CHILD)

@@ -998,7 +998,8 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
                   revolute_up(jx, Xb, Ia, pp);
                else
                {
-                  abi_up(type, jx, Xb, Ia); // :1156-1166
+                  if (type != JT_SIXDOF || (LOCKED && (flags & MF_LOCKED))) // an effort-source floating joint transmits no inertia: Ia = 0 stays 0
+                     abi_up(type, jx, Xb, Ia); // :1156-1166
                   pp = force_up(type, jx, Xb, pa);
                }
             }

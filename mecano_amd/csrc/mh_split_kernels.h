@@ -321,7 +321,8 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
             {
                const XF<T> Xb = load_xb<T>(c);
                const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
-               abi_up(type, jx, Xb, Ia); // :1156-1166
+               if (type != JT_SIXDOF) // (a floating joint transmits no inertia: Ia = 0 stays 0)
+                  abi_up(type, jx, Xb, Ia); // :1156-1166
                pp = force_up(type, jx, Xb, pa);
             }
             if (xs >= 0)
