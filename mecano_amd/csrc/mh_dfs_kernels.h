@@ -604,6 +604,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                }
                ABI<T> Ia = IA;
                SV<T> pa = pA;
+               bool handed_up = false;
                if (type == JT_REVOLUTE || type == JT_PRISMATIC)
                {
                   V3<T> ua, ul;
@@ -624,12 +625,19 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                      MH_HD(hn + 0) = cj.a.x, MH_HD(hn + 1) = cj.a.y, MH_HD(hn + 2) = cj.a.z, MH_HD(hn + 3) = cj.l.x, MH_HD(hn + 4) = cj.l.y, MH_HD(hn + 5) = cj.l.z;
                   if (parent >= 0)
                   {
-                     if (type == JT_REVOLUTE)
-                        rank1_down_revolute(Ia, ua, ul, dinv); // :1220-1226 (Ia S = 0: exact structural zeros)
-                     else
-                        rank1_down(Ia, ua, ul, dinv);
                      const T ud = u * dinv;
-                     pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
+                     if (type == JT_REVOLUTE)
+                     { // Ia S = 0: exact structural zeros -- and the hand-up in the SAME block, so that every product with them folds
+                        rank1_down_revolute(Ia, ua, ul, dinv);           // :1220-1226
+                        pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
+                        revolute_up(jx, Xb, Ia, pa);                     // :1156-1166; pa is now expressed in the parent's frame
+                        handed_up = true;
+                     }
+                     else
+                     {
+                        rank1_down(Ia, ua, ul, dinv);
+                        pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul};
+                     }
                   }
                }
                else if (type == JT_PLANAR || type == JT_SPHERICAL)
@@ -680,9 +688,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                if (parent >= 0)
                {
                   SV<T> pp = pa;
-                  if (type == JT_REVOLUTE)
-                     revolute_up(jx, Xb, Ia, pp);
-                  else
+                  if (!handed_up)
                   {
                      if (type != JT_SIXDOF) // (a floating joint transmits no inertia: Ia = 0 stays 0)
                         abi_up(type, jx, Xb, Ia); // :1156-1166
