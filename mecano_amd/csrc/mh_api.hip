@@ -603,8 +603,10 @@ mh_status launch_split_rt(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A,
       P.n_seg[k] = S.n_seg[k];
    if (algo == ALGO_RNEA)
       hipLaunchKernelGGL((mh::rnea_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
-   else
+   else if (algo == ALGO_ABA)
       hipLaunchKernelGGL((mh::aba_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
+   else
+      hipLaunchKernelGGL((mh::crba_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
    HIP_TRY(hipGetLastError());
    return MH_OK;
 }
@@ -927,6 +929,8 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             return MH_OK;
          }
          HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
+         if (model->split_rt.usable && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * (model->n >= 64 ? 2 : 1)))
+            return launch_split_rt<T>(algo, model, B, A, stream); // small batches: the tree split over four waves (mh_split_kernels.h)
          { if (ldsc) hipLaunchKernelGGL((mh::crba_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::crba_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
          break;
       }

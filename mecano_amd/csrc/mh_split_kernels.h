@@ -430,4 +430,146 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
       __syncthreads(); // the next group of configurations re-uses the block
    }
 }
+// ============================================================================================ CRBA
+// CompositeRigidBodyMassMatrixCalculator.java:588-707, 770-798.  The columns of a limb body need the joint transforms of its ancestors,
+// not their composite inertias: every wave finishes ALL columns of its limbs' bodies (walking up through the trunk with the trunk's
+// transforms, which every wave forms itself) before the barrier; a limb root leaves its composite inertia (10 values) in its exchange
+// record; after the barrier wave 0 folds the trunk's composite inertias and writes the trunk bodies' columns.  H was zeroed by the caller.
+template <typename T>
+__global__ void __launch_bounds__(256) crba_split_kernel(Args<T> A, SplitDev P)
+{
+   const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   const ciptr meta = as_const(P.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
+   const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
+   const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid;
+   const int n_seg = P.n_seg[wave], nv = m.nv;
+   const long groups = (A.B + 63) / 64;
+
+   for (long grp = blockIdx.x; grp < groups; grp += gridDim.x)
+   {
+      const long cfg0 = grp * 64 + tid;
+      const bool active = cfg0 < A.B;
+      const long cfg = active ? cfg0 : A.B - 1;
+      const T *qrow = A.q + cfg * A.q_bs;
+      T *H = A.out + cfg * A.v_bs; // v_bs / v_es carry the per-configuration / per-entry strides of H here
+      const long h_es = A.v_es;
+      auto transform = [&](int j) {
+         ciptr mi = meta + j * MI_STRIDE;
+         (void)joint_from_q<T>(mi[MI_TYPE], cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+      };
+      for (int k = 0; k < P.n_trunk; k++)
+         transform(trunk[k]);
+      for (int s = 0; s < n_seg; s++)
+      {
+         const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
+         for (int j = j0; j < j1; j++)
+            transform(j);
+      }
+      RI<T> rcarry;
+      bool have_carry = false;
+      auto body = [&](int j, int xk0, int xk1) {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
+         const CRef<T, false> c{CB + j * MC_STRIDE};
+         RI<T> Ic = load_inertia<T>(c);
+         if (have_carry)
+            add(Ic, rcarry);
+         if (flags & MF_HAS_ACC)
+            add(Ic, ws_load_ri(ws, ws_stride, mi[MI_SLOT_IA]));
+         for (int k = xk0; k < xk1; k++)
+            add(Ic, ws_load_ri(ws, ws_stride, xl[k]));
+         have_carry = false;
+         const int nd = dof_count(type);
+         ciptr dj = dof_map + mi[MI_DOF];
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         for (int k = 0; k < nd; k++)
+         {
+            SV<T> F = mul(Ic, unit_twist<T>(type, k)); // :663-667
+            const int col = dj[k];
+            if (active)
+            { // diagonal block (:700-707)
+               if (type == JT_REVOLUTE)
+                  H[((long)col * nv + col) * h_es] = F.a.z;
+               else if (type == JT_PRISMATIC)
+                  H[((long)col * nv + col) * h_es] = F.l.z;
+               else
+                  for (int r = 0; r < nd; r++)
+                     H[((long)dj[r] * nv + col) * h_es] = comp(F, dof_comp(type, r));
+            }
+            int prev = j, anc = parent; // ancestors (:783-792)
+            XF<T> Xp = Xb;
+            JX<T> jp = jx;
+            int tp = type;
+            while (anc >= 0)
+            {
+               F = force_up(tp, jp, Xp, F);
+               ciptr ma = meta + anc * MI_STRIDE;
+               const int ta = ma[MI_TYPE];
+               ciptr da = dof_map + ma[MI_DOF];
+               if (active)
+               {
+                  if (ta == JT_REVOLUTE)
+                     H[((long)da[0] * nv + col) * h_es] = F.a.z, H[((long)col * nv + da[0]) * h_es] = F.a.z;
+                  else if (ta == JT_PRISMATIC)
+                     H[((long)da[0] * nv + col) * h_es] = F.l.z, H[((long)col * nv + da[0]) * h_es] = F.l.z;
+                  else
+                     for (int r = 0; r < dof_count(ta); r++)
+                     {
+                        const T hv = comp(F, dof_comp(ta, r));
+                        H[((long)da[r] * nv + col) * h_es] = hv;
+                        H[((long)col * nv + da[r]) * h_es] = hv;
+                     }
+               }
+               prev = anc;
+               anc = ma[MI_PARENT];
+               if (anc >= 0)
+               {
+                  Xp = load_xb<T>(CRef<T, false>{CB + prev * MC_STRIDE});
+                  jp = joint_again<T>(ta, cfg_map, ma[MI_CFG], qrow, A.q_es, ws, ws_stride, ma[MI_SLOT_JP]);
+                  tp = ta;
+               }
+            }
+         }
+         if (parent >= 0)
+         {
+            rigid_up(type, jx, Xb, Ic); // :651-661
+            if (xs >= 0)
+               ws_store_ri(ws, ws_stride, xs, Ic); // a limb root: through the exchange record
+            else if (flags & MF_PARENT_ADJ)
+               rcarry = Ic, have_carry = true;
+            else
+            {
+               const int sp = meta[parent * MI_STRIDE + MI_SLOT_IA];
+               if (flags & MF_ACC_FIRST)
+                  ws_store_ri(ws, ws_stride, sp, Ic);
+               else
+               {
+                  RI<T> acc = ws_load_ri(ws, ws_stride, sp);
+                  add(acc, Ic);
+                  ws_store_ri(ws, ws_stride, sp, acc);
+               }
+            }
+         }
+      };
+      for (int s = n_seg - 1; s >= 0; s--)
+      {
+         const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
+         have_carry = false;
+         for (int j = j1 - 1; j >= j0; j--)
+            body(j, 0, 0);
+      }
+      __syncthreads(); // the limbs' composite inertias are in the workgroup's block
+      if (wave == 0)
+      {
+         have_carry = false;
+         for (int k = P.n_trunk - 1; k >= 0; k--)
+            body(trunk[k], xl_ofs[k], xl_ofs[k + 1]);
+      }
+      __syncthreads(); // the next group of configurations re-uses the block
+   }
+}
 } // namespace mh

@@ -1212,7 +1212,13 @@ def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
             T = lambda x: x.reshape(B, -1).t().contiguous()
             assert torch.equal(on.rnea(T(tq), T(tqd), T(tqdd), g, T(tf), layout=_lib.LAYOUT_SOA).t(), t)
             assert torch.equal(on.aba(T(tq), T(tqd), T(ttau), g, T(tf), layout=_lib.LAYOUT_SOA).t(), a)
+            if B <= 300:
+                H, H0 = on.crba(tq), off.crba(tq)
+                assert (H - H0).abs().max().item() <= (1e-12 if dtype == "f64" else 2e-4) * max(1.0, H0.abs().max().item())
+                assert torch.equal(H == 0, H0 == 0)  # unrelated branches: exact zeros in both
+                assert torch.equal(on.crba(T(tq), layout=_lib.LAYOUT_SOA).t().reshape(B, d.nv, d.nv), H)
             if B <= 67:
+                close(H.cpu().numpy().astype(np.float64), om.crba(q), tol, label="crba")
                 close(t.cpu().numpy().astype(np.float64), om.rnea(q, qd, qdd, g, fext), tol, label="rnea")
                 close(a.cpu().numpy().astype(np.float64), om.aba(q, qd, tau, g, fext), 1e-7 if dtype == "f64" else 5e-2, label="aba")
                 for cc, ca in ((False, True), (True, False)):
