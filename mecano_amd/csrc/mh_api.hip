@@ -184,10 +184,13 @@ struct mh_model
       bool usable = false;
       int n_trunk = 0, n_limbs = 0, slots = 0, est = 0, total = 0;
       int n_seg[mh::SPLIT_WAVES] = {};
-      int *d_meta = nullptr, *d_trunk = nullptr, *d_seg = nullptr, *d_xl_ofs = nullptr, *d_xl = nullptr;
-      std::vector<int> meta; // host copy of the adapted records (joint source modes invalidate it)
+      int *d_meta[3] = {nullptr, nullptr, nullptr}, *d_trunk = nullptr, *d_seg = nullptr, *d_xl_ofs = nullptr, *d_xl[3] = {nullptr, nullptr, nullptr}; // [0] fp32, [1] fp64, [2] no LDS share
+      int lds_slots[3] = {0, 0, 0}; // slots below this number live in LDS (the slot codes of the records say so), per record set
+      std::vector<int> meta;     // (body, field, value) patches of the adapted records
+      std::vector<int> xl;       // exchange slots of the limbs attached to the trunk bodies (plain slot numbers)
    } split_rt;
    int use_split_rt = -1; // MH_SPLIT_RT = 0 | 1: never / whenever usable (default: small batches)
+   int split_rt_lds = -1; // MH_SPLIT_RT_LDS = 0 | 1: the split kernels' workspace never / always with its LDS share (measurements)
    // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices)
    Workspace tr;
    // scratch of the composite entry points: efforts of the Newton-Euler sweep behind mh_aba_joint_wrenches_f64, pair lists of
@@ -393,21 +396,41 @@ void dfs_plans_drop(mh_model *m)
 void split_rt_free(mh_model *m)
 {
    mh_model::SplitRt &S = m->split_rt;
-   (void)hipFree(S.d_meta), (void)hipFree(S.d_trunk), (void)hipFree(S.d_seg), (void)hipFree(S.d_xl_ofs), (void)hipFree(S.d_xl);
-   S.d_meta = S.d_trunk = S.d_seg = S.d_xl_ofs = S.d_xl = nullptr;
+   for (int k = 0; k < 3; k++)
+      (void)hipFree(S.d_meta[k]), (void)hipFree(S.d_xl[k]), S.d_meta[k] = S.d_xl[k] = nullptr;
+   (void)hipFree(S.d_trunk), (void)hipFree(S.d_seg), (void)hipFree(S.d_xl_ofs);
+   S.d_trunk = S.d_seg = S.d_xl_ofs = nullptr;
    S.usable = false;
 }
 mh_status split_rt_upload_meta(mh_model *m)
-{ // the adapted body records: the model's with the (body, field, value) patches of the plan applied
+{ // the adapted body records: the model's with the (body, field, value) patches of the plan applied, then every workspace slot number
+  // turned into a slot CODE (home bit) for the precision's LDS share
    mh_model::SplitRt &S = m->split_rt;
    if (!S.usable)
       return MH_OK;
-   std::vector<int> meta = m->meta;
-   for (size_t k = 0; k + 2 < S.meta.size(); k += 3)
-      meta[(size_t)S.meta[k] * mh::MI_STRIDE + S.meta[k + 1]] = S.meta[k + 2];
-   if (!S.d_meta)
-      HIP_TRY(hipMalloc((void **)&S.d_meta, meta.size() * sizeof(int)));
-   HIP_TRY(hipMemcpy(S.d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+   static const int slot_fields[] = {mh::MI_SLOT_JP, mh::MI_SLOT_F, mh::MI_SLOT_VA, mh::MI_SLOT_C, mh::MI_SLOT_IA, mh::MI_SLOT_LK, mh::MI_HAND};
+   for (int k = 0; k < 3; k++)
+   {
+      const long elem = k == 0 ? 4 : 8;
+      const long cap = 160 * 1024 / (64 * elem);
+      S.lds_slots[k] = k == 2 ? 0 : (int)(S.slots <= cap ? S.slots : cap - mh::SPLIT_LDS_MARGIN); // everything, or a share with room for a group
+      std::vector<int> meta = m->meta;
+      for (size_t i = 0; i + 2 < S.meta.size(); i += 3)
+         meta[(size_t)S.meta[i] * mh::MI_STRIDE + S.meta[i + 1]] = S.meta[i + 2];
+      auto code = [&](int slot) { return slot >= 0 && slot < S.lds_slots[k] ? (slot | mh::DFS_LDS) : slot; };
+      for (int e = 0; e < m->n; e++)
+         for (int f : slot_fields)
+            meta[(size_t)e * mh::MI_STRIDE + f] = code(meta[(size_t)e * mh::MI_STRIDE + f]);
+      std::vector<int> xl = S.xl;
+      for (int &x : xl)
+         x = code(x);
+      if (!S.d_meta[k])
+         HIP_TRY(hipMalloc((void **)&S.d_meta[k], meta.size() * sizeof(int)));
+      HIP_TRY(hipMemcpy(S.d_meta[k], meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+      if (!S.d_xl[k])
+         HIP_TRY(hipMalloc((void **)&S.d_xl[k], xl.size() * sizeof(int)));
+      HIP_TRY(hipMemcpy(S.d_xl[k], xl.data(), xl.size() * sizeof(int), hipMemcpyHostToDevice));
+   }
    return MH_OK;
 }
 void split_rt_plan(mh_model *m)
@@ -580,7 +603,8 @@ void split_rt_plan(mh_model *m)
    auto up = [&](int **dst, const std::vector<int> &v) {
       return hipMalloc((void **)dst, v.size() * sizeof(int)) == hipSuccess && hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
    };
-   S.usable = up(&S.d_trunk, trunk_list) && up(&S.d_seg, seg) && up(&S.d_xl_ofs, xl_ofs) && up(&S.d_xl, xl);
+   S.xl = xl;
+   S.usable = up(&S.d_trunk, trunk_list) && up(&S.d_seg, seg) && up(&S.d_xl_ofs, xl_ofs);
    if (S.usable && split_rt_upload_meta(m) != MH_OK)
       S.usable = false;
    if (!S.usable)
@@ -592,22 +616,35 @@ mh_status launch_split_rt(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A,
    const mh_model::SplitRt &S = model->split_rt;
    const long groups = (B + 63) / 64;
    const int grid = (int)std::max<long>(1, std::min<long>(groups, model->cu_count));
+   // Which record set: everything in LDS when the block fits (no branches); else a share in LDS once the blocks of the workgroups of an
+   // XCD outgrow its L2 (measured on the fp64 humanoid: 44 us all-global vs 47 with a share at B = 4096, 71 vs 50 at 8192); else all global.
+   int k = sizeof(T) == 4 ? 0 : 1;
+   if (S.lds_slots[k] < S.slots && (size_t)S.slots * 64 * sizeof(T) * ((size_t)grid / 8 + 1) <= (size_t)3 << 20)
+      k = 2;
+   if (model->split_rt_lds >= 0)
+      k = model->split_rt_lds ? (sizeof(T) == 4 ? 0 : 1) : 2;
+   const int mode = S.lds_slots[k] >= S.slots ? 0 : (S.lds_slots[k] == 0 ? 1 : 2);
    mh_status st = ensure_bytes(model->ws, (size_t)S.slots * (size_t)grid * 64 * sizeof(T));
    if (st != MH_OK)
       return st;
    A.ws = (T *)model->ws.ptr;
    mh::SplitDev P{};
-   P.meta = S.d_meta, P.trunk = S.d_trunk, P.seg = S.d_seg, P.xl_ofs = S.d_xl_ofs, P.xl = S.d_xl;
+   P.meta = S.d_meta[k], P.trunk = S.d_trunk, P.seg = S.d_seg, P.xl_ofs = S.d_xl_ofs, P.xl = S.d_xl[k];
    P.n_trunk = S.n_trunk, P.slots = S.slots;
-   for (int k = 0; k < mh::SPLIT_WAVES; k++)
-      P.n_seg[k] = S.n_seg[k];
-   if (algo == ALGO_RNEA)
-      hipLaunchKernelGGL((mh::rnea_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
-   else if (algo == ALGO_ABA)
-      hipLaunchKernelGGL((mh::aba_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
-   else
-      hipLaunchKernelGGL((mh::crba_split_kernel<T>), dim3(grid), dim3(256), 0, stream, A, P);
-   HIP_TRY(hipGetLastError());
+   for (int w = 0; w < mh::SPLIT_WAVES; w++)
+      P.n_seg[w] = S.n_seg[w];
+   const size_t lds = mode == 1 ? 0 : (size_t)std::min(S.slots, S.lds_slots[k] + mh::SPLIT_LDS_MARGIN) * 64 * sizeof(T);
+   const void *kern = nullptr;
+#define MH_SPLIT_KERN(NAME) (mode == 0 ? (const void *)&mh::NAME<T, 0> : (mode == 1 ? (const void *)&mh::NAME<T, 1> : (const void *)&mh::NAME<T, 2>))
+   kern = algo == ALGO_RNEA ? MH_SPLIT_KERN(rnea_split_kernel) : (algo == ALGO_ABA ? MH_SPLIT_KERN(aba_split_kernel) : MH_SPLIT_KERN(crba_split_kernel));
+#undef MH_SPLIT_KERN
+   if (lds > 64 * 1024 && model->lds_attr[kern] < lds)
+   {
+      HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      model->lds_attr[kern] = lds;
+   }
+   void *args[] = {(void *)&A, (void *)&P};
+   HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(256), args, lds, stream));
    return MH_OK;
 }
 
@@ -1752,6 +1789,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->host_chunk = std::max(0, atoi(e));
    if (const char *e = getenv("MH_SPLIT_RT"))
       m->use_split_rt = atoi(e);
+   if (const char *e = getenv("MH_SPLIT_RT_LDS"))
+      m->split_rt_lds = atoi(e) != 0;
    if (m->use_split_rt != 0)
       split_rt_plan(m);
    try_load_spec(m, P);

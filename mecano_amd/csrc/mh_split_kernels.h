@@ -19,14 +19,92 @@
 #pragma once
 #include "mh_dfs_kernels.h"
 
-#ifndef MH_WS
-#define MH_WS(slot) ws[(long)(slot)*ws_stride]
-#endif
-
 namespace mh
 {
 constexpr int SPLIT_WAVES = 4;
 constexpr int SPLIT_MAX_SEG = 16; // limbs per wave
+// The workgroup's workspace block: the first slots live in LDS (a small batch gives a workgroup the CU to itself: 160 KB that would sit
+// idle, and a walk's chain of dependent workspace round trips is what these kernels wait for), the rest in the global block.  The slot
+// numbers in the adapted body records carry their home like the depth-first kernels' (DFS_LDS bit, mh_dfs_kernels.h: DStack, st_*);
+// a group of slots (a 6-vector, a 21 + 6 record, ...) is homed as a whole by its first slot.
+constexpr int SPLIT_LDS_MARGIN = 48; // slots past the boundary a group that starts below it may reach
+// MODE: 0 = every slot in LDS, 1 = every slot in the global block (no branch in either), 2 = as the slot code says
+template <typename T, class SK>
+MH_DEV T sw_ld(const SK &S, int code)
+{
+   if (SK::mode == 0 || (SK::mode == 2 && (code & DFS_LDS)))
+      return S.lds[(code & DFS_SLOT) * 64];
+   return S.glb[(long)code * 64];
+}
+template <typename T, class SK>
+MH_DEV void sw_st(const SK &S, int code, T v)
+{
+   if (SK::mode == 0 || (SK::mode == 2 && (code & DFS_LDS)))
+      S.lds[(code & DFS_SLOT) * 64] = v;
+   else
+      S.glb[(long)code * 64] = v;
+}
+template <typename T, class SK>
+MH_DEV void sw_store_ri(const SK &S, int code, const RI<T> &r)
+{
+   const T v[10] = {r.m, r.h.x, r.h.y, r.h.z, r.I.xx, r.I.xy, r.I.xz, r.I.yy, r.I.yz, r.I.zz};
+   if (SK::mode == 0 || (SK::mode == 2 && (code & DFS_LDS)))
+   {
+      const dfs_lds_ptr<T> sp = S.lds + (code & DFS_SLOT) * 64;
+#pragma unroll
+      for (int k = 0; k < 10; k++)
+         sp[k * 64] = v[k];
+   }
+   else
+   {
+      T *const sp = S.glb + (long)code * 64;
+#pragma unroll
+      for (int k = 0; k < 10; k++)
+         sp[k * 64] = v[k];
+   }
+}
+template <typename T, class SK>
+MH_DEV RI<T> sw_load_ri(const SK &S, int code)
+{
+   T v[10];
+   if (SK::mode == 0 || (SK::mode == 2 && (code & DFS_LDS)))
+   {
+      const dfs_lds_ptr<T> sp = S.lds + (code & DFS_SLOT) * 64;
+#pragma unroll
+      for (int k = 0; k < 10; k++)
+         v[k] = sp[k * 64];
+   }
+   else
+   {
+      const T *const sp = S.glb + (long)code * 64;
+#pragma unroll
+      for (int k = 0; k < 10; k++)
+         v[k] = sp[k * 64];
+   }
+   RI<T> r;
+   r.m = v[0], r.h = V3<T>{v[1], v[2], v[3]}, r.I = S3<T>{v[4], v[5], v[6], v[7], v[8], v[9]};
+   return r;
+}
+// joint transform on the first / a later visit of a body: (cos, sin) of revolute joints go through the workspace, the rest is re-read from q
+template <typename T, class SK>
+MH_DEV JX<T> sw_joint_from_q(const SK &S, int type, ciptr cfg_map, int cfg_ofs, const T *qrow, long q_es, int jp)
+{
+   const JX<T> jx = joint_from_q<T>(type, cfg_map, cfg_ofs, qrow, q_es, (T *)nullptr, 0, 0, false);
+   if (type == JT_REVOLUTE)
+      sw_st<T>(S, jp, jx.c), sw_st<T>(S, jp + 1, jx.s);
+   return jx;
+}
+template <typename T, class SK>
+MH_DEV JX<T> sw_joint_again(const SK &S, int type, ciptr cfg_map, int cfg_ofs, const T *qrow, long q_es, int jp)
+{
+   if (type == JT_REVOLUTE)
+   {
+      JX<T> jx;
+      jx.c = sw_ld<T>(S, jp), jx.s = sw_ld<T>(S, jp + 1), jx.d = T(0);
+      return jx;
+   }
+   return joint_again<T>(type, cfg_map, cfg_ofs, qrow, q_es, (const T *)nullptr, 0, 0);
+}
 struct SplitDev
 {
    const int *meta;    // [n][MI_STRIDE]: MI_FLAGS adapted, MI_HAND = exchange slot of a limb root (-1 otherwise)
@@ -39,7 +117,7 @@ struct SplitDev
 };
 
 // ============================================================================================ RNEA
-template <typename T>
+template <typename T, int MODE>
 __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
 {
    const DevModel &m = A.m;
@@ -47,8 +125,8 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
    const ciptr meta = as_const(P.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
    const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-   constexpr long ws_stride = 64;
-   T *ws = A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid;
+   extern __shared__ double lds_raw[];
+   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid};
    const V3<T> Z{T(0), T(0), T(0)};
    const int n_seg = P.n_seg[wave];
    const long groups = (A.B + 63) / 64;
@@ -81,11 +159,11 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
          else
          {
             const int sp = meta[parent * MI_STRIDE + MI_SLOT_VA];
-            vp = ws_load6(ws, ws_stride, sp);
-            ap = ws_load6(ws, ws_stride, sp + 6);
+            vp = st_load6<T>(S, sp);
+            ap = st_load6<T>(S, sp + 6);
          }
          const XF<T> Xb = load_xb<T>(c);
-         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const JX<T> jx = sw_joint_from_q<T>(S, type, cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
          const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, A.coriolis != 0);
          const SV<T> aJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qddrow, A.v_es, A.accel != 0);
          SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
@@ -96,11 +174,11 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
          SV<T> f = mul(I, a) + crf(v, mul(I, v));
          if (frow)
             f = f - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
-         ws_store6(ws, ws_stride, mi[MI_SLOT_F], f);
+         st_store6<T>(S, mi[MI_SLOT_F], f);
          if (flags & MF_STORE_VA)
          {
-            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
-            ws_store6(ws, ws_stride, mi[MI_SLOT_VA] + 6, a);
+            st_store6<T>(S, mi[MI_SLOT_VA], v);
+            st_store6<T>(S, mi[MI_SLOT_VA] + 6, a);
          }
          v_prev = v, a_prev = a;
       };
@@ -119,25 +197,25 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
          ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
          const CRef<T, false> c{CB + j * MC_STRIDE};
-         SV<T> f = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         SV<T> f = st_load6<T>(S, mi[MI_SLOT_F]);
          if (have_carry)
             f = f + carry;
          for (int k = xk0; k < xk1; k++) // trunk bodies: what the attached limbs handed up
-            f = f + ws_load6(ws, ws_stride, xl[k]);
+            f = f + st_load6<T>(S, xl[k]);
          if (active)
             write_joint_rows<T>(type, dof_map + mi[MI_DOF], trow, A.v_es, f);
          have_carry = false;
          if (parent >= 0)
          {
             const XF<T> Xb = load_xb<T>(c);
-            const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+            const JX<T> jx = sw_joint_again<T>(S, type, cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
             const SV<T> fp = force_up(type, jx, Xb, f);
             if (xs >= 0)
-               ws_store6(ws, ws_stride, xs, fp); // a limb root: through the exchange record
+               st_store6<T>(S, xs, fp); // a limb root: through the exchange record
             else if (flags & MF_PARENT_ADJ)
                carry = fp, have_carry = true;
             else
-               ws_add6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_F], fp);
+               st_add6<T>(S, meta[parent * MI_STRIDE + MI_SLOT_F], fp);
          }
       };
       for (int s = n_seg - 1; s >= 0; s--)
@@ -159,7 +237,7 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
 }
 
 // ============================================================================================ ABA
-template <typename T>
+template <typename T, int MODE>
 __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
 {
    const DevModel &m = A.m;
@@ -167,8 +245,8 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
    const ciptr meta = as_const(P.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
    const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-   constexpr long ws_stride = 64;
-   T *ws = A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid;
+   extern __shared__ double lds_raw[];
+   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid};
    const V3<T> Z{T(0), T(0), T(0)};
    const int n_seg = P.n_seg[wave];
    const long groups = (A.B + 63) / 64;
@@ -196,19 +274,19 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          else if (flags & MF_PARENT_ADJ)
             vp = v_prev;
          else
-            vp = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
+            vp = st_load6<T>(S, meta[parent * MI_STRIDE + MI_SLOT_VA]);
          const XF<T> Xb = load_xb<T>(c);
-         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const JX<T> jx = sw_joint_from_q<T>(S, type, cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
          const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
          const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
          const RI<T> I = load_inertia<T>(c);
          SV<T> p = crf(v, mul(I, v));
          if (frow)
             p = p - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
-         ws_store6(ws, ws_stride, mi[MI_SLOT_F], p);
-         ws_store6(ws, ws_stride, mi[MI_SLOT_C], crm(v, vJ));
+         st_store6<T>(S, mi[MI_SLOT_F], p);
+         st_store6<T>(S, mi[MI_SLOT_C], crm(v, vJ));
          if (flags & MF_STORE_VA)
-            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
+            st_store6<T>(S, mi[MI_SLOT_VA], v);
          v_prev = v;
       };
       for (int k = 0; k < P.n_trunk; k++)
@@ -228,18 +306,18 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
          const CRef<T, false> c{CB + j * MC_STRIDE};
          ABI<T> IA = abi_from_rigid(load_inertia<T>(c));
-         SV<T> pA = ws_load6(ws, ws_stride, mi[MI_SLOT_F]);
+         SV<T> pA = st_load6<T>(S, mi[MI_SLOT_F]);
          if (have_carry)
          {
             add(IA, Icarry);
             pA = pA + pcarry;
          }
          if (flags & MF_HAS_ACC)
-            add(IA, ws_load_abi(ws, ws_stride, mi[MI_SLOT_IA])); // (the bias wrenches of those children were added to slot F)
+            add(IA, st_load_abi<T>(S, mi[MI_SLOT_IA])); // (the bias wrenches of those children were added to slot F)
          for (int k = xk0; k < xk1; k++)
          { // trunk bodies: articulated inertia and bias wrench of the attached limbs
-            add(IA, ws_load_abi(ws, ws_stride, xl[k]));
-            pA = pA + ws_load6(ws, ws_stride, xl[k] + 21);
+            add(IA, st_load_abi<T>(S, xl[k]));
+            pA = pA + st_load6<T>(S, xl[k] + 21);
          }
          have_carry = false;
          const int sf = mi[MI_SLOT_F];
@@ -257,19 +335,19 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
                ua = V3<T>{IA.C.xz, IA.C.yz, IA.C.zz}, ul = V3<T>{IA.L.xz, IA.L.yz, IA.L.zz}, D = IA.L.zz, pz = pA.l.z;
             const T dinv = T(1) / D;                 // :1183
             const T u = taurow[di[0] * A.v_es] - pz; // :1200-1215
-            ws_store6(ws, ws_stride, sf, SV<T>{ua, ul});
-            MH_WS(sf + 6) = dinv;
-            MH_WS(sf + 7) = u;
+            st_store6<T>(S, sf, SV<T>{ua, ul});
+            sw_st<T>(S, sf + 6, dinv);
+            sw_st<T>(S, sf + 7, u);
             if (parent >= 0)
             {
-               const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+               const SV<T> cj = st_load6<T>(S, mi[MI_SLOT_C]);
                const T ud = u * dinv;
                if (type == JT_REVOLUTE)
                {
                   rank1_down_revolute(Ia, ua, ul, dinv);           // :1220-1226
                   pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
                   JX<T> jx;
-                  jx.c = MH_WS(mi[MI_SLOT_JP]), jx.s = MH_WS(mi[MI_SLOT_JP] + 1), jx.d = T(0);
+                  jx.c = sw_ld<T>(S, mi[MI_SLOT_JP]), jx.s = sw_ld<T>(S, mi[MI_SLOT_JP] + 1), jx.d = T(0);
                   revolute_up(jx, load_xb<T>(c), Ia, pa); // :1156-1166; pa is now expressed in the parent's frame
                   handed_up = true;
                }
@@ -288,14 +366,14 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
             const V3<T> tau3{taurow[di[0] * A.v_es], taurow[di[1] * A.v_es], taurow[di[2] * A.v_es]};
             const V3<T> u3 = tau3 - comp3(type, pA);
             const int sl = mi[MI_SLOT_LK];
-            ws_store6(ws, ws_stride, sl, U0), ws_store6(ws, ws_stride, sl + 6, U1), ws_store6(ws, ws_stride, sl + 12, U2);
-            MH_WS(sl + 18) = Di.xx, MH_WS(sl + 19) = Di.xy, MH_WS(sl + 20) = Di.xz, MH_WS(sl + 21) = Di.yy, MH_WS(sl + 22) = Di.yz, MH_WS(sl + 23) = Di.zz;
-            MH_WS(sl + 24) = u3.x, MH_WS(sl + 25) = u3.y, MH_WS(sl + 26) = u3.z;
+            st_store6<T>(S, sl, U0), st_store6<T>(S, sl + 6, U1), st_store6<T>(S, sl + 12, U2);
+            st_store6<T>(S, sl + 18, SV<T>{V3<T>{Di.xx, Di.xy, Di.xz}, V3<T>{Di.yy, Di.yz, Di.zz}});
+            sw_st<T>(S, sl + 24, u3.x), sw_st<T>(S, sl + 25, u3.y), sw_st<T>(S, sl + 26, u3.z);
             if (parent >= 0)
             {
                const SV<T> W0 = Di.xx * U0 + Di.xy * U1 + Di.xz * U2, W1 = Di.xy * U0 + Di.yy * U1 + Di.yz * U2, W2 = Di.xz * U0 + Di.yz * U1 + Di.zz * U2;
                rank1_pair_down(Ia, W0, U0), rank1_pair_down(Ia, W1, U1), rank1_pair_down(Ia, W2, U2);
-               const SV<T> cj = ws_load6(ws, ws_stride, mi[MI_SLOT_C]);
+               const SV<T> cj = st_load6<T>(S, mi[MI_SLOT_C]);
                pa = pA + mul(Ia, cj) + u3.x * W0 + u3.y * W1 + u3.z * W2;
             }
          }
@@ -304,7 +382,7 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
             const SV<T> tau{V3<T>{taurow[di[0] * A.v_es], taurow[di[1] * A.v_es], taurow[di[2] * A.v_es]},
                             V3<T>{taurow[di[3] * A.v_es], taurow[di[4] * A.v_es], taurow[di[5] * A.v_es]}};
             const SV<T> x = spd6_solve(IA, tau - pA);
-            ws_store6(ws, ws_stride, sf, x);
+            st_store6<T>(S, sf, x);
             if (parent >= 0)
             {
                Ia.A = S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)};
@@ -320,15 +398,15 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
             if (!handed_up)
             {
                const XF<T> Xb = load_xb<T>(c);
-               const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+               const JX<T> jx = sw_joint_again<T>(S, type, cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
                if (type != JT_SIXDOF) // (a floating joint transmits no inertia: Ia = 0 stays 0)
                   abi_up(type, jx, Xb, Ia); // :1156-1166
                pp = force_up(type, jx, Xb, pa);
             }
             if (xs >= 0)
             { // a limb root: through the exchange record
-               ws_store_abi(ws, ws_stride, xs, Ia);
-               ws_store6(ws, ws_stride, xs + 21, pp);
+               st_store_abi<T>(S, xs, Ia);
+               st_store6<T>(S, xs + 21, pp);
             }
             else if (flags & MF_PARENT_ADJ)
                Icarry = Ia, pcarry = pp, have_carry = true;
@@ -336,14 +414,14 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
             {
                ciptr pmi = meta + parent * MI_STRIDE;
                if (flags & MF_ACC_FIRST)
-                  ws_store_abi(ws, ws_stride, pmi[MI_SLOT_IA], Ia);
+                  st_store_abi<T>(S, pmi[MI_SLOT_IA], Ia);
                else
                {
-                  ABI<T> acc = ws_load_abi(ws, ws_stride, pmi[MI_SLOT_IA]);
+                  ABI<T> acc = st_load_abi<T>(S, pmi[MI_SLOT_IA]);
                   add(acc, Ia);
-                  ws_store_abi(ws, ws_stride, pmi[MI_SLOT_IA], acc);
+                  st_store_abi<T>(S, pmi[MI_SLOT_IA], acc);
                }
-               ws_add6(ws, ws_stride, pmi[MI_SLOT_F], pp);
+               st_add6<T>(S, pmi[MI_SLOT_F], pp);
             }
          }
       };
@@ -374,16 +452,16 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          else if (flags & MF_PARENT_ADJ)
             ap = a_prev;
          else
-            ap = ws_load6(ws, ws_stride, meta[parent * MI_STRIDE + MI_SLOT_VA]);
+            ap = st_load6<T>(S, meta[parent * MI_STRIDE + MI_SLOT_VA]);
          const XF<T> Xb = load_xb<T>(c);
-         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
-         SV<T> a = motion_down(type, jx, Xb, ap) + ws_load6(ws, ws_stride, mi[MI_SLOT_C]); // :1270-1273
+         const JX<T> jx = sw_joint_again<T>(S, type, cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
+         SV<T> a = motion_down(type, jx, Xb, ap) + st_load6<T>(S, mi[MI_SLOT_C]); // :1270-1273
          const int sf = mi[MI_SLOT_F];
          ciptr di = dof_map + mi[MI_DOF];
          if (type == JT_REVOLUTE || type == JT_PRISMATIC)
          {
-            const SV<T> U = ws_load6(ws, ws_stride, sf);
-            const T dinv = MH_WS(sf + 6), u = MH_WS(sf + 7);
+            const SV<T> U = st_load6<T>(S, sf);
+            const T dinv = sw_ld<T>(S, sf + 6), u = sw_ld<T>(S, sf + 7);
             const T qdd = dinv * (u - (dot(U.a, a.a) + dot(U.l, a.l))); // :1280-1282
             if (writes)
                orow[di[0] * A.v_es] = qdd;
@@ -395,10 +473,11 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          else if (type == JT_PLANAR || type == JT_SPHERICAL)
          {
             const int sl = mi[MI_SLOT_LK];
-            const SV<T> U0 = ws_load6(ws, ws_stride, sl), U1 = ws_load6(ws, ws_stride, sl + 6), U2 = ws_load6(ws, ws_stride, sl + 12);
-            const S3<T> Di{MH_WS(sl + 18), MH_WS(sl + 19), MH_WS(sl + 20), MH_WS(sl + 21), MH_WS(sl + 22), MH_WS(sl + 23)};
-            const V3<T> r{MH_WS(sl + 24) - (dot(U0.a, a.a) + dot(U0.l, a.l)), MH_WS(sl + 25) - (dot(U1.a, a.a) + dot(U1.l, a.l)),
-                          MH_WS(sl + 26) - (dot(U2.a, a.a) + dot(U2.l, a.l))};
+            const SV<T> U0 = st_load6<T>(S, sl), U1 = st_load6<T>(S, sl + 6), U2 = st_load6<T>(S, sl + 12);
+            const SV<T> dv = st_load6<T>(S, sl + 18);
+            const S3<T> Di{dv.a.x, dv.a.y, dv.a.z, dv.l.x, dv.l.y, dv.l.z};
+            const V3<T> r{sw_ld<T>(S, sl + 24) - (dot(U0.a, a.a) + dot(U0.l, a.l)), sw_ld<T>(S, sl + 25) - (dot(U1.a, a.a) + dot(U1.l, a.l)),
+                          sw_ld<T>(S, sl + 26) - (dot(U2.a, a.a) + dot(U2.l, a.l))};
             const V3<T> qdd = mul(Di, r);
             if (writes)
                orow[di[0] * A.v_es] = qdd.x, orow[di[1] * A.v_es] = qdd.y, orow[di[2] * A.v_es] = qdd.z;
@@ -406,7 +485,7 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          }
          else if (type == JT_SIXDOF)
          {
-            const SV<T> x = ws_load6(ws, ws_stride, sf);
+            const SV<T> x = st_load6<T>(S, sf);
             const SV<T> qdd = x - a;
             if (writes)
             {
@@ -416,7 +495,7 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
             a = x;
          }
          if (flags & MF_STORE_VA)
-            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], a);
+            st_store6<T>(S, mi[MI_SLOT_VA], a);
          a_prev = a;
       };
       for (int k = 0; k < P.n_trunk; k++)
@@ -435,7 +514,7 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
 // not their composite inertias: every wave finishes ALL columns of its limbs' bodies (walking up through the trunk with the trunk's
 // transforms, which every wave forms itself) before the barrier; a limb root leaves its composite inertia (10 values) in its exchange
 // record; after the barrier wave 0 folds the trunk's composite inertias and writes the trunk bodies' columns.  H was zeroed by the caller.
-template <typename T>
+template <typename T, int MODE>
 __global__ void __launch_bounds__(256) crba_split_kernel(Args<T> A, SplitDev P)
 {
    const DevModel &m = A.m;
@@ -443,8 +522,8 @@ __global__ void __launch_bounds__(256) crba_split_kernel(Args<T> A, SplitDev P)
    const ciptr meta = as_const(P.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
    const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
    const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-   constexpr long ws_stride = 64;
-   T *ws = A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid;
+   extern __shared__ double lds_raw[];
+   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid};
    const int n_seg = P.n_seg[wave], nv = m.nv;
    const long groups = (A.B + 63) / 64;
 
@@ -458,7 +537,7 @@ __global__ void __launch_bounds__(256) crba_split_kernel(Args<T> A, SplitDev P)
       const long h_es = A.v_es;
       auto transform = [&](int j) {
          ciptr mi = meta + j * MI_STRIDE;
-         (void)joint_from_q<T>(mi[MI_TYPE], cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         (void)sw_joint_from_q<T>(S, mi[MI_TYPE], cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
       };
       for (int k = 0; k < P.n_trunk; k++)
          transform(trunk[k]);
@@ -478,14 +557,14 @@ __global__ void __launch_bounds__(256) crba_split_kernel(Args<T> A, SplitDev P)
          if (have_carry)
             add(Ic, rcarry);
          if (flags & MF_HAS_ACC)
-            add(Ic, ws_load_ri(ws, ws_stride, mi[MI_SLOT_IA]));
+            add(Ic, sw_load_ri<T>(S, mi[MI_SLOT_IA]));
          for (int k = xk0; k < xk1; k++)
-            add(Ic, ws_load_ri(ws, ws_stride, xl[k]));
+            add(Ic, sw_load_ri<T>(S, xl[k]));
          have_carry = false;
          const int nd = dof_count(type);
          ciptr dj = dof_map + mi[MI_DOF];
          const XF<T> Xb = load_xb<T>(c);
-         const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
+         const JX<T> jx = sw_joint_again<T>(S, type, cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
          for (int k = 0; k < nd; k++)
          {
             SV<T> F = mul(Ic, unit_twist<T>(type, k)); // :663-667
@@ -529,7 +608,7 @@ __global__ void __launch_bounds__(256) crba_split_kernel(Args<T> A, SplitDev P)
                if (anc >= 0)
                {
                   Xp = load_xb<T>(CRef<T, false>{CB + prev * MC_STRIDE});
-                  jp = joint_again<T>(ta, cfg_map, ma[MI_CFG], qrow, A.q_es, ws, ws_stride, ma[MI_SLOT_JP]);
+                  jp = sw_joint_again<T>(S, ta, cfg_map, ma[MI_CFG], qrow, A.q_es, ma[MI_SLOT_JP]);
                   tp = ta;
                }
             }
@@ -538,19 +617,19 @@ __global__ void __launch_bounds__(256) crba_split_kernel(Args<T> A, SplitDev P)
          {
             rigid_up(type, jx, Xb, Ic); // :651-661
             if (xs >= 0)
-               ws_store_ri(ws, ws_stride, xs, Ic); // a limb root: through the exchange record
+               sw_store_ri<T>(S, xs, Ic); // a limb root: through the exchange record
             else if (flags & MF_PARENT_ADJ)
                rcarry = Ic, have_carry = true;
             else
             {
                const int sp = meta[parent * MI_STRIDE + MI_SLOT_IA];
                if (flags & MF_ACC_FIRST)
-                  ws_store_ri(ws, ws_stride, sp, Ic);
+                  sw_store_ri<T>(S, sp, Ic);
                else
                {
-                  RI<T> acc = ws_load_ri(ws, ws_stride, sp);
+                  RI<T> acc = sw_load_ri<T>(S, sp);
                   add(acc, Ic);
-                  ws_store_ri(ws, ws_stride, sp, acc);
+                  sw_store_ri<T>(S, sp, acc);
                }
             }
          }
