@@ -615,7 +615,11 @@ mh_status launch_split_rt(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A,
 {
    const mh_model::SplitRt &S = model->split_rt;
    const long groups = (B + 63) / 64;
-   const int grid = (int)std::max<long>(1, std::min<long>(groups, model->cu_count));
+   // workgroups per CU: the fp64 ABA holds ~300 registers (one wave per SIMD), the others fit two workgroups (measured on the humanoid at
+   // B = 32768, two groups per CU: RNEA 47 us with two resident workgroups against 66 looping one; tools/exp_split_rt_wgs.py)
+   static const int forced_wgs = getenv("MH_SPLIT_RT_WGS") ? std::max(1, atoi(getenv("MH_SPLIT_RT_WGS"))) : 0;
+   const int wgs = forced_wgs ? forced_wgs : ((algo == ALGO_ABA && sizeof(T) == 8) ? 1 : 2);
+   const int grid = (int)std::max<long>(1, std::min<long>(groups, (long)model->cu_count * wgs));
    // Which record set: everything in LDS when the block fits (no branches); else a share in LDS once the blocks of the workgroups of an
    // XCD outgrow its L2 (measured on the fp64 humanoid: 44 us all-global vs 47 with a share at B = 4096, 71 vs 50 at 8192); else all global.
    int k = sizeof(T) == 4 ? 0 : 1;
@@ -623,6 +627,8 @@ mh_status launch_split_rt(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A,
       k = 2;
    if (model->split_rt_lds >= 0)
       k = model->split_rt_lds ? (sizeof(T) == 4 ? 0 : 1) : 2;
+   if (grid > model->cu_count && (size_t)std::min(S.slots, S.lds_slots[k] + mh::SPLIT_LDS_MARGIN) * 64 * sizeof(T) > 80 * 1024)
+      k = 2; // two workgroups per CU: an LDS share above half the CU's would serialise them
    const int mode = S.lds_slots[k] >= S.slots ? 0 : (S.lds_slots[k] == 0 ? 1 : 2);
    mh_status st = ensure_bytes(model->ws, (size_t)S.slots * (size_t)grid * 64 * sizeof(T));
    if (st != MH_OK)
@@ -888,7 +894,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    }
    // Small batches of a model whose tree branches: the tree split over the four waves of a workgroup (mh_split_kernels.h)
    if (model->split_rt.usable && algo != ALGO_CRBA && !bodies && !joint_wrench && model->n_locked == 0 && !locked_in
-       && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * (model->n >= 64 ? 2 : 1))) // measured: profiles/r02_split_rt_sweep.txt
+       && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2)) // measured: profiles/r02_split_rt_sweep.txt
       return launch_split_rt<T>(algo, model, B, A, stream);
    // Run-time-topology RNEA / ABA on AoS matrices: for big batches of wide matrices go through transposed scratch copies
    // (mh::transpose_kernel).  External wrenches keep their own strides.  The depth-first RNEA reads AoS rows through LDS windows instead
@@ -966,7 +972,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             return MH_OK;
          }
          HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
-         if (model->split_rt.usable && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * (model->n >= 64 ? 2 : 1)))
+         if (model->split_rt.usable && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2))
             return launch_split_rt<T>(algo, model, B, A, stream); // small batches: the tree split over four waves (mh_split_kernels.h)
          { if (ldsc) hipLaunchKernelGGL((mh::crba_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::crba_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
          break;
