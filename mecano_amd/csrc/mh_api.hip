@@ -1985,7 +1985,7 @@ mh_status mh_reserve(mh_model_t m, int64_t max_batch)
             dfs_bytes = std::max(dfs_bytes, (size_t)((ch.hand_lds ? 0 : ch.hand) + plan->glb_slots) * (size_t)grid * 64 * elem);
          }
    if (m->split_rt.usable) // the run-time tree split: one workspace block per workgroup
-      dfs_bytes = std::max(dfs_bytes, (size_t)m->split_rt.slots * (size_t)std::max<long>(1, std::min<long>((max_batch + 63) / 64, m->cu_count)) * 64 * sizeof(double));
+      dfs_bytes = std::max(dfs_bytes, (size_t)m->split_rt.slots * (size_t)std::max<long>(1, std::min<long>((max_batch + 63) / 64, 2L * m->cu_count)) * 64 * sizeof(double));
    if (dfs_bytes > 0)
       st = ensure_bytes(m->ws, dfs_bytes);
    if (st == MH_OK && m->use_pair && (max_batch + 63) / 64 <= (long)m->cu_count)
