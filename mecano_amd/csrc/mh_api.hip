@@ -815,6 +815,8 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
                return fail(MH_ERR_HIP, "tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
          }
       }
+      if (model->split_rt.usable && model->n_locked == 0 && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2))
+         return launch_split_rt<T>(algo, model, B, A, stream); // small batches: the run-time tree split writes the per-body outputs too
       if (algo == ALGO_RNEA)
          { if (ldsc) hipLaunchKernelGGL((mh::rnea_kernel<T, true, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::rnea_kernel<T, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A); }
       else
@@ -893,7 +895,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       } // else: this (algorithm, memory plan) is not in the code object -- the run-time-topology kernels below serve the call
    }
    // Small batches of a model whose tree branches: the tree split over the four waves of a workgroup (mh_split_kernels.h)
-   if (model->split_rt.usable && algo != ALGO_CRBA && !bodies && !joint_wrench && model->n_locked == 0 && !locked_in
+   if (model->split_rt.usable && algo != ALGO_CRBA && model->n_locked == 0 && !locked_in
        && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2)) // measured: profiles/r02_split_rt_sweep.txt
       return launch_split_rt<T>(algo, model, B, A, stream);
    // Run-time-topology RNEA / ABA on AoS matrices: for big batches of wide matrices go through transposed scratch copies

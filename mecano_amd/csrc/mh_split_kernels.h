@@ -14,8 +14,8 @@
 //                    folds the trunk, reading the records of the limbs attached to each trunk body; (ABA) barrier.
 //
 // Same per-body arithmetic, workspace slots and flags as the sweep kernels of mh_kernels.h (rnea_kernel / aba_kernel; the body records
-// are a copy with the flags of the limb roots and trunk bodies adapted); plain calls only (no per-body outputs, no acceleration-source
-// joints).  InverseDynamicsCalculator.java:873-966, ForwardDynamicsCalculator.java:1085-1310.
+// are a copy with the flags of the limb roots and trunk bodies adapted), per-body accelerations / twists and joint wrenches included; no
+// acceleration-source joints.  InverseDynamicsCalculator.java:873-966, ForwardDynamicsCalculator.java:1085-1310.
 #pragma once
 #include "mh_dfs_kernels.h"
 
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
 
       // ---- outward sweep: velocities, accelerations, Newton-Euler wrench (InverseDynamicsCalculator.java:873-917)
       SV<T> v_prev{Z, Z}, a_prev{Z, Z};
-      auto outward = [&](int j) {
+      auto outward = [&](int j, bool writes) {
          ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
          const CRef<T, false> c{CB + j * MC_STRIDE};
@@ -170,6 +170,13 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
          const SV<T> a = motion_down(type, jx, Xb, ap) + aJ + crm(v, vJ);
          if (!A.coriolis)
             v = SV<T>{Z, Z};
+         if (writes)
+         { // optional per-body outputs (RigidBodyAccelerationProvider; as rnea_kernel<.., BODIES>)
+            if (A.body_acc)
+               store_body_motion<T>(c, A.body_acc + cfg * A.f_bs, A.f_es, mi[MI_EXT], a);
+            if (A.body_twist)
+               store_body_motion<T>(c, A.body_twist + cfg * A.f_bs, A.f_es, mi[MI_EXT], v);
+         }
          const RI<T> I = load_inertia<T>(c);
          SV<T> f = mul(I, a) + crf(v, mul(I, v));
          if (frow)
@@ -183,12 +190,12 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
          v_prev = v, a_prev = a;
       };
       for (int k = 0; k < P.n_trunk; k++)
-         outward(trunk[k]);
+         outward(trunk[k], active && wave == 0);
       for (int s = 0; s < n_seg; s++)
       {
          const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
          for (int j = j0; j < j1; j++)
-            outward(j);
+            outward(j, active);
       }
       // ---- inward sweep (:930-966)
       SV<T> carry{Z, Z};
@@ -203,7 +210,11 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
          for (int k = xk0; k < xk1; k++) // trunk bodies: what the attached limbs handed up
             f = f + st_load6<T>(S, xl[k]);
          if (active)
+         {
             write_joint_rows<T>(type, dof_map + mi[MI_DOF], trow, A.v_es, f);
+            if (A.joint_wrench) // InverseDynamicsCalculator.getComputedJointWrench (:578-585)
+               store_joint_wrench<T>(c, A.joint_wrench + cfg * A.f_bs, A.f_es, mi[MI_EXT], f);
+         }
          have_carry = false;
          if (parent >= 0)
          {
@@ -264,7 +275,7 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
 
       // ---- pass one (ForwardDynamicsCalculator.java:1085-1127): velocities, bias wrench p, bias acceleration c
       SV<T> v_prev{Z, Z};
-      auto pass1 = [&](int j) {
+      auto pass1 = [&](int j, bool writes) {
          ciptr mi = meta + j * MI_STRIDE;
          const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
          const CRef<T, false> c{CB + j * MC_STRIDE};
@@ -279,6 +290,8 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          const JX<T> jx = sw_joint_from_q<T>(S, type, cfg_map, mi[MI_CFG], qrow, A.q_es, mi[MI_SLOT_JP]);
          const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, true);
          const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         if (writes && A.body_twist)
+            store_body_motion<T>(c, A.body_twist + cfg * A.f_bs, A.f_es, mi[MI_EXT], v);
          const RI<T> I = load_inertia<T>(c);
          SV<T> p = crf(v, mul(I, v));
          if (frow)
@@ -290,12 +303,12 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          v_prev = v;
       };
       for (int k = 0; k < P.n_trunk; k++)
-         pass1(trunk[k]);
+         pass1(trunk[k], active && wave == 0);
       for (int s = 0; s < n_seg; s++)
       {
          const int j0 = seg[(wave * SPLIT_MAX_SEG + s) * 2], j1 = seg[(wave * SPLIT_MAX_SEG + s) * 2 + 1];
          for (int j = j0; j < j1; j++)
-            pass1(j);
+            pass1(j, active);
       }
       // ---- pass two (:1136-1254): articulated inertias and bias wrenches, leaves to root
       ABI<T> Icarry;
@@ -496,6 +509,8 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          }
          if (flags & MF_STORE_VA)
             st_store6<T>(S, mi[MI_SLOT_VA], a);
+         if (writes && A.body_acc)
+            store_body_motion<T>(c, A.body_acc + cfg * A.f_bs, A.f_es, mi[MI_EXT], a);
          a_prev = a;
       };
       for (int k = 0; k < P.n_trunk; k++)

@@ -1212,6 +1212,12 @@ def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
             T = lambda x: x.reshape(B, -1).t().contiguous()
             assert torch.equal(on.rnea(T(tq), T(tqd), T(tqdd), g, T(tf), layout=_lib.LAYOUT_SOA).t(), t)
             assert torch.equal(on.aba(T(tq), T(tqd), T(ttau), g, T(tf), layout=_lib.LAYOUT_SOA).t(), a)
+            if B <= 300 and dtype == "f64":  # per-body outputs and joint wrenches: written by the split kernels too
+                for got, want in zip(on.rnea_bodies(tq, tqd, tqdd, g, tf) + on.aba_bodies(tq, tqd, ttau, g, tf) + on.rnea_joint_wrenches(tq, tqd, tqdd, g, tf)
+                                     + on.aba_joint_wrenches(tq, tqd, ttau, g, tf),
+                                     off.rnea_bodies(tq, tqd, tqdd, g, tf) + off.aba_bodies(tq, tqd, ttau, g, tf) + off.rnea_joint_wrenches(tq, tqd, tqdd, g, tf)
+                                     + off.aba_joint_wrenches(tq, tqd, ttau, g, tf)):
+                    assert (got - want).abs().max().item() <= 1e-9 * max(1.0, want.abs().max().item())
             if B <= 300:
                 H, H0 = on.crba(tq), off.crba(tq)
                 assert (H - H0).abs().max().item() <= (1e-12 if dtype == "f64" else 2e-4) * max(1.0, H0.abs().max().item())
