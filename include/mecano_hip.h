@@ -168,7 +168,11 @@ mh_status mh_topology_key(const mh_model_desc *desc, char key_out[17], int32_t *
  * kernel sources that ship next to the library, csrc/; minutes for a 25-body tree) into out_dir (NULL: next to the library) and returns
  * its path.  Models created afterwards with the same tree shape and joint kinds load it (after the ABI-stamp check and the create-time
  * self-check).  Without it -- and for planar / spherical joints or trees deeper than 16 joints -- a model runs on the run-time-topology
- * kernels (same results; 4-7x slower at small batches).  A host without Python calls this once per robot, e.g. at installation.
+ * kernels (same results; about 2x slower at small batches of a branching tree, 3.5x at device-filling ones).  A host without Python calls
+ * this once per robot, e.g. at installation.  With MH_BUILD_FAST=1 in the environment only the tree-split RNEA / ABA / fused kernels for
+ * AoS matrices with identity index maps are built -- seconds instead of minutes; every other plan of the model (SoA, per-body outputs,
+ * mass matrix, ...) keeps running on the run-time-topology kernels.  MH_AUTO_BUILD=1 (2: the full set) makes mh_model_create do this by
+ * itself for a tree it finds no code object for, into MH_SPEC_DIR or next to the library.
  */
 mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap);
 

@@ -847,9 +847,14 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             *stepped = true;
       }
       const int rc = model->spec.launch_split(algo == ALGO_RNEA ? 0 : 1, sf, &A, (int)groups, (void *)stream);
-      if (rc != 0)
+      if (rc == 0)
+         return MH_OK;
+      if (rc != (int)hipErrorNotSupported)
          return fail(MH_ERR_HIP, "tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-      return MH_OK;
+      // a code object built without this plan (mh_build_code_object in its fast mode): the run-time-topology kernels serve the call
+      A.dt = T(0), A.q_next = nullptr, A.qd_next = nullptr;
+      if (stepped)
+         *stepped = false;
    }
    if (model->spec.launch && algo != ALGO_CRBA && model->use_spec && sizeof(T) == 8)
    {
@@ -889,9 +894,11 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
          A.ws_stride = (long)grid * 64;
       }
       const int rc = model->spec.launch(a, flags, &A, grid, (void *)stream);
-      if (rc != 0)
+      if (rc == 0)
+         return MH_OK;
+      if (rc != (int)hipErrorNotSupported)
          return fail(MH_ERR_HIP, "specialised kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-      return MH_OK;
+      A.ws = (T *)model->ws.ptr, A.ws_stride = L.lanes; // (a fast build without the whole-tree kernels: on to the run-time-topology kernels)
       } // else: this (algorithm, memory plan) is not in the code object -- the run-time-topology kernels below serve the call
    }
    // Small batches of a model whose tree branches: the tree split over the four waves of a workgroup (mh_split_kernels.h)
@@ -960,18 +967,21 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
                      lpg /= 2;
                const long ng = (B + lpg - 1) / lpg;
                const int rc = model->spec.launch_crba_split(&A, (int)std::min<long>(ng, (long)model->cu_count * 2), lpg, (void *)stream);
-               if (rc != 0)
+               if (rc == 0)
+                  return MH_OK;
+               if (rc != (int)hipErrorNotSupported)
                   return fail(MH_ERR_HIP, "tree-split CRBA launch failed: %s", hipGetErrorString((hipError_t)rc));
-               return MH_OK;
             }
             const bool packed = model->spec.crba_packed(sflags) != 0;
             if (!packed)
                HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream)); // direct-store kernel writes related entries only
             const int grid = packed ? (int)std::min<long>((B + 63) / 64, (long)model->cu_count) : L.grid;
             const int rc = model->spec.launch_crba(sflags, &A, grid, (void *)stream);
-            if (rc != 0)
+            if (rc == 0)
+               return MH_OK;
+            if (rc != (int)hipErrorNotSupported)
                return fail(MH_ERR_HIP, "specialised CRBA launch failed: %s", hipGetErrorString((hipError_t)rc));
-            return MH_OK;
+            // not in this code object (fast build): the run-time-topology kernels below
          }
          HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
          if (model->split_rt.usable && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2))
@@ -1424,6 +1434,7 @@ mh_status integrate_impl(mh_model_t model, int64_t B, double dt, const T *q, con
 } // namespace
 
 static void self_check_spec(mh_model *m);
+static mh_status build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap, bool fast);
 
 // =================================================================================================== C-ABI
 extern "C" {
@@ -1802,6 +1813,14 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    if (m->use_split_rt != 0)
       split_rt_plan(m);
    try_load_spec(m, P);
+   if (const char *ab = getenv("MH_AUTO_BUILD"); ab && atoi(ab) != 0 && !m->spec.handle && m->use_spec && m->variant == "generic")
+   { // no code object for this tree yet: build one now (hipcc on the box; fast form: seconds; MH_AUTO_BUILD=2: the full set, minutes)
+      char built[1024];
+      if (build_code_object(d, getenv("MH_SPEC_DIR"), built, sizeof built, atoi(ab) != 2) == MH_OK)
+         try_load_spec(m, P);
+      else
+         m->variant = std::string("generic (MH_AUTO_BUILD: ") + g_err + ")";
+   }
    if (!m->use_spec)
       m->variant = "generic";
    if (m->split_rt.usable && m->variant.compare(0, 7, "generic") == 0)
@@ -1888,6 +1907,10 @@ const char *mh_model_kernel_variant(mh_model_t m) { return m ? m->variant.c_str(
 // Builds the topology-specialised code object of a model with hipcc (what mecano_amd/build.py does), for hosts without Python.
 mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap)
 {
+   return build_code_object(desc, out_dir, path_out, path_cap, getenv("MH_BUILD_FAST") && atoi(getenv("MH_BUILD_FAST")) != 0);
+}
+static mh_status build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap, bool fast)
+{
    Plan P;
    mh_status st = plan_model(desc, P);
    if (st != MH_OK)
@@ -1934,9 +1957,11 @@ mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, c
       kinds += (e ? "," : "") + std::to_string(P.etype[e]);
    }
    const std::string out = std::string(out_dir ? out_dir : dir.c_str()) + "/libmecano_hip_topo_" + P.key + ".so";
-   const char *extra = getenv("MH_HIPCC_FLAGS"); // appended to the compiler flags (e.g. -DMH_SPEC_MINIMAL: only the tree-split kernels bench.py runs)
+   const char *extra = getenv("MH_HIPCC_FLAGS"); // appended to the compiler flags
+   // MH_BUILD_FAST=1: only the tree-split RNEA / ABA / fused kernels for AoS matrices with identity index maps (what a simulation or a
+   // controller calls) -- seconds instead of minutes; every other plan of the model keeps running on the run-time-topology kernels
    const std::string cmd = cc + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-signed-zeros -ffinite-math-only -fno-slp-vectorize "
-                           + std::string(extra ? extra : "") + " -DMH_TOPO_N="
+                           + std::string(fast ? "-DMH_SPEC_MINIMAL " : "") + std::string(extra ? extra : "") + " -DMH_TOPO_N="
                            + std::to_string(n) + " \"-DMH_TOPO_PARENTS=" + parents + "\" \"-DMH_TOPO_TYPES=" + kinds + "\" -o \"" + out + ".tmp\" \"" + src
                            + "\" && mv \"" + out + ".tmp\" \"" + out + "\"";
    const int rc = system(cmd.c_str());
@@ -2242,14 +2267,18 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    if (split_ok(model, 2, B, false))
    {
       const int rc2 = model->spec.launch_split(2, split_flags(model, 2, false), &A, (int)waves, opts.stream);
-      if (rc2 != 0)
+      if (rc2 == 0)
+         return MH_OK;
+      if (rc2 != (int)hipErrorNotSupported)
          return fail(MH_ERR_HIP, "fused tree-split kernel launch failed: %s", hipGetErrorString((hipError_t)rc2));
-      return MH_OK;
+      return two_calls(); // not in this code object (fast build)
    }
    if (!model->spec.supports(1, SPEC_ST_LDS | (model->ident_maps ? SPEC_IDENT : 0)))
    // no whole-tree ABA in this code object (trees with a tree-split form) and the tree-split launch was ruled out: two calls
       return two_calls();
    const int rc = model->spec.launch_fused(model->ident_maps ? SPEC_IDENT : 0, &A, (int)waves, opts.stream);
+   if (rc == (int)hipErrorNotSupported)
+      return two_calls();
    if (rc != 0)
       return fail(MH_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
    return MH_OK;

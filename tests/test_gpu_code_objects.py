@@ -138,3 +138,85 @@ def test_reference_benchmark_shapes_at_six_batch_sizes(torch_cuda, shape):
         close(hm.aba(tq, tqd, ttau, g, tf).cpu().numpy()[idx], om.aba(q[idx], qd[idx], tau[idx], g, fs), 1e-8, label="aba")
         if B <= 1000:
             close(hm.crba(tq).cpu().numpy()[idx], om.crba(q[idx]), 1e-10, label="crba")
+
+
+def test_fast_code_object_built_on_the_box_serves_what_it_has_and_falls_back_for_the_rest(torch_cuda, hip_lib, tmp_path, monkeypatch):
+    """mh_build_code_object with MH_BUILD_FAST=1 on an unregistered robot (hipcc on the box, seconds): the object holds the tree-split RNEA /
+    ABA / fused kernels for AoS matrices with identity maps only.  It passes the stamp check and the self-check, serves those calls, and
+    every other call of the model (SoA, mass matrix, per-body outputs, Coriolis, centroidal) runs on the run-time-topology kernels."""
+    torch = torch_cuda
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import MultiBodySystem, RigidBody
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(4242)
+    root = RigidBody("root")  # a small quadruped-like robot nobody registered: floating base, four 3-joint legs
+    base = rt.nextJointChain(rng, 1, ("sixdof",), rootBody=root, prefix="base")[0]
+    for k in range(4):
+        rt.nextJointChain(rng, 3, ("revolute",), rootBody=base.getSuccessor(), prefix=f"leg{k}_")
+    sys_ = MultiBodySystem.toMultiBodySystemInput(root)
+    desc = sys_.toModelDesc()
+    monkeypatch.setenv("MH_BUILD_FAST", "1")
+    d, keep = HipModel._c_desc(desc) if hasattr(HipModel, "_c_desc") else (None, None)
+    if d is None:
+        keep, d = [], _lib.MhModelDesc()
+        d.n_joints, d.nq, d.nv = int(desc.n_joints), int(desc.nq), int(desc.nv)
+        for k, dt in (("parent", np.int32), ("joint_type", np.int32), ("dof_indices", np.int32), ("cfg_indices", np.int32), ("axis", np.float64),
+                      ("X_before", np.float64), ("X_com", np.float64), ("inertia_J", np.float64), ("inertia_mass", np.float64), ("inertia_com", np.float64)):
+            a = np.ascontiguousarray(getattr(desc, k), dtype=dt)
+            keep.append(a)
+            setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
+    path = ctypes.create_string_buffer(1024)
+    assert hip_lib.mh_build_code_object(ctypes.byref(d), str(tmp_path).encode(), path, 1024) == 0, hip_lib.mh_last_error()
+    monkeypatch.setenv("MH_SPEC_DIR", str(tmp_path))
+    hm = HipModel(desc)
+    assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant  # stamp and self-check passed
+    om = OracleModel(desc)
+    g = (0.0, 0.0, -9.81)
+    B = 300
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    tq, tqd, tqdd, ttau = (dev(torch, x) for x in (q, qd, qdd, tau))
+    t_ref, a_ref = om.rnea(q, qd, qdd, g), om.aba(q, qd, tau, g)
+    close(hm.rnea(tq, tqd, tqdd, g).cpu().numpy(), t_ref, 1e-10, label="rnea")
+    close(hm.aba(tq, tqd, ttau, g).cpu().numpy(), a_ref, 1e-9, label="aba")
+    t2, a2 = hm.rnea_aba(tq, tqd, tqdd, ttau, g)
+    close(t2.cpu().numpy(), t_ref, 1e-10), close(a2.cpu().numpy(), a_ref, 1e-9)
+    T = lambda x: x.t().contiguous()
+    close(hm.rnea(T(tq), T(tqd), T(tqdd), g, layout=_lib.LAYOUT_SOA).t().cpu().numpy(), t_ref, 1e-10, label="rnea SoA (fallback)")
+    close(hm.crba(tq).cpu().numpy(), om.crba(q), 1e-10, label="crba (fallback)")
+    tb, acc, tw = hm.rnea_bodies(tq, tqd, tqdd, g)
+    close(tb.cpu().numpy(), t_ref, 1e-10, label="rnea bodies (fallback)")
+    H, C = hm.crba_coriolis(tq, tqd)
+    close(H.cpu().numpy(), om.crba(q), 1e-10, label="coriolis H (fallback)")
+
+
+def test_auto_build_at_model_creation(torch_cuda, tmp_path, monkeypatch):
+    """MH_AUTO_BUILD=1: mh_model_create builds the (fast) code object of a tree it has none for, loads it, and the next model of that
+    tree finds it on disk."""
+    torch = torch_cuda
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import MultiBodySystem, RigidBody
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(515)
+    root = RigidBody("root")
+    for k in range(3):  # three 4-joint fingers on a fixed palm
+        rt.nextJointChain(rng, 4, ("revolute",), rootBody=root, prefix=f"finger{k}_")
+    sys_ = MultiBodySystem.toMultiBodySystemInput(root)
+    desc = sys_.toModelDesc()
+    monkeypatch.setenv("MH_SPEC_DIR", str(tmp_path))
+    assert HipModel(desc).kernel_variant.startswith("generic")
+    monkeypatch.setenv("MH_AUTO_BUILD", "1")
+    hm = HipModel(desc)
+    assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant
+    monkeypatch.delenv("MH_AUTO_BUILD")
+    assert HipModel(desc).kernel_variant.startswith("topo:")  # found on disk now
+    q, qd, qdd, tau = rt.nextState(rng, sys_, 200)
+    g = (0.0, 0.0, -9.81)
+    t, a = hm.rnea_aba(dev(torch, q), dev(torch, qd), dev(torch, qdd), dev(torch, tau), g)
+    om = OracleModel(desc)
+    close(t.cpu().numpy(), om.rnea(q, qd, qdd, g), 1e-10), close(a.cpu().numpy(), om.aba(q, qd, tau, g), 1e-9)
