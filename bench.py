@@ -124,7 +124,7 @@ def live_traffic(B):
             env = dict(os.environ, TMPDIR="/tmp", MH_BENCH_PMC_INNER="1")
             subprocess.run([exe, "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                             "--steps", "20", "--warmup", "5", "--regions", "1", "--no-cpu-baseline", "--batch", str(B)],
-                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
