@@ -1,7 +1,8 @@
+"""Measurement helper (round 2): planner trunk weights of the run-time tree split (MH_SPLIT_RT_TRUNK_WEIGHT), B = 4096, models without a code object."""
 import os, sys
 os.environ["MH_DISABLE_SPEC"] = "1"
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mecano_amd import random_tools as rt
 from mecano_amd.engine import HipModel, HipTimer
 from mecano_amd.multibody import MultiBodySystem
