@@ -1,9 +1,9 @@
-// mh_split_kernels.h -- run-time-topology RNEA / ABA with the tree split over the FOUR waves of a workgroup (small batches).
+// mh_split_kernels.h -- run-time-topology RNEA / ABA / CRBA with the tree split over the FOUR waves of a workgroup (small batches).
 //
 // A batch of a few thousand configurations puts one wave per 64 configurations on the device: 64 waves on 1024 SIMDs at B = 4096, each
 // walking all n bodies one after the other.  The topology-specialised code objects split the tree over four waves at compile time
 // (mh_spec_kernels.h, Split<TP>); these kernels do the same for ANY model from a plan the host makes when the model is created
-// (mh_api.hip: split_plan): the TRUNK (bodies the split goes through: the root side of every branching that is used) and the LIMBS
+// (mh_api.hip: split_rt_plan): the TRUNK (bodies the split goes through: the root side of every branching that is used) and the LIMBS
 // (whole subtrees hanging off trunk bodies; joints are stored depth-first, so a limb is a contiguous index range), dealt to the waves
 // largest first.
 //
