@@ -9,6 +9,7 @@
 #include "mh_split_kernels.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <array>
@@ -1957,13 +1958,14 @@ static mh_status build_code_object(const mh_model_desc *desc, const char *out_di
       kinds += (e ? "," : "") + std::to_string(P.etype[e]);
    }
    const std::string out = std::string(out_dir ? out_dir : dir.c_str()) + "/libmecano_hip_topo_" + P.key + ".so";
+   const std::string tmp = out + ".tmp" + std::to_string((long)getpid());
    const char *extra = getenv("MH_HIPCC_FLAGS"); // appended to the compiler flags
    // MH_BUILD_FAST=1: only the tree-split RNEA / ABA / fused kernels for AoS matrices with identity index maps (what a simulation or a
    // controller calls) -- seconds instead of minutes; every other plan of the model keeps running on the run-time-topology kernels
    const std::string cmd = cc + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-signed-zeros -ffinite-math-only -fno-slp-vectorize "
                            + std::string(fast ? "-DMH_SPEC_MINIMAL " : "") + std::string(extra ? extra : "") + " -DMH_TOPO_N="
-                           + std::to_string(n) + " \"-DMH_TOPO_PARENTS=" + parents + "\" \"-DMH_TOPO_TYPES=" + kinds + "\" -o \"" + out + ".tmp\" \"" + src
-                           + "\" && mv \"" + out + ".tmp\" \"" + out + "\"";
+                           + std::to_string(n) + " \"-DMH_TOPO_PARENTS=" + parents + "\" \"-DMH_TOPO_TYPES=" + kinds + "\" -o \"" + tmp + "\" \"" + src
+                           + "\" && mv \"" + tmp + "\" \"" + out + "\""; // (rename is atomic: a concurrent build of the same tree cannot leave a torn file)
    const int rc = system(cmd.c_str());
    if (rc != 0)
       return fail(MH_ERR_HIP, "building the code object failed (exit status %d): %s", rc, cmd.c_str());
