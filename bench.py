@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="configurations per step: per GPU for the weak-scaling workloads, in total for --config 4 / 5")
     ap.add_argument("--regions", type=int, default=REGIONS, help="timed regions of --steps steps each; the median is reported (>= 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--separate", action="store_true", help="two calls per step (mh_rnea_f64, mh_aba_f64) instead of mh_rnea_aba_f64")
+    ap.add_argument("--separate", action="store_true", help="two calls per step (mh_rnea_f64, then mh_aba_f64 / mh_crba_f64) instead of mh_rnea_aba_f64 / mh_rnea_crba_f64")
     args = ap.parse_args()
 
     # the launcher's world must be what was asked for -- checked before anything touches a GPU or a process group
@@ -210,8 +210,10 @@ def main():
 
     # caller-owned output buffers, as the C-ABI prescribes (Mecano's calculators also write into pre-allocated matrices)
     tau, acc = torch.empty_like(tqd), torch.empty_like(tqd)
-    fused = cfg == 0 and not args.separate
-    fused_step = model.bind_rnea_aba(tq, tqd, tqdd, ttau, tau, acc, gravity) if fused else None
+    fused = cfg in (0, 3) and not args.separate
+    fused_key = {0: "rnea_aba", 3: "rnea_crba"}.get(cfg)
+    Hm = torch.empty((B, nv, nv), dtype=tdt, device="cuda") if (fused and cfg == 3) else None
+    fused_step = (model.bind_rnea_aba(tq, tqd, tqdd, ttau, tau, acc, gravity) if cfg == 0 else model.bind_rnea_crba(tq, tqd, tqdd, tau, Hm, gravity)) if fused else None
     jobs = {0: ("rnea", "aba"), 3: ("rnea", "crba"), 4: ("aba",), 5: ("rnea", "aba")}[cfg]
     outs = {}
 
@@ -234,7 +236,7 @@ def main():
         step()
     # ---- timed regions: exactly K steps each between barrier + synchronize pairs; HIP events on the launch stream
     K, R = args.steps, max(1, args.regions)
-    region_s, kernel_ms = [], {j: [] for j in (("rnea_aba",) if fused else jobs)}
+    region_s, kernel_ms = [], {j: [] for j in ((fused_key,) if fused else jobs)}
     for r in range(R):
         # fused: ONE event pair brackets the K launches of a region (per-launch event pairs put ~5 us of markers between two ~25 us
         # kernels); average launch duration = elapsed / K, gaps included.  Otherwise one event pair per launch.
@@ -266,7 +268,7 @@ def main():
             elapsed = float(t.item())
         region_s.append(elapsed)
         if fused:
-            kernel_ms["rnea_aba"].append(t_all.elapsed_ms() / K if K else 0.0)
+            kernel_ms[fused_key].append(t_all.elapsed_ms() / K if K else 0.0)
         else:
             for i, job in enumerate(jobs):
                 kernel_ms[job].append(float(np.mean([t.elapsed_ms() for t in per_launch[i]])) if K else 0.0)
@@ -278,7 +280,7 @@ def main():
     # ---- after the timed regions: one all-gather of the outputs over xGMI (north_star: "a final gather"), per-rank kernel times
     gather_ms, per_rank = None, None
     if world > 1:
-        last = acc if fused else outs.get("aba", outs.get("rnea"))
+        last = (acc if cfg == 0 else tau) if fused else outs.get("aba", outs.get("rnea"))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         full = mdist.all_gather_rows(last, B_total)
@@ -299,7 +301,7 @@ def main():
     idx = np.arange(0, B, max(1, B // 64))[:64]
     q64, qd64, qdd64, tau64 = (np.asarray(x[idx % base], dtype=np_dt).astype(np.float64) for x in (q, qd, qdd, tau_in))
     check = {"rows": int(len(idx)), "tol": 1e-10 if word == 8 else None}
-    got = {"rnea": tau if fused else outs.get("rnea"), "aba": acc if fused else outs.get("aba"), "crba": outs.get("crba")}
+    got = {"rnea": tau if fused else outs.get("rnea"), "aba": acc if fused else outs.get("aba"), "crba": Hm if fused else outs.get("crba")}
     ok = True
     for job in jobs:
         ref = {"rnea": lambda: om.rnea(q64, qd64, qdd64, gravity), "aba": lambda: om.aba(q64, qd64, tau64, gravity), "crba": lambda: om.crba(q64)}[job]()
@@ -314,9 +316,9 @@ def main():
     check["ok"] = bool(ok)
 
     fused_launch = fused and model.kernel_variant.startswith("topo:") and 2 * ((B + 63) // 64) <= 256
-    bytes_of = {"rnea": bytes_rnea, "aba": bytes_aba, "crba": bytes_crba, "rnea_aba": bytes_rnea + bytes_aba}
-    if fused:  # one launch computing both: 968 + 968 algorithmic bytes per configuration
-        dom, dom_name = "rnea_aba", ("rnea+aba fused" if fused_launch else "rnea+aba (two launches)")
+    bytes_of = {"rnea": bytes_rnea, "aba": bytes_aba, "crba": bytes_crba, "rnea_aba": bytes_rnea + bytes_aba, "rnea_crba": bytes_rnea + bytes_crba}
+    if fused:  # one launch computing both: 968 + 968 (config 3: 968 + 7448) algorithmic bytes per configuration
+        dom, dom_name = fused_key, fused_key.replace("_", "+") + (" fused" if fused_launch else " (two launches)")
     else:      # dominant kernel = the slowest launch of a step
         dom = max(kernels_ms, key=kernels_ms.get)
         dom_name = dom
@@ -332,14 +334,14 @@ def main():
     if pmc_bytes is not None and fused_launch:
         traffic, traffic_source = pmc_bytes, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, child processes of this run), 2 x FETCH + WRITE"
     else:
-        traffic, traffic_source = committed_traffic(fused_launch, B)
+        traffic, traffic_source = committed_traffic(fused_launch and cfg == 0, B)
     line = {
         "metric": names[cfg],
         "value": value, "unit": "configs/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3 if K else None, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": workloads[cfg],
-                   "entry_point": "mh_rnea_aba_f64" if fused else " + ".join(f"mh_{j}_{dtype}" for j in jobs),
+                   "entry_point": f"mh_{fused_key}_f64" if fused else " + ".join(f"mh_{j}_{dtype}" for j in jobs),
                    "batch_per_gpu": B, "global_batch": B_total, "nq": nq, "nv": nv, "bodies": desc.n_joints,
                    "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
                    "model_seed": MODEL_SEED if cfg != 5 else 128, "state_seed": STATE_SEED},

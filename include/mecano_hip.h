@@ -200,6 +200,15 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
                           const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out);
 
 /*
+ * InverseDynamicsCalculator.compute + CompositeRigidBodyMassMatrixCalculator.getMassMatrix for the SAME configurations in one call
+ * (what a whole-body controller evaluates per tick: algorithms/InverseDynamicsCalculator.java:496-501,
+ * algorithms/CompositeRigidBodyMassMatrixCalculator.java:344-348): tau_out [B][nv], H_out [B][nv][nv].  With a code object the two run
+ * side by side in ONE launch; otherwise as two launches, concurrently on small batches.  Same arguments as mh_rnea_f64 / mh_crba_f64.
+ */
+mh_status mh_rnea_crba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                           const double *f_ext, const mh_options *opts, double *tau_out, double *H_out);
+
+/*
  * ---- joint source modes (ForwardDynamicsCalculator.JointSourceMode, ForwardDynamicsCalculator.java:45-57, 400-444) ----
  * modes[n_joints], one per listed joint: MH_EFFORT_SOURCE (tau is the input, qdd the output; the default) or
  * MH_ACCELERATION_SOURCE (the joint is "locked" onto a given acceleration: qdd is the input, tau the output).  NULL resets every

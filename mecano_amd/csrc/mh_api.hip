@@ -122,6 +122,7 @@ struct SpecLib
    int (*launch_split)(int algo, int flags, const void *args, int groups, void *stream) = nullptr;
    int (*crba_split_usable)(void) = nullptr;
    int (*launch_crba_split)(const void *args, int groups, int lanes_per_group, void *stream) = nullptr;
+   int (*launch_rnea_crba)(const void *args, int rnea_groups, int crba_groups, int lanes_per_group, void *stream) = nullptr;
    int (*launch_coriolis)(int flags, const void *args, int grid, void *stream) = nullptr;
    int (*launch_centroidal)(int flags, const void *args, int grid, void *stream) = nullptr;
    unsigned long long (*abi)(void) = nullptr;
@@ -1252,6 +1253,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.launch_split = (decltype(s.launch_split))dlsym(h, "mh_spec_launch_split");
    s.crba_split_usable = (decltype(s.crba_split_usable))dlsym(h, "mh_spec_crba_split_usable");
    s.launch_crba_split = (decltype(s.launch_crba_split))dlsym(h, "mh_spec_launch_crba_split");
+   s.launch_rnea_crba = (decltype(s.launch_rnea_crba))dlsym(h, "mh_spec_launch_rnea_crba");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
    s.abi = (decltype(s.abi))dlsym(h, "mh_spec_abi");
@@ -2284,6 +2286,75 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    if (rc != 0)
       return fail(MH_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
    return MH_OK;
+}
+mh_status mh_rnea_crba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                           const double *f_ext, const mh_options *opts_in, double *tau_out, double *H_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (B == 0)
+      return MH_OK;
+   if (!q || !qd || !qdd || !gravity || !tau_out || !H_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   hipStream_t s = (hipStream_t)opts.stream;
+   const long groups = (B + 63) / 64;
+   // one launch: tree-split RNEA groups and tree-split CRBA groups side by side (code object with identity maps, AoS, no switches, no
+   // external wrenches through this path; batches that leave room for both on the device)
+   if (model->spec.launch_rnea_crba && model->use_spec && model->use_fused && model->ident_maps && model->dense_maps && opts.layout == MH_LAYOUT_AOS
+       && opts.consider_coriolis && opts.consider_accelerations && model->use_split != 0 && model->spec.split_usable && model->spec.split_usable()
+       && model->spec.crba_split_usable && model->spec.crba_split_usable() && groups <= (long)model->cu_count * 2)
+   {
+      mh::Args<double> A{};
+      A.m = dev_model<double>(model);
+      A.B = B;
+      A.q = q, A.qd = qd, A.in3 = qdd, A.fext = f_ext, A.out = tau_out;
+      A.in3b = nullptr, A.outb = H_out;
+      A.ws = nullptr, A.ws_stride = 0;
+      A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
+      A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
+      A.coriolis = 1, A.accel = 1;
+      int lpg = 64; // thin CRBA workgroups while that is what it takes to give every CU one: its write-out is bound by the stores in flight per CU
+      while (lpg > 16 && (B + lpg / 2 - 1) / (lpg / 2) + groups <= (long)model->cu_count)
+         lpg /= 2;
+      if (const char *e = getenv("MH_RNEA_CRBA_LPG")) // experiments: 16 / 32 / 64
+         lpg = std::max(16, std::min(64, atoi(e)));
+      const long ng = std::min<long>((B + lpg - 1) / lpg, (long)model->cu_count * 2);
+      const int rc = model->spec.launch_rnea_crba(&A, (int)groups, (int)ng, lpg, (void *)s);
+      if (rc == 0)
+         return MH_OK;
+      if (rc != (int)hipErrorNotSupported)
+         return fail(MH_ERR_HIP, "fused RNEA + CRBA launch failed: %s", hipGetErrorString((hipError_t)rc));
+   }
+   // two launches; side by side while the batch leaves most of the device idle (the CRBA on the model's own stream; it needs no workspace
+   // of the RNEA's kind when a code object serves it, and gets its own otherwise)
+   if (!model->use_pair || groups > (long)model->cu_count)
+   {
+      st = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
+      return st != MH_OK ? st : mh_crba_f64(model, B, q, &opts, H_out);
+   }
+   if (!model->pair_stream)
+   {
+      HIP_TRY(hipStreamCreateWithFlags(&model->pair_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&model->pair_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&model->pair_join, hipEventDisableTiming));
+   }
+   HIP_TRY(hipEventRecord(model->pair_fork, s));
+   HIP_TRY(hipStreamWaitEvent(model->pair_stream, model->pair_fork, 0));
+   mh_options ob = opts;
+   ob.stream = (void *)model->pair_stream;
+   std::swap(model->ws, model->ws_pair);
+   const mh_status rb = mh_crba_f64(model, B, q, &ob, H_out);
+   std::swap(model->ws, model->ws_pair);
+   const mh_status ra = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
+   HIP_TRY(hipEventRecord(model->pair_join, model->pair_stream));
+   HIP_TRY(hipStreamWaitEvent(s, model->pair_join, 0));
+   return rb != MH_OK ? rb : ra;
 }
 mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
                       const float *f_ext, const mh_options *opts, float *tau_out)

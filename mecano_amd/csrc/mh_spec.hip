@@ -394,6 +394,30 @@ int mh_spec_launch_crba_split(const void *args, int groups, int lanes_per_group,
    else
       return (int)hipErrorNotSupported;
 }
+// RNEA and CRBA of the same configurations in one launch (identity maps, AoS, rows staged in LDS): rnea_groups workgroups of 64
+// configurations for the RNEA + crba_groups workgroups of lanes_per_group for the CRBA; args->out = tau, args->outb = H
+int mh_spec_launch_rnea_crba(const void *args, int rnea_groups, int crba_groups, int lanes_per_group, void *stream)
+{
+#ifdef MH_SPEC_MINIMAL
+   return (int)hipErrorNotSupported;
+#else
+   if constexpr (SPL::usable())
+   {
+      const mh::Args<double> &A = *(const mh::Args<double> *)args;
+      auto kern = &mh::spec_rnea_crba_split_kernel<TP, double>;
+      const size_t lds = (size_t)std::max(split_lds_bytes(0, F_IO_LDS, A.m.nq, A.m.nv), mh_spec_crba_split_lds_bytes());
+      if (lds > 160 * 1024 || !mh_spec_crba_split_usable())
+         return (int)hipErrorNotSupported;
+      static LdsAttr attr;
+      if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
+         return (int)e;
+      hipLaunchKernelGGL(kern, dim3(rnea_groups + crba_groups), dim3(256), lds, (hipStream_t)stream, A, lanes_per_group, rnea_groups);
+      return (int)hipGetLastError();
+   }
+   else
+      return (int)hipErrorNotSupported;
+#endif
+}
 // algo: 0 = RNEA, 1 = ABA; fp64 only.  args points to mh::Args<double>.
 int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream)
 {

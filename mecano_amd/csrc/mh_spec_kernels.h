@@ -2203,10 +2203,10 @@ __global__ void __launch_bounds__(64) spec_crba_packed_kernel(Args<T> A)
 // composite inertia in the exchange area; after one barrier wave 0 finishes the trunk bodies' columns; after a second barrier the
 // four waves write a quarter of every matrix each, straight from the packed LDS image (zeros included, no memset).
 template <class TP, typename T>
-__global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg)
+MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const long nblocks, double __attribute__((address_space(3))) *lds_raw)
 { // lpg = configurations per workgroup (<= 64).  The write-out of 7.2 KB per configuration is bound by what ONE CU can have in
   // flight, so a small batch is spread over more, thinner workgroups (16 lanes of each wave active) to put every CU's store path to work.
-   extern __shared__ double lds_raw[];
+  // block / nblocks: this workgroup's position among the workgroups that do this job (a fused launch gives the rest another job).
    using CX = Ctx<T, false, true, WholeStore<TP, ST_GLOBAL_KIND>>;
    using HM = HMap<TP>;
    constexpr int NV = HM::NV, NE = NV * NV;
@@ -2219,7 +2219,7 @@ __global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg
    for (int e = threadIdx.x; e < NE; e += 256)
       tab[e] = (short)HM::slot_at(e);
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
-   for (long cfg0 = (long)blockIdx.x * lpg; cfg0 < A.B; cfg0 += (long)gridDim.x * lpg)
+   for (long cfg0 = block * lpg; cfg0 < A.B; cfg0 += nblocks * lpg)
    {
       const long cfg = cfg0 + lane;
       const bool active = lane < lpg && cfg < A.B;
@@ -2328,6 +2328,29 @@ __global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg
       MH_CSTAMP(6);
       __syncthreads(); // the image is free for the next slice
       MH_CSTAMP(7);
+   }
+}
+
+template <class TP, typename T>
+__global__ void __launch_bounds__(256) spec_crba_split_kernel(Args<T> A, int lpg)
+{
+   extern __shared__ double lds_raw[];
+   crba_split_group<TP, T>(A, lpg, blockIdx.x, gridDim.x, (double __attribute__((address_space(3))) *)lds_raw);
+}
+// RNEA and CRBA of the same configurations side by side in ONE launch (what a whole-body controller evaluates per tick:
+// InverseDynamicsCalculator + CompositeRigidBodyMassMatrixCalculator on one state): the first rnea_groups workgroups are tree-split RNEA
+// groups of 64 configurations (rows staged in LDS, identity maps), the others tree-split CRBA groups of lpg; A.outb = H.
+template <class TP, typename T>
+__global__ void __launch_bounds__(256) spec_rnea_crba_split_kernel(Args<T> A, int lpg, int rnea_groups)
+{
+   extern __shared__ double lds_raw[];
+   if ((int)blockIdx.x < rnea_groups)
+      split_group<TP, T, 0, true, true>(A, blockIdx.x, rnea_groups, (lds_ptr<T>)lds_raw);
+   else
+   {
+      Args<T> A2 = A;
+      A2.out = A.outb;
+      crba_split_group<TP, T>(A2, lpg, (long)blockIdx.x - rnea_groups, (long)gridDim.x - rnea_groups, (double __attribute__((address_space(3))) *)lds_raw);
    }
 }
 

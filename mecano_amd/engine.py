@@ -348,6 +348,25 @@ class HipModel:
                                        qdd_out.data_ptr()))
         return tau_out, qdd_out
 
+    def rnea_crba(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None):
+        """tau = RNEA(q, qd, qdd) and H = CRBA(q) in one call (mh_rnea_crba_f64; fp64, AoS, device tensors): (tau [B, nv], H [B, nv, nv])."""
+        import torch
+        lib = _lib.load()
+        for t in (q, qd, qdd) + ((f_ext,) if f_ext is not None else ()):
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("rnea_crba needs contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
+        if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd)):
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        self._check_f_ext(f_ext, B, _lib.LAYOUT_AOS)
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        tau_out = torch.empty_like(qd)
+        H = torch.empty((B, self.nv, self.nv), dtype=torch.float64, device=q.device)
+        _lib.check(lib.mh_rnea_crba_f64(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, f_ext.data_ptr() if f_ext is not None else None,
+                                        ctypes.byref(opts), tau_out.data_ptr(), H.data_ptr()))
+        return tau_out, H
+
     def bind_rnea_aba(self, q, qd, qdd, tau, tau_out, qdd_out, gravity=(0.0, 0.0, -9.81), f_ext=None):
         """Returns a zero-argument callable that issues mh_rnea_aba_f64 on the given (caller-owned, device-resident) buffers.
         All argument marshalling is done once here: a steady-state caller (a simulation loop, bench.py) pays one C call per step."""
@@ -366,6 +385,33 @@ class HipModel:
                 ctypes.c_void_p(tau.data_ptr()), g, ctypes.c_void_p(f_ext.data_ptr()) if f_ext is not None else None, ctypes.byref(opts),
                 ctypes.c_void_p(tau_out.data_ptr()), ctypes.c_void_p(qdd_out.data_ptr()))
         fn = lib.mh_rnea_aba_f64
+        keep = (tensors, g, opts)
+
+        def call(_fn=fn, _args=args, _keep=keep):
+            st = _fn(*_args)
+            if st:
+                _lib.check(st)
+
+        return call
+
+    def bind_rnea_crba(self, q, qd, qdd, tau_out, H_out, gravity=(0.0, 0.0, -9.81), f_ext=None):
+        """bind_rnea_aba's counterpart for mh_rnea_crba_f64: a zero-argument callable on caller-owned device buffers (H_out is [B, nv, nv])."""
+        import torch
+        lib = _lib.load()
+        tensors = (q, qd, qdd, tau_out, H_out) + ((f_ext,) if f_ext is not None else ())
+        for t in tensors:
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("bind_rnea_crba needs contiguous float64 tensors on the HIP device")
+        B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
+        if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau_out)) or tuple(H_out.shape) != (B, self.nv, self.nv):
+            raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
+        self._check_f_ext(f_ext, B, _lib.LAYOUT_AOS)
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        args = (self._h, ctypes.c_int64(B), ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(qd.data_ptr()), ctypes.c_void_p(qdd.data_ptr()), g,
+                ctypes.c_void_p(f_ext.data_ptr()) if f_ext is not None else None, ctypes.byref(opts), ctypes.c_void_p(tau_out.data_ptr()),
+                ctypes.c_void_p(H_out.data_ptr()))
+        fn = lib.mh_rnea_crba_f64
         keep = (tensors, g, opts)
 
         def call(_fn=fn, _args=args, _keep=keep):

@@ -1270,6 +1270,41 @@ def test_pair_call_without_a_code_object_runs_side_by_side(torch_cuda, monkeypat
             close(a_ref.cpu().numpy(), om.aba(q, qd, tau, g), 1e-10, label="aba")
 
 
+@pytest.mark.parametrize("spec", [True, False], ids=["code-object", "run-time-topology"])
+def test_rnea_crba_in_one_call(torch_cuda, monkeypatch, spec):
+    """mh_rnea_crba_f64 (InverseDynamicsCalculator + CompositeRigidBodyMassMatrixCalculator on the same state, BASELINE config 3): with the
+    humanoid's code object one launch whose work groups split between the two algorithms on small batches, two launches otherwise; bit for
+    bit the two separate calls, with and without external wrenches, on the default and a non-default stream, and the oracle's on a sample."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    if not spec:
+        monkeypatch.setenv("MH_DISABLE_SPEC", "1")
+    rng = np.random.default_rng(1234)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    hm, om = HipModel(d), OracleModel(d)
+    assert hm.kernel_variant.startswith("generic") != spec
+    g = (0.0, 0.0, -9.81)
+    for B in (1, 300, 4096, 8191, 40000):  # 40000: past the fused launch's range
+        q, qd, qdd, _ = rt.nextState(rng, sys_, B)
+        fx = rng.uniform(-10, 10, (B, hm.n_joints, 6))
+        tq, tqd, tqdd, tfx = (dev(torch, x) for x in (q, qd, qdd, fx))
+        H_ref = hm.crba(tq)
+        for f in (None, tfx):
+            t_ref = hm.rnea(tq, tqd, tqdd, g, f_ext=f)
+            for stream in (None, torch.cuda.Stream()):
+                with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+                    outs = [hm.rnea_crba(tq, tqd, tqdd, g, f_ext=f) for _ in range(3)]
+                torch.cuda.synchronize()
+                for t, H in outs:
+                    assert torch.equal(t, t_ref) and torch.equal(H, H_ref)
+        if B == 300:
+            close(t_ref.cpu().numpy(), om.rnea(q, qd, qdd, g, f_ext=fx), 1e-10, label="rnea")
+            close(H_ref.cpu().numpy(), om.crba(q), 1e-10, label="crba")
+
+
 def test_host_pointer_pipeline(torch_cuda, monkeypatch):
     """The host-pointer entry points (what a Java shim calls): batches above 1024 configurations travel in chunks through three streams.
     Pageable and pinned (mh_host_alloc) matrices, a chunk size that leaves a ragged last chunk and re-uses every ring slot, external
