@@ -276,6 +276,29 @@ mh_status mh_relative_acceleration_f64(mh_model_t model, int64_t B, const double
                                        const mh_options *opts, double *out);
 
 /*
+ * ---- joint torque regressor (JointTorqueRegressorCalculator.compute / getJointTorqueRegressorMatrix,
+ *      algorithms/JointTorqueRegressorCalculator.java:173-190, 450-453, 749-833; a caller of the inverse dynamics, :118, :181-182, :802-804) ----
+ * Y_out [B][nv][10 n_joints], one row-major nv x 10 n matrix per configuration (a DMatrixRMaj each):  tau = Y pi  for the inverse
+ * dynamics without external wrenches, with pi = (mass, com_x, com_y, com_z, Ixx, Ixy, Ixz, Iyy, Iyz, Izz) of every successor body in
+ * its body-fixed frame (:877-889; the columns of a body follow SpatialInertiaBasisOption, :514-516).  The ten columns of joint j's
+ * successor body start at column 10 j, j in mh_model_desc order -- the reference orders the blocks by the iteration order of a HashMap
+ * of rigid bodies (:85, :123, :318-329), which is not specified; getJointTorqueRegressorMatrixBlock(body) (:462-465) is the order-free
+ * accessor a shim maps onto this layout.  opts->consider_coriolis / consider_accelerations as in mh_rnea_f64
+ * (setConsiderCoriolisAndCentrifugalForces / setConsiderJointAccelerations, :489-502); opts->layout is the layout of q, qd, qdd.
+ * first_moment_columns = 0 reproduces the reference: its MCOM_X/Y/Z bases put a centre-of-mass offset on a body of zero mass (:579-581)
+ * and every term of the dynamic wrench carries the mass (tools/MecanoTools.java:632-702, 785-822), so those three columns are zero --
+ * except with consider_coriolis = 0, where the inverse dynamics passes no twist and computeDynamicMoment leaves c x a unscaled
+ * (tools/MecanoTools.java:650-692): the columns then hold the moment e x a, as the reference's do.
+ * first_moment_columns = 1 writes d tau / d (m c) there instead (the linear parametrisation used for identification: pi then holds
+ * m c in slots 1..3 and the moments of inertia about the origin of the body-fixed frame).  Device pointers, asynchronous on opts->stream;
+ * run-time-topology kernel for every model.
+ */
+mh_status mh_regressor_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                           const mh_options *opts, int32_t first_moment_columns, double *Y_out);
+mh_status mh_regressor_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
+                           const mh_options *opts, int32_t first_moment_columns, float *Y_out);
+
+/*
  * ---- Coriolis matrix (CompositeRigidBodyMassMatrixCalculator.setEnableCoriolisMatrixCalculation(true) + getMassMatrix / getCoriolisMatrix,
  *      algorithms/CompositeRigidBodyMassMatrixCalculator.java:271-274, 344-365, 604-630, 669-768; algorithms/FactorizedBodyInertia.java) ----
  * H_out and C_out [B][nv][nv] row-major (MH_LAYOUT_SOA: [nv*nv][B]):  tau = H qdd + C qd + G.  C is the reference's matrix entry for entry

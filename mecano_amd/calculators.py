@@ -3,6 +3,7 @@
 * ``InverseDynamicsCalculator``              algorithms/InverseDynamicsCalculator.java:186-251, 291-306, 318-403, 444-501, 567
 * ``ForwardDynamicsCalculator``              algorithms/ForwardDynamicsCalculator.java:112-196, 234-319, 348-381, 475-520, 556-567
 * ``CompositeRigidBodyMassMatrixCalculator`` algorithms/CompositeRigidBodyMassMatrixCalculator.java:157-233, 286-303, 344-348
+* ``JointTorqueRegressorCalculator``         algorithms/JointTorqueRegressorCalculator.java:101-133, 173-190, 360-502 (a caller of the first)
 
 Differences a user of the reference must know (all forced by batching, none changes results):
 
@@ -167,6 +168,79 @@ class InverseDynamicsCalculator(_Base):
             return None
         rows = self.input.getJointMatrixIndexProvider().getJointDoFIndices(joint)
         return self._tau[:, rows]
+
+
+class JointTorqueRegressorCalculator(_Base):
+    """algorithms/JointTorqueRegressorCalculator.java:101-133, 173-190, 360-502: tau = Y(q, qd, qdd) pi for the inverse dynamics without
+    external wrenches, ten parameters per body (SpatialInertiaBasisOption, :514-516).  One kernel evaluates every column of every
+    configuration (the reference: one second pass of the inverse dynamics per body and parameter).  Bodies are ordered like the system's
+    joints to consider (the reference: iteration order of a HashMap, :85, :318-348 -- use the per-body accessors when porting).  The
+    parameter vector is read once at construction, as the reference does (:130, :337-348).  numpy in -> numpy out; device tensors stay
+    on the device."""
+
+    PARAMETERS_PER_BODY = 10
+    BASES = ("M", "MCOM_X", "MCOM_Y", "MCOM_Z", "I_XX", "I_XY", "I_XZ", "I_YY", "I_YZ", "I_ZZ")
+
+    def __init__(self, input, firstMomentColumns: bool = False):
+        super().__init__(input, considerIgnoredSubtreesInertia=False)
+        self._coriolis, self._accel, self._first = True, True, bool(firstMomentColumns)
+        self._Y = None
+        self._joint_pos = {id(j): k for k, j in enumerate(self.input.getJointsToConsider())}
+        d = self.model.desc
+        n = d.n_joints
+        J = np.asarray(d.inertia_J, dtype=np.float64).reshape(n, 3, 3)
+        pi = np.zeros((n, 10))
+        pi[:, 0] = np.asarray(d.inertia_mass, dtype=np.float64)
+        pi[:, 1:4] = np.asarray(d.inertia_com, dtype=np.float64).reshape(n, 3) * (pi[:, 0:1] if self._first else 1.0)  # :877-889
+        for c, (a, b) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+            pi[:, 4 + c] = J[:, a, b]
+        self._pi = pi.reshape(-1)
+
+    def setConsiderCoriolisAndCentrifugalForces(self, flag: bool):
+        self._coriolis = bool(flag)
+
+    def setConsiderJointAccelerations(self, flag: bool):
+        self._accel = bool(flag)
+
+    def compute(self, q, qd, qdd):
+        """:173-190 for B configurations: Y [B, nv, 10 n]."""
+        if HipModel._is_torch(q):
+            self._Y = self.model.regressor(q, qd, qdd, self._gravity, self.layout, self._coriolis, self._accel, self._first)
+        else:
+            import torch
+            tq, tqd, tqdd = (torch.tensor(np.ascontiguousarray(x, dtype=np.float64), device="cuda") for x in (q, qd, qdd))
+            self._Y = self.model.regressor(tq, tqd, tqdd, self._gravity, self.layout, self._coriolis, self._accel, self._first).cpu().numpy()
+        return self._Y
+
+    def _body_index(self, body) -> int:
+        k = self._joint_pos.get(id(body.getParentJoint())) if body is not None and body.getParentJoint() is not None else None
+        if k is None:
+            raise ValueError("the body is not the successor of a joint this calculator considers")
+        return int(k)
+
+    def getJointTorqueRegressorMatrix(self):
+        return self._Y
+
+    def getJointTorqueRegressorMatrixBlock(self, body):
+        """:462-465: the nv x 10 block of ``body``"""
+        k = self._body_index(body)
+        return self._Y[:, :, 10 * k:10 * k + 10]
+
+    def getJointTorqueRegressorMatrixSlice(self, body, basis):
+        """:475-478: one column; ``basis`` an index 0..9 or a name of BASES"""
+        b = self.BASES.index(basis) if isinstance(basis, str) else int(basis)
+        return self._Y[:, :, 10 * self._body_index(body) + b]
+
+    def getParameterVector(self):
+        return self._pi
+
+    def getParameterVectorSlice(self, body):
+        k = self._body_index(body)
+        return self._pi[10 * k:10 * k + 10]
+
+    def getParameter(self, body, basis):
+        b = self.BASES.index(basis) if isinstance(basis, str) else int(basis)
+        return float(self._pi[10 * self._body_index(body) + b])
 
 
 class JointSourceMode:

@@ -1333,6 +1333,58 @@ mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, co
    HIP_TRY(hipGetLastError());
    return MH_OK;
 }
+// Joint torque regressor (JointTorqueRegressorCalculator): run-time-topology kernel
+template <typename T>
+mh_status regressor_impl(mh_model_t model, int64_t B, const T *q, const T *qd, const T *qdd, const double *gravity, const mh_options *opts_in,
+                         int32_t first_moment_columns, T *Y_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   if (B == 0)
+      return MH_OK;
+   if (!q || !qd || !qdd || !Y_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   st = ensure_workspace(model, B, sizeof(T));
+   if (st != MH_OK)
+      return st;
+   const Launch L = plan_launch(model, B);
+   hipStream_t stream = (hipStream_t)opts.stream;
+   mh::Args<T> A{};
+   A.m = dev_model<T>(model);
+   A.B = B;
+   A.q = q, A.qd = qd, A.in3 = qdd, A.out = Y_out;
+   A.ws = (T *)model->ws.ptr;
+   A.ws_stride = L.lanes;
+   const bool soa = opts.layout == MH_LAYOUT_SOA; // of the state matrices; Y is one row-major matrix per configuration either way
+   A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
+   A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
+   A.f_bs = (long)model->nv * model->n * 10, A.f_es = 1;
+   A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
+   A.coriolis = opts.consider_coriolis, A.accel = opts.consider_accelerations;
+   const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
+   const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
+   // entries of joints that do not support a body are zero, and so are the reference's centre-of-mass columns (mh_kernels.h)
+   HIP_TRY(hipMemsetAsync(Y_out, 0, (size_t)B * A.f_bs * sizeof(T), stream));
+   // the centre-of-mass columns: d tau / d (m c) on request; else the reference's -- zero, or e x a once the twist is switched off
+   const int mode = first_moment_columns ? 1 : (opts.consider_coriolis ? 0 : 2);
+#define MH_REG_LAUNCH(MODE) \
+   { if (ldsc) hipLaunchKernelGGL((mh::regressor_kernel<T, true, MODE>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::regressor_kernel<T, false, MODE>), dim3(L.grid), dim3(L.block), lds, stream, A); }
+   if (mode == 0)
+      MH_REG_LAUNCH(0)
+   else if (mode == 1)
+      MH_REG_LAUNCH(1)
+   else
+      MH_REG_LAUNCH(2)
+#undef MH_REG_LAUNCH
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
 template <typename T>
 mh_status centroidal_impl(mh_model_t model, int64_t B, const T *q, const T *qd, const double *frame, int32_t frame_mode, const mh_options *opts_in,
                           T *A_out, T *b_out, T *com_out)
@@ -2037,6 +2089,16 @@ mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double 
 mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out)
 {
    return launch<double>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
+}
+mh_status mh_regressor_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
+                           const mh_options *opts, int32_t first_moment_columns, double *Y_out)
+{
+   return regressor_impl<double>(model, B, q, qd, qdd, gravity, opts, first_moment_columns, Y_out);
+}
+mh_status mh_regressor_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
+                           const mh_options *opts, int32_t first_moment_columns, float *Y_out)
+{
+   return regressor_impl<float>(model, B, q, qd, qdd, gravity, opts, first_moment_columns, Y_out);
 }
 mh_status mh_crba_coriolis_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const mh_options *opts, double *H_out, double *C_out)
 {

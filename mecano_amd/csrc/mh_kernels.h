@@ -2003,6 +2003,153 @@ __global__ void __launch_bounds__(256) relative_acceleration_kernel(RelArgs<T> A
    }
 }
 
+// ============================================================================================ joint torque regressor
+// algorithms/JointTorqueRegressorCalculator.java:173-190, 749-833: tau = Y(q, qd, qdd) pi with pi = the ten inertial parameters of every
+// body (mass, centre-of-mass offset, Ixx, Ixy, Ixz, Iyy, Iyz, Izz in its body-fixed frame, :877-889).  The reference zeroes every inertia,
+// runs the first pass of the inverse dynamics once and its second pass once per (body, parameter) with that body's inertia set to the unit
+// basis (:795-806, :574-590).  A body alone carrying inertia loads exactly the joints between it and the root, so here one outward sweep
+// computes every body's twist and acceleration, forms the ten basis wrenches in the body-fixed frame (computeDynamicWrench,
+// spatial/interfaces/SpatialInertiaReadOnly.java:229-296) and carries them up the ancestors together; entries of joints that do not
+// support the body stay zero (memset by the host).  The bases MCOM_X/Y/Z set a centre-of-mass offset on a body of zero mass
+// (:579-581): with a twist every term of that wrench is multiplied by the mass (tools/MecanoTools.java:632-702, 785-822), so the
+// reference's columns 1..3 are zero -- MODE 0; without one (Coriolis and centrifugal terms switched off: the twist is null,
+// InverseDynamicsCalculator.java:937) computeDynamicMoment leaves c x a unscaled (tools/MecanoTools.java:650-692: the scale sits inside
+// the velocity branch), so the columns hold the moment e x a -- MODE 2.  MODE 1 writes the derivatives with respect to the first
+// moment m c instead (what an identification wants).
+// Y is [B][nv][10 n]: A.out, A.f_bs = nv * 10 n; the block of body `e` (caller's joint order) starts at column 10 e.
+template <typename T, bool LDSC, int MODE>
+__global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   const DevModel &m = A.m;
+   const T *CB = (const T *)m.consts;
+   if constexpr (LDSC)
+   {
+      T *C = (T *)lds_raw;
+      stage_consts<T>(m, C);
+      CB = C;
+   }
+   const ciptr meta = as_const(m.meta), dof_map = as_const(m.dof_map), cfg_map = as_const(m.cfg_map);
+   const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const long nlanes = (long)gridDim.x * blockDim.x;
+   constexpr long ws_stride = 64;
+   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
+   const V3<T> Z{T(0), T(0), T(0)};
+   const long ycols = (long)m.n * 10;
+   constexpr bool FM = MODE != 0;
+   constexpr int NW = FM ? 10 : 7; // wrenches carried: mass, (centre-of-mass columns,) six moments of inertia
+   constexpr int I0 = FM ? 4 : 1;
+
+   for (long cfg = lane; cfg < A.B; cfg += nlanes)
+   {
+      const T *qrow = A.q + cfg * A.q_bs;
+      const T *qdrow = A.qd + cfg * A.v_bs;
+      const T *qddrow = A.in3 + cfg * A.v_bs;
+      T *Y = A.out + cfg * A.f_bs;
+      SV<T> v_prev{Z, Z}, a_prev{Z, Z};
+      for (int j = 0; j < m.n; j++)
+      {
+         ciptr mi = meta + j * MI_STRIDE;
+         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const CRef<T, LDSC> c{CB + j * MC_STRIDE};
+         // ---- the first pass of the inverse dynamics (InverseDynamicsCalculator.java:873-917), as rnea_kernel runs it
+         SV<T> vp, ap;
+         if (parent < 0)
+         {
+            vp = SV<T>{Z, Z};
+            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}};
+         }
+         else if (flags & MF_PARENT_ADJ)
+            vp = v_prev, ap = a_prev;
+         else
+         {
+            const int sp = meta[parent * MI_STRIDE + MI_SLOT_VA];
+            vp = ws_load6(ws, ws_stride, sp);
+            ap = ws_load6(ws, ws_stride, sp + 6);
+         }
+         const XF<T> Xb = load_xb<T>(c);
+         const JX<T> jx = joint_from_q<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP], true);
+         const SV<T> vJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qdrow, A.v_es, A.coriolis != 0);
+         const SV<T> aJ = joint_vec<T>(type, dof_map, mi[MI_DOF], qddrow, A.v_es, A.accel != 0);
+         SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
+         const SV<T> a = motion_down(type, jx, Xb, ap) + aJ + crm(v, vJ);
+         if (!A.coriolis)
+            v = SV<T>{Z, Z};
+         if (flags & MF_STORE_VA)
+         {
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
+            ws_store6(ws, ws_stride, mi[MI_SLOT_VA] + 6, a);
+         }
+         v_prev = v, a_prev = a;
+         // ---- the basis wrenches of this body, in its body-fixed frame (:574-590 with computeDynamicWrench)
+         XF<T> Xf;
+         Xf.R = M3<T>{c[MC_RF + 0], c[MC_RF + 1], c[MC_RF + 2], c[MC_RF + 3], c[MC_RF + 4], c[MC_RF + 5], c[MC_RF + 6], c[MC_RF + 7], c[MC_RF + 8]};
+         Xf.p = V3<T>{c[MC_PF + 0], c[MC_PF + 1], c[MC_PF + 2]};
+         const SV<T> vb = motion_to_child(Xf, v), ab = motion_to_child(Xf, a);
+         const V3<T> w = vb.a, wd = ab.a;
+         SV<T> W[NW];
+         W[0] = SV<T>{Z, ab.l + cross(w, vb.l)}; // M: f = a + w x v (computeDynamicForceFast, tools/MecanoTools.java:728-752)
+         if constexpr (FM)
+         { // d/d(m c): n = h x a + w (v.h) - v (w.h);  f = -(h x wd) - w x (h x w)   (tools/MecanoTools.java:632-702, 785-822)
+            const V3<T> E[3] = {V3<T>{T(1), T(0), T(0)}, V3<T>{T(0), T(1), T(0)}, V3<T>{T(0), T(0), T(1)}};
+#pragma unroll
+            for (int e = 0; e < 3; e++)
+            {
+               const V3<T> h = E[e];
+               if constexpr (MODE == 2)
+                  W[1 + e] = SV<T>{cross(h, ab.l), Z}; // the reference without a twist: c x a, not scaled by the (zero) mass
+               else
+               {
+                  const V3<T> n = cross(h, ab.l) + (dot(vb.l, h) * w - dot(w, h) * vb.l);
+                  const V3<T> f = Z - (cross(h, wd) + cross(w, cross(h, w)));
+                  W[1 + e] = SV<T>{n, f};
+               }
+            }
+         }
+         // I_XX .. I_ZZ: n = E wd + w x (E w) (computeDynamicMomentFast, tools/MecanoTools.java:571-598); the off-diagonal bases are symmetric
+         W[I0 + 0] = SV<T>{V3<T>{wd.x, T(0), T(0)} + cross(w, V3<T>{w.x, T(0), T(0)}), Z};
+         W[I0 + 1] = SV<T>{V3<T>{wd.y, wd.x, T(0)} + cross(w, V3<T>{w.y, w.x, T(0)}), Z};
+         W[I0 + 2] = SV<T>{V3<T>{wd.z, T(0), wd.x} + cross(w, V3<T>{w.z, T(0), w.x}), Z};
+         W[I0 + 3] = SV<T>{V3<T>{T(0), wd.y, T(0)} + cross(w, V3<T>{T(0), w.y, T(0)}), Z};
+         W[I0 + 4] = SV<T>{V3<T>{T(0), wd.z, wd.y} + cross(w, V3<T>{T(0), w.z, w.y}), Z};
+         W[I0 + 5] = SV<T>{V3<T>{T(0), T(0), wd.z} + cross(w, V3<T>{T(0), T(0), w.z}), Z};
+#pragma unroll
+         for (int k = 0; k < NW; k++)
+            W[k] = force_to_parent(Xf, W[k]); // to the frame after the joint (InverseDynamicsCalculator.java:936-941)
+         // ---- second pass for this body alone (:930-959): the joints from here to the root carry the wrenches
+         T *Yb = Y + (long)mi[MI_EXT] * 10;
+         int cur = j, tc = type;
+         JX<T> jc = jx;
+         XF<T> Xc = Xb;
+         for (;;)
+         {
+            ciptr mc = meta + cur * MI_STRIDE;
+            ciptr dc = dof_map + mc[MI_DOF];
+            const int nd = dof_count(tc);
+            for (int r = 0; r < nd; r++)
+            {
+               T *yr = Yb + (long)dc[r] * ycols;
+               const int cp = dof_comp(tc, r);
+#pragma unroll
+               for (int k = 0; k < NW; k++)
+                  yr[k == 0 ? 0 : (FM ? k : k + 3)] = comp(W[k], cp);
+            }
+            const int up = mc[MI_PARENT];
+            if (up < 0)
+               break;
+#pragma unroll
+            for (int k = 0; k < NW; k++)
+               W[k] = force_up(tc, jc, Xc, W[k]);
+            ciptr mu = meta + up * MI_STRIDE;
+            tc = mu[MI_TYPE];
+            Xc = load_xb<T>(CRef<T, LDSC>{CB + up * MC_STRIDE});
+            jc = joint_again<T>(tc, cfg_map, mu[MI_CFG], qrow, A.q_es, ws, ws_stride, mu[MI_SLOT_JP]);
+            cur = up;
+         }
+      }
+   }
+}
+
 // ---- stamp of everything a topology-specialised code object shares with the library beyond the C-ABI: the argument structs it
 // reinterprets, the strides of the per-joint records, the canonical-frame convention.  mh_model_create refuses a code object whose stamp
 // differs (a stale libmecano_hip_topo_<key>.so would otherwise read a mis-laid-out struct or fold zeros that are not there).

@@ -463,6 +463,20 @@ class HipModel:
                                                                   C.data_ptr()))
         return H, C
 
+    def regressor(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), layout=_lib.LAYOUT_AOS, consider_coriolis=True, consider_accelerations=True,
+                  first_moment_columns=False):
+        """Joint torque regressor (JointTorqueRegressorCalculator.compute, JointTorqueRegressorCalculator.java:173-190): Y [B, nv, 10 n_joints]
+        with tau = Y pi; the ten columns of joint j's successor body start at column 10 j.  Device tensors (fp64 / fp32); ``layout`` is the
+        layout of q, qd, qdd.  ``first_moment_columns``: d tau / d (m c) in columns 1..3 of every body instead of the reference's zeros."""
+        import torch
+        B, dt, sfx, stream = self._device_inputs([q, qd, qdd], layout)
+        Y = torch.empty((B, self.nv, 10 * self.n_joints), dtype=dt, device=q.device)
+        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        opts = self._options(layout, consider_coriolis, consider_accelerations, stream)
+        _lib.check(getattr(_lib.load(), f"mh_regressor_{sfx}")(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, ctypes.byref(opts),
+                                                              1 if first_moment_columns else 0, Y.data_ptr()))
+        return Y
+
     def centroidal(self, q, qd=None, frame=None, at_com=False, layout=_lib.LAYOUT_AOS):
         """Centroidal momentum matrix, convective term and frame origin (CompositeRigidBodyMassMatrixCalculator.java:375-420, 801-839):
         (A [B, 6, nv], b [B, 6] or None without qd, com [B, 3]).  ``frame``: 12 numbers (R row-major, p), pose of the centroidal momentum

@@ -182,6 +182,50 @@ class OracleModel:
         _load().mo_crba_coriolis(self._h, B, _p(q), _p(qd), _p(H), _p(C))
         return H, C
 
+    # ---- JointTorqueRegressorCalculator (algorithms/JointTorqueRegressorCalculator.java)
+    REGRESSOR_BASES = ("M", "MCOM_X", "MCOM_Y", "MCOM_Z", "I_XX", "I_XY", "I_XZ", "I_YY", "I_YZ", "I_ZZ")  # SpatialInertiaBasisOption, :514-516
+
+    @staticmethod
+    def _basis_inertia(k):
+        """SpatialInertiaParameterBasis.setBasis (:574-590): (J [3, 3], mass, com [3]) of the unit basis ``k``."""
+        J, mass, com = np.zeros((3, 3)), 0.0, np.zeros(3)
+        if k == 0:
+            mass = 1.0
+        elif k <= 3:
+            com[k - 1] = 1.0
+        else:
+            a, b = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))[k - 4]
+            J[a, b] = J[b, a] = 1.0
+        return J, mass, com
+
+    def parameter_vector(self):
+        """getParameterVector (:397-400, :877-889): ten numbers per body -- mass, centre-of-mass offset, Ixx, Ixy, Ixz, Iyy, Iyz, Izz --
+        here in mh_model_desc joint order (the reference's order is a HashMap's iteration order, :85, :337-348)."""
+        d = self.desc
+        J = _c(d.inertia_J).reshape(self.n, 3, 3)
+        pi = np.zeros((self.n, 10))
+        pi[:, 0] = _c(d.inertia_mass)
+        pi[:, 1:4] = _c(d.inertia_com).reshape(self.n, 3)
+        for c, (a, b) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+            pi[:, 4 + c] = J[:, a, b]
+        return pi.reshape(-1)
+
+    def regressor(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), consider_coriolis=True, consider_accelerations=True, bodies=None):
+        """compute() (:173-190) the way the reference does it: every inertia zero (:733-745), then for each body and each basis its inertia
+        set to the unit basis (:795-806) and the inverse dynamics evaluated -- one column of Y [B, nv, 10 n] each.  (The reference reuses
+        the first pass and the wrenches of unmodified branches, :808-833; the numbers are those of a full evaluation.)"""
+        import dataclasses
+        q, qd, qdd = _c(q), _c(qd), _c(qdd)
+        B, n = q.shape[0], self.n
+        Y = np.zeros((B, self.nv, 10 * n))
+        for i in (range(n) if bodies is None else bodies):
+            for k in range(10):
+                J, mass, com = np.zeros((n, 3, 3)), np.zeros(n), np.zeros((n, 3))
+                J[i], mass[i], com[i] = self._basis_inertia(k)
+                om = OracleModel(dataclasses.replace(self.desc, inertia_J=J.reshape(-1), inertia_mass=mass, inertia_com=com.reshape(-1)))
+                Y[:, :, 10 * i + k] = om.rnea(q, qd, qdd, gravity, None, consider_coriolis, consider_accelerations)
+        return Y
+
     def centroidal(self, q, qd=None, frame=None, at_com=False):
         """Centroidal momentum matrix A [B, 6, nv], convective term b [B, 6] (None without qd) and the origin of the centroidal
         frame in ``frame`` [B, 3].  ``frame`` = 12 numbers (R row-major, p), pose of the centroidal momentum frame in the root body
