@@ -81,6 +81,8 @@ public final class MecanoHipNative
    static final MethodHandle RNEA_ABA = handle("mh_rnea_aba_f64", PAIR);
    /** (model, B, q, qd, qdd, gravity, f_ext|NULL, opts|NULL, tau_out, H_out): inverse dynamics and the mass matrix of the same state, one launch */
    static final MethodHandle RNEA_CRBA = handle("mh_rnea_crba_f64", DYNAMICS_2);
+   /** (model, B, q, qd, qdd, gravity, opts|NULL, first_moment_columns, Y_out): JointTorqueRegressorCalculator.compute for B configurations */
+   static final MethodHandle REGRESSOR = handle("mh_regressor_f64", status(ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
    /** (model, B, q, qd, tau, qdd_in, gravity, f_ext, opts, qdd_out, tau_out) */
    static final MethodHandle ABA_LOCKED = handle("mh_aba_locked_f64", PAIR);
    static final MethodHandle RNEA_BODIES = handle("mh_rnea_bodies_f64", DYNAMICS_3);
