@@ -219,6 +219,17 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
       return model;
    }
 
+   /** for the calculators built on this one (HipMultiBodyResponseCalculator shares the model and the joint source modes) */
+   HipMultiBodyModel model()
+   {
+      return model;
+   }
+
+   boolean hasAccelerationSources()
+   {
+      return anyAccelerationSource;
+   }
+
    public MultiBodySystemReadOnly getInput()
    {
       return input;

@@ -4,6 +4,7 @@
 * ``ForwardDynamicsCalculator``              algorithms/ForwardDynamicsCalculator.java:112-196, 234-319, 348-381, 475-520, 556-567
 * ``CompositeRigidBodyMassMatrixCalculator`` algorithms/CompositeRigidBodyMassMatrixCalculator.java:157-233, 286-303, 344-348
 * ``JointTorqueRegressorCalculator``         algorithms/JointTorqueRegressorCalculator.java:101-133, 173-190, 360-502 (a caller of the first)
+* ``MultiBodyResponseCalculator``            algorithms/MultiBodyResponseCalculator.java:120-140, 288-935 (a caller of the second)
 
 Differences a user of the reference must know (all forced by batching, none changes results):
 
@@ -324,6 +325,179 @@ class ForwardDynamicsCalculator(_Base):
         if self._wrenches is None:
             raise ValueError("call compute(q, qd, tau, wrenches=True) first")
         return self._wrenches[:, int(k), :]
+
+
+class MultiBodyResponseCalculator:
+    """algorithms/MultiBodyResponseCalculator.java:120-140, 224-250, 288-600, 608-840, 859-935, batched: the change in joint and body
+    accelerations (or, for impulses, velocities) a test wrench on a body or a test effort at a joint produces.  The reference walks the
+    disturbance up the articulated-body quantities its forward dynamics left behind (pA+ = -w, u+ = tau+ - S^T pA+, pa+ = pA+ + U D^-1 u+,
+    :1206-1252) and the change in acceleration back down (qdd+ = D^-1 (u+ - U^T a+_parent), :1301-1338): that is the forward dynamics'
+    own recursion with the velocities, the gravity and the efforts at zero and the test wrench as the only external wrench -- the bias
+    acceleration c and the term Ia c vanish with the velocities -- so this mirror asks the ABA kernels for exactly that, for B
+    configurations at once (acceleration-source joints keep a zero change, :1230-1238, 1275-1281, through ``mh_aba_locked_f64``).
+    The response is linear in the disturbance and independent of q-dot, gravity, efforts and standing external wrenches: the identity the
+    reference's tests pin is  qdd(with the test wrench) = qdd + propagateWrench()  (MultiBodyResponseCalculatorTest.java:301-344).
+
+    ``reset(q)`` sets the configurations (the reference reads them from the joints' frames) and forgets the disturbances; test wrenches
+    are [B, 6] (moment, force) on the target body, expressed in its body-fixed frame; efforts are [B] or [B, dofs of the joint]."""
+
+    def __init__(self, input):
+        self.forwardDynamicsCalculator = input if isinstance(input, ForwardDynamicsCalculator) else ForwardDynamicsCalculator(input)
+        fd = self.forwardDynamicsCalculator
+        self.input, self.model = fd.input, fd.model
+        self._joints = self.input.getJointsToConsider()
+        self._body_pos = {id(j.getSuccessor()): k for k, j in enumerate(self._joints)}
+        self._joint_pos = {id(j): k for k, j in enumerate(self._joints)}
+        self._provider = RigidBodyAccelerationProvider(self.input, None)
+        self._q = None
+        self._clear()
+
+    def getForwardDynamicsCalculator(self) -> ForwardDynamicsCalculator:
+        return self.forwardDynamicsCalculator
+
+    def _clear(self):
+        self._wrenches, self._efforts, self._change = None, None, None
+        self._provider.body_acc = self._provider.body_twist = None
+
+    def reset(self, q=None):
+        """:232-250; ``q`` [B, nq]: the configurations the responses are evaluated at (kept when omitted)."""
+        if q is not None:
+            self._q = q
+        self._clear()
+
+    # ---- array helpers: numpy in -> numpy out, device tensors stay on the device
+    def _zeros(self, *shape):
+        if HipModel._is_torch(self._q):
+            import torch
+            return torch.zeros(shape, dtype=self._q.dtype, device=self._q.device)
+        return np.zeros(shape)
+
+    def _like(self, x):
+        if HipModel._is_torch(self._q):
+            import torch
+            return x.to(device=self._q.device, dtype=self._q.dtype) if HipModel._is_torch(x) else torch.as_tensor(np.asarray(x), dtype=self._q.dtype, device=self._q.device)
+        return np.asarray(x.cpu().numpy() if HipModel._is_torch(x) else x, dtype=np.float64)
+
+    def _batch(self):
+        if self._q is None:
+            raise ValueError("call reset(q) with the configurations first")
+        return int(self._q.shape[0])
+
+    # ---- disturbances (:608-815); several calls accumulate (MultiBodyResponseCalculatorTest.java:749-877)
+    def applyRigidBodyWrench(self, target, wrench) -> bool:
+        """:608-627; False for a body this calculator does not consider."""
+        k = self._body_pos.get(id(target))
+        if k is None:
+            return False
+        B = self._batch()
+        if self._wrenches is None:
+            self._wrenches = self._zeros(B, self.model.n_joints, 6)
+        self._wrenches[:, k, :] += self._like(wrench).reshape(B, 6)
+        self._change = None
+        return True
+
+    applyRigidBodyImpulse = applyRigidBodyWrench  # :640-659: the same linear map, read as impulse -> change of twist
+
+    def applyJointWrench(self, target, effort) -> bool:
+        """:685-735; ``effort`` [B] (1-DoF joints) or [B, dofs]."""
+        k = self._joint_pos.get(id(target))
+        if k is None:
+            return False
+        B = self._batch()
+        rows = list(self.input.getJointMatrixIndexProvider().getJointDoFIndices(target))
+        if self._efforts is None:
+            self._efforts = self._zeros(B, self.model.nv)
+        self._efforts[:, rows] += self._like(effort).reshape(B, len(rows))
+        self._change = None
+        return True
+
+    applyJointImpulse = applyJointWrench  # :750-815
+
+    # ---- propagation (:823-840)
+    def _propagate(self):
+        if self._change is None:
+            B = self._batch()
+            zero_v = self._zeros(B, self.model.nv)
+            tau = self._efforts if self._efforts is not None else zero_v
+            g0 = (0.0, 0.0, 0.0)
+            fd = self.forwardDynamicsCalculator
+            if any(m == JointSourceMode.ACCELERATION_SOURCE for m in fd._modes):
+                self._change, _ = self.model.aba_locked(self._q, zero_v, tau, zero_v, g0, self._wrenches, fd.layout)
+            else:
+                self._change, self._provider.body_acc, _ = self.model.aba_bodies(self._q, zero_v, tau, g0, self._wrenches, fd.layout)
+                self._provider.body_twist = self._provider.body_acc
+        return self._change
+
+    def propagateWrench(self):
+        """:823-829: the change in joint accelerations, [B, nv]"""
+        return self._propagate()
+
+    def propagateImpulse(self):
+        """:836-842: the change in joint velocities, [B, nv]"""
+        return self._propagate()
+
+    def getAccelerationChangeProvider(self) -> RigidBodyAccelerationProvider:
+        """:859-862: getAccelerationOfBody(body) = the change in the body's spatial acceleration, in its body-fixed frame"""
+        self._propagate()
+        return self._provider
+
+    def getTwistChangeProvider(self) -> RigidBodyAccelerationProvider:
+        """:873-876: getTwistOfBody(body) = the change in the body's twist after an impulse"""
+        self._propagate()
+        return self._provider
+
+    def getJointAccelerationChange(self, joint):
+        """:887-904: the rows of the joint, [B, dofs]"""
+        rows = list(self.input.getJointMatrixIndexProvider().getJointDoFIndices(joint))
+        return self._propagate()[:, rows]
+
+    getJointTwistChange = getJointAccelerationChange  # :915-932
+
+    # ---- apparent inertias (:288-600): columns = responses to unit disturbances
+    def computeRigidBodyApparentSpatialInertiaInverse(self, target):
+        """:288-330 with inertiaFrame = the target's body-fixed frame: [B, 6, 6], change of the body's spatial acceleration per unit
+        wrench on it (symmetric); ``None`` for a body this calculator does not consider."""
+        k = self._body_pos.get(id(target))
+        if k is None:
+            return None
+        B = self._batch()
+        saved = (self._wrenches, self._efforts)
+        out = self._zeros(B, 6, 6)
+        for c in range(6):
+            self._clear()
+            w = self._zeros(B, 6)
+            w[:, c] = 1.0
+            self.applyRigidBodyWrench(target, w)
+            self._propagate()
+            if self._provider.body_acc is None:
+                raise ValueError("apparent inertias need every joint to be an effort source")
+            out[:, :, c] = self._provider.body_acc[:, k, :]
+        self._clear()
+        self._wrenches, self._efforts = saved
+        return out
+
+    def computeRigidBodyApparentLinearInertiaInverse(self, target):
+        """:449-500 with inertiaFrame = the target's body-fixed frame: [B, 3, 3], linear acceleration of the frame origin per unit force"""
+        M = self.computeRigidBodyApparentSpatialInertiaInverse(target)
+        return None if M is None else M[:, 3:, 3:]
+
+    def computeJointApparentInertiaInverse(self, target):
+        """:512-590: [B, dofs, dofs] (1-DoF joints: [B, 1, 1]), change of the joint's accelerations per unit effort"""
+        if self._joint_pos.get(id(target)) is None:
+            return None
+        B = self._batch()
+        rows = list(self.input.getJointMatrixIndexProvider().getJointDoFIndices(target))
+        saved = (self._wrenches, self._efforts)
+        out = self._zeros(B, len(rows), len(rows))
+        for c in range(len(rows)):
+            self._clear()
+            e = self._zeros(B, len(rows))
+            e[:, c] = 1.0
+            self.applyJointWrench(target, e)
+            out[:, :, c] = self._propagate()[:, rows]
+        self._clear()
+        self._wrenches, self._efforts = saved
+        return out
 
 
 class CompositeRigidBodyMassMatrixCalculator(_Base):
