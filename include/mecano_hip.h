@@ -278,13 +278,14 @@ mh_status mh_relative_acceleration_f64(mh_model_t model, int64_t B, const double
 /*
  * ---- joint torque regressor (JointTorqueRegressorCalculator.compute / getJointTorqueRegressorMatrix,
  *      algorithms/JointTorqueRegressorCalculator.java:173-190, 450-453, 749-833; a caller of the inverse dynamics, :118, :181-182, :802-804) ----
- * Y_out [B][nv][10 n_joints], one row-major nv x 10 n matrix per configuration (a DMatrixRMaj each):  tau = Y pi  for the inverse
+ * Y_out [B][nv][10 n_joints], one row-major nv x 10 n matrix per configuration (a DMatrixRMaj each; MH_LAYOUT_SOA: [nv][10 n_joints][B],
+ * every store coalesced -- several times faster to produce):  tau = Y pi  for the inverse
  * dynamics without external wrenches, with pi = (mass, com_x, com_y, com_z, Ixx, Ixy, Ixz, Iyy, Iyz, Izz) of every successor body in
  * its body-fixed frame (:877-889; the columns of a body follow SpatialInertiaBasisOption, :514-516).  The ten columns of joint j's
  * successor body start at column 10 j, j in mh_model_desc order -- the reference orders the blocks by the iteration order of a HashMap
  * of rigid bodies (:85, :123, :318-329), which is not specified; getJointTorqueRegressorMatrixBlock(body) (:462-465) is the order-free
  * accessor a shim maps onto this layout.  opts->consider_coriolis / consider_accelerations as in mh_rnea_f64
- * (setConsiderCoriolisAndCentrifugalForces / setConsiderJointAccelerations, :489-502); opts->layout is the layout of q, qd, qdd.
+ * (setConsiderCoriolisAndCentrifugalForces / setConsiderJointAccelerations, :489-502); opts->layout is the layout of q, qd, qdd and Y.
  * first_moment_columns = 0 reproduces the reference: its MCOM_X/Y/Z bases put a centre-of-mass offset on a body of zero mass (:579-581)
  * and every term of the dynamic wrench carries the mass (tools/MecanoTools.java:632-702, 785-822), so those three columns are zero --
  * except with consider_coriolis = 0, where the inverse dynamics passes no twist and computeDynamicMoment leaves c x a unscaled

@@ -1350,10 +1350,14 @@ mh_status regressor_impl(mh_model_t model, int64_t B, const T *q, const T *qd, c
       return MH_OK;
    if (!q || !qd || !qdd || !Y_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
-   st = ensure_workspace(model, B, sizeof(T));
+   const Launch L = plan_launch(model, B);
+   // small batches: up to eight waves per group of 64 configurations, each taking every parts-th body (mh_kernels.h)
+   int parts = (int)std::max<long>(1, std::min<long>(std::min<long>(8, model->n), (long)model->cu_count * 4 / L.grid)); // one wave per SIMD (measured: profiles/r02_regressor_rates.txt)
+   if (const char *e = getenv("MH_REGRESSOR_PARTS"))
+      parts = std::max(1, std::min(64, atoi(e)));
+   st = ensure_bytes(model->ws, (size_t)model->n_slots * (size_t)L.lanes * parts * sizeof(T));
    if (st != MH_OK)
       return st;
-   const Launch L = plan_launch(model, B);
    hipStream_t stream = (hipStream_t)opts.stream;
    mh::Args<T> A{};
    A.m = dev_model<T>(model);
@@ -1361,20 +1365,21 @@ mh_status regressor_impl(mh_model_t model, int64_t B, const T *q, const T *qd, c
    A.q = q, A.qd = qd, A.in3 = qdd, A.out = Y_out;
    A.ws = (T *)model->ws.ptr;
    A.ws_stride = L.lanes;
-   const bool soa = opts.layout == MH_LAYOUT_SOA; // of the state matrices; Y is one row-major matrix per configuration either way
+   const bool soa = opts.layout == MH_LAYOUT_SOA;
    A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
    A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
-   A.f_bs = (long)model->nv * model->n * 10, A.f_es = 1;
+   const long ysize = (long)model->nv * model->n * 10;
+   A.f_bs = soa ? 1 : ysize, A.f_es = soa ? B : 1; // strides of Y
    A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
    A.coriolis = opts.consider_coriolis, A.accel = opts.consider_accelerations;
    const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
    const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
    // entries of joints that do not support a body are zero, and so are the reference's centre-of-mass columns (mh_kernels.h)
-   HIP_TRY(hipMemsetAsync(Y_out, 0, (size_t)B * A.f_bs * sizeof(T), stream));
+   HIP_TRY(hipMemsetAsync(Y_out, 0, (size_t)B * ysize * sizeof(T), stream));
    // the centre-of-mass columns: d tau / d (m c) on request; else the reference's -- zero, or e x a once the twist is switched off
    const int mode = first_moment_columns ? 1 : (opts.consider_coriolis ? 0 : 2);
 #define MH_REG_LAUNCH(MODE) \
-   { if (ldsc) hipLaunchKernelGGL((mh::regressor_kernel<T, true, MODE>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::regressor_kernel<T, false, MODE>), dim3(L.grid), dim3(L.block), lds, stream, A); }
+   { if (ldsc) hipLaunchKernelGGL((mh::regressor_kernel<T, true, MODE>), dim3(L.grid, parts), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::regressor_kernel<T, false, MODE>), dim3(L.grid, parts), dim3(L.block), lds, stream, A); }
    if (mode == 0)
       MH_REG_LAUNCH(0)
    else if (mode == 1)

@@ -2016,7 +2016,8 @@ __global__ void __launch_bounds__(256) relative_acceleration_kernel(RelArgs<T> A
 // InverseDynamicsCalculator.java:937) computeDynamicMoment leaves c x a unscaled (tools/MecanoTools.java:650-692: the scale sits inside
 // the velocity branch), so the columns hold the moment e x a -- MODE 2.  MODE 1 writes the derivatives with respect to the first
 // moment m c instead (what an identification wants).
-// Y is [B][nv][10 n]: A.out, A.f_bs = nv * 10 n; the block of body `e` (caller's joint order) starts at column 10 e.
+// Y is [B][nv][10 n]: A.out, A.f_bs = nv * 10 n, A.f_es = 1 (MH_LAYOUT_SOA: [nv][10 n][B], f_bs = 1, f_es = B); the block of body `e`
+// (caller's joint order) starts at column 10 e.
 template <typename T, bool LDSC, int MODE>
 __global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
 {
@@ -2033,7 +2034,10 @@ __global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
    const long lane = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const long nlanes = (long)gridDim.x * blockDim.x;
    constexpr long ws_stride = 64;
-   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
+   // gridDim.y waves share a group of 64 configurations: each runs the whole first pass (a fifth of the work) and the wrenches and the
+   // climb of every gridDim.y-th body -- small batches spread over the device that way (the bodies' columns are independent)
+   const int part = blockIdx.y, parts = gridDim.y;
+   T *ws = A.ws + ((long)part * gridDim.x * (blockDim.x >> 6) + (lane >> 6)) * ((long)m.n_slots * 64) + (lane & 63);
    const V3<T> Z{T(0), T(0), T(0)};
    const long ycols = (long)m.n * 10;
    constexpr bool FM = MODE != 0;
@@ -2081,6 +2085,8 @@ __global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
             ws_store6(ws, ws_stride, mi[MI_SLOT_VA] + 6, a);
          }
          v_prev = v, a_prev = a;
+         if (j % parts != part)
+            continue;
          // ---- the basis wrenches of this body, in its body-fixed frame (:574-590 with computeDynamicWrench)
          XF<T> Xf;
          Xf.R = M3<T>{c[MC_RF + 0], c[MC_RF + 1], c[MC_RF + 2], c[MC_RF + 3], c[MC_RF + 4], c[MC_RF + 5], c[MC_RF + 6], c[MC_RF + 7], c[MC_RF + 8]};
@@ -2117,7 +2123,7 @@ __global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
          for (int k = 0; k < NW; k++)
             W[k] = force_to_parent(Xf, W[k]); // to the frame after the joint (InverseDynamicsCalculator.java:936-941)
          // ---- second pass for this body alone (:930-959): the joints from here to the root carry the wrenches
-         T *Yb = Y + (long)mi[MI_EXT] * 10;
+         T *Yb = Y + (long)mi[MI_EXT] * 10 * A.f_es;
          int cur = j, tc = type;
          JX<T> jc = jx;
          XF<T> Xc = Xb;
@@ -2126,24 +2132,52 @@ __global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
             ciptr mc = meta + cur * MI_STRIDE;
             ciptr dc = dof_map + mc[MI_DOF];
             const int nd = dof_count(tc);
+            // the parent's joint transform is fetched (workspace / q) before this level's stores and transforms: a lone wave has
+            // nothing else to cover that latency with
+            const int up = mc[MI_PARENT];
+            int tn = JT_FIXED;
+            XF<T> Xn = Xc;
+            JX<T> jn = jc;
+            if (up >= 0)
+            {
+               ciptr mu = meta + up * MI_STRIDE;
+               tn = mu[MI_TYPE];
+               Xn = load_xb<T>(CRef<T, LDSC>{CB + up * MC_STRIDE});
+               jn = joint_again<T>(tn, cfg_map, mu[MI_CFG], qrow, A.q_es, ws, ws_stride, mu[MI_SLOT_JP]);
+            }
             for (int r = 0; r < nd; r++)
             {
-               T *yr = Yb + (long)dc[r] * ycols;
                const int cp = dof_comp(tc, r);
+               T e[10];
+#pragma unroll
+               for (int k = 0; k < 10; k++)
+                  e[k] = T(0);
 #pragma unroll
                for (int k = 0; k < NW; k++)
-                  yr[k == 0 ? 0 : (FM ? k : k + 3)] = comp(W[k], cp);
+                  e[k == 0 ? 0 : (FM ? k : k + 3)] = comp(W[k], cp);
+               if (A.f_es == 1)
+               { // one matrix per configuration: the body's ten columns of this row are 80 (40) contiguous bytes, written as five pairs
+                  typedef T pair_t __attribute__((ext_vector_type(2)));
+                  pair_t *yr = (pair_t *)(Yb + (long)dc[r] * ycols);
+#pragma unroll
+                  for (int k = 0; k < 5; k++)
+                     yr[k] = pair_t{e[2 * k], e[2 * k + 1]};
+               }
+               else
+               { // MH_LAYOUT_SOA: [nv * 10 n][B], consecutive lanes write consecutive addresses
+                  T *yr = Yb + (long)dc[r] * ycols * A.f_es;
+#pragma unroll
+                  for (int k = 0; k < 10; k++)
+                     if (FM || k == 0 || k > 3)
+                        yr[(long)k * A.f_es] = e[k];
+               }
             }
-            const int up = mc[MI_PARENT];
             if (up < 0)
                break;
 #pragma unroll
             for (int k = 0; k < NW; k++)
                W[k] = force_up(tc, jc, Xc, W[k]);
-            ciptr mu = meta + up * MI_STRIDE;
-            tc = mu[MI_TYPE];
-            Xc = load_xb<T>(CRef<T, LDSC>{CB + up * MC_STRIDE});
-            jc = joint_again<T>(tc, cfg_map, mu[MI_CFG], qrow, A.q_es, ws, ws_stride, mu[MI_SLOT_JP]);
+            tc = tn, Xc = Xn, jc = jn;
             cur = up;
          }
       }

@@ -467,10 +467,10 @@ class HipModel:
                   first_moment_columns=False):
         """Joint torque regressor (JointTorqueRegressorCalculator.compute, JointTorqueRegressorCalculator.java:173-190): Y [B, nv, 10 n_joints]
         with tau = Y pi; the ten columns of joint j's successor body start at column 10 j.  Device tensors (fp64 / fp32); ``layout`` is the
-        layout of q, qd, qdd.  ``first_moment_columns``: d tau / d (m c) in columns 1..3 of every body instead of the reference's zeros."""
+        layout of q, qd, qdd and Y (SoA: Y [nv, 10 n_joints, B]).  ``first_moment_columns``: d tau / d (m c) in columns 1..3 of every body instead of the reference's zeros."""
         import torch
         B, dt, sfx, stream = self._device_inputs([q, qd, qdd], layout)
-        Y = torch.empty((B, self.nv, 10 * self.n_joints), dtype=dt, device=q.device)
+        Y = torch.empty((B, self.nv, 10 * self.n_joints) if layout == _lib.LAYOUT_AOS else (self.nv, 10 * self.n_joints, B), dtype=dt, device=q.device)
         g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
         opts = self._options(layout, consider_coriolis, consider_accelerations, stream)
         _lib.check(getattr(_lib.load(), f"mh_regressor_{sfx}")(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, ctypes.byref(opts),

@@ -109,7 +109,7 @@ def test_regressor_matches_oracle_and_inverse_dynamics(torch_cuda, family):
             tau = hm.rnea(tq, tqd, tqdd, G, consider_coriolis=cor, consider_accelerations=acc).cpu().numpy()
             close(Yh @ pi, tau, 1e-10, label=f"{family} Y pi cor={cor} acc={acc}")
         Ys = hm.regressor(tq.t().contiguous(), tqd.t().contiguous(), tqdd.t().contiguous(), G, layout=_lib.LAYOUT_SOA)
-        assert torch.equal(Ys, hm.regressor(tq, tqd, tqdd, G))
+        assert tuple(Ys.shape) == (d.nv, 10 * d.n_joints, B) and torch.equal(Ys.permute(2, 0, 1), hm.regressor(tq, tqd, tqdd, G))
 
 
 @pytest.mark.gpu

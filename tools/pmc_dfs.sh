@@ -19,7 +19,7 @@ for f in glob.glob(f"{out}/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
-    if "dfs" not in k and "rnea_kernel" not in k and "aba_kernel" not in k:
+    if "dfs" not in k and "rnea_kernel" not in k and "aba_kernel" not in k and "regressor" not in k:
         continue
     print(k)
     for c, v in sorted(cs.items()):
