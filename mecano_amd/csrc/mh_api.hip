@@ -1333,6 +1333,15 @@ mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, co
    HIP_TRY(hipGetLastError());
    return MH_OK;
 }
+// Joint torque regressor, small batches: up to eight waves per group of 64 configurations, each taking every parts-th body
+// (mh_kernels.h) -- as many as keep one wave per SIMD (measured: profiles/r02_regressor_rates.txt)
+static int regressor_parts(const mh_model *model, const Launch &L)
+{
+   int parts = (int)std::max<long>(1, std::min<long>(std::min<long>(8, model->n), (long)model->cu_count * 4 / L.grid));
+   if (const char *e = getenv("MH_REGRESSOR_PARTS"))
+      parts = std::max(1, std::min(64, atoi(e)));
+   return parts;
+}
 // Joint torque regressor (JointTorqueRegressorCalculator): run-time-topology kernel
 template <typename T>
 mh_status regressor_impl(mh_model_t model, int64_t B, const T *q, const T *qd, const T *qdd, const double *gravity, const mh_options *opts_in,
@@ -1351,10 +1360,7 @@ mh_status regressor_impl(mh_model_t model, int64_t B, const T *q, const T *qd, c
    if (!q || !qd || !qdd || !Y_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    const Launch L = plan_launch(model, B);
-   // small batches: up to eight waves per group of 64 configurations, each taking every parts-th body (mh_kernels.h)
-   int parts = (int)std::max<long>(1, std::min<long>(std::min<long>(8, model->n), (long)model->cu_count * 4 / L.grid)); // one wave per SIMD (measured: profiles/r02_regressor_rates.txt)
-   if (const char *e = getenv("MH_REGRESSOR_PARTS"))
-      parts = std::max(1, std::min(64, atoi(e)));
+   const int parts = regressor_parts(model, L);
    st = ensure_bytes(model->ws, (size_t)model->n_slots * (size_t)L.lanes * parts * sizeof(T));
    if (st != MH_OK)
       return st;
@@ -2041,6 +2047,12 @@ mh_status mh_reserve(mh_model_t m, int64_t max_batch)
    st = ensure_workspace(m, max_batch, sizeof(double));
    if (st != MH_OK)
       return st;
+   { // mh_regressor_*: one workspace block per wave, several waves per group of configurations on small batches
+      const Launch L = plan_launch(m, max_batch);
+      st = ensure_bytes(m->ws, (size_t)m->n_slots * (size_t)L.lanes * regressor_parts(m, L) * sizeof(double));
+      if (st != MH_OK)
+         return st;
+   }
    // the whole-tree specialised ABA keeps its hand-over store in the same workspace (more slots than the run-time-topology plan of a
    // chain), and big AoS batches of wide matrices go through transposed scratch copies: reserve both, so that compute calls allocate nothing
    if (m->spec.aba_slots)
