@@ -258,10 +258,10 @@ def main():
                     per_launch[i][k].stop(stream)
         t_all.stop(stream)
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0  # this rank's K steps, done; the closing barrier + synchronize follow, then the MAX over ranks
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
