@@ -176,7 +176,10 @@ mh_status mh_topology_key(const mh_model_desc *desc, char key_out[17], int32_t *
  */
 mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap);
 
-/* Pre-allocate device workspace for batches up to max_batch so that compute calls allocate nothing. */
+/* Pre-allocate device workspace for batches up to max_batch so that compute calls allocate nothing.  After it (and one first call of
+ * each entry point, which sets kernel attributes once) the device-pointer entry points only enqueue work on opts->stream -- kernels,
+ * memsets, and for a pair call without a fused kernel an event fork / join with a stream of the model's own: they can be captured in a
+ * HIP graph and replayed (tests/test_gpu_parity.py::test_entry_points_are_graph_capturable). */
 mh_status mh_reserve(mh_model_t model, int64_t max_batch);
 
 /*

@@ -1305,6 +1305,54 @@ def test_rnea_crba_in_one_call(torch_cuda, monkeypatch, spec):
             close(H_ref.cpu().numpy(), om.crba(q), 1e-10, label="crba")
 
 
+@pytest.mark.parametrize("spec", [True, False], ids=["code-object", "run-time-topology"])
+def test_entry_points_are_graph_capturable(torch_cuda, monkeypatch, spec):
+    """After mh_reserve the device entry points only enqueue work on opts->stream (kernels, memsets, for the pair call of a model
+    without a fused kernel an event fork / join with the model's second stream): a HIP graph captured around mh_rnea_aba_f64,
+    mh_rnea_crba_f64 and a simulation step replays to the eager results, bit for bit."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    if not spec:
+        monkeypatch.setenv("MH_DISABLE_SPEC", "1")
+    rng = np.random.default_rng(31)
+    sys_ = rt.nextHumanoid(rng)
+    hm = HipModel(sys_.toModelDesc())
+    assert hm.kernel_variant.startswith("generic") != spec
+    B = 1000
+    hm.reserve(B)
+    q, qd, qdd, tau = (dev(torch, x) for x in rt.nextState(rng, sys_, B))
+    g = (0.0, 0.0, -9.81)
+    t_ref, a_ref = hm.rnea_aba(q, qd, qdd, tau, g)
+    t2_ref, H_ref = hm.rnea_crba(q, qd, qdd, g)
+    qn_ref, qdn_ref, _ = hm.step(1.0e-3, q, qd, tau, g)
+    torch.cuda.synchronize()
+    t_out, a_out, t2_out = torch.empty_like(qd), torch.empty_like(qd), torch.empty_like(qd)
+    H_out = torch.empty((B, hm.nv, hm.nv), dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        pair = hm.bind_rnea_aba(q, qd, qdd, tau, t_out, a_out, g)
+        both = hm.bind_rnea_crba(q, qd, qdd, t2_out, H_out, g)
+        pair(), both()  # (first calls outside the capture: one-time function attributes)
+        qs, qds = q.clone(), qd.clone()
+        hm.step(1.0e-3, qs, qds, tau, g, inplace=True)
+        torch.cuda.synchronize()
+        for t in (t_out, a_out, t2_out, H_out):
+            t.zero_()
+        qs.copy_(q), qds.copy_(qd)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            pair(), both()
+            hm.step(1.0e-3, qs, qds, tau, g, inplace=True)
+    torch.cuda.synchronize()
+    assert not t_out.any()  # captured, not executed
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(t_out, t_ref) and torch.equal(a_out, a_ref) and torch.equal(t2_out, t2_ref) and torch.equal(H_out, H_ref)
+    assert torch.equal(qs, qn_ref) and torch.equal(qds, qdn_ref)
+
+
 def test_host_pointer_pipeline(torch_cuda, monkeypatch):
     """The host-pointer entry points (what a Java shim calls): batches above 1024 configurations travel in chunks through three streams.
     Pageable and pinned (mh_host_alloc) matrices, a chunk size that leaves a ragged last chunk and re-uses every ring slot, external
