@@ -123,6 +123,7 @@ struct SpecLib
    int (*crba_split_usable)(void) = nullptr;
    int (*launch_crba_split)(const void *args, int groups, int lanes_per_group, void *stream) = nullptr;
    int (*launch_rnea_crba)(const void *args, int rnea_groups, int crba_groups, int lanes_per_group, void *stream) = nullptr;
+   long (*rnea_crba_lds_bytes)(int lanes_per_group, int nq, int nv) = nullptr;
    int (*launch_coriolis)(int flags, const void *args, int grid, void *stream) = nullptr;
    int (*launch_centroidal)(int flags, const void *args, int grid, void *stream) = nullptr;
    unsigned long long (*abi)(void) = nullptr;
@@ -1254,6 +1255,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.crba_split_usable = (decltype(s.crba_split_usable))dlsym(h, "mh_spec_crba_split_usable");
    s.launch_crba_split = (decltype(s.launch_crba_split))dlsym(h, "mh_spec_launch_crba_split");
    s.launch_rnea_crba = (decltype(s.launch_rnea_crba))dlsym(h, "mh_spec_launch_rnea_crba");
+   s.rnea_crba_lds_bytes = (decltype(s.rnea_crba_lds_bytes))dlsym(h, "mh_spec_rnea_crba_lds_bytes");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
    s.abi = (decltype(s.abi))dlsym(h, "mh_spec_abi");
@@ -2398,8 +2400,15 @@ mh_status mh_rnea_crba_f64(mh_model_t model, int64_t B, const double *q, const d
       A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
       A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
       A.coriolis = 1, A.accel = 1;
-      int lpg = 64; // thin CRBA workgroups while that is what it takes to give every CU one: its write-out is bound by the stores in flight per CU
-      while (lpg > 16 && (B + lpg / 2 - 1) / (lpg / 2) + groups <= (long)model->cu_count)
+      // thin CRBA workgroups: its write-out is bound by the stores in flight per CU.  Every workgroup must be resident at once (the RNEA
+      // groups would otherwise queue behind the CRBA's): one per CU, two where the thinner image leaves LDS for it (202 registers: two
+      // waves per SIMD)
+      auto resident = [&](int l) {
+         const long lds = model->spec.rnea_crba_lds_bytes ? model->spec.rnea_crba_lds_bytes(l, model->nq, model->nv) : 160 * 1024;
+         return (long)model->cu_count * (2 * lds <= 160 * 1024 ? 2 : 1);
+      };
+      int lpg = 64;
+      while (lpg > 16 && (B + lpg / 2 - 1) / (lpg / 2) + groups <= resident(lpg / 2))
          lpg /= 2;
       if (const char *e = getenv("MH_RNEA_CRBA_LPG")) // experiments: 16 / 32 / 64
          lpg = std::max(16, std::min(64, atoi(e)));

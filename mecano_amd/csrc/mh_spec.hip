@@ -373,9 +373,16 @@ int mh_spec_launch_centroidal(int flags, const void *args, int grid, void *strea
 #endif
 }
 // tree-split CRBA: identity maps, AoS, packed image + limb exchange in LDS
-long mh_spec_crba_split_lds_bytes(void)
-{ // lane-major image (odd pitch) + limb exchange + entry -> slot table
-   return (long)((mh::HMap<TP>::T.n_slots | 1) + SPL::n_limbs() * 10) * 64 * sizeof(double) + (long)((mh::HMap<TP>::NV * mh::HMap<TP>::NV * 2 + 7) & ~7);
+static long crba_split_lds(int lanes_per_group)
+{ // lane-major image (odd pitch) of lanes_per_group rows + limb exchange [slot][64] + entry -> slot table
+   return ((long)(mh::HMap<TP>::T.n_slots | 1) * lanes_per_group + (long)SPL::n_limbs() * 10 * 64) * (long)sizeof(double)
+          + (long)((mh::HMap<TP>::NV * mh::HMap<TP>::NV * 2 + 7) & ~7);
+}
+long mh_spec_crba_split_lds_bytes(void) { return crba_split_lds(64); }
+// LDS of one workgroup of the fused RNEA + CRBA launch with CRBA groups of lanes_per_group configurations (the host sizes the grid by it)
+long mh_spec_rnea_crba_lds_bytes(int lanes_per_group, int nq, int nv)
+{
+   return std::max(split_lds_bytes(0, F_IO_LDS, nq, nv), crba_split_lds(lanes_per_group));
 }
 int mh_spec_crba_split_usable(void) { return SPL::usable() && mh_spec_crba_split_lds_bytes() <= 160 * 1024 ? 1 : 0; }
 int mh_spec_launch_crba_split(const void *args, int groups, int lanes_per_group, void *stream)
@@ -384,7 +391,7 @@ int mh_spec_launch_crba_split(const void *args, int groups, int lanes_per_group,
    {
       const mh::Args<double> &A = *(const mh::Args<double> *)args;
       auto kern = &mh::spec_crba_split_kernel<TP, double>;
-      const size_t lds = (size_t)mh_spec_crba_split_lds_bytes();
+      const size_t lds = (size_t)crba_split_lds(std::max(1, std::min(64, lanes_per_group)));
       static LdsAttr attr;
       if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
          return (int)e;
@@ -405,7 +412,7 @@ int mh_spec_launch_rnea_crba(const void *args, int rnea_groups, int crba_groups,
    {
       const mh::Args<double> &A = *(const mh::Args<double> *)args;
       auto kern = &mh::spec_rnea_crba_split_kernel<TP, double>;
-      const size_t lds = (size_t)std::max(split_lds_bytes(0, F_IO_LDS, A.m.nq, A.m.nv), mh_spec_crba_split_lds_bytes());
+      const size_t lds = (size_t)mh_spec_rnea_crba_lds_bytes(std::max(1, std::min(64, lanes_per_group)), A.m.nq, A.m.nv);
       if (lds > 160 * 1024 || !mh_spec_crba_split_usable())
          return (int)hipErrorNotSupported;
       static LdsAttr attr;

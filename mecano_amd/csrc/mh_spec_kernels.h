@@ -2215,7 +2215,10 @@ MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const 
    const int lane = threadIdx.x & 63;
    const lds_ptr<T> img = (lds_ptr<T>)lds_raw;
    // entry -> slot table of the write-out, staged once (the lookups sit in a dependent chain: LDS latency, not global)
-   short __attribute__((address_space(3))) *tab = (short __attribute__((address_space(3))) *)(img + 64 * NSP + Split<TP>::n_limbs() * 10 * 64);
+   // LDS: image of lpg rows | limb exchange [slot][64] | table -- a thin workgroup asks for a thin image (mh_spec.hip: crba_split_lds),
+   // which is what lets two workgroups share a CU
+   const int img_words = __builtin_amdgcn_readfirstlane(lpg) * NSP;
+   short __attribute__((address_space(3))) *tab = (short __attribute__((address_space(3))) *)(img + img_words + Split<TP>::n_limbs() * 10 * 64);
    for (int e = threadIdx.x; e < NE; e += 256)
       tab[e] = (short)HM::slot_at(e);
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
@@ -2240,7 +2243,7 @@ MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const 
       cx.nv = NV;
       cx.wave = wave;
       cx.xbase = img + lane * NSP;
-      cx.lx = img + 64 * NSP + lane;
+      cx.lx = img + img_words + lane;
       MH_CSTAMP(1);
       if (active)
          split_crba_limbs<TP, 0, T, CX>(cx);
