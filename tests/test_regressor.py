@@ -209,3 +209,15 @@ def test_regressor_calculator_mirror(torch_cuda):
     idc.setConsiderJointAccelerations(False)
     idc.compute(q, qd, qdd)
     close(rc.getJointTorqueRegressorMatrix() @ pi, idc.getJointTauMatrix(), 1e-10, label="calculator no accelerations")
+
+
+@pytest.mark.gpu
+def test_identification_example_predicts_unseen_torques(torch_cuda):
+    """examples/identify_parameters.py: parameters regressed on Y (first-moment columns) reproduce the inverse dynamics of new states."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("identify_parameters", os.path.join(os.path.dirname(__file__), "..", "examples", "identify_parameters.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fit, err, scale, rank = mod.main(samples=512, verbose=False)
+    assert rank < 70 and fit <= 1e-9 * max(1.0, scale) and err <= 1e-8 * max(1.0, scale), (fit, err, scale, rank)
