@@ -214,17 +214,12 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
       return out;
    }
 
-   HipMultiBodyModel getModel()
+   public HipMultiBodyModel getModel()
    {
       return model;
    }
 
    /** for the calculators built on this one (HipMultiBodyResponseCalculator shares the model and the joint source modes) */
-   HipMultiBodyModel model()
-   {
-      return model;
-   }
-
    boolean hasAccelerationSources()
    {
       return anyAccelerationSource;

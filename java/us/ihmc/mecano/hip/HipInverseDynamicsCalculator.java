@@ -224,7 +224,7 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
       return out;
    }
 
-   HipMultiBodyModel getModel()
+   public HipMultiBodyModel getModel()
    {
       return model;
    }

@@ -50,7 +50,7 @@ public class HipMultiBodyResponseCalculator implements AutoCloseable
    {
       this.forwardDynamicsCalculator = forwardDynamicsCalculator;
       ownsForwardDynamicsCalculator = owns;
-      model = forwardDynamicsCalculator.model();
+      model = forwardDynamicsCalculator.getModel();
    }
 
    /** java:224-227 */
