@@ -250,6 +250,21 @@ mh_status ensure_workspace(mh_model *m, int64_t B, size_t elem)
    return ensure_bytes(m->ws, (size_t)m->n_slots * (size_t)L.lanes * elem);
 }
 
+// Kernels whose per-body columns are independent (mass matrix, Coriolis matrix, centroidal momentum matrix, joint torque regressor), small
+// batches: up to eight waves per group of 64 configurations, each taking every parts-th body (mh_kernels.h) -- as many as keep one
+// wave per SIMD (measured: profiles/r02_regressor_rates.txt, profiles/r02_column_parts.txt)
+static int regressor_parts(const mh_model *model, const Launch &L)
+{
+   int parts = (int)std::max<long>(1, std::min<long>(std::min<long>(8, model->n), (long)model->cu_count * 4 / L.grid));
+   if (const char *e = getenv("MH_REGRESSOR_PARTS"))
+      parts = std::max(1, std::min(64, atoi(e)));
+   return parts;
+}
+static mh_status ensure_parts_workspace(mh_model *m, const Launch &L, int parts, size_t elem)
+{
+   return ensure_bytes(m->ws, (size_t)m->n_slots * (size_t)L.lanes * (size_t)parts * elem);
+}
+
 template <typename T>
 mh::DevModel dev_model(const mh_model *m)
 {
@@ -989,7 +1004,13 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
          HIP_TRY(hipMemsetAsync(out, 0, hbytes, stream));
          if (model->split_rt.usable && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2))
             return launch_split_rt<T>(algo, model, B, A, stream); // small batches: the tree split over four waves (mh_split_kernels.h)
-         { if (ldsc) hipLaunchKernelGGL((mh::crba_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::crba_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
+         {
+            const int parts = regressor_parts(model, L);
+            if (const mh_status sp = ensure_parts_workspace(model, L, parts, sizeof(T)); sp != MH_OK)
+               return sp;
+            A.ws = (T *)model->ws.ptr;
+            if (ldsc) hipLaunchKernelGGL((mh::crba_kernel<T, true>), dim3(L.grid, parts), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::crba_kernel<T, false>), dim3(L.grid, parts), dim3(L.block), lds, stream, A);
+         }
          break;
       }
    }
@@ -1298,10 +1319,11 @@ mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, co
       return MH_OK;
    if (!q || !qd || !H_out || !C_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
-   st = ensure_workspace(model, B, sizeof(T));
+   const Launch L = plan_launch(model, B);
+   const int parts = regressor_parts(model, L);
+   st = ensure_parts_workspace(model, L, parts, sizeof(T));
    if (st != MH_OK)
       return st;
-   const Launch L = plan_launch(model, B);
    hipStream_t stream = (hipStream_t)opts.stream;
    mh::Args<T> A{};
    A.m = dev_model<T>(model);
@@ -1331,18 +1353,9 @@ mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, co
             return fail(MH_ERR_HIP, "specialised Coriolis kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
       }
    }
-   { if (ldsc) hipLaunchKernelGGL((mh::coriolis_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::coriolis_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
+   { if (ldsc) hipLaunchKernelGGL((mh::coriolis_kernel<T, true>), dim3(L.grid, parts), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::coriolis_kernel<T, false>), dim3(L.grid, parts), dim3(L.block), lds, stream, A); }
    HIP_TRY(hipGetLastError());
    return MH_OK;
-}
-// Joint torque regressor, small batches: up to eight waves per group of 64 configurations, each taking every parts-th body
-// (mh_kernels.h) -- as many as keep one wave per SIMD (measured: profiles/r02_regressor_rates.txt)
-static int regressor_parts(const mh_model *model, const Launch &L)
-{
-   int parts = (int)std::max<long>(1, std::min<long>(std::min<long>(8, model->n), (long)model->cu_count * 4 / L.grid));
-   if (const char *e = getenv("MH_REGRESSOR_PARTS"))
-      parts = std::max(1, std::min(64, atoi(e)));
-   return parts;
 }
 // Joint torque regressor (JointTorqueRegressorCalculator): run-time-topology kernel
 template <typename T>
@@ -1363,7 +1376,7 @@ mh_status regressor_impl(mh_model_t model, int64_t B, const T *q, const T *qd, c
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    const Launch L = plan_launch(model, B);
    const int parts = regressor_parts(model, L);
-   st = ensure_bytes(model->ws, (size_t)model->n_slots * (size_t)L.lanes * parts * sizeof(T));
+   st = ensure_parts_workspace(model, L, parts, sizeof(T));
    if (st != MH_OK)
       return st;
    hipStream_t stream = (hipStream_t)opts.stream;
@@ -1416,10 +1429,11 @@ mh_status centroidal_impl(mh_model_t model, int64_t B, const T *q, const T *qd, 
       return MH_OK;
    if (!q || !A_out || (b_out && !qd))
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer (the convective term needs qd)");
-   st = ensure_workspace(model, B, sizeof(T));
+   const Launch L = plan_launch(model, B);
+   const int parts = regressor_parts(model, L);
+   st = ensure_parts_workspace(model, L, parts, sizeof(T));
    if (st != MH_OK)
       return st;
-   const Launch L = plan_launch(model, B);
    hipStream_t stream = (hipStream_t)opts.stream;
    mh::CentArgs<T> A{};
    A.m = dev_model<T>(model);
@@ -1454,7 +1468,7 @@ mh_status centroidal_impl(mh_model_t model, int64_t B, const T *q, const T *qd, 
             return fail(MH_ERR_HIP, "specialised centroidal kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
       }
    }
-   { if (ldsc) hipLaunchKernelGGL((mh::centroidal_kernel<T, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::centroidal_kernel<T, false>), dim3(L.grid), dim3(L.block), lds, stream, A); }
+   { if (ldsc) hipLaunchKernelGGL((mh::centroidal_kernel<T, true>), dim3(L.grid, parts), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::centroidal_kernel<T, false>), dim3(L.grid, parts), dim3(L.block), lds, stream, A); }
    HIP_TRY(hipGetLastError());
    return MH_OK;
 }

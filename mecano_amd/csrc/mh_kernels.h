@@ -1383,7 +1383,10 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
    // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
    // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
    constexpr long ws_stride = 64;
-   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
+   // gridDim.y waves may share a group of 64 configurations (small batches): each runs the sweeps that build the per-body state and
+   // takes the columns of every gridDim.y-th body -- the columns of different bodies are independent
+   const int part = blockIdx.y, parts = gridDim.y;
+   T *ws = A.ws + ((long)part * gridDim.x * (blockDim.x >> 6) + (lane >> 6)) * ((long)m.n_slots * 64) + (lane & 63);
    const int nv = m.nv;
 
    for (long cfg = lane; cfg < A.B; cfg += nlanes)
@@ -1413,7 +1416,7 @@ __global__ void __launch_bounds__(256) crba_kernel(Args<T> A)
          ciptr dj = dof_map + mi[MI_DOF];
          const XF<T> Xb = load_xb<T>(c);
          const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
-         for (int k = 0; k < nd; k++)
+         for (int k = 0; k < (j % parts == part ? nd : 0); k++)
          {
             SV<T> F = mul(Ic, unit_twist<T>(type, k)); // :663-667
             const int col = dj[k];
@@ -1559,7 +1562,10 @@ __global__ void __launch_bounds__(256) coriolis_kernel(Args<T> A)
    // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
    // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
    constexpr long ws_stride = 64;
-   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
+   // gridDim.y waves may share a group of 64 configurations (small batches): each runs the sweeps that build the per-body state and
+   // takes the columns of every gridDim.y-th body -- the columns of different bodies are independent
+   const int part = blockIdx.y, parts = gridDim.y;
+   T *ws = A.ws + ((long)part * gridDim.x * (blockDim.x >> 6) + (lane >> 6)) * ((long)m.n_slots * 64) + (lane & 63);
    const int nv = m.nv;
    const V3<T> Z{T(0), T(0), T(0)};
 
@@ -1612,7 +1618,7 @@ __global__ void __launch_bounds__(256) coriolis_kernel(Args<T> A)
          ciptr dj = dof_map + mi[MI_DOF];
          const XF<T> Xb = load_xb<T>(c);
          const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
-         for (int k = 0; k < nd; k++)
+         for (int k = 0; k < (j % parts == part ? nd : 0); k++)
          {
             const SV<T> S = unit_twist<T>(type, k);
             const SV<T> Sd = crm(vj, S);            // :620-626
@@ -1729,7 +1735,10 @@ __global__ void __launch_bounds__(256) centroidal_kernel(CentArgs<T> A)
    // the workspace is a block of [slot][64 lanes] per wave: a slot offset is a scalar shifted by a constant, not a 64-bit multiply by a
    // run-time stride (which was four scalar instructions in front of every one of the kernel's ~350 workspace accesses)
    constexpr long ws_stride = 64;
-   T *ws = A.ws + (lane >> 6) * ((long)m.n_slots * 64) + (lane & 63);
+   // gridDim.y waves may share a group of 64 configurations (small batches): each runs the sweeps that build the per-body state and
+   // takes the columns of every gridDim.y-th body -- the columns of different bodies are independent
+   const int part = blockIdx.y, parts = gridDim.y;
+   T *ws = A.ws + ((long)part * gridDim.x * (blockDim.x >> 6) + (lane >> 6)) * ((long)m.n_slots * 64) + (lane & 63);
    const int nv = m.nv;
    const V3<T> Z{T(0), T(0), T(0)};
    XF<T> Xf; // centroidal frame -> root body frame
@@ -1799,7 +1808,7 @@ __global__ void __launch_bounds__(256) centroidal_kernel(CentArgs<T> A)
          ciptr dj = dof_map + mi[MI_DOF];
          const XF<T> Xb = load_xb<T>(c);
          const JX<T> jx = joint_again<T>(type, cfg_map, mi[MI_CFG], qrow, A.q_es, ws, ws_stride, mi[MI_SLOT_JP]);
-         for (int k = 0; k < nd; k++)
+         for (int k = 0; k < (j % parts == part ? nd : 0); k++)
          {
             SV<T> F = mul(Ic, unit_twist<T>(type, k)); // :663-667
             int prev = j, anc = parent;
@@ -1857,19 +1866,25 @@ __global__ void __launch_bounds__(256) centroidal_kernel(CentArgs<T> A)
       {
          const T inv_m = T(1) / root_I.m;
          shift = tmul(Xf.R, inv_m * root_I.h - Xf.p);
-         for (int col = 0; col < nv; col++)
-         { // moving the origin by `shift`: n' = n - shift x f
-            const V3<T> fl{Am[(3 * nv + col) * A.a_es], Am[(4 * nv + col) * A.a_es], Am[(5 * nv + col) * A.a_es]};
-            const V3<T> d = cross(shift, fl);
-            Am[(0 * nv + col) * A.a_es] -= d.x, Am[(1 * nv + col) * A.a_es] -= d.y, Am[(2 * nv + col) * A.a_es] -= d.z;
+         for (int j = part; j < m.n; j += parts) // (the columns this wave wrote)
+         {
+            ciptr mi = meta + j * MI_STRIDE;
+            ciptr dj = dof_map + mi[MI_DOF];
+            for (int k = 0; k < dof_count(mi[MI_TYPE]); k++)
+            { // moving the origin by `shift`: n' = n - shift x f
+               const long col = dj[k];
+               const V3<T> fl{Am[(3 * nv + col) * A.a_es], Am[(4 * nv + col) * A.a_es], Am[(5 * nv + col) * A.a_es]};
+               const V3<T> d = cross(shift, fl);
+               Am[(0 * nv + col) * A.a_es] -= d.x, Am[(1 * nv + col) * A.a_es] -= d.y, Am[(2 * nv + col) * A.a_es] -= d.z;
+            }
          }
       }
-      if (A.com)
+      if (A.com && part == 0)
       {
          T *crow = A.com + cfg * A.c_bs;
          crow[0] = shift.x, crow[A.c_es] = shift.y, crow[2 * A.c_es] = shift.z;
       }
-      if (with_b)
+      if (with_b && part == 0)
       {
          const V3<T> fl = tmul(Xf.R, root_f.l);
          const V3<T> fa = tmul(Xf.R, root_f.a - cross(Xf.p, root_f.l)) - cross(shift, fl);
