@@ -126,6 +126,8 @@ struct SpecLib
    long (*rnea_crba_lds_bytes)(int lanes_per_group, int nq, int nv) = nullptr;
    int (*launch_coriolis)(int flags, const void *args, int grid, void *stream) = nullptr;
    int (*launch_centroidal)(int flags, const void *args, int grid, void *stream) = nullptr;
+   int (*launch_coriolis_parts)(int flags, const void *args, int grid, int parts, void *stream) = nullptr;
+   int (*launch_centroidal_parts)(int flags, const void *args, int grid, int parts, void *stream) = nullptr;
    unsigned long long (*abi)(void) = nullptr;
 };
 enum : int
@@ -1279,6 +1281,8 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.rnea_crba_lds_bytes = (decltype(s.rnea_crba_lds_bytes))dlsym(h, "mh_spec_rnea_crba_lds_bytes");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
+   s.launch_coriolis_parts = (decltype(s.launch_coriolis_parts))dlsym(h, "mh_spec_launch_coriolis_parts");
+   s.launch_centroidal_parts = (decltype(s.launch_centroidal_parts))dlsym(h, "mh_spec_launch_centroidal_parts");
    s.abi = (decltype(s.abi))dlsym(h, "mh_spec_abi");
    // the code object reinterprets the library's argument structs and folds parts of the canonical-frame convention at compile time:
    // it must have been built from the same headers (a stale or foreign libmecano_hip_topo_<key>.so is refused, visibly)
@@ -1346,7 +1350,11 @@ mh_status coriolis_impl(mh_model_t model, int64_t B, const T *q, const T *qd, co
       { // topology-specialised recursion: ancestors' transforms and velocities in registers, no workspace
          const long waves = (B + 63) / 64;
          const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * 4));
-         const int rc = model->spec.launch_coriolis(model->ident_maps ? SPEC_IDENT : 0, &A, grid, (void *)stream);
+         Launch G = L;
+         G.grid = grid; // small batches: several waves per group of configurations, each writing every parts-th body's columns
+         const int rc = model->spec.launch_coriolis_parts
+                           ? model->spec.launch_coriolis_parts(model->ident_maps ? SPEC_IDENT : 0, &A, grid, regressor_parts(model, G), (void *)stream)
+                           : model->spec.launch_coriolis(model->ident_maps ? SPEC_IDENT : 0, &A, grid, (void *)stream);
          if (rc == 0)
             return MH_OK;
          if (rc != (int)hipErrorNotSupported)
@@ -1461,7 +1469,11 @@ mh_status centroidal_impl(mh_model_t model, int64_t B, const T *q, const T *qd, 
       {
          const long waves = (B + 63) / 64;
          const int grid = (int)std::max<long>(1, std::min(waves, (long)model->cu_count * 4));
-         const int rc = model->spec.launch_centroidal(model->ident_maps ? SPEC_IDENT : 0, &A, grid, (void *)stream);
+         Launch G = L;
+         G.grid = grid;
+         const int rc = model->spec.launch_centroidal_parts
+                           ? model->spec.launch_centroidal_parts(model->ident_maps ? SPEC_IDENT : 0, &A, grid, regressor_parts(model, G), (void *)stream)
+                           : model->spec.launch_centroidal(model->ident_maps ? SPEC_IDENT : 0, &A, grid, (void *)stream);
          if (rc == 0)
             return MH_OK;
          if (rc != (int)hipErrorNotSupported)

@@ -337,41 +337,47 @@ int mh_spec_launch_crba(int flags, const void *args, int grid, void *stream)
 #endif
 }
 // mass + Coriolis matrix (fp64): one wave per 64 configurations, direct stores into zero-filled H and C (A.out, A.outb; strides f_bs, f_es)
-int mh_spec_launch_coriolis(int flags, const void *args, int grid, void *stream)
+// parts waves per group of 64 configurations, each writing the columns of every parts-th body (small batches; bodies are tracked in a
+// 64-bit mask)
+int mh_spec_launch_coriolis_parts(int flags, const void *args, int grid, int parts, void *stream)
 {
 #ifdef MH_SPEC_MINIMAL
    return (int)hipErrorNotSupported;
 #else
    const mh::Args<double> &A = *(const mh::Args<double> *)args;
+   const dim3 g(grid, TP::N <= 64 ? std::max(1, std::min(parts, (int)TP::N)) : 1);
    // the fast variant: identity index maps, AoS matrices (entry stride 1, nv = the tree's DoFs): compile-time entry offsets
    if ((flags & F_IDENT) && A.f_es == 1 && A.m.nv == TR::total_dofs())
-      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true, true>), g, dim3(64), 0, (hipStream_t)stream, A);
    else if (flags & F_IDENT)
-      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, true, false>), g, dim3(64), 0, (hipStream_t)stream, A);
    else
-      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, false, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_coriolis_kernel<TP, double, false, false>), g, dim3(64), 0, (hipStream_t)stream, A);
    return (int)hipGetLastError();
 #endif
 }
+int mh_spec_launch_coriolis(int flags, const void *args, int grid, void *stream) { return mh_spec_launch_coriolis_parts(flags, args, grid, 1, stream); }
 // centroidal momentum matrix (+ convective term when args->b is not NULL) (fp64): one wave per 64 configurations, A zero-filled by the caller
-int mh_spec_launch_centroidal(int flags, const void *args, int grid, void *stream)
+int mh_spec_launch_centroidal_parts(int flags, const void *args, int grid, int parts, void *stream)
 {
 #ifdef MH_SPEC_MINIMAL
    return (int)hipErrorNotSupported;
 #else
    const mh::CentArgs<double> &A = *(const mh::CentArgs<double> *)args;
    const bool id = flags & F_IDENT, wb = A.b != nullptr;
+   const dim3 g(grid, TP::N <= 64 ? std::max(1, std::min(parts, (int)TP::N)) : 1);
    if (id && wb)
-      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, true, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, true, true>), g, dim3(64), 0, (hipStream_t)stream, A);
    else if (id)
-      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, true, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, true, false>), g, dim3(64), 0, (hipStream_t)stream, A);
    else if (wb)
-      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, false, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, false, true>), g, dim3(64), 0, (hipStream_t)stream, A);
    else
-      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, false, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, A);
+      hipLaunchKernelGGL((mh::spec_centroidal_kernel<TP, double, false, false>), g, dim3(64), 0, (hipStream_t)stream, A);
    return (int)hipGetLastError();
 #endif
 }
+int mh_spec_launch_centroidal(int flags, const void *args, int grid, void *stream) { return mh_spec_launch_centroidal_parts(flags, args, grid, 1, stream); }
 // tree-split CRBA: identity maps, AoS, packed image + limb exchange in LDS
 static long crba_split_lds(int lanes_per_group)
 { // lane-major image (odd pitch) of lanes_per_group rows + limb exchange [slot][64] + entry -> slot table

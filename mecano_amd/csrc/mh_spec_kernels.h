@@ -550,6 +550,7 @@ struct Ctx
    LaneStore<T, SP> st;
    int nv;                       // CRBA: rows of H
    int wave;                     // tree-split kernels: which wave of the workgroup this is
+   unsigned long long own;       // Coriolis / centroidal kernels: bit J = this wave writes the columns of body J (several waves may share a group of configurations)
    lds_ptr<T> xbase;             // tree-split kernels: limb -> trunk exchange area in LDS (+ lane)
 
    MH_DEV int ci(int k) const { return IDENT ? k : cfg_map[k]; }
@@ -1516,7 +1517,8 @@ struct CorSub
          add(out.I, acc.I);
          add(out.B, acc.B);
       }
-      columns<0>(cx, path, out.I, out.B);
+      if ((cx.own >> (J & 63)) & 1)
+         columns<0>(cx, path, out.I, out.B);
       if constexpr (TP::parent[J] >= 0)
       {
          const T *cp = cx.C + J * MC_STRIDE;
@@ -1640,7 +1642,8 @@ struct CentSub
          add(out.I, acc.I);
          out.f = out.f + acc.f;
       }
-      columns<0>(cx, path, out.I);
+      if ((cx.own >> (J & 63)) & 1)
+         columns<0>(cx, path, out.I);
       {
          const T *cp = cx.C + J * MC_STRIDE;
          asm volatile("" : "+s"(cp));
@@ -2365,10 +2368,16 @@ __global__ void __launch_bounds__(64) spec_coriolis_kernel(Args<T> A)
    using CX = Ctx<T, false, IDENT, WholeStore<TP, ST_GLOBAL_KIND>>;
    const long lane = (long)blockIdx.x * 64 + threadIdx.x, nlanes = (long)gridDim.x * 64;
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
+   // gridDim.y waves share a group of 64 configurations (small batches): each runs the whole recursion for the composite inertias and
+   // writes the columns of every gridDim.y-th body
+   unsigned long long own = 0;
+   for (int j = blockIdx.y; j < TP::N; j += gridDim.y)
+      own |= 1ull << (j & 63);
    for (long cfg = lane; cfg < A.B; cfg += nlanes)
    {
       CX cx;
       fill_ctx<T>(cx, A, cfg);
+      cx.own = own;
       cx.frow = nullptr;
       cx.orow = A.out + cfg * A.f_bs;
       cx.orow2 = A.outb + cfg * A.f_bs;
@@ -2391,9 +2400,13 @@ __global__ void __launch_bounds__(64) spec_centroidal_kernel(CentArgs<T> A)
    const long lane = (long)blockIdx.x * 64 + threadIdx.x, nlanes = (long)gridDim.x * 64;
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
    const V3<T> Z{T(0), T(0), T(0)};
+   unsigned long long own = 0; // (as in spec_coriolis_kernel)
+   for (int j = blockIdx.y; j < TP::N; j += gridDim.y)
+      own |= 1ull << (j & 63);
    for (long cfg = lane; cfg < A.B; cfg += nlanes)
    {
       CX cx;
+      cx.own = own;
       const void *pc = A.m.consts;
       const int *pd = A.m.dof_map, *pq = A.m.cfg_map, *pm = A.m.meta;
       int nv = A.m.nv;
@@ -2422,13 +2435,21 @@ __global__ void __launch_bounds__(64) spec_centroidal_kernel(CentArgs<T> A)
       {
          shift = tmul(cx.xf.R, (T(1) / total.I.m) * total.I.h - cx.xf.p);
          T *Am = cx.arow;
-         for (int col = 0; col < nv; col++)
-         { // moving the origin by `shift`: n' = n - shift x f
-            const V3<T> fl{Am[(3L * nv + col) * es], Am[(4L * nv + col) * es], Am[(5L * nv + col) * es]};
-            const V3<T> d = cross(shift, fl);
-            Am[(0L * nv + col) * es] -= d.x, Am[(1L * nv + col) * es] -= d.y, Am[(2L * nv + col) * es] -= d.z;
+         for (int j = blockIdx.y; j < TP::N; j += gridDim.y) // (the columns this wave wrote)
+         {
+            const int *mj = pm + j * MI_STRIDE;
+            const int *dj = pd + mj[MI_DOF];
+            for (int k = 0; k < dof_count(mj[MI_TYPE]); k++)
+            { // moving the origin by `shift`: n' = n - shift x f
+               const long col = dj[k];
+               const V3<T> fl{Am[(3L * nv + col) * es], Am[(4L * nv + col) * es], Am[(5L * nv + col) * es]};
+               const V3<T> d = cross(shift, fl);
+               Am[(0L * nv + col) * es] -= d.x, Am[(1L * nv + col) * es] -= d.y, Am[(2L * nv + col) * es] -= d.z;
+            }
          }
       }
+      if (blockIdx.y != 0)
+         continue; // the centre of mass and the convective term are written once
       if (A.com)
       {
          T *crow = A.com + cfg * A.c_bs;
