@@ -221,3 +221,34 @@ def test_identification_example_predicts_unseen_torques(torch_cuda):
     spec.loader.exec_module(mod)
     fit, err, scale, rank = mod.main(samples=512, verbose=False)
     assert rank < 70 and fit <= 1e-9 * max(1.0, scale) and err <= 1e-8 * max(1.0, scale), (fit, err, scale, rank)
+
+
+@pytest.mark.gpu
+def test_regressor_and_pair_call_argument_errors(torch_cuda):
+    """Status codes of mh_regressor_f64 and mh_rnea_crba_f64: an empty batch is MH_OK with NULL pointers, NULL state / output pointers are
+    MH_ERR_INVALID_ARGUMENT, a negative batch MH_ERR_BAD_DIMENSION; after mh_reserve the calls succeed at the reserved size."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    lib = _lib.load()
+    sys_ = rt.nextHumanoid(np.random.default_rng(3))
+    hm = HipModel(sys_.toModelDesc())
+    hm.reserve(300)
+    import ctypes
+    g = (ctypes.c_double * 3)(0.0, 0.0, -9.81)
+    assert lib.mh_regressor_f64(hm._h, 0, None, None, None, g, None, 0, None) == 0
+    assert lib.mh_rnea_crba_f64(hm._h, 0, None, None, None, g, None, None, None, None) == 0
+    q, qd, qdd, _ = (dev(torch, x) for x in rt.nextState(np.random.default_rng(4), sys_, 300))
+    Y = torch.empty((300, hm.nv, 10 * hm.n_joints), dtype=torch.float64, device="cuda")
+    H = torch.empty((300, hm.nv, hm.nv), dtype=torch.float64, device="cuda")
+    t = torch.empty_like(qd)
+    assert lib.mh_regressor_f64(hm._h, 300, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, None, 0, None) == 1
+    assert b"NULL" in lib.mh_last_error()
+    assert lib.mh_regressor_f64(hm._h, 300, q.data_ptr(), None, qdd.data_ptr(), g, None, 0, Y.data_ptr()) == 1
+    assert lib.mh_regressor_f64(hm._h, -5, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, None, 0, Y.data_ptr()) == 2
+    assert lib.mh_rnea_crba_f64(hm._h, 300, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, None, None, t.data_ptr(), None) == 1
+    assert lib.mh_rnea_crba_f64(hm._h, 300, q.data_ptr(), qd.data_ptr(), None, g, None, None, t.data_ptr(), H.data_ptr()) == 1
+    assert lib.mh_regressor_f64(hm._h, 300, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, None, 0, Y.data_ptr()) == 0
+    assert lib.mh_rnea_crba_f64(hm._h, 300, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, None, None, t.data_ptr(), H.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(t, hm.rnea(q, qd, qdd)) and torch.equal(H, hm.crba(q))
