@@ -27,6 +27,7 @@
 // Same arithmetic primitives as the other kernels (mh_device.h, mh_kernels.h); per-body outputs, joint wrenches and
 // acceleration-source joints stay on the sweep kernels of mh_kernels.h.
 #pragma once
+#include <type_traits>
 #include "mh_kernels.h"
 
 namespace mh
@@ -302,6 +303,12 @@ MH_DEV void write_joint_rows(int type, ciptr di, T *row, long es, const SV<T> &f
 // The depth stack: m.rnea_stack slots of LDS ([slot][64]) + this wave's block of the global workspace A.ws ([wave][slot][64]); the slot
 // codes in the bodies' records say which (DStack).
 // WIN: AoS state rows are read through LDS windows (identity index maps), see window_refill.
+// the joint kind of an event as a run-time value (the per-kind dispatch passes std::integral_constant instead)
+struct KindRt
+{
+   int v;
+   MH_DEV operator int() const { return v; }
+};
 template <typename T, bool WIN, int MODE>
 __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
 {
@@ -367,7 +374,11 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
             const int ev = prog[e];
             const int j = ev >> EV_BODY_SHIFT;
             ciptr mi = meta + j * MI_STRIDE;
-            const int parent = mi[MI_PARENT], type = mi[MI_TYPE], nch = mi[MI_NCH], fr = mi[MI_DFS_R];
+            const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], nch = mi[MI_NCH], fr = mi[MI_DFS_R];
+            // one dispatch on the joint kind per event, then straight-line code of that kind (the kind as a compile-time constant folds
+            // every test below: the run-time form was a maze of ~150 basic blocks per event)
+            auto body = [&](auto kind) {
+            const int type = kind; // a compile-time constant after inlining, except for KindRt
             const CRef<T, false> c{CB + j * MC_STRIDE};
             const XF<T> Xb = load_xb<T>(c);
             const In<T> in = nxt;
@@ -454,6 +465,19 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                      st_add6<T>(S, mi[MI_PFR_R], fp);
                }
             }
+            }; // body
+            if constexpr (WIN) // (the build with the LDS windows has no registers to spare for six copies of the body: 761 -> 1415 us)
+               body(KindRt{type_rt});
+            else
+            switch (type_rt)
+            {
+               case JT_REVOLUTE: body(std::integral_constant<int, JT_REVOLUTE>{}); break;
+               case JT_PRISMATIC: body(std::integral_constant<int, JT_PRISMATIC>{}); break;
+               case JT_SIXDOF: body(std::integral_constant<int, JT_SIXDOF>{}); break;
+               case JT_PLANAR: body(std::integral_constant<int, JT_PLANAR>{}); break;
+               case JT_SPHERICAL: body(std::integral_constant<int, JT_SPHERICAL>{}); break;
+               default: body(std::integral_constant<int, JT_FIXED>{}); break;
+            }
          }
       }
    }
@@ -527,7 +551,9 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             const int ev = prog[e];
             const int j = ev >> EV_BODY_SHIFT;
             ciptr mi = meta + j * MI_STRIDE;
-            const int parent = mi[MI_PARENT], type = mi[MI_TYPE], nch = mi[MI_NCH], fr = mi[MI_DFS_A], hf = mi[MI_HAND];
+            const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], nch = mi[MI_NCH], fr = mi[MI_DFS_A], hf = mi[MI_HAND];
+            auto body = [&](auto kind) { // one dispatch on the joint kind per event (rnea_dfs_kernel)
+            const int type = kind;
             const int jxs = jx_slots(type);
             const CRef<T, false> c{CB + j * MC_STRIDE};
             const XF<T> Xb = load_xb<T>(c);
@@ -706,6 +732,19 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   }
                }
             }
+            }; // body
+            if constexpr (WIN)
+               body(KindRt{type_rt});
+            else
+            switch (type_rt)
+            {
+               case JT_REVOLUTE: body(std::integral_constant<int, JT_REVOLUTE>{}); break;
+               case JT_PRISMATIC: body(std::integral_constant<int, JT_PRISMATIC>{}); break;
+               case JT_SIXDOF: body(std::integral_constant<int, JT_SIXDOF>{}); break;
+               case JT_PLANAR: body(std::integral_constant<int, JT_PLANAR>{}); break;
+               case JT_SPHERICAL: body(std::integral_constant<int, JT_SPHERICAL>{}); break;
+               default: body(std::integral_constant<int, JT_FIXED>{}); break;
+            }
          }
          // ---- outward part: pass three (:1259-1310), joint accelerations root to leaves
          SV<T> a_reg{Z, Z};
@@ -720,7 +759,9 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
          for (int j = 0; j < m.n; j++)
          {
             ciptr mi = meta + j * MI_STRIDE;
-            const int parent = mi[MI_PARENT], type = mi[MI_TYPE], nch = mi[MI_NCH], fr = mi[MI_DFS_A], hf = mi[MI_HAND];
+            const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], nch = mi[MI_NCH], fr = mi[MI_DFS_A], hf = mi[MI_HAND];
+            auto body = [&](auto kind) {
+            const int type = kind;
             const CRef<T, false> c{CB + j * MC_STRIDE};
             const In<T> in = nxt;
             prefetch_q(j + 1);
@@ -790,6 +831,19 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             if (nch >= 2)
                st_store6<T>(S, fr, a); // later children re-read it
             a_reg = a;
+            }; // body
+            if constexpr (WIN)
+               body(KindRt{type_rt});
+            else
+            switch (type_rt)
+            {
+               case JT_REVOLUTE: body(std::integral_constant<int, JT_REVOLUTE>{}); break;
+               case JT_PRISMATIC: body(std::integral_constant<int, JT_PRISMATIC>{}); break;
+               case JT_SIXDOF: body(std::integral_constant<int, JT_SIXDOF>{}); break;
+               case JT_PLANAR: body(std::integral_constant<int, JT_PLANAR>{}); break;
+               case JT_SPHERICAL: body(std::integral_constant<int, JT_SPHERICAL>{}); break;
+               default: body(std::integral_constant<int, JT_FIXED>{}); break;
+            }
          }
       }
 #undef MH_HD
