@@ -16,6 +16,7 @@
 #include "mh_device.h"
 
 #include <cstddef>
+#include <type_traits>
 
 namespace mh
 {
@@ -788,7 +789,9 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       for (int j = 0; j < m.n; j++)
       {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         auto body = [&](auto kind) { // one dispatch on the joint kind per body, straight-line code per kind (mh_dfs_kernels.h)
+         const int type = kind;
          const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          if (!MH_SWEEP_AHEAD)
             pre1(j);
@@ -834,6 +837,16 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
          if (flags & MF_STORE_VA)
             ws_store6(ws, ws_stride, mi[MI_SLOT_VA], v);
          v_prev = v;
+         }; // body
+         switch (type_rt)
+         {
+            case JT_REVOLUTE: body(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: body(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: body(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: body(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: body(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: body(std::integral_constant<int, JT_FIXED>{}); break;
+         }
       }
       // ---- pass two (:1136-1254): articulated inertias and bias wrenches, leaves to root
       ABI<T> Icarry;
@@ -858,7 +871,9 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       for (int j = m.n - 1; j >= 0; j--)
       {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         auto body = [&](auto kind) { // one dispatch on the joint kind per body, straight-line code per kind (mh_dfs_kernels.h)
+         const int type = kind;
          const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          ABI<T> IA = abi_from_rigid(load_inertia<T>(c));
          if (!MH_SWEEP_AHEAD)
@@ -1021,6 +1036,16 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
                ws_add6(ws, ws_stride, pmi[MI_SLOT_F], pp);
             }
          }
+         }; // body
+         switch (type_rt)
+         {
+            case JT_REVOLUTE: body(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: body(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: body(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: body(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: body(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: body(std::integral_constant<int, JT_FIXED>{}); break;
+         }
       }
       // ---- pass three (:1259-1310): joint accelerations, root to leaves
       SV<T> a_prev{Z, Z};
@@ -1044,7 +1069,9 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
       for (int j = 0; j < m.n; j++)
       {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         auto body = [&](auto kind) { // one dispatch on the joint kind per body, straight-line code per kind (mh_dfs_kernels.h)
+         const int type = kind;
          const CRef<T, LDSC> c{CB + j * MC_STRIDE};
          if (!MH_SWEEP_AHEAD)
             pre3(j);
@@ -1145,6 +1172,16 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
                store_body_motion<T>(c, A.body_acc + cfg * A.f_bs, A.f_es, mi[MI_EXT], a);
          }
          a_prev = a;
+         }; // body
+         switch (type_rt)
+         {
+            case JT_REVOLUTE: body(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: body(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: body(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: body(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: body(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: body(std::integral_constant<int, JT_FIXED>{}); break;
+         }
       }
    }
 }
