@@ -17,6 +17,7 @@
 // are a copy with the flags of the limb roots and trunk bodies adapted), per-body accelerations / twists and joint wrenches included; no
 // acceleration-source joints.  InverseDynamicsCalculator.java:873-966, ForwardDynamicsCalculator.java:1085-1310.
 #pragma once
+#include <type_traits>
 #include "mh_dfs_kernels.h"
 
 namespace mh
@@ -146,7 +147,9 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
       SV<T> v_prev{Z, Z}, a_prev{Z, Z};
       auto outward = [&](int j, bool writes) {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         auto kbody = [&](auto kind) {
+         const int type = kind;
          const CRef<T, false> c{CB + j * MC_STRIDE};
          SV<T> vp, ap;
          if (parent < 0)
@@ -188,6 +191,16 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
             st_store6<T>(S, mi[MI_SLOT_VA] + 6, a);
          }
          v_prev = v, a_prev = a;
+         }; // kbody
+         switch (type_rt)
+         { // one dispatch on the joint kind per body step, straight-line code per kind (mh_dfs_kernels.h)
+            case JT_REVOLUTE: kbody(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: kbody(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: kbody(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: kbody(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: kbody(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: kbody(std::integral_constant<int, JT_FIXED>{}); break;
+         }
       };
       for (int k = 0; k < P.n_trunk; k++)
          outward(trunk[k], active && wave == 0);
@@ -202,7 +215,9 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
       bool have_carry = false;
       auto inward = [&](int j, int xk0, int xk1) {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
+         auto kbody = [&](auto kind) {
+         const int type = kind;
          const CRef<T, false> c{CB + j * MC_STRIDE};
          SV<T> f = st_load6<T>(S, mi[MI_SLOT_F]);
          if (have_carry)
@@ -227,6 +242,16 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
                carry = fp, have_carry = true;
             else
                st_add6<T>(S, meta[parent * MI_STRIDE + MI_SLOT_F], fp);
+         }
+         }; // kbody
+         switch (type_rt)
+         { // one dispatch on the joint kind per body step, straight-line code per kind (mh_dfs_kernels.h)
+            case JT_REVOLUTE: kbody(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: kbody(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: kbody(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: kbody(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: kbody(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: kbody(std::integral_constant<int, JT_FIXED>{}); break;
          }
       };
       for (int s = n_seg - 1; s >= 0; s--)
@@ -277,7 +302,9 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
       SV<T> v_prev{Z, Z};
       auto pass1 = [&](int j, bool writes) {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         auto kbody = [&](auto kind) {
+         const int type = kind;
          const CRef<T, false> c{CB + j * MC_STRIDE};
          SV<T> vp;
          if (parent < 0)
@@ -301,6 +328,16 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          if (flags & MF_STORE_VA)
             st_store6<T>(S, mi[MI_SLOT_VA], v);
          v_prev = v;
+         }; // kbody
+         switch (type_rt)
+         { // one dispatch on the joint kind per body step, straight-line code per kind (mh_dfs_kernels.h)
+            case JT_REVOLUTE: kbody(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: kbody(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: kbody(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: kbody(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: kbody(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: kbody(std::integral_constant<int, JT_FIXED>{}); break;
+         }
       };
       for (int k = 0; k < P.n_trunk; k++)
          pass1(trunk[k], active && wave == 0);
@@ -316,7 +353,9 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
       bool have_carry = false;
       auto pass2 = [&](int j, int xk0, int xk1) {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS], xs = mi[MI_HAND];
+         auto kbody = [&](auto kind) {
+         const int type = kind;
          const CRef<T, false> c{CB + j * MC_STRIDE};
          ABI<T> IA = abi_from_rigid(load_inertia<T>(c));
          SV<T> pA = st_load6<T>(S, mi[MI_SLOT_F]);
@@ -437,6 +476,16 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
                st_add6<T>(S, pmi[MI_SLOT_F], pp);
             }
          }
+         }; // kbody
+         switch (type_rt)
+         { // one dispatch on the joint kind per body step, straight-line code per kind (mh_dfs_kernels.h)
+            case JT_REVOLUTE: kbody(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: kbody(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: kbody(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: kbody(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: kbody(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: kbody(std::integral_constant<int, JT_FIXED>{}); break;
+         }
       };
       for (int s = n_seg - 1; s >= 0; s--)
       {
@@ -457,7 +506,9 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
       SV<T> a_prev{Z, Z};
       auto pass3 = [&](int j, bool writes) {
          ciptr mi = meta + j * MI_STRIDE;
-         const int parent = mi[MI_PARENT], type = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         const int parent = mi[MI_PARENT], type_rt = mi[MI_TYPE], flags = mi[MI_FLAGS];
+         auto kbody = [&](auto kind) {
+         const int type = kind;
          const CRef<T, false> c{CB + j * MC_STRIDE};
          SV<T> ap;
          if (parent < 0)
@@ -512,6 +563,16 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          if (writes && A.body_acc)
             store_body_motion<T>(c, A.body_acc + cfg * A.f_bs, A.f_es, mi[MI_EXT], a);
          a_prev = a;
+         }; // kbody
+         switch (type_rt)
+         { // one dispatch on the joint kind per body step, straight-line code per kind (mh_dfs_kernels.h)
+            case JT_REVOLUTE: kbody(std::integral_constant<int, JT_REVOLUTE>{}); break;
+            case JT_PRISMATIC: kbody(std::integral_constant<int, JT_PRISMATIC>{}); break;
+            case JT_SIXDOF: kbody(std::integral_constant<int, JT_SIXDOF>{}); break;
+            case JT_PLANAR: kbody(std::integral_constant<int, JT_PLANAR>{}); break;
+            case JT_SPHERICAL: kbody(std::integral_constant<int, JT_SPHERICAL>{}); break;
+            default: kbody(std::integral_constant<int, JT_FIXED>{}); break;
+         }
       };
       for (int k = 0; k < P.n_trunk; k++)
          pass3(trunk[k], active && wave == 0);
