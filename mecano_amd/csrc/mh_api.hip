@@ -167,7 +167,8 @@ struct mh_model
    int use_win = 1;       // MH_DFS_WIN=0: AoS rows are read per lane instead of through LDS windows (A/B measurements)
    int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
    int dfs_budget = -1;   // MH_DFS_BUDGET: cap of the stack's LDS budget in slots per wave (measurements)
-   int dfs_aba64 = 0;     // MH_DFS_ABA64=1: fp64 forward dynamics on the depth-first kernel too (measurements)
+   int dfs_aba64 = 0;     // fp64 forward dynamics on the depth-first kernel too: bushy trees (below), or MH_DFS_ABA64=0|1
+   int n_nonadjacent = 0; // bodies whose parent is not the body before them in engine order (branch points of the tree)
    int dfs_transpose = -1; // MH_DFS_TRANSPOSE = 0 | 1: depth-first kernels on big AoS batches never / always through transposed scratch copies
    double *d_consts64 = nullptr;
    float *d_consts32 = nullptr;
@@ -1668,6 +1669,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       int flags = 0;
       if (pe >= 0 && pe == e - 1)
          flags |= mh::MF_PARENT_ADJ;
+      else if (pe >= 0)
+         m->n_nonadjacent++;
       bool nonadj_child = false;
       for (int ch : children[i])
          if (engine_of[ch] != e + 1)
@@ -1888,6 +1891,11 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_dfs = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_TRANSPOSE"))
       m->dfs_transpose = atoi(e) != 0;
+   // fp64 forward dynamics at device-filling batches: the sweep kernel accumulates the children of a branching body through the workspace
+   // (read-modify-write per extra child), the depth-first one keeps them on its stack -- measured on the reference's 30-joint shapes at
+   // B = 262 144 (profiles/r02_generic_fp64_rates.txt): random trees 1253 -> 989 us and 1384 -> 1288 us on the depth-first kernel, chains
+   // and the humanoid (4 branches in 24 joints) 3-12 % faster on the sweep.  Bushy = at least three branching bodies in ten.
+   m->dfs_aba64 = m->n_nonadjacent * 10 >= 3 * std::max(1, m->n - 1);
    if (const char *e = getenv("MH_DFS_ABA64"))
       m->dfs_aba64 = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_BUDGET"))
