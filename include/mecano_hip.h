@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 2
+#define MH_ABI_VERSION 3
 
 /* ---- status codes (the Java shim maps them back to Mecano's exception types) ---- */
 typedef enum mh_status
@@ -128,8 +128,14 @@ typedef struct mh_options
    int32_t consider_coriolis;      /* InverseDynamicsCalculator.setConsiderCoriolisAndCentrifugalForces (java:291-296); RNEA only; default 1 */
    int32_t consider_accelerations; /* InverseDynamicsCalculator.setConsiderJointAccelerations (java:301-306); RNEA only; default 1 */
    int32_t layout;                 /* mh_layout of every batched matrix of the call */
-   int32_t reserved0;
+   int32_t use_root_acceleration;  /* 0 (default): the root body accelerates with (0, -gravity), the `gravity` argument of the call
+                                    * (setGravity, InverseDynamicsCalculator.java:318-348, ForwardDynamicsCalculator.java:234-264).
+                                    * non-zero: with root_acceleration below; the call's `gravity` argument is ignored and may be NULL */
    void *stream;                   /* hipStream_t to launch on; NULL = the device's null stream */
+   double root_acceleration[6];    /* InverseDynamicsCalculator.setRootAcceleration(SpatialAccelerationReadOnly) (java:413-427) and
+                                    * ForwardDynamicsCalculator.setRootAcceleration (java:330-343): spatial acceleration of the root body
+                                    * (angular x y z, then linear x y z), expressed in the root body's frame, of the root body's frame
+                                    * relative to an inertial frame -- what a moving / rotating base contributes; (0, 0, 0, -g) is gravity */
 } mh_options;
 
 typedef struct mh_model *mh_model_t;

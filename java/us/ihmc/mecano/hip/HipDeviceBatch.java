@@ -20,22 +20,67 @@ public final class HipDeviceBatch implements AutoCloseable
    final HipMultiBodyModel model;
    final int batchSize;
    final MemorySegment q, qd, qdd, tau, fExt, bodyAcceleration, bodyTwist, jointWrench, pairOutput;
+   /** doubles each device buffer holds, in the order of {@link #buffers()}: every copy is checked against it */
+   private final long[] capacity;
 
    public HipDeviceBatch(HipMultiBodyModel model, int batchSize)
    {
+      if (batchSize < 0)
+         throw new IllegalArgumentException("negative batch size " + batchSize);
       this.model = model;
       this.batchSize = batchSize;
-      long B = batchSize;
-      q = allocate(B * model.nq);
-      qd = allocate(B * model.nv);
-      qdd = allocate(B * model.nv);
-      tau = allocate(B * model.nv);
-      fExt = allocate(B * 6 * model.numberOfJoints);
-      bodyAcceleration = allocate(B * 6 * model.numberOfJoints);
-      bodyTwist = allocate(B * 6 * model.numberOfJoints);
-      jointWrench = allocate(B * 6 * model.numberOfJoints);
-      pairOutput = allocate(B * 6); // one (base, body) pair of mh_relative_acceleration_f64
-      MecanoHipNative.invoke(() -> (int) MecanoHipNative.RESERVE.invokeExact(model.handle, (long) batchSize));
+      long B = batchSize, wrenches = B * 6 * model.numberOfJoints;
+      capacity = new long[] {B * model.nq, B * model.nv, B * model.nv, B * model.nv, wrenches, wrenches, wrenches, wrenches, B * 6};
+      MemorySegment[] made = new MemorySegment[capacity.length];
+      try
+      {
+         for (int i = 0; i < made.length; i++)
+            made[i] = allocate(capacity[i]);
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.RESERVE.invokeExact(model.handle, (long) batchSize));
+      }
+      catch (RuntimeException | Error e)
+      { // a later allocation failed: the earlier ones must not leak
+         for (MemorySegment buffer : made)
+            if (buffer != null)
+               free(buffer);
+         throw e;
+      }
+      q = made[0];
+      qd = made[1];
+      qdd = made[2];
+      tau = made[3];
+      fExt = made[4];
+      bodyAcceleration = made[5];
+      bodyTwist = made[6];
+      jointWrench = made[7];
+      pairOutput = made[8]; // one (base, body) pair of mh_relative_acceleration_f64
+   }
+
+   private MemorySegment[] buffers()
+   {
+      return new MemorySegment[] {q, qd, qdd, tau, fExt, bodyAcceleration, bodyTwist, jointWrench, pairOutput};
+   }
+
+   /** doubles the given device buffer of this batch holds; a pointer that is not one of this batch's buffers is refused */
+   private long capacityOf(MemorySegment deviceBuffer)
+   {
+      MemorySegment[] all = buffers();
+      for (int i = 0; i < all.length; i++)
+         if (all[i].address() == deviceBuffer.address())
+            return capacity[i];
+      throw new IllegalArgumentException("not a buffer of this batch");
+   }
+
+   private static void free(MemorySegment buffer)
+   {
+      try
+      {
+         int ignored = (int) MecanoHipNative.DEVICE_FREE.invokeExact(buffer);
+      }
+      catch (Throwable t)
+      {
+         // freeing is best effort on the error path
+      }
    }
 
    private static MemorySegment allocate(long doubles)
@@ -51,6 +96,10 @@ public final class HipDeviceBatch implements AutoCloseable
    /** host matrix (rows = configurations) -> device buffer */
    public void upload(DMatrixRMaj matrix, MemorySegment deviceBuffer)
    {
+      long expected = capacityOf(deviceBuffer);
+      if (matrix.getNumElements() != expected) // a larger matrix would be written past the allocation, into neighbouring device buffers
+         throw new IllegalArgumentException("matrix has " + matrix.getNumElements() + " elements, the device buffer holds " + expected + " (batch of "
+                                            + batchSize + ")");
       try (Arena arena = Arena.ofConfined())
       {
          MemorySegment host = arena.allocateFrom(JAVA_DOUBLE, matrix.data);
@@ -63,6 +112,8 @@ public final class HipDeviceBatch implements AutoCloseable
    /** device buffer -> host matrix (reshaped to rows x columns) */
    public void download(MemorySegment deviceBuffer, int rows, int columns, DMatrixRMaj matrixToPack)
    {
+      if ((long) rows * columns > capacityOf(deviceBuffer))
+         throw new IllegalArgumentException(rows + " x " + columns + " exceeds the " + capacityOf(deviceBuffer) + " doubles of the device buffer");
       matrixToPack.reshape(rows, columns);
       try (Arena arena = Arena.ofConfined())
       {
@@ -123,7 +174,7 @@ public final class HipDeviceBatch implements AutoCloseable
    @Override
    public void close()
    {
-      for (MemorySegment buffer : new MemorySegment[] {q, qd, qdd, tau, fExt, bodyAcceleration, bodyTwist, jointWrench, pairOutput})
+      for (MemorySegment buffer : buffers())
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.DEVICE_FREE.invokeExact(buffer));
    }
 }

@@ -5,12 +5,18 @@ import java.lang.foreign.MemorySegment;
 import java.util.List;
 import java.util.function.Function;
 
+import org.ejml.data.DMatrix;
 import org.ejml.data.DMatrixRMaj;
 
 import us.ihmc.euclid.tuple3D.interfaces.Tuple3DReadOnly;
 import us.ihmc.mecano.algorithms.ForwardDynamicsCalculator.JointSourceMode;
+import us.ihmc.mecano.multiBodySystem.interfaces.JointBasics;
 import us.ihmc.mecano.multiBodySystem.interfaces.JointReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.MultiBodySystemReadOnly;
+import us.ihmc.mecano.multiBodySystem.interfaces.RigidBodyReadOnly;
+import us.ihmc.mecano.spatial.interfaces.FixedFrameWrenchBasics;
+import us.ihmc.mecano.spatial.interfaces.SpatialAccelerationReadOnly;
+import us.ihmc.mecano.spatial.interfaces.WrenchReadOnly;
 
 import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
 
@@ -24,6 +30,9 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
    private final MultiBodySystemReadOnly input;
    private final HipMultiBodyModel model;
    private final double[] gravity = new double[3];
+   private double[] rootAcceleration; // six components (angular, linear) once setRootAcceleration was called, else null (gravity rules)
+   private HipSingleState single;     // the one-configuration face (compute() / compute(DMatrix) / compute(DMatrix, DMatrix))
+   private boolean singleResult;
    private DMatrixRMaj externalWrenches;
    private final int[] sourceModes;
    private boolean anyAccelerationSource;
@@ -58,6 +67,119 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
       gravity[0] = gravityX;
       gravity[1] = gravityY;
       gravity[2] = gravityZ;
+      rootAcceleration = null; // the last setter wins: both write the root acceleration in the reference (java:259-264, 340)
+   }
+
+   /**
+    * ForwardDynamicsCalculator.setRootAcceleration(SpatialAccelerationReadOnly) (java:330-343): angular and linear part, root-body
+    * coordinates -- mh_options.root_acceleration.
+    */
+   public void setRootAcceleration(SpatialAccelerationReadOnly newRootAcceleration)
+   {
+      newRootAcceleration.checkReferenceFrameMatch(input.getRootBody().getBodyFixedFrame(), input.getRootBody().getBodyFixedFrame().getRootFrame(),
+                                                   input.getRootBody().getBodyFixedFrame());
+      rootAcceleration = new double[] {newRootAcceleration.getAngularPartX(), newRootAcceleration.getAngularPartY(), newRootAcceleration.getAngularPartZ(),
+                                       newRootAcceleration.getLinearPartX(), newRootAcceleration.getLinearPartY(), newRootAcceleration.getLinearPartZ()};
+   }
+
+   private HipSingleState single()
+   {
+      if (single == null)
+         single = new HipSingleState(input, model);
+      return single;
+   }
+
+   /** getExternalWrench(rigidBody) (java:353-369): the live external wrench of that body for the one-configuration calls. */
+   public FixedFrameWrenchBasics getExternalWrench(RigidBodyReadOnly rigidBody)
+   {
+      return single().getExternalWrench(rigidBody);
+   }
+
+   /** setExternalWrench(rigidBody, externalWrench) (java:371-381). */
+   public void setExternalWrench(RigidBodyReadOnly rigidBody, WrenchReadOnly externalWrench)
+   {
+      single().setExternalWrench(rigidBody, externalWrench);
+   }
+
+   /** setExternalWrenchesToZero() (java:348-351). */
+   public void setExternalWrenchesToZero()
+   {
+      externalWrenches = null;
+      if (single != null)
+         single.setExternalWrenchesToZero();
+   }
+
+   /** compute() (java:475-478): configuration, velocity and efforts (accelerations of acceleration-source joints) from the joints. */
+   public void compute()
+   {
+      compute((DMatrix) null, (DMatrix) null);
+   }
+
+   /** compute(DMatrix jointTauInput) (java:489-492). */
+   public void compute(DMatrix jointTauInput)
+   {
+      compute(jointTauInput, (DMatrix) null);
+   }
+
+   /**
+    * compute(DMatrix jointTauInput, DMatrix jointAccelerationInput) (java:508-520), the reference's own signature: one configuration,
+    * read from the joints, through the HIP path.  Afterwards getJointAccelerationMatrix() / getJointTauMatrix() are nv x 1 like the
+    * reference's, getComputedJointAcceleration(joint) is N x 1, writeComputedJointAccelerations writes them into the joints.
+    */
+   public void compute(DMatrix jointTauInput, DMatrix jointAccelerationInput)
+   {
+      HipSingleState s = single();
+      s.readConfigurationAndVelocity();
+      s.readEfforts(jointTauInput);
+      if (anyAccelerationSource)
+         s.readAccelerations(jointAccelerationInput);
+      boolean wrenches = s.packExternalWrenches();
+      DMatrixRMaj keep = externalWrenches;
+      externalWrenches = wrenches ? s.wrenchRow : null;
+      try
+      { // the batched path with B = 1: row vectors share their backing arrays with the column vectors
+         DMatrixRMaj q = DMatrixRMaj.wrap(1, model.nq, s.q.data), qd = DMatrixRMaj.wrap(1, model.nv, s.qd.data), tau = DMatrixRMaj.wrap(1, model.nv, s.tau.data);
+         compute(q, qd, tau, anyAccelerationSource ? DMatrixRMaj.wrap(1, model.nv, s.qdd.data) : null);
+      }
+      finally
+      {
+         externalWrenches = keep;
+      }
+      jointAccelerationMatrix.reshape(model.nv, 1); // same numbers, the reference's shape
+      jointTauMatrix.reshape(model.nv, 1);
+      singleResult = true;
+   }
+
+   /** getComputedJointAcceleration(joint) (java:600-610): N x 1 after a one-configuration compute, null for a joint that is not considered. */
+   public DMatrixRMaj getComputedJointAcceleration(JointReadOnly joint)
+   {
+      if (!singleResult)
+         throw new IllegalStateException("compute(), compute(DMatrix) or compute(DMatrix, DMatrix) first");
+      return single().rowsOf(joint, jointAccelerationMatrix);
+   }
+
+   /** writeComputedJointAcceleration(joint) (java:699-708). */
+   public boolean writeComputedJointAcceleration(JointBasics joint)
+   {
+      DMatrixRMaj jointAcceleration = getComputedJointAcceleration(joint);
+      if (jointAcceleration == null)
+         return false;
+      joint.setJointAcceleration(0, jointAcceleration);
+      return true;
+   }
+
+   /** writeComputedJointAccelerations(JointBasics[]) (java:670-674). */
+   public void writeComputedJointAccelerations(JointBasics[] joints)
+   {
+      for (JointBasics joint : joints)
+         writeComputedJointAcceleration(joint);
+   }
+
+   /** writeComputedJointAccelerations(List) (java:684-688). */
+   public void writeComputedJointAccelerations(List<? extends JointBasics> joints)
+   {
+      for (int i = 0; i < joints.size(); i++)
+         writeComputedJointAcceleration(joints.get(i));
    }
 
    /** B x 6 n, (moment, force) per successor body in its body-fixed frame (setExternalWrench, java:348-381); null = none. */
@@ -121,10 +243,11 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
          throw new org.ejml.MatrixDimensionException("Acceleration-source joints need their accelerations: B x " + model.nv);
       jointAccelerationMatrix.reshape(B, model.nv);
       jointTauMatrix.reshape(B, model.nv);
+      singleResult = false;
       try (Arena arena = Arena.ofConfined())
       {
          MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity);
-         MemorySegment options = MecanoHipNative.options(arena, true, true);
+         MemorySegment options = MecanoHipNative.options(arena, true, true, rootAcceleration);
          if (!anyAccelerationSource)
          { // host-pointer entry point: chunked copies overlapped with the kernels
             MemorySegment qSeg = arena.allocateFrom(JAVA_DOUBLE, q.data), qdSeg = arena.allocateFrom(JAVA_DOUBLE, qd.data),
@@ -163,7 +286,7 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
    {
       try (Arena arena = Arena.ofConfined())
       {
-         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true);
+         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true, rootAcceleration);
          MemorySegment f = withExternalWrenches ? batch.fExt : MemorySegment.NULL;
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.ABA_BODIES.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.qd, batch.tau, g, f,
                                                                                   options, batch.qdd, batch.bodyAcceleration, batch.bodyTwist));
@@ -181,7 +304,7 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
    {
       try (Arena arena = Arena.ofConfined())
       {
-         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true);
+         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true, rootAcceleration);
          MemorySegment f = withExternalWrenches ? batch.fExt : MemorySegment.NULL;
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.ABA_INTEGRATE.invokeExact(model.handle, (long) batch.batchSize, dt, batch.q, batch.qd, batch.tau, g, f,
                                                                                      options, batch.qdd, batch.q, batch.qd));

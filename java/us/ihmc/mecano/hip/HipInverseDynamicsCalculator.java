@@ -3,12 +3,19 @@ package us.ihmc.mecano.hip;
 import java.lang.foreign.Arena;
 import java.lang.foreign.MemorySegment;
 
+import java.util.List;
+
+import org.ejml.data.DMatrix;
 import org.ejml.data.DMatrixRMaj;
 
 import us.ihmc.euclid.tuple3D.interfaces.Tuple3DReadOnly;
+import us.ihmc.mecano.multiBodySystem.interfaces.JointBasics;
 import us.ihmc.mecano.multiBodySystem.interfaces.JointReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.MultiBodySystemReadOnly;
 import us.ihmc.mecano.multiBodySystem.interfaces.RigidBodyReadOnly;
+import us.ihmc.mecano.spatial.interfaces.FixedFrameWrenchBasics;
+import us.ihmc.mecano.spatial.interfaces.SpatialAccelerationReadOnly;
+import us.ihmc.mecano.spatial.interfaces.WrenchReadOnly;
 
 import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
 import static java.lang.foreign.ValueLayout.JAVA_INT;
@@ -28,6 +35,9 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
    private final MultiBodySystemReadOnly input;
    private final HipMultiBodyModel model;
    private final double[] gravity = new double[3];
+   private double[] rootAcceleration; // six components (angular, linear) once setRootAcceleration was called, else null (gravity rules)
+   private HipSingleState single;     // the one-configuration face (compute() / compute(DMatrix)), created on first use
+   private boolean singleResult;      // the last compute was a one-configuration one: results are column vectors like the reference's
    private boolean considerCoriolisAndCentrifugalForces = true, considerJointAccelerations = true;
    private DMatrixRMaj externalWrenches; // B x 6 n, (moment, force) per successor body in its body-fixed frame; null = none
    private final DMatrixRMaj jointTauMatrix = new DMatrixRMaj(0, 0);
@@ -74,12 +84,103 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
       gravity[0] = gravityX;
       gravity[1] = gravityY;
       gravity[2] = gravityZ;
+      rootAcceleration = null; // the reference stores (0, -g) in the root acceleration: the last setter wins (java:343-348)
    }
 
-   /** Root linear acceleration; gravity g is the root acceleration -g (java:343-348, 424). */
+   /**
+    * InverseDynamicsCalculator.setRootAcceleration(SpatialAccelerationReadOnly) (java:413-427): the root's spatial acceleration, angular
+    * and linear part, expressed in the root body's frame -- mh_options.root_acceleration.  It replaces what setGravitationalAcceleration
+    * stored (both write the same field in the reference, java:343-348), and the other way round.
+    */
+   public void setRootAcceleration(SpatialAccelerationReadOnly newRootAcceleration)
+   {
+      newRootAcceleration.checkReferenceFrameMatch(input.getRootBody().getBodyFixedFrame(), input.getRootBody().getBodyFixedFrame().getRootFrame(),
+                                                   input.getRootBody().getBodyFixedFrame()); // java:420: ReferenceFrameMismatchException
+      rootAcceleration = new double[] {newRootAcceleration.getAngularPartX(), newRootAcceleration.getAngularPartY(), newRootAcceleration.getAngularPartZ(),
+                                       newRootAcceleration.getLinearPartX(), newRootAcceleration.getLinearPartY(), newRootAcceleration.getLinearPartZ()};
+   }
+
+   /** Shorthand: the linear part alone (a translating base); gravity g is the root acceleration (0, -g) (java:343-348). */
    public void setRootAcceleration(Tuple3DReadOnly linearAcceleration)
    {
-      setGravitationalAcceleration(-linearAcceleration.getX(), -linearAcceleration.getY(), -linearAcceleration.getZ());
+      rootAcceleration = new double[] {0.0, 0.0, 0.0, linearAcceleration.getX(), linearAcceleration.getY(), linearAcceleration.getZ()};
+   }
+
+   private HipSingleState single()
+   {
+      if (single == null)
+         single = new HipSingleState(input, model);
+      return single;
+   }
+
+   /** getExternalWrench(rigidBody) (java:444-461): the live external wrench of that body for the one-configuration calls; modify in place. */
+   public FixedFrameWrenchBasics getExternalWrench(RigidBodyReadOnly rigidBody)
+   {
+      return single().getExternalWrench(rigidBody);
+   }
+
+   /** setExternalWrench(rigidBody, externalWrench) (java:463-472): stored in the body-fixed frame (setMatchingFrame). */
+   public void setExternalWrench(RigidBodyReadOnly rigidBody, WrenchReadOnly externalWrench)
+   {
+      single().setExternalWrench(rigidBody, externalWrench);
+   }
+
+   /**
+    * compute() (java:481-484): the reference's own signature.  Configuration, velocity and desired acceleration are read from the joints
+    * (the caller has set them, as it does for the reference), one configuration goes through the HIP path, and the results are the
+    * reference's: getJointTauMatrix() is nv x 1, getComputedJointTau(joint) is N x 1, writeComputedJointWrenches writes them back.
+    */
+   public void compute()
+   {
+      compute((DMatrix) null);
+   }
+
+   /** compute(DMatrix jointAccelerationMatrix) (java:496-501): accelerations from the given nv x 1 matrix instead of the joints. */
+   public void compute(DMatrix jointAccelerationMatrix)
+   {
+      HipSingleState s = single();
+      s.readConfigurationAndVelocity();
+      s.readAccelerations(jointAccelerationMatrix);
+      boolean wrenches = s.packExternalWrenches();
+      lastBatch = null;
+      try (Arena arena = Arena.ofConfined())
+      {
+         MemorySegment qSeg = arena.allocateFrom(JAVA_DOUBLE, s.q.data), qdSeg = arena.allocateFrom(JAVA_DOUBLE, s.qd.data),
+               qddSeg = arena.allocateFrom(JAVA_DOUBLE, s.qdd.data), g = arena.allocateFrom(JAVA_DOUBLE, gravity);
+         MemorySegment f = wrenches ? arena.allocateFrom(JAVA_DOUBLE, s.wrenchRow.data) : MemorySegment.NULL;
+         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration);
+         MemorySegment tau = arena.allocate(JAVA_DOUBLE, Math.max(1L, model.nv));
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.RNEA_HOST.invokeExact(model.handle, 1L, qSeg, qdSeg, qddSeg, g, f, options, tau));
+         jointTauMatrix.reshape(model.nv, 1);
+         MemorySegment.copy(tau, JAVA_DOUBLE, 0, jointTauMatrix.data, 0, model.nv);
+      }
+      singleResult = true;
+   }
+
+   /** writeComputedJointWrench(joint) (java:639-653): joint.setJointTau(0, getComputedJointTau(joint)) after a one-configuration compute. */
+   public boolean writeComputedJointWrench(JointBasics joint)
+   {
+      if (!singleResult)
+         throw new IllegalStateException("compute() or compute(DMatrix) first: a batch of configurations cannot be written into one joint");
+      DMatrixRMaj jointTau = single().rowsOf(joint, jointTauMatrix);
+      if (jointTau == null)
+         return false;
+      joint.setJointTau(0, jointTau);
+      return true;
+   }
+
+   /** writeComputedJointWrenches(JointBasics[]) (java:613-617). */
+   public void writeComputedJointWrenches(JointBasics[] joints)
+   {
+      for (JointBasics joint : joints)
+         writeComputedJointWrench(joint);
+   }
+
+   /** writeComputedJointWrenches(List) (java:625-629). */
+   public void writeComputedJointWrenches(List<? extends JointBasics> joints)
+   {
+      for (int i = 0; i < joints.size(); i++)
+         writeComputedJointWrench(joints.get(i));
    }
 
    /**
@@ -97,6 +198,8 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
    public void setExternalWrenchesToZero()
    {
       externalWrenches = null;
+      if (single != null)
+         single.setExternalWrenchesToZero();
    }
 
    /** tau = ID(q, qd, qdd) for every row; q: B x nq, qd and qdd: B x nv (InverseDynamicsCalculator.compute(DMatrix), java:496-501). */
@@ -109,12 +212,13 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
          throw new org.ejml.MatrixDimensionException("External wrenches: expected " + B + " rows");
       jointTauMatrix.reshape(B, model.nv);
       lastBatch = null;
+      singleResult = false;
       try (Arena arena = Arena.ofConfined())
       {
          MemorySegment qSeg = arena.allocateFrom(JAVA_DOUBLE, q.data), qdSeg = arena.allocateFrom(JAVA_DOUBLE, qd.data),
                qddSeg = arena.allocateFrom(JAVA_DOUBLE, qdd.data), g = arena.allocateFrom(JAVA_DOUBLE, gravity);
          MemorySegment f = externalWrenches == null ? MemorySegment.NULL : arena.allocateFrom(JAVA_DOUBLE, externalWrenches.data);
-         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations);
+         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration);
          MemorySegment tau = arena.allocate(JAVA_DOUBLE, Math.max(1L, (long) B * model.nv));
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.RNEA_HOST.invokeExact(model.handle, (long) B, qSeg, qdSeg, qddSeg, g, f, options, tau));
          MemorySegment.copy(tau, JAVA_DOUBLE, 0, jointTauMatrix.data, 0, B * model.nv);
@@ -129,11 +233,12 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
    public void compute(HipDeviceBatch batch, boolean withExternalWrenches)
    {
       lastBatch = batch;
+      singleResult = false;
       try (Arena arena = Arena.ofConfined())
       {
          MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity);
          MemorySegment f = withExternalWrenches ? batch.fExt : MemorySegment.NULL;
-         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations);
+         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration);
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.RNEA_BODIES.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.qd, batch.qdd, g, f,
                                                                                    options, batch.tau, batch.bodyAcceleration, batch.bodyTwist));
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.RNEA_JOINT_WRENCHES.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.qd,
@@ -152,6 +257,8 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
    /** getComputedJointTau(joint) (java:587-602): the joint's columns of the tau matrix, B x N. */
    public DMatrixRMaj getComputedJointTau(JointReadOnly joint)
    {
+      if (singleResult)
+         return single().rowsOf(joint, jointTauMatrix); // N x 1, like the reference's
       if (model.indexOf(joint) < 0)
          return null;
       int[] columns = input.getJointMatrixIndexProvider().getJointDoFIndices(joint);
@@ -200,7 +307,7 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
       try (Arena arena = Arena.ofConfined())
       {
          MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), bases = arena.allocateFrom(JAVA_INT, baseIndex), bodies = arena.allocateFrom(JAVA_INT, bodyIndex);
-         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations);
+         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration);
          MemorySegment twist = considerCoriolisAndCentrifugalForces ? batch.bodyTwist : MemorySegment.NULL;
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.RELATIVE_ACCELERATION.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.bodyAcceleration,
                                                                                              twist, g, 1, bases, bodies, options, batch.pairOutput));

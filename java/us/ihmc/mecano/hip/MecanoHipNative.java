@@ -15,7 +15,7 @@ import static java.lang.foreign.ValueLayout.JAVA_INT;
 import static java.lang.foreign.ValueLayout.JAVA_LONG;
 
 /**
- * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h, ABI version 2.  NOT compiled in this repository's image (no JVM
+ * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h, ABI version 3.  NOT compiled in this repository's image (no JVM
  * there); it is the reference-side stub a Mecano maintainer adds.  One downcall handle per C entry point the shim classes use; every
  * entry point returns an mh_status int which {@link #check(int)} maps back to the exception types Mecano itself throws.
  * <p>
@@ -36,9 +36,16 @@ public final class MecanoHipNative
       return FunctionDescriptor.of(JAVA_INT, arguments);
    }
 
-   /** struct mh_options { int32 consider_coriolis, consider_accelerations, layout, reserved0; void *stream; } */
+   /** the ABI version this binding was written against (include/mecano_hip.h: MH_ABI_VERSION); checked when the class loads */
+   static final int ABI = 3;
+
+   /**
+    * struct mh_options { int32 consider_coriolis, consider_accelerations, layout, use_root_acceleration; void *stream; double
+    * root_acceleration[6]; }
+    */
    static final StructLayout OPTIONS = MemoryLayout.structLayout(JAVA_INT.withName("consider_coriolis"), JAVA_INT.withName("consider_accelerations"),
-                                                                JAVA_INT.withName("layout"), JAVA_INT.withName("reserved0"), ADDRESS.withName("stream"));
+                                                                JAVA_INT.withName("layout"), JAVA_INT.withName("use_root_acceleration"),
+                                                                ADDRESS.withName("stream"), MemoryLayout.sequenceLayout(6, JAVA_DOUBLE).withName("root_acceleration"));
 
    static final MethodHandle ABI_VERSION = handle("mh_abi_version", FunctionDescriptor.of(JAVA_INT));
    static final MethodHandle LAST_ERROR = handle("mh_last_error", FunctionDescriptor.of(ADDRESS));
@@ -108,16 +115,42 @@ public final class MecanoHipNative
    static final MethodHandle COPY_TO_HOST = handle("mh_copy_to_host", status(ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
    static final MethodHandle STREAM_SYNCHRONIZE = handle("mh_stream_synchronize", status(ADDRESS));
 
-   /** An mh_options in `arena`: the calculators' switches, AoS layout (rows = configurations), the null stream. */
+   /** An mh_options in `arena`: the calculators' switches, AoS layout (rows = configurations), the null stream, gravity as the root acceleration. */
    static MemorySegment options(Arena arena, boolean considerCoriolis, boolean considerAccelerations)
+   {
+      return options(arena, considerCoriolis, considerAccelerations, null);
+   }
+
+   /**
+    * The same with an explicit root acceleration (setRootAcceleration(SpatialAccelerationReadOnly), InverseDynamicsCalculator.java:413-427):
+    * six doubles (angular, linear) in root-body coordinates, or null for "the call's gravity argument as (0, -g)".
+    */
+   static MemorySegment options(Arena arena, boolean considerCoriolis, boolean considerAccelerations, double[] rootAcceleration)
    {
       MemorySegment options = arena.allocate(OPTIONS);
       options.set(JAVA_INT, 0, considerCoriolis ? 1 : 0);
       options.set(JAVA_INT, 4, considerAccelerations ? 1 : 0);
       options.set(JAVA_INT, 8, 0);
-      options.set(JAVA_INT, 12, 0);
+      options.set(JAVA_INT, 12, rootAcceleration == null ? 0 : 1);
       options.set(ADDRESS, 16, MemorySegment.NULL);
+      for (int k = 0; k < 6; k++)
+         options.set(JAVA_DOUBLE, 24 + 8L * k, rootAcceleration == null ? 0.0 : rootAcceleration[k]);
       return options;
+   }
+
+   static
+   {
+      int version;
+      try
+      {
+         version = (int) ABI_VERSION.invokeExact();
+      }
+      catch (Throwable t)
+      {
+         throw new ExceptionInInitializerError(t);
+      }
+      if (version != ABI)
+         throw new UnsatisfiedLinkError("libmecano_hip.so reports ABI version " + version + ", this binding was written for " + ABI);
    }
 
    /** mh_status -> the exception Mecano's own calculators would have thrown (SURVEY.md section 8b, "Errors"). */

@@ -33,7 +33,7 @@ class MhModelDesc(ctypes.Structure):
 
 class MhOptions(ctypes.Structure):
     _fields_ = [("consider_coriolis", ctypes.c_int32), ("consider_accelerations", ctypes.c_int32), ("layout", ctypes.c_int32),
-                ("reserved0", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+                ("use_root_acceleration", ctypes.c_int32), ("stream", ctypes.c_void_p), ("root_acceleration", ctypes.c_double * 6)]
 
 
 CENTROIDAL_FRAME_FIXED, CENTROIDAL_FRAME_AT_COM = 0, 1

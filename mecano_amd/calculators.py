@@ -59,9 +59,63 @@ class _Base:
         else:
             raise ValueError("gravity is a scalar (z) or three components")
 
-    def setRootAcceleration(self, linearAcceleration):
-        """Root linear acceleration a0; gravity g is applied as a0 = -g (InverseDynamicsCalculator.java:343-348,424)."""
-        self._gravity = -np.asarray(linearAcceleration, dtype=np.float64).reshape(3)
+    def setRootAcceleration(self, rootAcceleration):
+        """``setRootAcceleration(SpatialAccelerationReadOnly)`` (InverseDynamicsCalculator.java:413-427, ForwardDynamicsCalculator.java:330-343):
+        the spatial acceleration of the root body, (angular x y z, linear x y z) in root-body coordinates -- what a rotating / accelerating
+        base contributes; it replaces whatever setGravitationalAcceleration stored (gravity g is the root acceleration (0, -g), :343-348).
+        Three entries are taken as the linear part alone."""
+        a = np.asarray(rootAcceleration, dtype=np.float64).reshape(-1)
+        if a.size == 3:
+            a = np.concatenate([np.zeros(3), a])
+        if a.size != 6:
+            raise ValueError("a root acceleration has six components (angular, linear)")
+        self._gravity = a.copy()  # six entries: passed on as mh_options.root_acceleration
+
+    # ---- the ONE-configuration face: the reference's own signatures (compute(), compute(DMatrix), setExternalWrench(body, wrench),
+    # writeComputed...) on top of the batched path with B = 1.  State is read from the joints in the order of the index provider
+    # (MultiBodySystemTools.extractJointsState, tools/MultiBodySystemTools.java:1433-1491), exactly what the reference does implicitly
+    # through the joints' reference frames.
+    def _joints_in_order(self):
+        return self.input.getJointMatrixIndexProvider().getIndexedJointsInOrder()
+
+    def _extract(self, which, size):
+        from .multibody import MultiBodySystemTools
+        m = np.zeros((size, 1))
+        MultiBodySystemTools.extractJointsState(self._joints_in_order(), which, m)
+        return m.reshape(1, size)
+
+    def _column(self, matrix, size, what):
+        m = np.asarray(matrix, dtype=np.float64)
+        if m.size != size or (m.ndim == 2 and m.shape[1] != 1):  # MatrixDimensionException in the reference (ForwardDynamicsCalculator.java:522-533)
+            raise _lib.MecanoHipError(2, f"{what}: expected {size} x 1, got {tuple(m.shape)}")
+        return m.reshape(1, size)
+
+    def getExternalWrench(self, rigidBody):
+        """``getExternalWrench(rigidBody)`` (InverseDynamicsCalculator.java:444-461, ForwardDynamicsCalculator.java:353-369): the live
+        external wrench of that body for the one-configuration calls -- six numbers (moment, force) expressed in the body-fixed frame,
+        where the reference keeps it (setMatchingFrame); modify it in place."""
+        w = self.__dict__.setdefault("_single_wrenches", {})
+        joints = self._joints_in_order()
+        if id(rigidBody) not in {id(j.getSuccessor()) for j in joints}:
+            raise KeyError("the rigid-body is not a successor of a joint this calculator considers")
+        return w.setdefault(id(rigidBody), np.zeros(6))
+
+    def setExternalWrench(self, rigidBody, externalWrench):
+        """``setExternalWrench(rigidBody, externalWrench)`` (:463-472 / :371-381); the wrench is given in the body-fixed frame."""
+        self.getExternalWrench(rigidBody)[:] = np.asarray(externalWrench, dtype=np.float64).reshape(6)
+
+    def _single_f_ext(self):
+        w = self.__dict__.get("_single_wrenches") or {}
+        if not any(np.any(v != 0.0) for v in w.values()):
+            return None
+        joints = self._joints_in_order()
+        return np.stack([w.get(id(j.getSuccessor()), np.zeros(6)) for j in joints])[None, :, :]
+
+    def _rows_of(self, joint, column):
+        if id(joint) not in {id(j) for j in self._joints_in_order()}:
+            return None
+        rows = self.input.getJointMatrixIndexProvider().getJointDoFIndices(joint)
+        return np.asarray(column).reshape(-1, 1)[rows]
 
     # ---- external wrenches: InverseDynamicsCalculator.java:444-472 / ForwardDynamicsCalculator.java:348-381
     def setExternalWrenches(self, f_ext):
@@ -70,6 +124,7 @@ class _Base:
 
     def setExternalWrenchesToZero(self):
         self._f_ext = None
+        self.__dict__.pop("_single_wrenches", None)
 
 
 class RigidBodyAccelerationProvider:
@@ -130,9 +185,27 @@ class InverseDynamicsCalculator(_Base):
     def setConsiderJointAccelerations(self, flag: bool):
         self._accel = bool(flag)
 
-    def compute(self, q, qd, qdd, bodies: bool = False, wrenches: bool = False):
-        """``bodies=True`` also fills the acceleration provider (InverseDynamicsCalculator.java:242-250, 660-663); ``wrenches=True``
-        keeps the 6-D wrench of every joint for getComputedJointWrench (:578-585)."""
+    def compute(self, *args, bodies: bool = False, wrenches: bool = False):
+        """Batched: ``compute(q, qd, qdd)``; ``bodies=True`` also fills the acceleration provider (InverseDynamicsCalculator.java:242-250,
+        660-663), ``wrenches=True`` keeps the 6-D wrench of every joint for getComputedJointWrench (:578-585).
+        The reference's own signatures: ``compute()`` (:481-484: configuration, velocity and desired acceleration read from the joints) and
+        ``compute(jointAccelerationMatrix)`` (:496-501: nv x 1) evaluate ONE configuration through the same HIP path; afterwards
+        getJointTauMatrix() is nv x 1 and writeComputedJointWrenches(joints) stores the efforts in the joints."""
+        if len(args) <= 1:
+            from .multibody import JointStateType
+            nq, nv = self.model.nq, self.model.nv
+            q, qd = self._extract(JointStateType.CONFIGURATION, nq), self._extract(JointStateType.VELOCITY, nv)
+            qdd = self._extract(JointStateType.ACCELERATION, nv) if not args or args[0] is None else self._column(args[0], nv, "jointAccelerationMatrix")
+            keep, self._f_ext = self._f_ext, self._single_f_ext()
+            try:
+                self.compute(q, qd, qdd, bodies=bodies, wrenches=wrenches)
+            finally:
+                self._f_ext = keep
+            self._tau = np.asarray(self._tau).reshape(nv, 1)
+            self._single = True
+            return self._tau
+        q, qd, qdd = args
+        self._single = False
         self._last_q, self._wrenches = q, None
         if wrenches:
             self._tau, self._wrenches = self.model.rnea_joint_wrenches(q, qd, qdd, self._gravity, self._f_ext, self.layout, self._coriolis,
@@ -163,8 +236,26 @@ class InverseDynamicsCalculator(_Base):
             raise ValueError("call compute(q, qd, qdd, wrenches=True) first")
         return self._wrenches[:, int(k), :]
 
+    def writeComputedJointWrench(self, joint) -> bool:
+        """``writeComputedJointWrench(joint)`` (:639-653): joint.setJointTau(0, getComputedJointTau(joint)); False for a joint this
+        calculator does not consider.  After a one-configuration compute."""
+        if not getattr(self, "_single", False):
+            raise ValueError("compute() or compute(jointAccelerationMatrix) first: a batch cannot be written into one joint")
+        tau = self._rows_of(joint, self._tau)
+        if tau is None:
+            return False
+        joint.setJointTau(0, tau)
+        return True
+
+    def writeComputedJointWrenches(self, joints):
+        """``writeComputedJointWrenches(JointBasics[] | List)`` (:613-629)."""
+        for joint in joints:
+            self.writeComputedJointWrench(joint)
+
     def getComputedJointTau(self, joint):
         """:587-602: the rows of the joint in the tau matrix"""
+        if getattr(self, "_single", False):
+            return self._rows_of(joint, self._tau)  # N x 1, like the reference's
         if id(joint) not in self._joint_pos or self._tau is None:
             return None
         rows = self.input.getJointMatrixIndexProvider().getJointDoFIndices(joint)
@@ -287,9 +378,33 @@ class ForwardDynamicsCalculator(_Base):
         """ForwardDynamicsCalculator.java:170-180, 715-718; filled by ``compute(..., bodies=True)``."""
         return self._provider
 
-    def compute(self, q, qd, tau, qdd=None, bodies: bool = False, wrenches: bool = False):
-        """``compute(q, qd, tau)`` (:475-490) or, with acceleration-source joints, ``compute(q, qd, tau, qdd)`` (:508-520): tau is
-        read for the effort sources, qdd for the acceleration sources.  ``wrenches=True`` keeps the joint wrenches (getJointWrench)."""
+    def compute(self, *args, bodies: bool = False, wrenches: bool = False):
+        """Batched: ``compute(q, qd, tau)`` or, with acceleration-source joints, ``compute(q, qd, tau, qdd)``: tau is read for the
+        effort sources, qdd for the acceleration sources.  ``wrenches=True`` keeps the joint wrenches (getJointWrench).
+        The reference's own signatures evaluate ONE configuration read from the joints: ``compute()`` (ForwardDynamicsCalculator.java:475-478),
+        ``compute(jointTauInput)`` (:489-492) and ``compute(jointTauInput, jointAccelerationInput)`` (:508-520), matrices nv x 1; afterwards
+        getJointAccelerationMatrix() / getJointTauMatrix() are nv x 1 and writeComputedJointAccelerations(joints) stores the result."""
+        if len(args) <= 2:
+            from .multibody import JointStateType
+            nq, nv = self.model.nq, self.model.nv
+            q, qd = self._extract(JointStateType.CONFIGURATION, nq), self._extract(JointStateType.VELOCITY, nv)
+            tau = self._extract(JointStateType.EFFORT, nv) if not args or args[0] is None else self._column(args[0], nv, "jointTauInput")
+            locked = any(m == JointSourceMode.ACCELERATION_SOURCE for m in self._modes)
+            qdd = None
+            if locked:
+                qdd = (self._extract(JointStateType.ACCELERATION, nv) if len(args) < 2 or args[1] is None
+                       else self._column(args[1], nv, "jointAccelerationInput"))
+            keep, self._f_ext = self._f_ext, self._single_f_ext()
+            try:
+                self.compute(q, qd, tau, qdd, bodies=bodies, wrenches=wrenches)
+            finally:
+                self._f_ext = keep
+            self._qdd, self._tau = np.asarray(self._qdd).reshape(nv, 1), np.asarray(self._tau).reshape(nv, 1)
+            self._single = True
+            return self._qdd
+        q, qd, tau = args[:3]
+        qdd = args[3] if len(args) > 3 else None
+        self._single = False
         self._last_q, self._wrenches = q, None
         if wrenches and not any(m == JointSourceMode.ACCELERATION_SOURCE for m in self._modes):
             self._qdd, self._wrenches = self.model.aba_joint_wrenches(q, qd, tau, self._gravity, self._f_ext, self.layout)
@@ -311,6 +426,25 @@ class ForwardDynamicsCalculator(_Base):
 
     def getJointAccelerationMatrix(self):
         return self._qdd
+
+    def getComputedJointAcceleration(self, joint):
+        """``getComputedJointAcceleration(joint)`` (:600-610): N x 1 after a one-configuration compute, None for a joint that is not considered."""
+        if not getattr(self, "_single", False):
+            raise ValueError("compute(), compute(tau) or compute(tau, qdd) first")
+        return self._rows_of(joint, self._qdd)
+
+    def writeComputedJointAcceleration(self, joint) -> bool:
+        """``writeComputedJointAcceleration(joint)`` (:699-708)."""
+        a = self.getComputedJointAcceleration(joint)
+        if a is None:
+            return False
+        joint.setJointAcceleration(0, a)
+        return True
+
+    def writeComputedJointAccelerations(self, joints):
+        """``writeComputedJointAccelerations(JointBasics[] | List)`` (:670-688)."""
+        for joint in joints:
+            self.writeComputedJointAcceleration(joint)
 
     def getJointTauMatrix(self):
         """Efforts of all joints: the inputs for effort sources, the computed ones for acceleration sources (:556-567)."""

@@ -129,6 +129,10 @@ struct SpecLib
    int (*launch_coriolis_parts)(int flags, const void *args, int grid, int parts, void *stream) = nullptr;
    int (*launch_centroidal_parts)(int flags, const void *args, int grid, int parts, void *stream) = nullptr;
    unsigned long long (*abi)(void) = nullptr;
+   // bias-split forward dynamics (mh_zv_kernels.h)
+   int (*zv_usable)(void) = nullptr;
+   long (*zv_lds_bytes)(int nq, int nv) = nullptr;
+   int (*launch_zv)(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, void *stream) = nullptr;
 };
 enum : int
 {
@@ -184,6 +188,12 @@ struct mh_model
    hipEvent_t pair_fork = nullptr, pair_join = nullptr;
    Workspace ws_pair;
    int use_pair = 1; // MH_DISABLE_PAIR=1: always one after the other
+   // bias-split forward dynamics (mh_zv_kernels.h): tau - h(q, qd) rows, one flag per 64 configurations (a launch stores its epoch there),
+   // an error word in mapped host memory that a timed-out wait sets (read at the next call of the model)
+   Workspace zv_tau, zv_flags;
+   int zv_epoch = 0;
+   int *zv_error_host = nullptr, *zv_error_dev = nullptr;
+   int use_zv = 1;        // MH_ZV=0: never; 1: while every job's workgroup gets a CU of its own (default); 2: whenever the call qualifies
    // run-time tree split (mh_split_kernels.h): plan made at creation, device copies, workspace blocks
    struct SplitRt
    {
@@ -280,6 +290,25 @@ mh::DevModel dev_model(const mh_model *m)
    return d;
 }
 
+// Root acceleration of a call: (0, -g) for the gravity vector, or opts->root_acceleration (angular, linear) when the caller set one
+// (InverseDynamicsCalculator.java:343-348 / 413-427, ForwardDynamicsCalculator.java:259-264 / 330-343).  The kernels take minus the linear
+// part in (gx, gy, gz) and the angular part in (rax, ray, raz).
+template <class ARGS>
+void set_root_acceleration(ARGS &A, const mh_options &o, const double *gravity)
+{
+   using T = decltype(A.gx);
+   if (o.use_root_acceleration)
+   {
+      A.rax = (T)o.root_acceleration[0], A.ray = (T)o.root_acceleration[1], A.raz = (T)o.root_acceleration[2];
+      A.gx = (T)-o.root_acceleration[3], A.gy = (T)-o.root_acceleration[4], A.gz = (T)-o.root_acceleration[5];
+   }
+   else
+   {
+      A.rax = T(0), A.ray = T(0), A.raz = T(0);
+      A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
+   }
+}
+
 mh_status check_common(mh_model_t model, int64_t B, const mh_options *opts)
 {
    if (!model)
@@ -317,6 +346,67 @@ bool split_ok(const mh_model *m, int algo, int64_t B, bool soa)
    const long groups = (B + 63) / 64;
    const long waves = groups * 4 * (algo == 2 ? 2 : 1);
    return waves <= (long)m->cu_count * 4 * m->fused_factor; // fused: while the batch cannot give every SIMD a wave of its own
+}
+
+// Bias-split forward dynamics (mh_zv_kernels.h): AoS matrices, dense index maps, every joint an effort source, no per-body outputs.
+// The launch puts `jobs` workgroups of four waves on every 64 configurations, each with a CU's LDS nearly to itself: it pays while they
+// all fit the device at once (measured, humanoid: pair 16.6 vs 18.3 us at B = 4096, 25.4 vs 19.3 at 8192; forward dynamics alone 17.0 vs
+// 18.9 us at 8192, 31.2 vs 20.0 at 16384 -- profiles/r03_zv_vs_tree_split.txt); beyond that the tree-split kernels serve the call.
+bool zv_ok(const mh_model *m, int64_t B, bool soa, int jobs)
+{
+   if (!m->spec.launch_zv || !m->spec.zv_usable || !m->spec.zv_usable() || !m->use_spec || !m->use_zv || m->use_split == 0)
+      return false;
+   if (soa || !m->dense_maps || m->force_io == 0 || m->n_locked > 0)
+      return false;
+   const long lds = m->spec.zv_lds_bytes(m->nq, m->nv);
+   return lds > 0 && lds <= 160 * 1024 && (m->use_zv == 2 || (B + 63) / 64 * jobs <= (long)m->cu_count);
+}
+// A wait of an earlier bias-split launch that ran into its wall-clock limit (the producer workgroup never published): surfaced here
+mh_status zv_check_error(mh_model *m)
+{
+   if (m->zv_error_host && *(volatile int *)m->zv_error_host != 0)
+   {
+      *(volatile int *)m->zv_error_host = 0;
+      return fail(MH_ERR_HIP, "a bias-split forward dynamics launch gave up waiting for its bias rows (results of that launch are invalid)");
+   }
+   return MH_OK;
+}
+// jobs = 2: A.in3b = tau, A.outb = qdd.  jobs = 3: additionally A.in3 = qdd, A.out = tau.  Returns hipErrorNotSupported (as int) in *rc
+// when the code object lacks the plan.
+mh_status zv_launch(mh_model *m, mh::Args<double> &A, int jobs, hipStream_t stream, int *rc)
+{
+   const size_t groups = (size_t)((A.B + 63) / 64);
+   mh_status st = ensure_bytes(m->zv_tau, (size_t)A.B * m->nv * sizeof(double));
+   if (st != MH_OK)
+      return st;
+   if (m->zv_flags.bytes < groups * sizeof(int))
+   {
+      st = ensure_bytes(m->zv_flags, std::max<size_t>(groups, 1024) * sizeof(int));
+      if (st != MH_OK)
+         return st;
+      // zeroed ON THE LAUNCH STREAM: a plain hipMemset is not ordered against kernels of other streams (seen here as a rare refusal by the
+      // create-time self-check: the memset landed after the bias job had stored its flag, and the inertia job ran into its time limit)
+      HIP_TRY(hipMemsetAsync(m->zv_flags.ptr, 0, m->zv_flags.bytes, stream));
+      m->zv_epoch = 0;
+   }
+   if (!m->zv_error_host)
+   {
+      HIP_TRY(hipHostMalloc((void **)&m->zv_error_host, sizeof(int), hipHostMallocMapped));
+      *m->zv_error_host = 0;
+      HIP_TRY(hipHostGetDevicePointer((void **)&m->zv_error_dev, m->zv_error_host, 0));
+   }
+   if (m->zv_epoch == 0x7fffffff)
+   { // the flags have seen every positive value: start over
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemsetAsync(m->zv_flags.ptr, 0, m->zv_flags.bytes, stream));
+      m->zv_epoch = 0;
+   }
+   const int epoch = ++m->zv_epoch;
+   int flags = SPEC_IO_LDS | (m->ident_maps ? SPEC_IDENT : 0);
+   *rc = m->spec.launch_zv(flags, &A, m->zv_tau.ptr, (int *)m->zv_flags.ptr, m->zv_error_dev, epoch, jobs, (void *)stream);
+   if (*rc != 0 && *rc != (int)hipErrorNotSupported)
+      return fail(MH_ERR_HIP, "bias-split kernel launch failed: %s", hipGetErrorString((hipError_t)*rc));
+   return MH_OK;
 }
 
 enum Algo
@@ -779,7 +869,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       return st;
    if (B == 0)
       return MH_OK; // an empty batch has nothing to read or write: NULL pointers are fine
-   if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || !gravity)))
+   if (!q || !out || (algo != ALGO_CRBA && (!qd || !in3 || (!gravity && !opts.use_root_acceleration))))
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    if (algo == ALGO_ABA && model->n_locked > 0 && !locked_in)
       return fail(MH_ERR_INVALID_ARGUMENT, "%d joint(s) are acceleration sources: forward dynamics needs their accelerations, use mh_aba_locked_f64",
@@ -812,7 +902,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
    A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
    A.f_bs = soa ? 1 : (long)model->n * 6, A.f_es = soa ? B : 1;
-   A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
+   set_root_acceleration(A, opts, gravity);
    A.coriolis = opts.consider_coriolis, A.accel = opts.consider_accelerations;
    const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
    const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
@@ -851,6 +941,21 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
       { if (ldsc) hipLaunchKernelGGL((mh::aba_kernel<T, true, true>), dim3(L.grid), dim3(L.block), lds, stream, A); else hipLaunchKernelGGL((mh::aba_kernel<T, false, true>), dim3(L.grid), dim3(L.block), lds, stream, A); }
       HIP_TRY(hipGetLastError());
       return MH_OK;
+   }
+   if constexpr (sizeof(T) == 8)
+   {
+      if (algo == ALGO_ABA && !q_next && zv_ok(model, B, soa, 2))
+      { // forward dynamics as two jobs side by side: bias efforts | articulated inertias, then the bias fold (mh_zv_kernels.h)
+         if (const mh_status se = zv_check_error(model); se != MH_OK)
+            return se;
+         A.in3b = in3, A.outb = out;
+         int rc = 0;
+         if (const mh_status sz = zv_launch(model, A, 2, stream, &rc); sz != MH_OK)
+            return sz;
+         if (rc == 0)
+            return MH_OK;
+         A.in3b = nullptr, A.outb = nullptr; // not in this code object: the plans below
+      }
    }
    if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
    {
@@ -1066,7 +1171,7 @@ mh_status launch_host(int kind, mh_model_t model, int64_t B, const T *q, const T
    if (B == 0)
       return MH_OK;
    const bool crba = kind == ALGO_CRBA, pair = kind == HOST_PAIR;
-   if (!q || !out || (!crba && (!qd || !in3 || !gravity)) || (pair && (!in4 || !out2)))
+   if (!q || !out || (!crba && (!qd || !in3 || (!gravity && !opts.use_root_acceleration))) || (pair && (!in4 || !out2)))
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    st = host_pipeline_init(model);
    if (st != MH_OK)
@@ -1279,6 +1384,9 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.crba_split_usable = (decltype(s.crba_split_usable))dlsym(h, "mh_spec_crba_split_usable");
    s.launch_crba_split = (decltype(s.launch_crba_split))dlsym(h, "mh_spec_launch_crba_split");
    s.launch_rnea_crba = (decltype(s.launch_rnea_crba))dlsym(h, "mh_spec_launch_rnea_crba");
+   s.zv_usable = (decltype(s.zv_usable))dlsym(h, "mh_spec_zv_usable");
+   s.zv_lds_bytes = (decltype(s.zv_lds_bytes))dlsym(h, "mh_spec_zv_lds_bytes");
+   s.launch_zv = (decltype(s.launch_zv))dlsym(h, "mh_spec_launch_zv");
    s.rnea_crba_lds_bytes = (decltype(s.rnea_crba_lds_bytes))dlsym(h, "mh_spec_rnea_crba_lds_bytes");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
@@ -1400,7 +1508,7 @@ mh_status regressor_impl(mh_model_t model, int64_t B, const T *q, const T *qd, c
    A.v_bs = soa ? 1 : model->nv, A.v_es = soa ? B : 1;
    const long ysize = (long)model->nv * model->n * 10;
    A.f_bs = soa ? 1 : ysize, A.f_es = soa ? B : 1; // strides of Y
-   A.gx = gravity ? (T)gravity[0] : T(0), A.gy = gravity ? (T)gravity[1] : T(0), A.gz = gravity ? (T)gravity[2] : T(0);
+   set_root_acceleration(A, opts, gravity);
    A.coriolis = opts.consider_coriolis, A.accel = opts.consider_accelerations;
    const bool ldsc = MH_GENERIC_LDS_CONSTS || model->lds_consts;
    const size_t lds = ldsc ? (size_t)model->n * mh::MC_STRIDE * sizeof(T) : 0;
@@ -1560,8 +1668,10 @@ void mh_options_default(mh_options *opts)
    opts->consider_coriolis = 1;
    opts->consider_accelerations = 1;
    opts->layout = MH_LAYOUT_AOS;
-   opts->reserved0 = 0;
+   opts->use_root_acceleration = 0;
    opts->stream = nullptr;
+   for (int k = 0; k < 6; k++)
+      opts->root_acceleration[k] = 0.0;
 }
 
 mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
@@ -1870,6 +1980,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_split = atoi(e);
    if (const char *e = getenv("MH_DISABLE_FUSED"))
       m->use_fused = atoi(e) ? 0 : 1;
+   if (const char *e = getenv("MH_ZV"))
+      m->use_zv = atoi(e);
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
       m->lds_wave_factor = atoi(e);
    if (const char *e = getenv("MH_SPEC_IO"))
@@ -1955,6 +2067,10 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
    (void)hipFree(m->ws_pair.ptr);
+   (void)hipFree(m->zv_tau.ptr);
+   (void)hipFree(m->zv_flags.ptr);
+   if (m->zv_error_host)
+      (void)hipHostFree(m->zv_error_host);
    if (m->pair_stream)
    {
       (void)hipStreamDestroy(m->pair_stream);
@@ -2247,7 +2363,7 @@ mh_status mh_relative_acceleration_f64(mh_model_t model, int64_t B, const double
       return fail(MH_ERR_BAD_DIMENSION, "negative number of pairs %d", n_pairs);
    if (B == 0 || n_pairs == 0)
       return MH_OK;
-   if (!q || !body_acc || !gravity || !base_joints || !body_joints || !out)
+   if (!q || !body_acc || (!gravity && !opts.use_root_acceleration) || !base_joints || !body_joints || !out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / pair / output pointer");
    model->pairs_host.resize((size_t)n_pairs * 2);
    for (int k = 0; k < n_pairs; k++)
@@ -2272,7 +2388,7 @@ mh_status mh_relative_acceleration_f64(mh_model_t model, int64_t B, const double
    A.q_bs = soa ? 1 : model->nq, A.q_es = soa ? B : 1;
    A.f_bs = soa ? 1 : (long)model->n * 6, A.f_es = soa ? B : 1;
    A.o_bs = soa ? 1 : (long)n_pairs * 6, A.o_es = soa ? B : 1;
-   A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
+   set_root_acceleration(A, opts, gravity);
    if (opts.consider_coriolis && !body_twist)
       return fail(MH_ERR_INVALID_ARGUMENT, "body_twist is NULL but velocities are considered (opts->consider_coriolis)");
    const int block = 64;
@@ -2335,7 +2451,7 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
       return st;
    if (B == 0)
       return MH_OK;
-   if (!q || !qd || !qdd || !tau || !gravity || !tau_out || !qdd_out)
+   if (!q || !qd || !qdd || !tau || (!gravity && !opts.use_root_acceleration) || !tau_out || !qdd_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    const long waves = (B + 63) / 64;
    const bool fusable = model->n_locked == 0 && model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
@@ -2381,8 +2497,18 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    A.dt = 0.0, A.q_next = nullptr, A.qd_next = nullptr;
    A.ws = nullptr, A.ws_stride = 0;
    A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
-   A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
+   set_root_acceleration(A, opts, gravity);
    A.coriolis = 1, A.accel = 1;
+   if (zv_ok(model, B, false, 3))
+   { // three jobs in one launch: bias efforts | articulated inertias + bias fold | the inverse dynamics output (mh_zv_kernels.h)
+      if (const mh_status se = zv_check_error(model); se != MH_OK)
+         return se;
+      int rc3 = 0;
+      if (const mh_status sz = zv_launch(model, A, 3, (hipStream_t)opts.stream, &rc3); sz != MH_OK)
+         return sz;
+      if (rc3 == 0)
+         return MH_OK;
+   }
    if (split_ok(model, 2, B, false))
    {
       const int rc2 = model->spec.launch_split(2, split_flags(model, 2, false), &A, (int)waves, opts.stream);
@@ -2415,7 +2541,7 @@ mh_status mh_rnea_crba_f64(mh_model_t model, int64_t B, const double *q, const d
       return st;
    if (B == 0)
       return MH_OK;
-   if (!q || !qd || !qdd || !gravity || !tau_out || !H_out)
+   if (!q || !qd || !qdd || (!gravity && !opts.use_root_acceleration) || !tau_out || !H_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    hipStream_t s = (hipStream_t)opts.stream;
    const long groups = (B + 63) / 64;
@@ -2432,7 +2558,7 @@ mh_status mh_rnea_crba_f64(mh_model_t model, int64_t B, const double *q, const d
       A.in3b = nullptr, A.outb = H_out;
       A.ws = nullptr, A.ws_stride = 0;
       A.q_bs = model->nq, A.q_es = 1, A.v_bs = model->nv, A.v_es = 1, A.f_bs = (long)model->n * 6, A.f_es = 1;
-      A.gx = gravity[0], A.gy = gravity[1], A.gz = gravity[2];
+      set_root_acceleration(A, opts, gravity);
       A.coriolis = 1, A.accel = 1;
       // thin CRBA workgroups: its write-out is bound by the stores in flight per CU.  Every workgroup must be resident at once (the RNEA
       // groups would otherwise queue behind the CRBA's): one per CU, two where the thinner image leaves LDS for it (202 registers: two
@@ -2840,6 +2966,11 @@ static void self_check_spec(mh_model *m)
       mh_options o;
       mh_options_default(&o);
       o.layout = L == 0 ? MH_LAYOUT_AOS : MH_LAYOUT_SOA;
+      // a rotating, accelerating base: every plan starts its outward sweep from the full 6-D root acceleration
+      o.use_root_acceleration = 1;
+      const double root_acc[6] = {0.11, -0.07, 0.05, -0.3, 0.2, 9.81};
+      for (int k = 0; k < 6; k++)
+         o.root_acceleration[k] = root_acc[k];
       const double *dq = d_in[L], *dqd = dq + (size_t)B * nq, *dqdd = dqd + (size_t)B * nv, *dtau = dqdd + (size_t)B * nv;
       double *o1 = d_out, *o2 = o1 + (size_t)B * nv, *o3 = o2 + (size_t)B * std::max(nq, 6 * n);
       hipLaunchKernelGGL(fill_nan_kernel, dim3(64), dim3(256), 0, (hipStream_t) nullptr, (unsigned long long *)d_out, out_doubles);
@@ -2884,17 +3015,26 @@ static void self_check_spec(mh_model *m)
             continue; // the run-time-topology kernels cannot serve this call either: nothing to compare
          ref.resize(used);
          (void)hipMemcpy(ref.data(), d_out, used * sizeof(double), hipMemcpyDeviceToHost);
-         for (int pretend = 0; pretend < 2 && failure.empty(); pretend++)
+         // plan 0: the real CU count; 1: a pretended single CU (device-filling plans); 2: the bias-split forward dynamics switched off
+         // (the tree-split kernels it replaced still serve SoA calls, simulation steps and models with acceleration sources)
+         const int zv_was = m->use_zv;
+         const bool zv_plan = (what == CK_ABA || what == CK_FUSED) && L == 0 && zv_was && zv_ok(m, B, false, what == CK_FUSED ? 3 : 2);
+         for (int plan = 0; plan < (zv_plan ? 3 : 2) && failure.empty(); plan++)
          {
+            const int pretend = plan == 1 ? 1 : 0;
             m->cu_count = pretend ? 1 : real_cus;
+            m->use_zv = plan == 2 ? 0 : zv_was;
             st = run(what, L, used);
             const hipError_t sync = hipDeviceSynchronize();
             m->cu_count = real_cus;
+            m->use_zv = zv_was;
+            if (st == MH_OK)
+               st = zv_check_error(m);
             char buf[320];
             if (st != MH_OK || sync != hipSuccess)
             {
-               snprintf(buf, sizeof buf, "%s (%s, %s plan) failed: %s", kCheckNames[what], L ? "SoA" : "AoS", pretend ? "device-filling" : "small-batch",
-                        st != MH_OK ? g_err : hipGetErrorString(sync));
+               snprintf(buf, sizeof buf, "%s (%s, %s plan) failed: %s", kCheckNames[what], L ? "SoA" : "AoS",
+                        plan == 2 ? "tree-split" : (pretend ? "device-filling" : "small-batch"), st != MH_OK ? g_err : hipGetErrorString(sync));
                failure = buf;
                break;
             }
@@ -2926,7 +3066,7 @@ static void self_check_spec(mh_model *m)
             const double tol = (what == CK_ABA || what == CK_FUSED || what == CK_STEP || what == CK_BODIES_ABA) ? 1.0e-8 : 1.0e-10;
             if (verbose)
                fprintf(stderr, "[mh self-check] %-28s %s %-14s  |diff| %.3e  |ref| %.3e  unwritten-mismatch %d (word %zu)\n", kCheckNames[what], L ? "SoA" : "AoS",
-                       pretend ? "device-filling" : "small-batch", err, scale, (int)nan_mismatch, first_bad);
+                       plan == 2 ? "tree-split" : (pretend ? "device-filling" : "small-batch"), err, scale, (int)nan_mismatch, first_bad);
             if (nan_mismatch || err > tol * scale)
             {
                char where[96] = "";
@@ -2934,7 +3074,7 @@ static void self_check_spec(mh_model *m)
                   snprintf(where, sizeof where, ", output word %zu %s", first_bad,
                            bad_is_unwritten ? "left unwritten" : "written although the run-time-topology kernels do not write it");
                snprintf(buf, sizeof buf, "%s (%s, %s plan) differs from the run-time-topology kernels by %.3e (|ref| <= %.3e%s)", kCheckNames[what],
-                        L ? "SoA" : "AoS", pretend ? "device-filling" : "small-batch", err, scale, where);
+                        L ? "SoA" : "AoS", plan == 2 ? "tree-split" : (pretend ? "device-filling" : "small-batch"), err, scale, where);
                failure = buf;
             }
          }

@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                if (parent < 0)
                {
                   vp = SV<T>{Z, Z};
-                  ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :343-348
+                  ap = root_acceleration(A); // :343-348
                }
                else if (ev & EV_PARENT_REGS)
                   vp = v_reg, ap = a_reg;
@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             prefetch_q(j + 1);
             SV<T> ap;
             if (parent < 0)
-               ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :259-264
+               ap = root_acceleration(A); // :259-264
             else if (parent == j - 1)
                ap = a_reg;
             else

@@ -120,7 +120,8 @@ struct Args
    long q_bs, q_es; // batch stride / element stride of configuration matrices
    long v_bs, v_es; // ... of velocity-sized matrices
    long f_bs, f_es; // ... of the external wrench array (element = joint * 6 + component)
-   T gx, gy, gz;
+   T gx, gy, gz;    // minus the LINEAR part of the root acceleration (the gravity vector when it was given as one)
+   T rax, ray, raz; // ANGULAR part of the root acceleration (InverseDynamicsCalculator.setRootAcceleration, java:413-427); 0 with a gravity vector
    int coriolis, accel;
    // second job of a fused RNEA+ABA launch (specialised kernels only): tau in, qdd out
    // aba_kernel<.., LOCKED>: in3b = given accelerations of the ACCELERATION_SOURCE joints, outb = tau of all joints (may be NULL)
@@ -138,6 +139,14 @@ struct Args
    T *q_next, *qd_next;
 };
 
+// spatial acceleration of the root body (angular, linear), in root-body coordinates: (0, -g) for a gravity vector
+// (InverseDynamicsCalculator.java:343-348, ForwardDynamicsCalculator.java:259-264) or what setRootAcceleration was given (:413-427 / :340)
+template <class ARGS>
+MH_DEV auto root_acceleration(const ARGS &A) -> SV<std::remove_cv_t<std::remove_reference_t<decltype(A.gx)>>>
+{
+   using T = std::remove_cv_t<std::remove_reference_t<decltype(A.gx)>>;
+   return SV<T>{V3<T>{A.rax, A.ray, A.raz}, V3<T>{-A.gx, -A.gy, -A.gz}};
+}
 template <typename T, class CR>
 MH_DEV XF<T> load_xb(const CR &c)
 {
@@ -537,7 +546,7 @@ __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)
          if (parent < 0)
          {
             vp = SV<T>{Z, Z};
-            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // InverseDynamicsCalculator.java:343-348
+            ap = root_acceleration(A); // InverseDynamicsCalculator.java:343-348
          }
          else if (flags & MF_PARENT_ADJ)
          {
@@ -732,6 +741,61 @@ MH_DEV SV<T> spd6_solve(const ABI<T> &I, SV<T> b)
       for (int j = k + 1; j < 6; j++)
          x[k] -= M[k][j] * x[j];
    }
+   return SV<T>{V3<T>{x[0], x[1], x[2]}, V3<T>{x[3], x[4], x[5]}};
+}
+
+// The same in two steps (bias-split forward dynamics, mh_zv_kernels.h): the factor depends on the configuration only and is formed while
+// the bias efforts are still being computed elsewhere; the substitution runs once they have arrived.  f[0..14] = L (row-wise, k < j),
+// f[15..20] = 1 / D.
+template <typename T>
+struct LDL6
+{
+   T f[21];
+};
+__host__ __device__ constexpr int ldl6_index(int k, int j) { return k * 5 - k * (k - 1) / 2 + (j - k - 1); } // k < j
+template <typename T>
+MH_DEV LDL6<T> spd6_factor(const ABI<T> &I)
+{
+   T M[6][6];
+   M[0][0] = I.A.xx, M[0][1] = I.A.xy, M[0][2] = I.A.xz, M[1][1] = I.A.yy, M[1][2] = I.A.yz, M[2][2] = I.A.zz;
+   M[0][3] = I.C.xx, M[0][4] = I.C.xy, M[0][5] = I.C.xz, M[1][3] = I.C.yx, M[1][4] = I.C.yy, M[1][5] = I.C.yz;
+   M[2][3] = I.C.zx, M[2][4] = I.C.zy, M[2][5] = I.C.zz;
+   M[3][3] = I.L.xx, M[3][4] = I.L.xy, M[3][5] = I.L.xz, M[4][4] = I.L.yy, M[4][5] = I.L.yz, M[5][5] = I.L.zz;
+   LDL6<T> F;
+#pragma unroll
+   for (int k = 0; k < 6; k++)
+   {
+      const T dinv = T(1) / M[k][k];
+      F.f[15 + k] = dinv;
+#pragma unroll
+      for (int j = k + 1; j < 6; j++)
+      {
+         const T l = M[k][j] * dinv;
+#pragma unroll
+         for (int i = k + 1; i <= j; i++)
+            M[i][j] -= M[k][i] * l;
+         F.f[ldl6_index(k, j)] = l;
+      }
+   }
+   return F;
+}
+template <typename T>
+MH_DEV SV<T> spd6_solve(const LDL6<T> &F, SV<T> b)
+{
+   T x[6] = {b.a.x, b.a.y, b.a.z, b.l.x, b.l.y, b.l.z};
+#pragma unroll
+   for (int k = 0; k < 6; k++)
+#pragma unroll
+      for (int j = k + 1; j < 6; j++)
+         x[j] -= F.f[ldl6_index(k, j)] * x[k];
+#pragma unroll
+   for (int k = 0; k < 6; k++)
+      x[k] *= F.f[15 + k];
+#pragma unroll
+   for (int k = 5; k >= 0; k--)
+#pragma unroll
+      for (int j = k + 1; j < 6; j++)
+         x[k] -= F.f[ldl6_index(k, j)] * x[j];
    return SV<T>{V3<T>{x[0], x[1], x[2]}, V3<T>{x[3], x[4], x[5]}};
 }
 
@@ -1081,7 +1145,7 @@ __global__ void __launch_bounds__(256) aba_kernel(Args<T> A)
             pre3(j + 1);
          SV<T> ap;
          if (parent < 0)
-            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :259-264
+            ap = root_acceleration(A); // :259-264
          else if (flags & MF_PARENT_ADJ)
             ap = a_prev;
          else
@@ -1952,6 +2016,7 @@ struct RelArgs
    int n_pairs;
    long q_bs, q_es, f_bs, f_es, o_bs, o_es;
    T gx, gy, gz;
+   T rax, ray, raz;
 };
 template <typename T>
 MH_DEV XF<T> compose(const XF<T> &a, const XF<T> &b)
@@ -2037,7 +2102,7 @@ __global__ void __launch_bounds__(256) relative_acceleration_kernel(RelArgs<T> A
                        X2.R.xz * X1.R.xx + X2.R.yz * X1.R.yx + X2.R.zz * X1.R.zx, X2.R.xz * X1.R.xy + X2.R.yz * X1.R.yy + X2.R.zz * X1.R.zy,
                        X2.R.xz * X1.R.xz + X2.R.yz * X1.R.yz + X2.R.zz * X1.R.zz};
          X12.p = tmul(X2.R, X1.p - X2.p);
-         const SV<T> a_root{Z, V3<T>{-A.gx, -A.gy, -A.gz}};
+         const SV<T> a_root = root_acceleration(A);
          SV<T> a1 = b1 < 0 ? a_root : load6(arow, b1);
          const SV<T> a2 = b2 < 0 ? a_root : load6(arow, b2);
          if (trow)
@@ -2113,7 +2178,7 @@ __global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
          if (parent < 0)
          {
             vp = SV<T>{Z, Z};
-            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}};
+            ap = root_acceleration(A);
          }
          else if (flags & MF_PARENT_ADJ)
             vp = v_prev, ap = a_prev;

@@ -6,6 +6,7 @@
 // libmecano_hip.so dlopen()s it from its own directory when a model with this topology is created
 // (mh_model_create) and routes mh_rnea_f64 / mh_aba_f64 to it; every other model and dtype runs on the generic kernels.
 #include "mh_spec_kernels.h"
+#include "mh_zv_kernels.h"
 
 #include <algorithm>
 #include <atomic>
@@ -162,7 +163,7 @@ long split_lds_bytes(int algo, int flags, int nq, int nv)
       return std::max(split_lds_bytes(0, flags, nq, nv), split_lds_bytes(1, flags, nq, nv));
    long b = (long)(SPL::n_limbs() * (algo == 0 ? 6 : 27) + (algo == 1 ? SPL::TRUNK_SLOTS : SPL::RNEA_TRUNK_SLOTS)) * 64 * sizeof(double);
    if (flags & F_IO_LDS)
-      b += (long)(nq + 2 * nv) * 64 * sizeof(double);
+      b += (long)(nq + (algo == 1 ? 3 : 2) * nv) * 64 * sizeof(double); // forward dynamics: result rows of their own (split_group)
    return b;
 }
 template <class K>
@@ -257,6 +258,56 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
       return (int)go_split_algo<false, true>(algo, A, groups, s, occ3);
    return (int)go_split_algo<false, false>(algo, A, groups, s, occ3);
 #endif
+}
+// ---- bias-split forward dynamics (mh_zv_kernels.h): AoS matrices with dense index maps, rows staged in LDS
+long mh_spec_zv_lds_bytes(int nq, int nv)
+{
+   if constexpr (!SPL::usable())
+      return 0;
+   const long inertia = (long)(SPL::n_limbs() * mh::ZV_XW + SPL::ZV_TRUNK_SLOTS + nq + 2 * nv) * 64 * (long)sizeof(double);
+   return std::max(inertia, split_lds_bytes(0, F_IO_LDS, nq, nv));
+}
+int mh_spec_zv_usable(void) { return SPL::usable() ? 1 : 0; }
+#ifdef MH_ZV_PROBE
+int mh_spec_zv_probe_read(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mh::zv_probe), bytes); }
+#endif
+// jobs = 2: qdd = ABA(q, qd, tau) with args->in3b = tau, args->outb = qdd.  jobs = 3: additionally args->out = RNEA(q, qd, args->in3).
+// taup: scratch [B][nv]; sync_flags: ceil(B / 64) ints that never held `epoch` before; error: one int, set when a wait timed out.
+int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, void *stream)
+{
+   if constexpr (SPL::usable())
+   {
+      const mh::Args<double> &A = *(const mh::Args<double> *)args;
+      if (!(flags & F_IO_LDS) || (jobs != 2 && jobs != 3))
+         return (int)hipErrorNotSupported;
+      const size_t lds = (size_t)mh_spec_zv_lds_bytes(A.m.nq, A.m.nv);
+      if (lds > 160 * 1024)
+         return (int)hipErrorNotSupported;
+      const long groups = (A.B + 63) / 64, padded = (groups + 7) / 8 * 8;
+      const mh::ZvSync sy{sync_flags, error, epoch, jobs};
+      hipStream_t s = (hipStream_t)stream;
+      if (flags & F_IDENT)
+      {
+         static LdsAttr attr;
+         auto kern = &mh::spec_zv_kernel<TP, double, true>;
+         if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
+            return (int)e;
+         hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A, (double *)taup, sy);
+         return (int)hipGetLastError();
+      }
+#ifdef MH_SPEC_MINIMAL
+      return (int)hipErrorNotSupported;
+#else
+      static LdsAttr attr2;
+      auto kern = &mh::spec_zv_kernel<TP, double, false>;
+      if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr2); e != hipSuccess)
+         return (int)e;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A, (double *)taup, sy);
+      return (int)hipGetLastError();
+#endif
+   }
+   else
+      return (int)hipErrorNotSupported;
 }
 // the tree-split plan of this topology, for tests and documentation: out[0] = usable, [1] = staged trunk, [2] = limbs, [3] = sub-trunks,
 // [4] = root trunk body, then per limb (root body, bodies, ABA owner wave, RNEA / CRBA owner wave, late) and per wave the body after

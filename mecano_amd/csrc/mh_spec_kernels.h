@@ -69,6 +69,17 @@ struct Tree
    {
       return TP::type[j] == JT_REVOLUTE ? 9 : (TP::type[j] == JT_PRISMATIC ? 7 : (TP::type[j] == JT_SIXDOF ? 6 : 0));
    }
+   // bias-split forward dynamics (mh_zv_kernels.h): revolute 9 (U/D, 1/D, cos, sin), prismatic 7, sixdof 21 (LDL^T factor of IA), fixed 0.
+   // What the bias fold leaves for the outward sweep (u/D; IA^-1 u) overwrites 1/D / the factor where one wave owns the body (limbs, in
+   // registers); trunk bodies are folded by every wave at its own pace through LDS, so there it gets slots of its own (shared = false).
+   static constexpr int zv_slots_of(int j, bool shared)
+   {
+      return TP::type[j] == JT_REVOLUTE ? (shared ? 9 : 10) : (TP::type[j] == JT_PRISMATIC ? (shared ? 7 : 8) : (TP::type[j] == JT_SIXDOF ? (shared ? 21 : 27) : 0));
+   }
+   static constexpr int zv_result_slot(int j, bool shared)
+   { // first slot of u/D (1-DoF) or IA^-1 u (6-DoF)
+      return TP::type[j] == JT_REVOLUTE ? (shared ? 6 : 9) : (TP::type[j] == JT_PRISMATIC ? (shared ? 6 : 7) : (shared ? 0 : 21));
+   }
    static constexpr int aba_slot(int j)
    {
       int s = 0;
@@ -162,6 +173,10 @@ struct Split
       int trunk_slot[N + 1] = {};
       int reg_slot[N] = {};
       int n_limbs = 0, reg_slots = 0;
+      // the same placement for the bias-split forward dynamics (mh_zv_kernels.h): a 6-DoF joint keeps its LDL^T factor (21) there
+      int zv_trunk_slot[N + 1] = {};
+      int zv_reg_slot[N] = {};
+      int zv_reg_slots = 0;
       bool usable = false;
       // RNEA / CRBA keep the plain greedy assignment; `owner` is the ABA's, phase-aware when the trunk is staged
       int owner_plain[N] = {};
@@ -424,6 +439,19 @@ struct Split
       }
       for (int w = 0; w < WAVES; w++)
          P.reg_slots = regs[w] > P.reg_slots ? regs[w] : P.reg_slots;
+      int zregs[WAVES] = {};
+      for (int j = 0; j < N; j++)
+      {
+         P.zv_trunk_slot[j + 1] = P.zv_trunk_slot[j] + (P.trunk[j] ? TR::zv_slots_of(j, false) : 0);
+         if (!P.trunk[j])
+         {
+            const int w = P.owner[P.limb_of[j]];
+            P.zv_reg_slot[j] = zregs[w];
+            zregs[w] += TR::zv_slots_of(j, true);
+         }
+      }
+      for (int w = 0; w < WAVES; w++)
+         P.zv_reg_slots = zregs[w] > P.zv_reg_slots ? zregs[w] : P.zv_reg_slots;
       return P;
    }
    static constexpr Plan P = make();
@@ -456,6 +484,10 @@ struct Split
    static constexpr int TRUNK_SLOTS = P.trunk_slot[N];
    static constexpr int reg_slot(int j) { return P.reg_slot[j]; }
    static constexpr int reg_slots() { return P.reg_slots; }
+   static constexpr int zv_trunk_slot(int j) { return P.zv_trunk_slot[j]; }
+   static constexpr int ZV_TRUNK_SLOTS = P.zv_trunk_slot[N];
+   static constexpr int zv_reg_slot(int j) { return P.zv_reg_slot[j]; }
+   static constexpr int zv_reg_slots() { return P.zv_reg_slots; }
 };
 
 template <typename T>
@@ -531,7 +563,9 @@ struct LaneStore
 
 // Everything one lane needs to walk the tree.  IO_LDS: state rows staged in LDS.  IDENT: the index maps are the identity
 // (Mecano's default JointMatrixIndexProvider over joints in depth-first order), so every row index is a compile-time constant.
-template <typename T, bool IO_LDS, bool IDENT, class SP, bool BODIES = false>
+// OUTMODE 1 (bias job of the bias-split forward dynamics, mh_zv_kernels.h): out(k, v) leaves in3(k) - v, i.e. with in3 = tau and the
+// accelerations switched off the inverse-dynamics walk writes tau - h(q, qd) instead of h
+template <typename T, bool IO_LDS, bool IDENT, class SP, bool BODIES = false, int OUTMODE = 0>
 struct Ctx
 {
    // BODIES: the kernel also writes every successor body's spatial acceleration / twist (RigidBodyAccelerationProvider; SURVEY.md
@@ -545,7 +579,7 @@ struct Ctx
    T *orow2;     // Coriolis kernel: this configuration's C (orow: its H); entry stride f_es
    long q_es, v_es, f_es;
    lds_ptr<T> lq, lqd, lx, lo; // this lane's rows in LDS (IO_LDS); lo = output row (may alias lx)
-   V3<T> a0l;              // linear part of the root acceleration (-g)
+   V3<T> a0a, a0l;         // angular and linear part of the root acceleration ((0, -g) for a gravity vector)
    int coriolis, accel;
    LaneStore<T, SP> st;
    int nv;                       // CRBA: rows of H
@@ -578,6 +612,8 @@ struct Ctx
    }
    MH_DEV void out(int k, T v) const
    {
+      if constexpr (OUTMODE == 1)
+         v = in3(k) - v;
       if constexpr (IO_LDS)
          lo[di(k)] = v;
       else
@@ -759,7 +795,7 @@ MH_DEV void rnea_roots(const CX &cx)
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       const V3<T> Z{T(0), T(0), T(0)};
-      (void)RneaSub<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
+      (void)RneaSub<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx, SV<T>{Z, Z}, SV<T>{cx.a0a, cx.a0l});
       rnea_roots<TP, T, CX, MODE, K + 1>(cx);
    }
 }
@@ -773,7 +809,7 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
    constexpr int TYPE = TP::type[J];
    constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
    const V3<T> Z{T(0), T(0), T(0)};
-   SV<T> vp{Z, Z}, ap{Z, cx.a0l};
+   SV<T> vp{Z, Z}, ap{cx.a0a, cx.a0l};
    if constexpr (TP::parent[J] >= 0)
       trunk_va<TP, TP::parent[J], T, CX, FK>(cx, vp, ap);
    MH_BODY_FENCE();
@@ -1142,7 +1178,7 @@ MH_DEV void aba_roots_out(const CX &cx)
    if constexpr (K < Tree<TP>::n_children(-1))
    {
       const V3<T> Z{T(0), T(0), T(0)};
-      AbaOut<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx, SV<T>{Z, Z}, SV<T>{Z, cx.a0l});
+      AbaOut<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx, SV<T>{Z, Z}, SV<T>{cx.a0a, cx.a0l});
       aba_roots_out<TP, T, CX, MODE, K + 1>(cx);
    }
 }
@@ -1726,15 +1762,22 @@ MH_DEV void fill_ctx(CX &cx, const Args<T> &A, long cfg)
    cx.bacc = A.body_acc ? A.body_acc + cfg * A.f_bs : nullptr;
    cx.btw = A.body_twist ? A.body_twist + cfg * A.f_bs : nullptr;
    cx.q_es = A.q_es, cx.v_es = A.v_es, cx.f_es = A.f_es;
-   cx.a0l = V3<T>{-A.gx, -A.gy, -A.gz};
+   cx.a0a = V3<T>{A.rax, A.ray, A.raz}, cx.a0l = V3<T>{-A.gx, -A.gy, -A.gz};
    cx.coriolis = A.coriolis, cx.accel = A.accel;
 }
 
-// Touches every 64-byte line of the model constants and index maps with one scalar load each, all in flight together, so
-// that the per-body s_load batches of the walk hit the scalar cache instead of each paying a miss on the way (with one wave
-// per CU nobody else warms it).  Results are discarded.
+// Touches every 64-byte line of the model constants and index maps with one scalar load each, all in flight together, and waits
+// for them.  Round 1 added it so that the per-body s_load batches would hit the scalar cache.  Round 3 measured what it costs with
+// real-time stamps around it (tools/exp_zv_probe.py): 6.4 us per launch on the 25-body humanoid (144 lines; the scalar cache takes its
+// misses a few at a time) -- and the walk behind it is no faster for it (8.3 vs 8.7 us).  Off by default: the fused launch at B = 4096
+// went from 25.9 to 18.1 us per step with this alone.  -DMH_WARM_SCALAR_CACHE=1 brings it back for A/B measurements.
+#ifndef MH_WARM_SCALAR_CACHE
+#define MH_WARM_SCALAR_CACHE 0
+#endif
 MH_DEV void warm_scalar_cache(const void *p, int bytes)
 {
+   if constexpr (!MH_WARM_SCALAR_CACHE)
+      return;
    typedef const int __attribute__((address_space(4))) * cip;
    cip a = (cip)(unsigned long long)p;
    int acc = 0;
@@ -1844,7 +1887,7 @@ MH_DEV void split_rnea_limbs_of(const CX &cx, SV<T> &vp, SV<T> &ap)
          if constexpr (P != PC)
          {
             const V3<T> Z{T(0), T(0), T(0)};
-            vp = SV<T>{Z, Z}, ap = SV<T>{Z, cx.a0l};
+            vp = SV<T>{Z, Z}, ap = SV<T>{cx.a0a, cx.a0l};
             if constexpr (P >= 0)
                trunk_va<TP, P, T, CX, K>(cx, vp, ap);
          }
@@ -2015,8 +2058,13 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
    const int lane = threadIdx.x & 63;
    const int nq = A.m.nq, nv = A.m.nv;
    // LDS map: exchange [n_limbs * XW][64] | trunk hand-over slots [TRUNK_SLOTS][64] (ABA) or parked trunk wrenches [RNEA_TRUNK_SLOTS][64] (RNEA) | [64][nq] q | [64][nv] qd | [64][nv] qdd|tau -> result
+   // Forward dynamics writes its results to rows of their own (lres): every wave reads the trunk's tau entries in its own inward trunk
+   // pass while wave 0, which writes the trunk's accelerations, may already be in its outward sweep -- written in place over tau they
+   // could be read back as efforts by a wave that is late (found in round 3 on the bias-split kernel, where the window is wide; here it
+   // is a few hundred instructions of the root body's step, never observed, closed all the same).  Inverse dynamics keeps writing in
+   // place: an effort is written by the one wave that read the acceleration in that slot.
    const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * XW * 64, lq = lst + (ALGO == 1 ? S::TRUNK_SLOTS : S::RNEA_TRUNK_SLOTS) * 64,
-                    lqd = lq + 64 * nq, lx = lqd + 64 * nv;
+                    lqd = lq + 64 * nq, lx = lqd + 64 * nv, lres = ALGO == 1 && IO_LDS ? lx + 64 * nv : lx;
 #ifdef MH_PROBE // experiment builds: s_memtime stamps per wave and phase, written behind the B * nv results (tools/exp_probe.py)
 #define MH_STAMP(k)                                                                                                                        \
    do                                                                                                                                      \
@@ -2041,7 +2089,7 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
       }
       CX cx;
       fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
-      cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = cx.lx;
+      cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = lres + lane * nv;
       cx.wave = wave;
       cx.xbase = lxc + lane;
       cx.st.lbase = lst + lane;
@@ -2084,7 +2132,7 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
          { // fused simulation step: q, qd and the fresh qdd rows of the 64 configurations all sit in LDS -- integrate them in place
            // (MultiBodySystemStateIntegrator.java:365-441, 503-575, 710-733) and stream the new state out with the accelerations
             if (lane < rows)
-               integrate_rows<TP, 0, T>(wave, lq + lane * nq, lqd + lane * nv, lx + lane * nv, A.dt, T(0.5) * A.dt * A.dt);
+               integrate_rows<TP, 0, T>(wave, lq + lane * nq, lqd + lane * nv, lres + lane * nv, A.dt, T(0.5) * A.dt * A.dt);
             __syncthreads();
             wave_copy_out<T, 256>(A.q_next + cfg0 * nq, lq, rows * nq);
             wave_copy_out<T, 256>(A.qd_next + cfg0 * nv, lqd, rows * nv);
@@ -2092,7 +2140,7 @@ MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> l
       }
       if constexpr (IO_LDS)
       {
-         wave_copy_out<T, 256>(A.out + cfg0 * nv, lx, rows * nv);
+         wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
          __syncthreads();
       }
       MH_STAMP(7);
@@ -2418,7 +2466,7 @@ __global__ void __launch_bounds__(64) spec_centroidal_kernel(CentArgs<T> A)
       cx.qdrow = WITH_B ? A.qd + cfg * A.v_bs : nullptr;
       cx.in3row = nullptr, cx.frow = nullptr, cx.orow = nullptr, cx.orow2 = nullptr;
       cx.q_es = A.q_es, cx.v_es = A.v_es, cx.f_es = 0;
-      cx.a0l = Z;
+      cx.a0a = Z, cx.a0l = Z;
       cx.coriolis = 1, cx.accel = 0;
       cx.nv = nv, cx.wave = 0;
       cx.xf.R = M3<T>{A.fR[0], A.fR[1], A.fR[2], A.fR[3], A.fR[4], A.fR[5], A.fR[6], A.fR[7], A.fR[8]};

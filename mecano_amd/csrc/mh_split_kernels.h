@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
          if (parent < 0)
          {
             vp = SV<T>{Z, Z};
-            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :343-348
+            ap = root_acceleration(A); // :343-348
          }
          else if (flags & MF_PARENT_ADJ)
             vp = v_prev, ap = a_prev;
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
          const CRef<T, false> c{CB + j * MC_STRIDE};
          SV<T> ap;
          if (parent < 0)
-            ap = SV<T>{Z, V3<T>{-A.gx, -A.gy, -A.gz}}; // :259-264
+            ap = root_acceleration(A); // :259-264
          else if (flags & MF_PARENT_ADJ)
             ap = a_prev;
          else

@@ -1,0 +1,659 @@
+// mh_zv_kernels.h -- bias-split forward dynamics for the tree-split code objects (gfx950).
+//
+// ForwardDynamicsCalculator.java:1085-1310 in one wave per limb is a chain of heavy body steps, and every step carries the velocity-
+// dependent terms (v, c = v x vJ, p = v x* I v, Ia c) next to the 6 x 6 congruence of the articulated inertia.  The accelerations are
+//     qdd = H(q)^-1 (tau - h(q, qd)),        h = inverse dynamics at zero acceleration (gravity and external wrenches included),
+// and the articulated inertias depend on q alone.  So the work is cut into two jobs that run SIDE BY SIDE on different workgroups:
+//
+//   bias job  (4 waves)  tau' = tau - RNEA(q, qd, 0, g, f_ext): the tree-split inverse dynamics of mh_spec_kernels.h with the
+//                        accelerations switched off, written to a scratch matrix and published with a release flag per 64 configurations;
+//   inertia job (4 waves) pass two of the reference WITHOUT bias terms (IA, U, D^-1 per body; :1146-1235 with p = c = 0), then -- once
+//                        the flag is up -- the bias fold (pA' = sum X* pa'_c, u = tau' - S^T pA', pa' = pA' + U D^-1 u; 6-vectors only)
+//                        and pass three from a zero root acceleration (:1263-1305 with c = 0: gravity already sits in h).
+//
+// The serial chain of the inertia job loses the velocity terms (a third of its fp64 instructions and ~100 registers of live state); the
+// bias job is as long as an inverse dynamics call and finishes first, so the flag is normally up when the inertia job asks for it.
+// A third job of the same launch computes the inverse dynamics output of mh_rnea_aba_f64.
+//
+// Deadlock freedom: a consumer workgroup spins only on the flag of a producer with a LOWER workgroup id (dispatched earlier, never
+// waiting for anything itself); the spin is bounded by a wall-clock limit after which the launch reports an error instead of hanging.
+#pragma once
+#include "mh_spec_kernels.h"
+
+namespace mh
+{
+template <class TP>
+struct ZvStore
+{
+   static constexpr int REG_SLOTS = Split<TP>::zv_reg_slots();
+   static constexpr int kind(int j) { return Split<TP>::is_trunk(j) ? ST_LDS_KIND : ST_REG_KIND; }
+   static constexpr int index(int j) { return Split<TP>::is_trunk(j) ? Split<TP>::zv_trunk_slot(j) : Split<TP>::zv_reg_slot(j); }
+};
+#ifdef MH_ZV_PROBE // experiment builds: 100 MHz real-time stamps per group, job, wave and phase (tools/exp_zv_probe.py)
+__device__ unsigned long long zv_probe[4096 * 3 * 4 * 16];
+#define ZV_STAMP(job, ph)                                                                                                                  \
+   do                                                                                                                                      \
+   {                                                                                                                                       \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                                      \
+      if ((threadIdx.x & 63) == 0 && k < 4096)                                                                                             \
+         zv_probe[((k * 3 + (job)) * 4 + (threadIdx.x >> 6)) * 16 + (ph)] = t_;                                                            \
+   } while (0)
+#else
+#define ZV_STAMP(job, ph)
+#endif
+constexpr int ZV_XW = 21; // limb -> trunk exchange record: the articulated inertia (A 6, L 6, C 9); the bias fold reuses its first 6 slots
+
+template <int LIMB, class CX, typename T>
+MH_DEV void x_put_ia(const CX &cx, const ABI<T> &I)
+{
+   constexpr int XW = ZV_XW;
+   x_put<LIMB, XW, 0, CX, T>(cx, I.A.xx), x_put<LIMB, XW, 1, CX, T>(cx, I.A.xy), x_put<LIMB, XW, 2, CX, T>(cx, I.A.xz);
+   x_put<LIMB, XW, 3, CX, T>(cx, I.A.yy), x_put<LIMB, XW, 4, CX, T>(cx, I.A.yz), x_put<LIMB, XW, 5, CX, T>(cx, I.A.zz);
+   x_put<LIMB, XW, 6, CX, T>(cx, I.L.xx), x_put<LIMB, XW, 7, CX, T>(cx, I.L.xy), x_put<LIMB, XW, 8, CX, T>(cx, I.L.xz);
+   x_put<LIMB, XW, 9, CX, T>(cx, I.L.yy), x_put<LIMB, XW, 10, CX, T>(cx, I.L.yz), x_put<LIMB, XW, 11, CX, T>(cx, I.L.zz);
+   x_put<LIMB, XW, 12, CX, T>(cx, I.C.xx), x_put<LIMB, XW, 13, CX, T>(cx, I.C.xy), x_put<LIMB, XW, 14, CX, T>(cx, I.C.xz);
+   x_put<LIMB, XW, 15, CX, T>(cx, I.C.yx), x_put<LIMB, XW, 16, CX, T>(cx, I.C.yy), x_put<LIMB, XW, 17, CX, T>(cx, I.C.yz);
+   x_put<LIMB, XW, 18, CX, T>(cx, I.C.zx), x_put<LIMB, XW, 19, CX, T>(cx, I.C.zy), x_put<LIMB, XW, 20, CX, T>(cx, I.C.zz);
+}
+template <int LIMB, class CX, typename T>
+MH_DEV ABI<T> x_get_ia(const CX &cx)
+{
+   constexpr int XW = ZV_XW;
+   ABI<T> I;
+   I.A = S3<T>{x_get<LIMB, XW, 0, CX, T>(cx), x_get<LIMB, XW, 1, CX, T>(cx), x_get<LIMB, XW, 2, CX, T>(cx),
+               x_get<LIMB, XW, 3, CX, T>(cx), x_get<LIMB, XW, 4, CX, T>(cx), x_get<LIMB, XW, 5, CX, T>(cx)};
+   I.L = S3<T>{x_get<LIMB, XW, 6, CX, T>(cx), x_get<LIMB, XW, 7, CX, T>(cx), x_get<LIMB, XW, 8, CX, T>(cx),
+               x_get<LIMB, XW, 9, CX, T>(cx), x_get<LIMB, XW, 10, CX, T>(cx), x_get<LIMB, XW, 11, CX, T>(cx)};
+   I.C = M3<T>{x_get<LIMB, XW, 12, CX, T>(cx), x_get<LIMB, XW, 13, CX, T>(cx), x_get<LIMB, XW, 14, CX, T>(cx),
+               x_get<LIMB, XW, 15, CX, T>(cx), x_get<LIMB, XW, 16, CX, T>(cx), x_get<LIMB, XW, 17, CX, T>(cx),
+               x_get<LIMB, XW, 18, CX, T>(cx), x_get<LIMB, XW, 19, CX, T>(cx), x_get<LIMB, XW, 20, CX, T>(cx)};
+   return I;
+}
+template <typename T>
+MH_DEV ABI<T> abi_zero()
+{
+   ABI<T> z;
+   z.A = S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)};
+   z.L = z.A;
+   z.C = M3<T>{T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+   return z;
+}
+template <int J, int K0, class CX, typename T>
+MH_DEV void st_put_ldl(const CX &cx, const LDL6<T> &F)
+{ // 21 hand-over slots of a 6-DoF body
+   cx.st.template put<J, 0>(F.f[0]), cx.st.template put<J, 1>(F.f[1]), cx.st.template put<J, 2>(F.f[2]), cx.st.template put<J, 3>(F.f[3]);
+   cx.st.template put<J, 4>(F.f[4]), cx.st.template put<J, 5>(F.f[5]), cx.st.template put<J, 6>(F.f[6]), cx.st.template put<J, 7>(F.f[7]);
+   cx.st.template put<J, 8>(F.f[8]), cx.st.template put<J, 9>(F.f[9]), cx.st.template put<J, 10>(F.f[10]), cx.st.template put<J, 11>(F.f[11]);
+   cx.st.template put<J, 12>(F.f[12]), cx.st.template put<J, 13>(F.f[13]), cx.st.template put<J, 14>(F.f[14]), cx.st.template put<J, 15>(F.f[15]);
+   cx.st.template put<J, 16>(F.f[16]), cx.st.template put<J, 17>(F.f[17]), cx.st.template put<J, 18>(F.f[18]), cx.st.template put<J, 19>(F.f[19]);
+   cx.st.template put<J, 20>(F.f[20]);
+}
+template <int J, class CX, typename T>
+MH_DEV LDL6<T> st_get_ldl(const CX &cx)
+{
+   LDL6<T> F;
+   F.f[0] = cx.st.template get<J, 0>(), F.f[1] = cx.st.template get<J, 1>(), F.f[2] = cx.st.template get<J, 2>(), F.f[3] = cx.st.template get<J, 3>();
+   F.f[4] = cx.st.template get<J, 4>(), F.f[5] = cx.st.template get<J, 5>(), F.f[6] = cx.st.template get<J, 6>(), F.f[7] = cx.st.template get<J, 7>();
+   F.f[8] = cx.st.template get<J, 8>(), F.f[9] = cx.st.template get<J, 9>(), F.f[10] = cx.st.template get<J, 10>(), F.f[11] = cx.st.template get<J, 11>();
+   F.f[12] = cx.st.template get<J, 12>(), F.f[13] = cx.st.template get<J, 13>(), F.f[14] = cx.st.template get<J, 14>(), F.f[15] = cx.st.template get<J, 15>();
+   F.f[16] = cx.st.template get<J, 16>(), F.f[17] = cx.st.template get<J, 17>(), F.f[18] = cx.st.template get<J, 18>(), F.f[19] = cx.st.template get<J, 19>();
+   F.f[20] = cx.st.template get<J, 20>();
+   return F;
+}
+
+// ---- inward sweep without bias terms (ForwardDynamicsCalculator.java:1146-1235 with p = c = 0): returns the articulated inertia the
+//      subtree hands to its parent, in the parent's frame.  MODE as in AbaIn: 0 whole subtree, 1 trunk pass (limb roots come from the
+//      exchange area), 2 the root body alone of a staged trunk, 3 a late limb carrying the workgroup's first barrier.
+template <class TP, int J, typename T, class CX, int MODE = 0>
+struct ZvIn
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx, ABI<T> &acc)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         constexpr int C = Tree<TP>::child(J, K);
+         ABI<T> c;
+         if constexpr ((MODE == 1 || MODE == 2) && !Split<TP>::is_trunk(C))
+            c = x_get_ia<Split<TP>::limb_index(C), CX, T>(cx);
+         else if constexpr (MODE == 2)
+            c = x_get_ia<Split<TP>::sub_slot(C), CX, T>(cx);
+         else
+            c = ZvIn<TP, C, T, CX, MODE>::run(cx);
+         if constexpr (K == 0)
+            acc = c;
+         else
+            add(acc, c);
+         children<K + 1>(cx, acc);
+      }
+   }
+   static MH_DEV ABI<T> run(const CX &cx)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr bool HAS_PARENT = TP::parent[J] >= 0;
+      constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
+      constexpr int CO = Tree<TP>::cfg_ofs(J);
+      ABI<T> up = abi_zero<T>();
+      if constexpr (!LEAF)
+         children<0>(cx, up);
+      if constexpr (MODE == 3 && Split<TP>::is_cut(J))
+         __syncthreads(); // barrier 1 of the staged trunk: the early limbs of every wave are in the exchange area
+      MH_BODY_FENCE();
+      const T *cp = cx.C + J * MC_STRIDE;
+      asm volatile("" : "+s"(cp)); // the constants are read where they are used, never kept across a subtree
+      const CRef<T, false> c{cp};
+      const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
+      const RI<T> I = load_inertia<T>(c);
+      const XF<T> Xb = load_xb_j<TP, J, T>(c);
+      MH_BODY_FENCE();
+      const JX<T> jx = spec_joint_from<TYPE, T>(jq);
+      ABI<T> IA = abi_from_rigid(I);
+      if constexpr (!LEAF)
+         add(IA, up);
+      ABI<T> out = abi_zero<T>();
+      if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+      {
+         V3<T> ua, ul;
+         T D;
+         if constexpr (TYPE == JT_REVOLUTE)
+            ua = V3<T>{IA.A.xz, IA.A.yz, IA.A.zz}, ul = V3<T>{IA.C.zx, IA.C.zy, IA.C.zz}, D = IA.A.zz;
+         else
+            ua = V3<T>{IA.C.xz, IA.C.yz, IA.C.zz}, ul = V3<T>{IA.L.xz, IA.L.yz, IA.L.zz}, D = IA.L.zz;
+         const T dinv = T(1) / D;
+         const V3<T> sa = dinv * ua, sl = dinv * ul;
+         cx.st.template put<J, 0>(sa.x), cx.st.template put<J, 1>(sa.y), cx.st.template put<J, 2>(sa.z);
+         cx.st.template put<J, 3>(sl.x), cx.st.template put<J, 4>(sl.y), cx.st.template put<J, 5>(sl.z);
+         cx.st.template put<J, 6>(dinv);
+         if constexpr (TYPE == JT_REVOLUTE)
+         {
+            cx.st.template put<J, 7>(jx.c);
+            cx.st.template put<J, 8>(jx.s);
+         }
+         if constexpr (HAS_PARENT)
+         {
+            if constexpr (TYPE == JT_REVOLUTE)
+               rank1_down_revolute(IA, ua, ul, dinv);
+            else
+               rank1_down(IA, ua, ul, dinv);
+            abi_up(TYPE, jx, Xb, IA);
+            out = IA;
+         }
+      }
+      else if constexpr (TYPE == JT_SIXDOF)
+         st_put_ldl<J, 0, CX, T>(cx, spd6_factor(IA)); // S = 1: U = D = IA, nothing is left for the parent (Ia = 0)
+      else if constexpr (HAS_PARENT)
+      { // fixed joint
+         abi_up(TYPE, jx, Xb, IA);
+         out = IA;
+      }
+      MH_BODY_FENCE();
+      return out;
+   }
+};
+
+// ---- the bias fold: pA' = sum over the children of X* pa'_c;  u = tau' - S^T pA';  pa' = pA' + U D^-1 u  (:1224-1235 with c = 0).
+//      Returns pa' in the parent's frame.  MODE 0: whole subtree; 1: trunk pass, limb roots come from the exchange area.
+template <class TP, int J, typename T, class CX, int MODE = 0>
+struct ZvFold
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx, SV<T> &pA)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         constexpr int C = Tree<TP>::child(J, K);
+         SV<T> c;
+         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+            c = x_get6<Split<TP>::limb_index(C), ZV_XW, 0, CX, T>(cx);
+         else
+            c = ZvFold<TP, C, T, CX, MODE>::run(cx);
+         if constexpr (K == 0)
+            pA = c;
+         else
+            pA = pA + c;
+         children<K + 1>(cx, pA);
+      }
+   }
+   static MH_DEV SV<T> run(const CX &cx)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr bool HAS_PARENT = TP::parent[J] >= 0;
+      constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
+      constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
+      constexpr int RS = Tree<TP>::zv_result_slot(J, !Split<TP>::is_trunk(J));
+      const V3<T> Z{T(0), T(0), T(0)};
+      SV<T> pA{Z, Z};
+      if constexpr (!LEAF)
+         children<0>(cx, pA);
+      MH_BODY_FENCE();
+      const T *cp = cx.C + J * MC_STRIDE;
+      asm volatile("" : "+s"(cp));
+      const CRef<T, false> c{cp};
+      SV<T> up{Z, Z};
+      if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+      {
+         const T tau = cx.in3(DO);
+         JX<T> jx;
+         jx.c = T(1), jx.s = T(0), jx.d = T(0);
+         if constexpr (TYPE == JT_REVOLUTE)
+            jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>();
+         else if constexpr (HAS_PARENT)
+            jx.d = cx.q(CO);
+         const V3<T> sa{cx.st.template get<J, 0>(), cx.st.template get<J, 1>(), cx.st.template get<J, 2>()};
+         const V3<T> sl{cx.st.template get<J, 3>(), cx.st.template get<J, 4>(), cx.st.template get<J, 5>()};
+         const T dinv = cx.st.template get<J, 6>();
+         const T u = tau - (TYPE == JT_REVOLUTE ? pA.a.z : pA.l.z);
+         cx.st.template put<J, RS>(u * dinv);
+         if constexpr (HAS_PARENT)
+         {
+            const XF<T> Xb = load_xb_j<TP, J, T>(c);
+            const SV<T> pa = pA + SV<T>{u * sa, u * sl};
+            up = force_up(TYPE, jx, Xb, pa);
+         }
+      }
+      else if constexpr (TYPE == JT_SIXDOF)
+      {
+         const SV<T> tau = spec_vec<TYPE, DO, 1, CX, T>(cx, true);
+         const SV<T> x = spd6_solve(st_get_ldl<J, CX, T>(cx), tau - pA);
+         cx.st.template put<J, RS + 0>(x.a.x), cx.st.template put<J, RS + 1>(x.a.y), cx.st.template put<J, RS + 2>(x.a.z);
+         cx.st.template put<J, RS + 3>(x.l.x), cx.st.template put<J, RS + 4>(x.l.y), cx.st.template put<J, RS + 5>(x.l.z);
+         if constexpr (HAS_PARENT)
+         {
+            const JX<T> jx = spec_joint<TYPE, CO, CX, T>(cx);
+            up = force_up(TYPE, jx, load_xb_j<TP, J, T>(c), tau); // Ia = 0, pa = tau
+         }
+      }
+      else if constexpr (HAS_PARENT)
+      {
+         JX<T> jx;
+         jx.c = T(1), jx.s = T(0), jx.d = T(0);
+         up = force_up(TYPE, jx, load_xb_j<TP, J, T>(c), pA);
+      }
+      MH_BODY_FENCE();
+      return up;
+   }
+};
+
+// ---- outward sweep from a zero root acceleration (:1263-1305 with c = 0).  MODE 1: a limb hanging off this trunk body is continued
+//      only by the wave that owns it; the trunk itself is walked by every wave, its outputs written by wave 0.
+template <class TP, int J, typename T, class CX, int MODE = 0>
+struct ZvOut
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx, const SV<T> &a)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         constexpr int C = Tree<TP>::child(J, K);
+         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+         {
+            if (cx.wave == Split<TP>::owner(Split<TP>::limb_index(C)))
+               ZvOut<TP, C, T, CX, 0>::run(cx, a);
+         }
+         else
+            ZvOut<TP, C, T, CX, MODE>::run(cx, a);
+         children<K + 1>(cx, a);
+      }
+   }
+   static MH_DEV void run(const CX &cx, const SV<T> &ap)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr bool HAS_PARENT = TP::parent[J] >= 0;
+      constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
+      constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
+      constexpr int RS = Tree<TP>::zv_result_slot(J, !Split<TP>::is_trunk(J));
+      const T *cp = cx.C + J * MC_STRIDE;
+      asm volatile("" : "+s"(cp));
+      const CRef<T, false> c{cp};
+      const V3<T> Z{T(0), T(0), T(0)};
+      SV<T> a{Z, Z};
+      if constexpr (HAS_PARENT)
+      {
+         JX<T> jx;
+         jx.c = T(1), jx.s = T(0), jx.d = T(0);
+         if constexpr (TYPE == JT_REVOLUTE)
+            jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>();
+         else if constexpr (TYPE != JT_FIXED)
+            jx = spec_joint<TYPE, CO, CX, T>(cx);
+         a = motion_down(TYPE, jx, load_xb_j<TP, J, T>(c), ap);
+      }
+      if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+      {
+         const V3<T> sa{cx.st.template get<J, 0>(), cx.st.template get<J, 1>(), cx.st.template get<J, 2>()};
+         const V3<T> sl{cx.st.template get<J, 3>(), cx.st.template get<J, 4>(), cx.st.template get<J, 5>()};
+         const T qdd = cx.st.template get<J, RS>() - (dot(sa, a.a) + dot(sl, a.l));
+         if (MODE == 0 || cx.wave == 0)
+            cx.out(DO, qdd);
+         if constexpr (TYPE == JT_REVOLUTE)
+            a.a.z += qdd;
+         else
+            a.l.z += qdd;
+      }
+      else if constexpr (TYPE == JT_SIXDOF)
+      {
+         const SV<T> x{V3<T>{cx.st.template get<J, RS + 0>(), cx.st.template get<J, RS + 1>(), cx.st.template get<J, RS + 2>()},
+                       V3<T>{cx.st.template get<J, RS + 3>(), cx.st.template get<J, RS + 4>(), cx.st.template get<J, RS + 5>()}};
+         if (MODE == 0 || cx.wave == 0)
+            spec_write<TYPE, DO, CX, T>(cx, x - a);
+         a = x;
+      }
+      MH_BODY_FENCE();
+      if constexpr (!LEAF)
+         children<0>(cx, a);
+   }
+};
+
+template <class TP, typename T, class CX, int MODE, int K = 0>
+MH_DEV void zv_roots_in(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      (void)ZvIn<TP, Tree<TP>::child(-1, K), T, CX, MODE>::run(cx);
+      zv_roots_in<TP, T, CX, MODE, K + 1>(cx);
+   }
+}
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void zv_roots_fold(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      (void)ZvFold<TP, Tree<TP>::child(-1, K), T, CX, 1>::run(cx);
+      zv_roots_fold<TP, T, CX, K + 1>(cx);
+   }
+}
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void zv_roots_out(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      const V3<T> Z{T(0), T(0), T(0)};
+      ZvOut<TP, Tree<TP>::child(-1, K), T, CX, 1>::run(cx, SV<T>{Z, Z});
+      zv_roots_out<TP, T, CX, K + 1>(cx);
+   }
+}
+// the limbs of wave W: LATE = -1 all of them (plain split), 0 / 1 the early / late ones of a staged trunk
+template <class TP, int W, int K, int LATE, typename T, class CX>
+MH_DEV void zv_limbs_in_of(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if constexpr (S::owner(K) == W && (LATE < 0 || (S::is_late(K) ? 1 : 0) == LATE))
+         x_put_ia<K, CX, T>(cx, ZvIn<TP, S::limb_root(K), T, CX, (LATE >= 0 && S::cut_limb(W) == K ? 3 : 0)>::run(cx));
+      zv_limbs_in_of<TP, W, K + 1, LATE, T, CX>(cx);
+   }
+}
+template <class TP, int W, int I, typename T, class CX>
+MH_DEV void zv_subtrunks_of(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (I < S::n_sub())
+   {
+      constexpr int ST = S::sub_top(I);
+      if constexpr (S::sub_owner(ST) == W)
+         x_put_ia<S::sub_slot(ST), CX, T>(cx, ZvIn<TP, ST, T, CX, 1>::run(cx));
+      zv_subtrunks_of<TP, W, I + 1, T, CX>(cx);
+   }
+}
+// limb phases of the inward sweep, wave by wave; a staged trunk passes its first barrier in here exactly once per wave
+template <class TP, int W, typename T, class CX>
+MH_DEV void zv_limbs_in(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+      {
+         if constexpr (S::staged())
+         {
+            zv_limbs_in_of<TP, W, 0, 0, T, CX>(cx);
+            if constexpr (S::cut_limb(W) < 0)
+               __syncthreads();
+            zv_limbs_in_of<TP, W, 0, 1, T, CX>(cx);
+            zv_subtrunks_of<TP, W, 0, T, CX>(cx);
+         }
+         else
+            zv_limbs_in_of<TP, W, 0, -1, T, CX>(cx);
+      }
+      else
+         zv_limbs_in<TP, W + 1, T, CX>(cx);
+   }
+}
+template <class TP, int W, int K, typename T, class CX>
+MH_DEV void zv_limbs_fold_of(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if constexpr (S::owner(K) == W)
+         x_put6<K, ZV_XW, 0, CX, T>(cx, ZvFold<TP, S::limb_root(K), T, CX, 0>::run(cx));
+      zv_limbs_fold_of<TP, W, K + 1, T, CX>(cx);
+   }
+}
+template <class TP, int W, typename T, class CX>
+MH_DEV void zv_limbs_fold(const CX &cx)
+{
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+         zv_limbs_fold_of<TP, W, 0, T, CX>(cx);
+      else
+         zv_limbs_fold<TP, W + 1, T, CX>(cx);
+   }
+}
+
+// rows of one matrix, global -> LDS, all NT threads of the workgroup (N entries per configuration, `rows` configurations)
+template <typename T, int N, int NT>
+MH_DEV void zv_stage_rows(lds_ptr<T> dst, const T *src, int rows)
+{
+   constexpr int U = (64 * N + NT - 1) / NT;
+   T r[U];
+   const int n = rows * N, t = threadIdx.x;
+#pragma unroll
+   for (int u = 0; u < U; u++)
+      r[u] = t + NT * u < n ? src[t + NT * u] : T(0);
+#pragma unroll
+   for (int u = 0; u < U; u++)
+      if (t + NT * u < 64 * N)
+         dst[t + NT * u] = r[u];
+}
+
+struct ZvSync
+{
+   int *flags;     // one per 64 configurations; the bias job stores `epoch` there once its rows are in memory
+   int *error;     // set to 1 when an inertia job gave up waiting (wall-clock limit): the host turns it into MH_ERR_HIP
+   int epoch;
+   int jobs;       // 2: bias + inertia (mh_aba_f64); 3: + the inverse dynamics of mh_rnea_aba_f64
+};
+constexpr unsigned long long ZV_WAIT_TICKS = 20000000ull; // 0.2 s of the 100 MHz real-time counter
+
+// The hand-off follows the one form MI355X_MICROARCH.md lists as valid without agent-scope fences (a release fence writes back the whole
+// L2: 7-11 us measured here; an acquire fence invalidates it): every byte of the bias rows is stored sc1 (write-through) and loaded sc1
+// (served past the L1), every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier behind which ONE lane
+// stores the flag sc1, and the consumer's polling wave joins a workgroup barrier before any wave loads the rows.
+// Returns once the flag of group k holds this launch's epoch, or after the wall-clock limit.
+MH_DEV void zv_wait(const ZvSync &sy, long k)
+{
+   const int *f = sy.flags + k;
+   if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sy.epoch)
+      return;
+   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+   for (;;)
+   {
+      __builtin_amdgcn_s_sleep(1);
+      if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sy.epoch)
+         return;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > ZV_WAIT_TICKS)
+      {
+         if ((threadIdx.x & 63) == 0)
+            __hip_atomic_store(sy.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         return;
+      }
+   }
+}
+// rows of one matrix, LDS -> global, write-through (sc1), all NT threads
+template <typename T, int NT>
+MH_DEV void zv_publish_rows(T *dst, lds_ptr<T> src, int n)
+{
+   for (int i = threadIdx.x; i < n; i += NT)
+      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// rows of one matrix, global -> LDS, every load sc1 (past the L1), all NT threads
+template <typename T, int N, int NT>
+MH_DEV void zv_fetch_rows(lds_ptr<T> dst, const T *src, int rows)
+{
+   constexpr int U = (64 * N + NT - 1) / NT;
+   T r[U];
+   const int n = rows * N, t = threadIdx.x;
+#pragma unroll
+   for (int u = 0; u < U; u++)
+      r[u] = t + NT * u < n ? __hip_atomic_load(src + t + NT * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+#pragma unroll
+   for (int u = 0; u < U; u++)
+      if (t + NT * u < 64 * N)
+         dst[t + NT * u] = r[u];
+}
+
+// bias job of group k: taup rows = tau - RNEA(q, qd, 0); A.in3 = tau
+template <class TP, typename T, bool IDENT>
+MH_DEV void zv_bias_group(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, const ZvSync &sy)
+{
+   using S = Split<TP>;
+   using CX = Ctx<T, true, IDENT, SplitStore<TP>, false, 1>;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const int nq = A.m.nq, nv = A.m.nv;
+   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * 6 * 64, lq = lst + S::RNEA_TRUNK_SLOTS * 64, lqd = lq + 64 * nq, lx = lqd + 64 * nv;
+   ZV_STAMP(0, 14);
+   const long cfg0 = k * 64;
+   const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+   const bool active = lane < rows;
+   ZV_STAMP(0, 0);
+   wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
+   __syncthreads();
+   ZV_STAMP(0, 1);
+   CX cx;
+   fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+   cx.coriolis = 1, cx.accel = 0;
+   cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = cx.lx;
+   cx.wave = wave;
+   cx.xbase = lxc + lane;
+   cx.st.lbase = lst + lane;
+   cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+   if (active)
+      split_rnea_limbs<TP, 0, T, CX>(cx);
+   ZV_STAMP(0, 2);
+   __syncthreads();
+   ZV_STAMP(0, 3);
+   if (active && wave == 0)
+      rnea_trunk_roots<TP, T, CX>(cx);
+   ZV_STAMP(0, 4);
+   __syncthreads();
+   zv_publish_rows<T, 256>(taup + cfg0 * nv, lx, rows * nv);
+   ZV_STAMP(0, 5);
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have been acknowledged ...
+   ZV_STAMP(0, 6);
+   __syncthreads();
+   if (threadIdx.x == 0) // ... so the flag, stored behind the barrier, is never seen ahead of them
+      __hip_atomic_store(sy.flags + k, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   ZV_STAMP(0, 7);
+}
+
+// inertia job of group k: qdd rows from q and the bias rows; A.out = qdd
+template <class TP, typename T, bool IDENT>
+MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup, const ZvSync &sy)
+{
+   using S = Split<TP>;
+   using CX = Ctx<T, true, IDENT, ZvStore<TP>>;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const int nq = A.m.nq, nv = A.m.nv;
+   // LDS map: exchange [n_limbs * 21][64] | trunk hand-over slots [ZV_TRUNK_SLOTS][64] | [64][nq] q | [64][nv] tau' | [64][nv] qdd.
+   // The results get rows of their own: every wave folds the trunk at its own pace, reading the trunk's tau' entries, while wave 0 --
+   // which writes the trunk's accelerations -- may already be in its outward sweep (written in place they raced: seen as wrong limb
+   // accelerations of the other waves on a tree whose wave 0 is the first to finish its fold).
+   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * ZV_XW * 64, lq = lst + S::ZV_TRUNK_SLOTS * 64, lx = lq + 64 * nq, lres = lx + 64 * nv;
+   ZV_STAMP(1, 14);
+   const long cfg0 = k * 64;
+   const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+   const bool active = lane < rows;
+   ZV_STAMP(1, 0);
+   zv_stage_rows<T, Tree<TP>::total_cfgs(), 256>(lq, A.q + cfg0 * nq, rows);
+   __syncthreads();
+   ZV_STAMP(1, 1);
+   CX cx;
+   fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+   cx.lq = lq + lane * nq, cx.lqd = lq, cx.lx = lx + lane * nv, cx.lo = lres + lane * nv;
+   cx.wave = wave;
+   cx.xbase = lxc + lane;
+   cx.st.lbase = lst + lane;
+   cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+   if (active) // (lane 0 of every wave is active, so each wave reaches the barrier a staged trunk carries in here)
+      zv_limbs_in<TP, 0, T, CX>(cx);
+   ZV_STAMP(1, 2);
+   __syncthreads(); // every limb's (and sub-trunk's) articulated inertia is in the exchange area
+   ZV_STAMP(1, 3);
+   if (active)
+      zv_roots_in<TP, T, CX, (S::staged() ? 2 : 1)>(cx);
+   ZV_STAMP(1, 4);
+   if (wave == 0)
+      zv_wait(sy, k);
+   __syncthreads(); // the polling wave has seen the flag: now every wave may load the rows
+   ZV_STAMP(1, 5);
+   zv_fetch_rows<T, Tree<TP>::total_dofs(), 256>(lx, taup + cfg0 * nv, rows);
+   __syncthreads(); // bias rows staged; nobody reads the exchange area's inertias any more
+   ZV_STAMP(1, 6);
+   asm volatile("" ::: "memory");
+   if (active)
+      zv_limbs_fold<TP, 0, T, CX>(cx);
+   ZV_STAMP(1, 7);
+   __syncthreads(); // every limb's bias wrench is in the exchange area
+   ZV_STAMP(1, 8);
+   if (active)
+   {
+      zv_roots_fold<TP, T, CX>(cx);
+      ZV_STAMP(1, 9);
+      asm volatile("" ::: "memory");
+      zv_roots_out<TP, T, CX>(cx);
+   }
+   ZV_STAMP(1, 10);
+   __syncthreads();
+   wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
+   ZV_STAMP(1, 11);
+}
+
+// One launch, jobs * ceil(B / 64) workgroups (padded to blocks of eight): blocks of eight consecutive workgroup ids share a role, so
+// the bias job, the inertia job (and the inverse dynamics job) of the same 64 configurations have ids that differ by a multiple of
+// eight -- the dispatcher deals ids round-robin to the eight XCDs, which puts them behind the same L2 -- and the producer's id is lower.
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(256) spec_zv_kernel(Args<T> A, T *taup, ZvSync sy)
+{
+   extern __shared__ double lds_raw[];
+   const int blk = (int)blockIdx.x;
+   const int role = (blk >> 3) % sy.jobs;
+   const long k = (long)(blk / (8 * sy.jobs)) * 8 + (blk & 7);
+   if (k * 64 >= A.B)
+      return;
+   ZV_STAMP(role, 15);
+   if (role == 0)
+   {
+      Args<T> A2 = A;
+      A2.in3 = A.in3b;
+      zv_bias_group<TP, T, IDENT>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
+   }
+   else if (role == 1)
+   {
+      Args<T> A2 = A;
+      A2.out = A.outb;
+      zv_aba_group<TP, T, IDENT>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
+   }
+   else
+   {
+      split_group<TP, T, 0, IDENT, true>(A, k, (A.B + 63) / 64, (lds_ptr<T>)lds_raw);
+      ZV_STAMP(2, 1);
+   }
+}
+} // namespace mh

@@ -59,14 +59,28 @@ class HipModel:
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
-    def _options(layout, consider_coriolis=True, consider_accelerations=True, stream=None):
+    def _options(layout, consider_coriolis=True, consider_accelerations=True, stream=None, root_acceleration=None):
         o = _lib.MhOptions()
         o.consider_coriolis = int(bool(consider_coriolis))
         o.consider_accelerations = int(bool(consider_accelerations))
         o.layout = int(layout)
-        o.reserved0 = 0
+        o.use_root_acceleration = 0 if root_acceleration is None else 1
         o.stream = stream
+        for k in range(6):
+            o.root_acceleration[k] = 0.0 if root_acceleration is None else float(root_acceleration[k])
         return o
+
+    @staticmethod
+    def _root(gravity):
+        """The `gravity` argument of the compute calls: a 3-vector g (the root body accelerates with (0, -g): setGravity,
+        InverseDynamicsCalculator.java:318-348) or a 6-vector, the root's spatial acceleration itself, angular then linear
+        (setRootAcceleration, InverseDynamicsCalculator.java:413-427; mh_options.root_acceleration).  Returns (g[3] for the C call, the 6 or None)."""
+        a = [float(v) for v in np.asarray(gravity, dtype=np.float64).reshape(-1)]
+        if len(a) == 6:
+            return (ctypes.c_double * 3)(0.0, 0.0, 0.0), a
+        if len(a) != 3:
+            raise _lib.MecanoHipError(2, f"gravity must have 3 entries (or 6: a root acceleration), got {len(a)}")
+        return (ctypes.c_double * 3)(*a), None
 
     @staticmethod
     def _is_torch(x):
@@ -91,7 +105,7 @@ class HipModel:
 
     def _run(self, kind, q, qd, x3, gravity, f_ext, layout, consider_coriolis, consider_accelerations):
         lib = _lib.load()
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
+        g, ra = self._root(gravity)
         if self._is_torch(q):
             import torch
             dt = q.dtype
@@ -109,7 +123,7 @@ class HipModel:
                     raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
             self._check_f_ext(f_ext, B, layout)
             stream = torch.cuda.current_stream(q.device).cuda_stream
-            opts = self._options(layout, consider_coriolis, consider_accelerations, stream)
+            opts = self._options(layout, consider_coriolis, consider_accelerations, stream, root_acceleration=ra)
             sfx = "f64" if dt == torch.float64 else "f32"
             if kind == "crba":
                 shape = (B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B)
@@ -126,7 +140,7 @@ class HipModel:
         sfx = "f32" if ndt == np.float32 else "f64"
         q = _np(q, ndt)
         B = self._batch(q, self.nq, layout)
-        opts = self._options(layout, consider_coriolis, consider_accelerations, None)
+        opts = self._options(layout, consider_coriolis, consider_accelerations, None, root_acceleration=ra)
         if kind == "crba":
             out = np.empty((B, self.nv, self.nv) if layout == _lib.LAYOUT_AOS else (self.nv * self.nv, B), dtype=ndt)
             _lib.check(getattr(lib, f"mh_crba_{sfx}_host")(self._h, B, q.ctypes.data, ctypes.byref(opts), out.ctypes.data))
@@ -185,8 +199,8 @@ class HipModel:
         if any(self._batch(x, self.nv, layout) != B for x in (qd, tau, qdd_in)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         self._check_f_ext(f_ext, B, layout)
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(layout, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(layout, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         qdd_out, tau_out = torch.empty_like(qd), torch.empty_like(qd)
         fn = lib.mh_aba_locked_f64 if dt == torch.float64 else lib.mh_aba_locked_f32
         _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), tau.data_ptr(), qdd_in.data_ptr(), g,
@@ -209,8 +223,8 @@ class HipModel:
         if self._batch(qd, self.nv, layout) != B or self._batch(x3, self.nv, layout) != B:
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         self._check_f_ext(f_ext, B, layout)
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(layout, consider_coriolis, consider_accelerations, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(layout, consider_coriolis, consider_accelerations, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         out = torch.empty_like(qd)
         shape = (B, self.n_joints, 6) if layout == _lib.LAYOUT_AOS else (self.n_joints * 6, B)
         if kind in ("rnea_wrenches", "aba_wrenches"):
@@ -262,8 +276,8 @@ class HipModel:
         if base.shape != body.shape:
             raise _lib.MecanoHipError(2, "base and body index lists differ in length")
         n_pairs = int(base.shape[0])
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(layout, consider_velocities, True, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(layout, consider_velocities, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         out = torch.empty((B, n_pairs, 6) if layout == _lib.LAYOUT_AOS else (n_pairs * 6, B), dtype=torch.float64, device=q.device)
         _lib.check(lib.mh_relative_acceleration_f64(self._h, B, q.data_ptr(), body_acc.data_ptr(),
                                                     body_twist.data_ptr() if body_twist is not None else None, g, n_pairs, base.ctypes.data,
@@ -307,8 +321,8 @@ class HipModel:
         if self._batch(qd, self.nv, _lib.LAYOUT_AOS) != B or self._batch(tau, self.nv, _lib.LAYOUT_AOS) != B:
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         self._check_f_ext(f_ext, B, _lib.LAYOUT_AOS)
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         qn, vn = (q, qd) if inplace else (q.clone(), qd.clone())
         qdd = torch.empty_like(qd)
         _lib.check(lib.mh_aba_integrate_f64(self._h, B, float(dt), q.data_ptr(), qd.data_ptr(), tau.data_ptr(), g,
@@ -328,8 +342,8 @@ class HipModel:
             f = None if f_ext is None else _np(f_ext, np.float64)
             self._check_f_ext(f, B, _lib.LAYOUT_AOS)
             tau_out, qdd_out = out if out is not None else (np.empty_like(qd), np.empty_like(qd))
-            g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-            opts = self._options(_lib.LAYOUT_AOS)
+            g, ra = self._root(gravity)
+            opts = self._options(_lib.LAYOUT_AOS, root_acceleration=ra)
             _lib.check(lib.mh_rnea_aba_f64_host(self._h, B, q.ctypes.data, qd.ctypes.data, qdd.ctypes.data, tau.ctypes.data, g,
                                                 None if f is None else f.ctypes.data, ctypes.byref(opts), tau_out.ctypes.data, qdd_out.ctypes.data))
             return tau_out, qdd_out
@@ -340,8 +354,8 @@ class HipModel:
         B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
         if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         tau_out, qdd_out = torch.empty_like(qd), torch.empty_like(qd)
         _lib.check(lib.mh_rnea_aba_f64(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), tau.data_ptr(), g,
                                        f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts), tau_out.data_ptr(),
@@ -359,8 +373,8 @@ class HipModel:
         if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         self._check_f_ext(f_ext, B, _lib.LAYOUT_AOS)
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         tau_out = torch.empty_like(qd)
         H = torch.empty((B, self.nv, self.nv), dtype=torch.float64, device=q.device)
         _lib.check(lib.mh_rnea_crba_f64(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, f_ext.data_ptr() if f_ext is not None else None,
@@ -379,8 +393,8 @@ class HipModel:
         B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
         if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau, tau_out, qdd_out)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         args = (self._h, ctypes.c_int64(B), ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(qd.data_ptr()), ctypes.c_void_p(qdd.data_ptr()),
                 ctypes.c_void_p(tau.data_ptr()), g, ctypes.c_void_p(f_ext.data_ptr()) if f_ext is not None else None, ctypes.byref(opts),
                 ctypes.c_void_p(tau_out.data_ptr()), ctypes.c_void_p(qdd_out.data_ptr()))
@@ -406,8 +420,8 @@ class HipModel:
         if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau_out)) or tuple(H_out.shape) != (B, self.nv, self.nv):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         self._check_f_ext(f_ext, B, _lib.LAYOUT_AOS)
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream)
+        g, ra = self._root(gravity)
+        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         args = (self._h, ctypes.c_int64(B), ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(qd.data_ptr()), ctypes.c_void_p(qdd.data_ptr()), g,
                 ctypes.c_void_p(f_ext.data_ptr()) if f_ext is not None else None, ctypes.byref(opts), ctypes.c_void_p(tau_out.data_ptr()),
                 ctypes.c_void_p(H_out.data_ptr()))
@@ -471,8 +485,8 @@ class HipModel:
         import torch
         B, dt, sfx, stream = self._device_inputs([q, qd, qdd], layout)
         Y = torch.empty((B, self.nv, 10 * self.n_joints) if layout == _lib.LAYOUT_AOS else (self.nv, 10 * self.n_joints, B), dtype=dt, device=q.device)
-        g = (ctypes.c_double * 3)(*[float(v) for v in gravity])
-        opts = self._options(layout, consider_coriolis, consider_accelerations, stream)
+        g, ra = self._root(gravity)
+        opts = self._options(layout, consider_coriolis, consider_accelerations, stream, root_acceleration=ra)
         _lib.check(getattr(_lib.load(), f"mh_regressor_{sfx}")(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), g, ctypes.byref(opts),
                                                               1 if first_moment_columns else 0, Y.data_ptr()))
         return Y

@@ -193,6 +193,56 @@ class Joint:
     def getConfigurationMatrixSize(self) -> int:
         return self.configurationMatrixSize
 
+    # ---- joint state, as JointBasics / JointReadOnly carry it (multiBodySystem/interfaces/JointBasics.java:150-224,
+    # JointReadOnly.java:438-514): the matrix forms the calculators' one-configuration calls and MultiBodySystemTools.extractJointsState /
+    # insertJointsState go through.  Each returns rowStart + the rows it consumed, like the reference.  A floating joint's configuration
+    # is (qx, qy, qz, qs, x, y, z), its velocity / acceleration / effort (angular, linear) in the frame after the joint
+    # (SixDoFJointReadOnly.java:21-68); a fresh joint sits at the identity, at rest.
+    def _state(self, which):
+        st = self.__dict__.setdefault("_joint_state", {})
+        if which not in st:
+            n = self.configurationMatrixSize if which == "q" else self.degreesOfFreedom
+            a = np.zeros(n)
+            if which == "q" and self.joint_type in (SIXDOF, SPHERICAL):
+                a[3] = 1.0  # identity quaternion
+            st[which] = a
+        return st[which]
+
+    def _set(self, which, rowStart, matrix):
+        a = self._state(which)
+        m = np.asarray(matrix, dtype=np.float64).reshape(-1)
+        a[:] = m[rowStart:rowStart + a.size]
+        return rowStart + a.size
+
+    def _get(self, which, rowStart, matrixToPack):
+        a = self._state(which)
+        np.asarray(matrixToPack).reshape(-1)[rowStart:rowStart + a.size] = a
+        return rowStart + a.size
+
+    def setJointConfiguration(self, rowStart, matrix):
+        return self._set("q", rowStart, matrix)
+
+    def setJointVelocity(self, rowStart, matrix):
+        return self._set("qd", rowStart, matrix)
+
+    def setJointAcceleration(self, rowStart, matrix):
+        return self._set("qdd", rowStart, matrix)
+
+    def setJointTau(self, rowStart, matrix):
+        return self._set("tau", rowStart, matrix)
+
+    def getJointConfiguration(self, rowStart, matrixToPack):
+        return self._get("q", rowStart, matrixToPack)
+
+    def getJointVelocity(self, rowStart, matrixToPack):
+        return self._get("qd", rowStart, matrixToPack)
+
+    def getJointAcceleration(self, rowStart, matrixToPack):
+        return self._get("qdd", rowStart, matrixToPack)
+
+    def getJointTau(self, rowStart, matrixToPack):
+        return self._get("tau", rowStart, matrixToPack)
+
     def subtreeList(self) -> List["Joint"]:
         out = [self]
         if self.successor is not None:
@@ -213,6 +263,31 @@ class OneDoFJoint(Joint):
 
     def getJointAxis(self):
         return self.jointAxis
+
+    # OneDoFJointBasics.setQ / setQd / setQdd / setTau and their getters (multiBodySystem/interfaces/OneDoFJointBasics.java)
+    def setQ(self, q):
+        self._state("q")[0] = float(q)
+
+    def setQd(self, qd):
+        self._state("qd")[0] = float(qd)
+
+    def setQdd(self, qdd):
+        self._state("qdd")[0] = float(qdd)
+
+    def setTau(self, tau):
+        self._state("tau")[0] = float(tau)
+
+    def getQ(self):
+        return float(self._state("q")[0])
+
+    def getQd(self):
+        return float(self._state("qd")[0])
+
+    def getQdd(self):
+        return float(self._state("qdd")[0])
+
+    def getTau(self):
+        return float(self._state("tau")[0])
 
 
 class RevoluteJoint(OneDoFJoint):
@@ -285,6 +360,30 @@ class JointMatrixIndexProvider:
 
     def getJointConfigurationIndices(self, joint: Joint) -> List[int]:
         return self._cfg[id(joint)]
+
+
+class JointStateType:
+    """tools/JointStateType.java"""
+    CONFIGURATION, VELOCITY, ACCELERATION, EFFORT = "q", "qd", "qdd", "tau"
+
+
+class MultiBodySystemTools:
+    """The two state-packing helpers of tools/MultiBodySystemTools.java the calculators' callers use (extractJointsState :1433-1491,
+    insertJointsState :1578-1637): joints in the given order, each taking getConfigurationMatrixSize() / getDegreesOfFreedom() rows."""
+
+    @staticmethod
+    def extractJointsState(joints, stateSelection, matrixToPack):
+        row = 0
+        for j in joints:
+            row = j._get(stateSelection, row, matrixToPack)
+        return row
+
+    @staticmethod
+    def insertJointsState(joints, stateSelection, matrix):
+        row = 0
+        for j in joints:
+            row = j._set(stateSelection, row, matrix)
+        return row
 
 
 @dataclass

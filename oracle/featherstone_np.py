@@ -119,13 +119,19 @@ class Model:
         return self.dof_idx[self.dof_ofs[i]:self.dof_ofs[i + 1]]
 
 
+def _root_acceleration(g):
+    """(0, -g) for a gravity 3-vector; a 6-vector is the root's spatial acceleration itself (angular, linear)."""
+    g = np.asarray(g, dtype=float).reshape(-1)
+    return g.copy() if g.size == 6 else np.concatenate([np.zeros(3), -g])
+
+
 def rnea(m: Model, q, qd, qdd, g, fext=None, return_wrenches=False):
     n = m.n
     v = [None] * n
     a = [None] * n
     f = [None] * n
     Xup = [None] * n  # parent -> child motion transform
-    a0 = np.concatenate([np.zeros(3), -np.asarray(g, dtype=float)])
+    a0 = _root_acceleration(g)
     for i in range(n):
         Xcp = m.X_child_to_parent(i, q)
         Xup[i] = np.linalg.inv(Xcp)
@@ -208,7 +214,7 @@ def aba(m: Model, q, qd, tau, g, fext=None):
             pA[p] = pA[p] + Xup[i].T @ pa
     a = [None] * n
     qdd = np.zeros(m.nv)
-    a0 = np.concatenate([np.zeros(3), -np.asarray(g, dtype=float)])
+    a0 = _root_acceleration(g)
     for i in range(n):
         p = m.parent[i]
         ap = Xup[i] @ (a0 if p < 0 else a[p]) + c[i]
@@ -284,7 +290,7 @@ def relative_acceleration_dense(m: Model, q, qd, qdd, g, base, body):
     subtract like vectors),  A_rel = a_2 - X_{1->2} a_1 + v_2 x (X_{1->2} v_1).  Independent of the cross-product recipe the C oracle
     restates from SpatialAccelerationBasics.changeFrame."""
     v, J, Jd, X0 = _body_jacobians(m, q, qd)
-    a0 = np.concatenate([np.zeros(3), -np.asarray(g, dtype=float)])
+    a0 = _root_acceleration(g)
     n = m.n
     Xc = np.asarray(m.d.X_com).reshape(n, 12)
 

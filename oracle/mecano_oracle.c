@@ -436,13 +436,36 @@ static _Thread_local double *tap_acc = NULL, *tap_twist = NULL;
 /* per-joint wrench (InverseDynamicsCalculator.getComputedJointWrench, :578-585): what passTwo leaves in jointWrench, frame after the joint */
 static _Thread_local double *tap_wrench = NULL;
 
+/* Root acceleration (InverseDynamicsCalculator.java:343-348 / 413-427, ForwardDynamicsCalculator.java:259-264 / 330-343): setGravity stores
+ * (0, -g); setRootAcceleration stores the given spatial acceleration (angular, linear; root-body coordinates) in the same field.  The
+ * entry points take the gravity vector; mo_set_root_acceleration (thread-local, like the calculators' field) overrides it until cleared. */
+static _Thread_local int root_override_set = 0;
+static _Thread_local double root_override[6];
+void mo_set_root_acceleration(const double *a6)
+{
+   root_override_set = a6 != NULL;
+   if (a6)
+      memcpy(root_override, a6, sizeof root_override);
+}
+static void root_acceleration(const double g[3], double a_root[6])
+{
+   if (root_override_set)
+      memcpy(a_root, root_override, 6 * sizeof(double));
+   else
+   {
+      a_root[0] = a_root[1] = a_root[2] = 0.0;
+      a_root[3] = -g[0], a_root[4] = -g[1], a_root[5] = -g[2];
+   }
+}
+
 static void rnea_one(const mo_model *m, const double *q, const double *qd, const double *qdd, const double g[3], const double *fext,
                      int coriolis, int accel, double *tau)
 {
    static _Thread_local mo_kin K;
    static _Thread_local double acc[MO_MAX_JOINTS][6], wrench[MO_MAX_JOINTS][6];
    xf_t W_world, T;
-   double a_root[6] = {0, 0, 0, -g[0], -g[1], -g[2]}; /* :343-348 */
+   double a_root[6]; /* :343-348, :413-427 */
+   root_acceleration(g, a_root);
    double zero6[6] = {0};
    xf_identity(&W_world);
    kinematics(m, q, qd, &K);
@@ -834,7 +857,8 @@ static int aba_one(const mo_model *m, const double *q, const double *qd, const d
       }
    }
    /* ---- pass three: root to leaves */
-   double a_root[6] = {0, 0, 0, -g[0], -g[1], -g[2]}; /* :259-264 */
+   double a_root[6]; /* :259-264, :330-343 */
+   root_acceleration(g, a_root);
    for (int i = 0; i < m->n; i++)
    {
       int p = m->parent[i], nd = m->ndof[i];
@@ -1604,7 +1628,9 @@ void mo_relative_acceleration(void *h, long B, const double *q, const double *qd
    static _Thread_local mo_kin K;
    static _Thread_local double acc[MO_MAX_JOINTS][6], tw[MO_MAX_JOINTS][6];
    double *tau = (double *)malloc(sizeof(double) * (size_t)(m->nv > 0 ? m->nv : 1));
-   const double a_root[6] = {0, 0, 0, -g[0], -g[1], -g[2]}, zero6[6] = {0};
+   double a_root[6];
+   const double zero6[6] = {0};
+   root_acceleration(g, a_root);
    xf_t W_world, T;
    xf_identity(&W_world);
    for (long b = 0; b < B; b++)

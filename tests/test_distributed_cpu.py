@@ -81,3 +81,28 @@ def test_pack_unpack_roundtrip():
     assert d2.n_joints == d.n_joints and d2.nq == d.nq and d2.nv == d.nv
     for f in ("parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices"):
         assert np.array_equal(np.asarray(getattr(d2, f)), np.asarray(getattr(d, f)))
+
+
+def test_bench_self_launcher_starts_one_process_per_rank(tmp_path, monkeypatch):
+    """bench.self_launch (what `python3 bench.py --gpus N` runs when no launcher set WORLD_SIZE): N child processes with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*, rank 0's stdout relayed, first non-zero exit code returned -- exercised with a stand-in script (no GPU here)."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    script = tmp_path / "fake_bench.py"
+    script.write_text("import os, sys\n"
+                      "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                      "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                      "open(os.path.join(os.path.dirname(__file__), f'rank{r}of{w}'), 'w').close()\n"
+                      "print('{\"rank\": %d}' % r)\n"
+                      "sys.exit(3 if (r == 1 and 'fail' in sys.argv) else 0)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    for argv, want in ((["bench.py", "--gpus", "3"], 0), (["bench.py", "--gpus", "3", "fail"], 3)):
+        monkeypatch.setattr(sys, "argv", argv)
+        out = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.__file__ = {str(script)!r}; "
+                              f"sys.argv = {argv!r}; sys.exit(bench.self_launch(3))"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == want, out.stderr
+        assert out.stdout.strip() == '{"rank": 0}'  # only rank 0's line is relayed
+        assert all((tmp_path / f"rank{r}of3").exists() for r in range(3))

@@ -423,8 +423,9 @@ def test_every_specialised_variant(torch_cuda, B):
         try:
             off = {"MH_SPEC_SPLIT": "0"}
             for env in ({"MH_DISABLE_SPEC": "1"}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "1", **off},
-                        {"MH_SPEC_IO": "1", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "1", "MH_SPEC_ST": "1", **off}, {"MH_SPEC_SPLIT": "1"}, {}):
-                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT"):
+                        {"MH_SPEC_IO": "1", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "1", "MH_SPEC_ST": "1", **off}, {"MH_SPEC_SPLIT": "1"}, {},
+                        {"MH_ZV": "0"}, {"MH_ZV": "2"}):  # bias-split forward dynamics never / at every batch size (default: small batches)
+                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV"):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 hm = HipModel(d)
@@ -437,7 +438,7 @@ def test_every_specialised_variant(torch_cuda, B):
                 close(t2.cpu().numpy()[idx], t_ref)
                 close(a2.cpu().numpy()[idx], a_ref)
         finally:
-            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT"):
+            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV"):
                 os.environ.pop(k, None)
         assert any(v.startswith("generic") for v in seen) and any(v.startswith("topo:") for v in seen), seen
 
@@ -1402,6 +1403,9 @@ def _two_rank_worker(rank, world, port, B, out_dir):
     r, w, _ = mdist.init_from_env()
     torch.cuda.set_device(0)  # both ranks share the one GPU of the box
     desc = mdist.broadcast_model_desc(rt.humanoid30Desc() if rank == 0 else None, src=0)
+    # bit for bit needs ONE formulation of the forward dynamics at every shard size: by default the launch picks the bias-split form
+    # for batches whose workgroups all fit the device and the tree-split form beyond (equal to ~1e-13, not to the bit)
+    os.environ["MH_ZV"] = "0"
     hm = HipModel(desc)
     sys_ = rt.nextHumanoid(np.random.default_rng(43))
     q, qd, qdd, tau = rt.nextState(np.random.default_rng(7), sys_, B)  # the same full batch on every rank
@@ -1432,3 +1436,102 @@ def test_two_ranks_sharing_one_gpu_reproduce_the_single_rank_result(torch_cuda, 
     s.close()
     mp.spawn(_two_rank_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_bench_launches_its_own_ranks(torch_cuda):
+    """`python3 bench.py --gpus 2` with no external launcher: a GPU-free parent starts two fresh rank processes (here both on the box's one
+    GPU, gloo as the transport), relays rank 0's line and returns its exit code -- ONE JSON line with n_gpus = 2, both ranks counted by
+    the communicator, the timed outputs checked against the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MECANO_DIST_BACKEND="gloo", MH_BENCH_NO_PMC="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--regions", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak"
+    assert line["rccl_ranks"] == {"world_size": 2, "ranks_counted": 2}
+    assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
+    assert line["check"]["ok"] is True
+    assert len(line["per_rank"]) == 2
+
+
+@pytest.mark.parametrize("case", ["humanoid", "arm", "torso", "mixed_tree", "floating_onedof_tree", "planar_spherical"])
+def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
+    """mh_options.root_acceleration: setRootAcceleration(SpatialAccelerationReadOnly) (InverseDynamicsCalculator.java:413-427,
+    ForwardDynamicsCalculator.java:330-343) -- a rotating, accelerating base.  Every kernel family that starts its outward sweep at the root
+    (bias-split, tree-split and whole-tree code objects; run-time tree split, depth-first and sweep kernels; per-body outputs, joint
+    wrenches, relative accelerations; fp32) against the oracle with the same 6-D root acceleration, AoS and SoA, and through the
+    calculator mirror; a purely linear root acceleration equals the gravity shorthand bit for bit."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.calculators import ForwardDynamicsCalculator, InverseDynamicsCalculator
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(zlib.crc32(("root6" + case).encode()))
+    fam = families()
+    sys_ = {"humanoid": lambda: rt.nextHumanoid(rng), "arm": lambda: system_of(rt.nextJointChain(rng, 7, ("revolute",))),
+            "torso": lambda: rt.nextFixedBaseTorso(rng), "mixed_tree": lambda: system_of(fam["mixed_tree"](rng, 14)),
+            "floating_onedof_tree": lambda: system_of(fam["floating_onedof_tree"](rng, 12)),
+            "planar_spherical": lambda: system_of(rt.nextJointTree(rng, 9, ("revolute", "planar", "spherical", "prismatic")))}[case]()
+    d = sys_.toModelDesc()
+    om = OracleModel(d)
+    a0 = rng.uniform(-2, 2, 6)
+    a0[5] += 9.81
+    T = lambda x: x.t().contiguous()
+    for B in (1, 100, 4096, 9000, 40000):
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
+        idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 64)), [B - 1]]))
+        t_ref, a_ref = om.rnea(q[idx], qd[idx], qdd[idx], a0, fext[idx]), om.aba(q[idx], qd[idx], tau[idx], a0, fext[idx])
+        cond = "mixed" in case or "planar" in case  # random mixed trees: forward dynamics conditioning (as in test_random_families_match_oracle)
+        tq, tqd, tqdd, ttau, tf = (dev(torch, x) for x in (q, qd, qdd, tau, fext))
+        for env in ({}, {"MH_DISABLE_SPEC": "1"}, {"MH_ZV": "0"}, {"MH_ZV": "2"}, {"MH_DISABLE_SPEC": "1", "MH_DFS": "0"}):
+            if B > 9000 and env.get("MH_DFS") == "0":
+                continue
+            for k in ("MH_DISABLE_SPEC", "MH_ZV", "MH_DFS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            hm = HipModel(d)
+            t = hm.rnea(tq, tqd, tqdd, a0, tf)
+            a = hm.aba(tq, tqd, ttau, a0, tf)
+            close(t.cpu().numpy()[idx], t_ref)
+            close(a.cpu().numpy()[idx], a_ref, 1e-8 if cond else TOL)
+            close(hm.rnea(T(tq), T(tqd), T(tqdd), a0, tf.reshape(B, -1).t().contiguous(), layout=_lib.LAYOUT_SOA).t().cpu().numpy()[idx], t_ref)
+            close(hm.aba(T(tq), T(tqd), T(ttau), a0, tf.reshape(B, -1).t().contiguous(), layout=_lib.LAYOUT_SOA).t().cpu().numpy()[idx], a_ref,
+                  1e-8 if cond else TOL)
+            t2, a2 = hm.rnea_aba(tq, tqd, tqdd, ttau, a0, tf)
+            close(t2.cpu().numpy()[idx], t_ref)
+            close(a2.cpu().numpy()[idx], a_ref, 1e-8 if cond else TOL)
+            if B <= 4096:
+                # per-body accelerations (the root acceleration is what they are measured against), joint wrenches
+                _, acc_b, tw_b = hm.rnea_bodies(tq, tqd, tqdd, a0, tf)
+                r_tau, r_acc, r_tw = om.rnea_bodies(q[idx], qd[idx], qdd[idx], a0, fext[idx])
+                close(acc_b.cpu().numpy()[idx], r_acc), close(tw_b.cpu().numpy()[idx], r_tw)
+                _, w = hm.rnea_joint_wrenches(tq, tqd, tqdd, a0, tf)
+                close(w.cpu().numpy()[idx], om.rnea_wrenches(q[idx], qd[idx], qdd[idx], a0, fext[idx])[1])
+                # fp32 with the forward bound of the fp32 tests
+                f32 = lambda x: x.to(torch.float32)
+                t32 = hm.rnea(f32(tq), f32(tqd), f32(tqdd), a0, f32(tf)).cpu().numpy().astype(np.float64)[idx]
+                assert np.abs(t32 - t_ref).max() <= 64 * d.n_joints * 2.0 ** -24 * max(1.0, np.abs(t_ref).max())
+            # the linear part alone is the gravity shorthand
+            lin = np.concatenate([np.zeros(3), a0[3:]])
+            assert torch.equal(hm.rnea(tq, tqd, tqdd, lin, tf), hm.rnea(tq, tqd, tqdd, -a0[3:], tf))
+            assert torch.equal(hm.aba(tq, tqd, ttau, lin, tf), hm.aba(tq, tqd, ttau, -a0[3:], tf))
+    for k in ("MH_DISABLE_SPEC", "MH_ZV", "MH_DFS"):
+        monkeypatch.delenv(k, raising=False)
+    # the calculators, as the reference's callers drive them: setRootAcceleration(six components) replaces the gravity term
+    B = 64
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    idc, fdc = InverseDynamicsCalculator(sys_), ForwardDynamicsCalculator(sys_)
+    idc.setGravitationalAcceleration(-9.81), fdc.setGravitationalAcceleration(-9.81)
+    idc.setRootAcceleration(a0), fdc.setRootAcceleration(a0)
+    idc.compute(q, qd, qdd), fdc.compute(q, qd, tau)
+    close(np.asarray(idc.getJointTauMatrix()), om.rnea(q, qd, qdd, a0))
+    close(np.asarray(fdc.getJointAccelerationMatrix()), om.aba(q, qd, tau, a0), 1e-8 if ("mixed" in case or "planar" in case) else TOL)

@@ -635,3 +635,55 @@ def test_relative_accelerations(family):
         nov = om.relative_acceleration(q, qd, qdd, base, body, g, consider_coriolis=False)
         nov_ref = om.relative_acceleration(q, 0 * qd, qdd, base, body, g)
         assert np.abs(nov - nov_ref).max() <= 1e-10 * max(1.0, np.abs(nov_ref).max())
+
+
+# ---- the six-dimensional root acceleration (InverseDynamicsCalculator.setRootAcceleration, java:413-427; ForwardDynamicsCalculator.java:330-343)
+@pytest.mark.parametrize("family", ["revolute_tree", "onedof_tree", "onedof_chain", "mixed_tree"])
+def test_root_acceleration_six_components(family):
+    """A root acceleration with an ANGULAR part (a rotating, accelerating base).  Three pins, none of them the oracle checking itself by
+    the same path: (i) the independent textbook Featherstone with the same a0; (ii) the same mechanism hung on a 6-DoF joint that sits at
+    the identity, at rest, and accelerates with a0 under no gravity -- every other joint must see the same efforts; (iii) ABA inverts RNEA
+    under that root acceleration, and a purely linear a0 reproduces setGravity(-a0)."""
+    rng = np.random.default_rng(zlib.crc32(("root6" + family).encode()))
+    for it in range(4):
+        n = int(rng.integers(2, 11))
+        joints = FAMILIES[family](rng, n)
+        sys_ = system_of(joints)
+        d = sys_.toModelDesc()
+        om, fm = OracleModel(d), fs.Model(d)
+        B = 3
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        a0 = rng.uniform(-2, 2, 6)
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
+        t = om.rnea(q, qd, qdd, a0, fext)
+        for b in range(B):  # (i)
+            t2 = fs.rnea(fm, q[b], qd[b], qdd[b], a0, fext[b])
+            assert np.allclose(t[b], t2, rtol=0, atol=1e-10 * max(1.0, np.abs(t2).max()))
+            a2 = fs.aba(fm, q[b], qd[b], tau[b], a0, fext[b])
+            assert np.allclose(om.aba(q[b:b + 1], qd[b:b + 1], tau[b:b + 1], a0, fext[b:b + 1])[0], a2, rtol=0, atol=1e-9 * max(1.0, np.abs(a2).max()))
+        # (iii)
+        back = om.aba(q, qd, t, a0, fext)
+        assert np.abs(back - qdd).max() <= 50 * FLOATING_JOINT_EPSILON * max(1.0, np.abs(qdd).max())
+        lin = np.concatenate([np.zeros(3), a0[3:]])
+        assert np.array_equal(om.rnea(q, qd, qdd, lin, fext), om.rnea(q, qd, qdd, -a0[3:], fext))
+        assert np.array_equal(om.rnea(q, qd, qdd, (0.0, 0.0, -9.81)), om.rnea(q, qd, qdd, (0, 0, 0, 0, 0, 9.81)))
+        # (ii) floating copy: parents shift by one, the new joint 0 is a 6-DoF joint with identity offsets and a massive carrier body
+        dd = ModelDesc(
+            n_joints=d.n_joints + 1, nq=d.nq + 7, nv=d.nv + 6,
+            parent=np.concatenate([[-1], np.asarray(d.parent) + 1]).astype(np.int32),
+            joint_type=np.concatenate([[2], np.asarray(d.joint_type)]).astype(np.int32),
+            axis=np.concatenate([[0.0, 0.0, 1.0], np.asarray(d.axis).reshape(-1)]),
+            X_before=np.concatenate([np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=float), np.asarray(d.X_before).reshape(-1)]),
+            X_com=np.concatenate([np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=float), np.asarray(d.X_com).reshape(-1)]),
+            inertia_J=np.concatenate([np.eye(3).reshape(-1) * 3.0, np.asarray(d.inertia_J).reshape(-1)]),
+            inertia_mass=np.concatenate([[5.0], np.asarray(d.inertia_mass)]),
+            inertia_com=np.concatenate([np.zeros(3), np.asarray(d.inertia_com).reshape(-1)]),
+            dof_indices=np.concatenate([np.arange(6), np.asarray(d.dof_indices) + 6]).astype(np.int32),
+            cfg_indices=np.concatenate([np.arange(7), np.asarray(d.cfg_indices) + 7]).astype(np.int32))
+        of = OracleModel(dd)
+        qf = np.concatenate([np.tile([0.0, 0, 0, 1, 0, 0, 0], (B, 1)), q], axis=1)
+        qdf = np.concatenate([np.zeros((B, 6)), qd], axis=1)
+        qddf = np.concatenate([np.tile(a0, (B, 1)), qdd], axis=1)
+        fextf = np.concatenate([np.zeros((B, 1, 6)), fext], axis=1)
+        tf = of.rnea(qf, qdf, qddf, (0.0, 0.0, 0.0), fextf)
+        assert np.abs(tf[:, 6:] - t).max() <= 1e-10 * max(1.0, np.abs(t).max())
