@@ -207,8 +207,9 @@ struct mh_model
    } split_rt;
    int use_split_rt = -1; // MH_SPLIT_RT = 0 | 1: never / whenever usable (default: small batches)
    int split_rt_lds = -1; // MH_SPLIT_RT_LDS = 0 | 1: the split kernels' workspace never / always with its LDS share (measurements)
-   // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices)
-   Workspace tr;
+   // AoS -> SoA scratch copies of the state matrices for the run-time-topology kernels (big batches of wide matrices); tr_pair: the
+   // copies of the forward dynamics call that runs beside the inverse dynamics call on pair_stream (they would share addresses otherwise)
+   Workspace tr, tr_pair;
    // scratch of the composite entry points: efforts of the Newton-Euler sweep behind mh_aba_joint_wrenches_f64, pair lists of
    // mh_relative_acceleration_f64
    Workspace aux, pairs;
@@ -2067,6 +2068,7 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
    (void)hipFree(m->ws_pair.ptr);
+   (void)hipFree(m->tr_pair.ptr);
    (void)hipFree(m->zv_tau.ptr);
    (void)hipFree(m->zv_flags.ptr);
    if (m->zv_error_host)
@@ -2478,9 +2480,11 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
       HIP_TRY(hipStreamWaitEvent(model->pair_stream, model->pair_fork, 0));
       mh_options ob = opts;
       ob.stream = (void *)model->pair_stream;
-      std::swap(model->ws, model->ws_pair); // every launch path sizes and reads model->ws
+      std::swap(model->ws, model->ws_pair); // every launch path sizes and reads model->ws ...
+      std::swap(model->tr, model->tr_pair); // ... and model->tr when it goes through transposed copies of the state matrices
       const mh_status rb = mh_aba_f64(model, B, q, qd, tau, gravity, f_ext, &ob, qdd_out);
       std::swap(model->ws, model->ws_pair);
+      std::swap(model->tr, model->tr_pair);
       const mh_status ra = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
       HIP_TRY(hipEventRecord(model->pair_join, model->pair_stream)); // join even after an error: the caller's stream must not run ahead
       HIP_TRY(hipStreamWaitEvent(s, model->pair_join, 0));

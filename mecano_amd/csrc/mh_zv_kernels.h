@@ -145,12 +145,16 @@ struct ZvIn
       const CRef<T, false> c{cp};
       const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const RI<T> I = load_inertia<T>(c);
-      const XF<T> Xb = load_xb_j<TP, J, T>(c);
       MH_BODY_FENCE();
-      const JX<T> jx = spec_joint_from<TYPE, T>(jq);
       ABI<T> IA = abi_from_rigid(I);
       if constexpr (!LEAF)
          add(IA, up);
+      MH_BODY_FENCE();
+      // the pose is requested only now, when the ten inertia constants have been consumed: requested together they hold 44 SGPRs next to
+      // the kernel's arguments, more than the file has, and every use became a v_readlane from a spill lane (15 % of the instructions of
+      // this chain); the sincos and the rank-1 downdate in front of its first use cover the latency
+      const XF<T> Xb = load_xb_j<TP, J, T>(c);
+      const JX<T> jx = spec_joint_from<TYPE, T>(jq);
       ABI<T> out = abi_zero<T>();
       if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
       {
@@ -591,8 +595,24 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    cx.xbase = lxc + lane;
    cx.st.lbase = lst + lane;
    cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+#ifdef MH_ZV_TWICE // experiment: the inward limb phase a second time, through a warm instruction cache (stamps 12 = first pass done)
+#pragma unroll 1
+   for (int rep = 0; rep < 2; rep++)
+   {
+      asm volatile("" ::: "memory");
+      if (active)
+         zv_limbs_in<TP, 0, T, CX>(cx);
+      if (rep == 0)
+      {
+         ZV_STAMP(1, 12);
+         __syncthreads();
+         ZV_STAMP(1, 13);
+      }
+   }
+#else
    if (active) // (lane 0 of every wave is active, so each wave reaches the barrier a staged trunk carries in here)
       zv_limbs_in<TP, 0, T, CX>(cx);
+#endif
    ZV_STAMP(1, 2);
    __syncthreads(); // every limb's (and sub-trunk's) articulated inertia is in the exchange area
    ZV_STAMP(1, 3);
@@ -628,8 +648,11 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
 // One launch, jobs * ceil(B / 64) workgroups (padded to blocks of eight): blocks of eight consecutive workgroup ids share a role, so
 // the bias job, the inertia job (and the inverse dynamics job) of the same 64 configurations have ids that differ by a multiple of
 // eight -- the dispatcher deals ids round-robin to the eight XCDs, which puts them behind the same L2 -- and the producer's id is lower.
+#ifndef MH_ZV_KERNEL_ATTR
+#define MH_ZV_KERNEL_ATTR
+#endif
 template <class TP, typename T, bool IDENT>
-__global__ void __launch_bounds__(256) spec_zv_kernel(Args<T> A, T *taup, ZvSync sy)
+__global__ void __launch_bounds__(256) MH_ZV_KERNEL_ATTR spec_zv_kernel(Args<T> A, T *taup, ZvSync sy)
 {
    extern __shared__ double lds_raw[];
    const int blk = (int)blockIdx.x;

@@ -32,7 +32,7 @@ def dev(torch, x, dtype=None):
     return torch.tensor(np.ascontiguousarray(x), device="cuda", dtype=dtype or torch.float64)
 
 
-from helpers import close  # noqa: E402  (logs every achieved error; absolute=True asserts |x - ref| <= tol outright)
+from helpers import close, close_aba, f32_aba_backward_tol, f32_aba_forward_factor, f32_forward_tol  # noqa: E402  (logs every achieved error; absolute=True asserts |x - ref| <= tol outright)
 
 
 def system_of(joints):
@@ -77,8 +77,11 @@ def test_random_families_match_oracle(torch_cuda, family):
         for fext in (None, rng.uniform(-1, 1, (B, d.n_joints, 6))):
             close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), g, dev(torch, fext)).cpu().numpy(), om.rnea(q, qd, qdd, g, fext))
             ref = om.aba(q, qd, tau, g, fext)
-            close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g, dev(torch, fext)).cpu().numpy(), ref,
-                  TOL if "mixed" not in family else 1e-8)
+            got = hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), g, dev(torch, fext)).cpu().numpy()
+            if "mixed" not in family:
+                close(got, ref, TOL)
+            elif d.nv:  # random mixed trees: a bound per row from the conditioning of its own mass matrix, not a flat 1e-8
+                close_aba(got, ref, om.crba(q), d.n_joints, label="aba_f64")
         close(hm.crba(dev(torch, q)).cpu().numpy(), om.crba(q))
 
 
@@ -181,7 +184,7 @@ def test_config4_humanoid_aba_one_gpu_shard(torch_cuda):
 
 def test_config5_random_128_body_tree_fp32(torch_cuda):
     """BASELINE.json configs[4]: random 128-body tree, mixed Revolute / Prismatic / SixDoF joints, fp32.
-    fp32 bounds are derived where they are asserted (u = 2^-24): RNEA and CRBA forward bounds ~ n u max|ref|; ABA by its backward
+    fp32 bounds are derived in tests/helpers.py (u = 2^-24): RNEA and CRBA forward bounds ~ sqrt(8 n) u max|ref|; ABA by its backward
     error in tau-space plus a forward bound scaled by cond(H) of each sampled row; all against the fp64 oracle."""
     torch = torch_cuda
     from mecano_amd import random_tools as rt
@@ -200,16 +203,16 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
     f32 = torch.float32
     t32 = hm.rnea(dev(torch, q, f32), dev(torch, qd, f32), dev(torch, qdd, f32), g).cpu().numpy()
     assert t32.dtype == np.float32
-    close(t32[idx].astype(np.float64), ref, 64 * d.n_joints * 2.0 ** -24, label="rnea_f32")  # forward sums over <= n bodies: 64 n u max|tau|
+    close(t32[idx].astype(np.float64), ref, f32_forward_tol(d.n_joints), label="rnea_f32")  # helpers.py: 4 sqrt(8 n) u max|tau|
     t64 = hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), g)
     close(t64.cpu().numpy()[idx], ref, 1e-9)
     a64 = hm.aba(dev(torch, q), dev(torch, qd), t64, g).cpu().numpy()
     assert np.abs(a64 - qdd).max() < 1e-5  # ill-conditioned deep random tree; the reference asks 1e-4 on such systems
     # ---- fp32 ABA and CRBA against the fp64 oracle (sampled rows).  u = 2^-24.  Derived bounds:
-    #  * CRBA is a forward computation (sums of products along paths of <= n bodies): |H32 - H| <= 16 n u max|H|.
+    #  * CRBA is a forward computation (sums of products along paths of <= n bodies): |H32 - H| <= 4 sqrt(8 n) u max|H| (helpers.py).
     #  * ABA solves H qdd = tau - bias: a backward-stable solve in precision u has |dqdd| <= c n u cond(H) |qdd|, which on this tree
     #    (cond_inf(H) of 1e4 .. 1e8, printed) is vacuous for the worst rows -- so the assertion that binds is the BACKWARD error:
-    #    RNEA64(q, qd, qdd32) must reproduce tau to 64 n u (|tau| + |bias|)_inf, i.e. qdd32 is the exact answer of a problem perturbed
+    #    RNEA64(q, qd, qdd32) must reproduce tau to 16 sqrt(8 n) u (|tau| + |bias|)_inf, i.e. qdd32 is the exact answer of a problem perturbed
     #    by fp32 rounding; the forward error is asserted against cond(H) from the oracle's own H on every sampled row.
     from helpers import record_parity
     u32, n = 2.0 ** -24, d.n_joints
@@ -217,19 +220,19 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
     assert a32.dtype == np.float64 and np.isfinite(a32).all()
     H_ref = om.crba(q[idx])
     H32 = hm.crba(dev(torch, q, f32)).cpu().numpy().astype(np.float64)[idx]
-    close(H32, H_ref, 16 * n * u32, label="crba_f32")
+    close(H32, H_ref, f32_forward_tol(n), label="crba_f32")
     assert np.array_equal(H32 == 0, H_ref == 0)  # the structural zeros (unrelated branches) are exact in fp32 too
     a_ref = om.aba(q[idx], qd[idx], tau[idx], g)
     bias = om.rnea(q[idx], qd[idx], np.zeros_like(qdd[idx]), g)
     back = om.rnea(q[idx], qd[idx], a32[idx], g)  # exact (fp64) inverse dynamics of the fp32 answer
     scale = np.abs(tau[idx]).max() + np.abs(bias).max()
     berr = np.abs(back - tau[idx]).max()
-    record_parity(berr, 64 * n * u32 * scale, "aba_f32 backward error")
-    assert berr <= 64 * n * u32 * scale, (berr, scale)
+    record_parity(berr, f32_aba_backward_tol(n) * scale, "aba_f32 backward error")
+    assert berr <= f32_aba_backward_tol(n) * scale, (berr, scale)
     conds = np.array([np.linalg.cond(H_ref[k], np.inf) for k in range(len(idx))])
     ferr = np.abs(a32[idx] - a_ref).max(axis=1) / np.maximum(1.0, np.abs(a_ref).max(axis=1))
-    record_parity(float((ferr / (conds * u32)).max()), 16.0 * n, "aba_f32 forward error / (cond_inf(H) u)")
-    assert (ferr <= 16 * n * u32 * conds).all(), (ferr.max(), conds.min(), conds.max())
+    record_parity(float((ferr / (conds * u32)).max()), f32_aba_forward_factor(n), "aba_f32 forward error / (cond_inf(H) u)")
+    assert (ferr <= f32_aba_forward_factor(n) * u32 * conds).all(), (ferr.max(), conds.min(), conds.max())
     print(f"config 5 fp32 ABA: backward err {berr:.2e} (scale {scale:.1e}), forward err max {ferr.max():.2e}, cond(H) {conds.min():.1e}..{conds.max():.1e}")
     # big AoS batches of wide matrices go through transposed scratch copies (mh::transpose_kernel): same numbers as the direct AoS
     # path (B < 8192 above), as the SoA path, and as the oracle; ragged batch size, external wrenches keep their AoS strides
@@ -251,7 +254,7 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
     fq, fqd, fqdd, ftau = (dev(torch, x, f32) for x in (q, qd, qdd, tau))
     assert torch.equal(hm.aba(fq, fqd, ftau, g), hm.aba(T(fq), T(fqd), T(ftau), g, layout=_lib.LAYOUT_SOA).t())
     assert torch.equal(hm.rnea(fq, fqd, fqdd, g), hm.rnea(T(fq), T(fqd), T(fqdd), g, layout=_lib.LAYOUT_SOA).t())
-    close(hm.rnea(fq, fqd, fqdd, g).cpu().numpy().astype(np.float64)[idx], om.rnea(q[idx], qd[idx], qdd[idx], g), 64 * d.n_joints * 2.0 ** -24, label="rnea_f32 big batch")
+    close(hm.rnea(fq, fqd, fqdd, g).cpu().numpy().astype(np.float64)[idx], om.rnea(q[idx], qd[idx], qdd[idx], g), f32_forward_tol(d.n_joints), label="rnea_f32 big batch")
 
 
 def test_layouts_soa_equals_aos(torch_cuda):
@@ -1180,7 +1183,6 @@ def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
     monkeypatch.setenv("MH_DISABLE_SPEC", "1")
     rng = np.random.default_rng(2718)
     tdt = torch.float64 if dtype == "f64" else torch.float32
-    tol = 1e-10 if dtype == "f64" else 2e-3
     kinds_all = ("revolute", "prismatic", "sixdof", "fixed", "planar", "spherical")
     systems = [system_of(rt.nextJointTree(rng, 40, kinds_all)), system_of(rt.nextJointTree(rng, 23, ("revolute", "prismatic"))),
                system_of(rt.nextFloatingChain(rng, 24, ("revolute",), tree=True)), rt.nextHumanoid(rng)]
@@ -1201,6 +1203,7 @@ def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
         n_split += "run-time tree split" in on.kernel_variant  # (a tree whose split would not shorten the path keeps the one-wave kernels)
         print(d.n_joints, "joints:", on.kernel_variant)
         om = OracleModel(d)
+        tol = 1e-10 if dtype == "f64" else f32_forward_tol(d.n_joints)  # fp32: 4 sqrt(8 n) u (tests/helpers.py), not a flat 2e-3
         for B in (1, 67, 300, 20000):
             q, qd, qdd, tau = rt.nextState(rng, sys_, B)
             fext = rng.uniform(-1, 1, (B, d.n_joints, 6))
@@ -1208,7 +1211,7 @@ def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
             t, a = on.rnea(tq, tqd, tqdd, g, tf), on.aba(tq, tqd, ttau, g, tf)
             t0, a0 = off.rnea(tq, tqd, tqdd, g, tf), off.aba(tq, tqd, ttau, g, tf)
             scale_t, scale_a = max(1.0, t0.abs().max().item()), max(1.0, a0.abs().max().item())
-            assert (t - t0).abs().max().item() <= (1e-12 if dtype == "f64" else 2e-4) * scale_t
+            assert (t - t0).abs().max().item() <= (1e-12 if dtype == "f64" else 2 * tol) * scale_t
             assert (a - a0).abs().max().item() <= (1e-9 if dtype == "f64" else 2e-2) * scale_a  # mixed trees: ABA conditioning, cf. the 1e-8 of test_mixed_tree
             T = lambda x: x.reshape(B, -1).t().contiguous()
             assert torch.equal(on.rnea(T(tq), T(tqd), T(tqdd), g, T(tf), layout=_lib.LAYOUT_SOA).t(), t)
@@ -1221,13 +1224,14 @@ def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
                     assert (got - want).abs().max().item() <= 1e-9 * max(1.0, want.abs().max().item())
             if B <= 300:
                 H, H0 = on.crba(tq), off.crba(tq)
-                assert (H - H0).abs().max().item() <= (1e-12 if dtype == "f64" else 2e-4) * max(1.0, H0.abs().max().item())
+                assert (H - H0).abs().max().item() <= (1e-12 if dtype == "f64" else 2 * tol) * max(1.0, H0.abs().max().item())
                 assert torch.equal(H == 0, H0 == 0)  # unrelated branches: exact zeros in both
                 assert torch.equal(on.crba(T(tq), layout=_lib.LAYOUT_SOA).t().reshape(B, d.nv, d.nv), H)
             if B <= 67:
-                close(H.cpu().numpy().astype(np.float64), om.crba(q), tol, label="crba")
+                H_ref = om.crba(q)
+                close(H.cpu().numpy().astype(np.float64), H_ref, tol, label="crba")
                 close(t.cpu().numpy().astype(np.float64), om.rnea(q, qd, qdd, g, fext), tol, label="rnea")
-                close(a.cpu().numpy().astype(np.float64), om.aba(q, qd, tau, g, fext), 1e-7 if dtype == "f64" else 5e-2, label="aba")
+                close_aba(a.cpu().numpy(), om.aba(q, qd, tau, g, fext), H_ref, d.n_joints, 2.0 ** -53 if dtype == "f64" else 2.0 ** -24, label="aba")
                 for cc, ca in ((False, True), (True, False)):
                     o = on.rnea(tq, tqd, tqdd, g, tf, consider_coriolis=cc, consider_accelerations=ca)
                     close(o.cpu().numpy().astype(np.float64), om.rnea(q, qd, qdd, g, fext, cc, ca), tol, label="rnea switches")
@@ -1490,6 +1494,7 @@ def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
         idx = np.unique(np.concatenate([np.arange(0, B, max(1, B // 64)), [B - 1]]))
         t_ref, a_ref = om.rnea(q[idx], qd[idx], qdd[idx], a0, fext[idx]), om.aba(q[idx], qd[idx], tau[idx], a0, fext[idx])
         cond = "mixed" in case or "planar" in case  # random mixed trees: forward dynamics conditioning (as in test_random_families_match_oracle)
+        H_idx = om.crba(q[idx]) if cond else None
         tq, tqd, tqdd, ttau, tf = (dev(torch, x) for x in (q, qd, qdd, tau, fext))
         for env in ({}, {"MH_DISABLE_SPEC": "1"}, {"MH_ZV": "0"}, {"MH_ZV": "2"}, {"MH_DISABLE_SPEC": "1", "MH_DFS": "0"}):
             if B > 9000 and env.get("MH_DFS") == "0":
@@ -1502,7 +1507,10 @@ def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
             t = hm.rnea(tq, tqd, tqdd, a0, tf)
             a = hm.aba(tq, tqd, ttau, a0, tf)
             close(t.cpu().numpy()[idx], t_ref)
-            close(a.cpu().numpy()[idx], a_ref, 1e-8 if cond else TOL)
+            if cond:
+                close_aba(a.cpu().numpy()[idx], a_ref, H_idx, d.n_joints, label="aba_f64 root acceleration")
+            else:
+                close(a.cpu().numpy()[idx], a_ref, TOL)
             close(hm.rnea(T(tq), T(tqd), T(tqdd), a0, tf.reshape(B, -1).t().contiguous(), layout=_lib.LAYOUT_SOA).t().cpu().numpy()[idx], t_ref)
             close(hm.aba(T(tq), T(tqd), T(ttau), a0, tf.reshape(B, -1).t().contiguous(), layout=_lib.LAYOUT_SOA).t().cpu().numpy()[idx], a_ref,
                   1e-8 if cond else TOL)
@@ -1519,7 +1527,7 @@ def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
                 # fp32 with the forward bound of the fp32 tests
                 f32 = lambda x: x.to(torch.float32)
                 t32 = hm.rnea(f32(tq), f32(tqd), f32(tqdd), a0, f32(tf)).cpu().numpy().astype(np.float64)[idx]
-                assert np.abs(t32 - t_ref).max() <= 64 * d.n_joints * 2.0 ** -24 * max(1.0, np.abs(t_ref).max())
+                assert np.abs(t32 - t_ref).max() <= f32_forward_tol(d.n_joints) * max(1.0, np.abs(t_ref).max())
             # the linear part alone is the gravity shorthand
             lin = np.concatenate([np.zeros(3), a0[3:]])
             assert torch.equal(hm.rnea(tq, tqd, tqdd, lin, tf), hm.rnea(tq, tqd, tqdd, -a0[3:], tf))
@@ -1535,3 +1543,113 @@ def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
     idc.compute(q, qd, qdd), fdc.compute(q, qd, tau)
     close(np.asarray(idc.getJointTauMatrix()), om.rnea(q, qd, qdd, a0))
     close(np.asarray(fdc.getJointAccelerationMatrix()), om.aba(q, qd, tau, a0), 1e-8 if ("mixed" in case or "planar" in case) else TOL)
+
+
+@pytest.mark.parametrize("force_transpose", ["1", None])
+def test_pair_call_side_by_side_with_transposed_scratch_copies(torch_cuda, monkeypatch, force_transpose):
+    """the side-by-side pair path swapped only the workspace; when BOTH launches go through transposed scratch copies
+    of the state matrices (wide matrices, 8192 <= B <= 16384, no fused kernel) they shared the copies' addresses across two streams.
+    A 40-joint chain (nq + nv = 80) with a permuted index provider, AoS, B = 8192: mh_rnea_aba_f64 call after call, without a
+    synchronisation in between, must equal the two separate calls bit for bit and the oracle on a sample."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(4242)
+    sys_ = system_of(rt.nextJointChain(rng, 40, ("revolute", "prismatic")))
+    d = sys_.toModelDesc()
+    perm_v, perm_q = rng.permutation(d.nv).astype(np.int32), rng.permutation(d.nq).astype(np.int32)
+    d.dof_indices = perm_v[np.asarray(d.dof_indices)]
+    d.cfg_indices = perm_q[np.asarray(d.cfg_indices)]
+    if force_transpose:
+        monkeypatch.setenv("MH_GENERIC_TRANSPOSE", force_transpose)
+    hm, om = HipModel(d), OracleModel(d)
+    assert hm.kernel_variant.startswith("generic")
+    g = (0.1, -0.2, -9.81)
+    B = 8192
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    q2, qd2, qdd2, tau2 = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(qdd), np.zeros_like(tau)
+    q2[:, perm_q], qd2[:, perm_v], qdd2[:, perm_v], tau2[:, perm_v] = q, qd, qdd, tau
+    tq, tqd, tqdd, ttau = (dev(torch, x) for x in (q2, qd2, qdd2, tau2))
+    t_ref, a_ref = hm.rnea(tq, tqd, tqdd, g), hm.aba(tq, tqd, ttau, g)
+    torch.cuda.synchronize()
+    outs = [hm.rnea_aba(tq, tqd, tqdd, ttau, g) for _ in range(6)]
+    torch.cuda.synchronize()
+    for t, a in outs:
+        assert torch.equal(t, t_ref) and torch.equal(a, a_ref)
+    idx = np.arange(0, B, 128)
+    close(t_ref.cpu().numpy()[idx], om.rnea(q2[idx], qd2[idx], qdd2[idx], g), 1e-10, label="rnea")
+    close(a_ref.cpu().numpy()[idx], om.aba(q2[idx], qd2[idx], tau2[idx], g), 1e-8, label="aba")
+
+
+@pytest.mark.parametrize("layout_name", ["aos", "soa"])
+def test_config5_at_its_full_per_gpu_shard(torch_cuda, layout_name):
+    """BASELINE.json configs[4] at the size one GPU of eight really runs: 1 048 576 / 8 = 131 072 configurations of the random 128-body
+    tree in fp32 (other LDS budgets, frame homes and depth-first plans than the 4096 / 8229 of test_config5_random_128_body_tree_fp32),
+    AoS and SoA, RNEA and ABA: 256 sampled rows against the fp64 oracle (derived fp32 bounds of tests/helpers.py; forward dynamics by its
+    backward error) and, on every row, the round trip RNEA(ABA(tau)) = tau within the backward bound.  8192 distinct states are drawn
+    on the host and tiled on the device (as bench.py does: drawing 131 072 x 362 numbers with numpy takes longer than the test)."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(128)
+    sys_ = system_of(rt.nextJointTree(rng, 128, ("revolute", "prismatic", "sixdof")))
+    d = sys_.toModelDesc()
+    B, base, n = 131072, 8192, d.n_joints
+    q, qd, qdd, tau = rt.nextState(np.random.default_rng(2342), sys_, base)
+    g = (0.0, 0.0, -9.81)
+    hm, om = HipModel(d), OracleModel(d)
+    f32 = torch.float32
+    soa = layout_name == "soa"
+    layout = _lib.LAYOUT_SOA if soa else _lib.LAYOUT_AOS
+    tile = lambda x: dev(torch, x, f32).repeat(B // base, 1)
+    tq, tqd, tqdd, ttau = (tile(x) for x in (q, qd, qdd, tau))
+    put = (lambda x: x.t().contiguous()) if soa else (lambda x: x)
+    rows = (lambda x: x.t()) if soa else (lambda x: x)
+    t32 = rows(hm.rnea(put(tq), put(tqd), put(tqdd), g, layout=layout))
+    a32 = rows(hm.aba(put(tq), put(tqd), put(ttau), g, layout=layout))
+    assert t32.shape == (B, d.nv) and a32.shape == (B, d.nv) and t32.dtype == f32
+    idx = np.unique(np.concatenate([np.arange(0, B, B // 255), [B - 1]]))[:256]
+    src = idx % base
+    t_ref = om.rnea(q[src], qd[src], qdd[src], g)
+    close(t32[torch.as_tensor(idx, device="cuda")].cpu().numpy().astype(np.float64), t_ref, f32_forward_tol(n), label=f"rnea_f32 {layout_name} 131072")
+    a_s = a32[torch.as_tensor(idx, device="cuda")].cpu().numpy().astype(np.float64)
+    bias = om.rnea(q[src], qd[src], np.zeros_like(qdd[src]), g)
+    scale = np.abs(tau[src]).max() + np.abs(bias).max()
+    berr = np.abs(om.rnea(q[src], qd[src], a_s, g) - tau[src]).max()
+    from helpers import record_parity
+    record_parity(berr, f32_aba_backward_tol(n) * scale, f"aba_f32 backward error {layout_name} 131072")
+    assert berr <= f32_aba_backward_tol(n) * scale, (berr, scale)
+    # every row: the tiles of one state are bit for bit the same, and the fp32 inverse dynamics of the fp32 accelerations returns the efforts
+    assert torch.equal(t32.reshape(B // base, base, d.nv)[0], t32.reshape(B // base, base, d.nv)[-1])
+    assert torch.equal(a32.reshape(B // base, base, d.nv)[0], a32.reshape(B // base, base, d.nv)[-1])
+    back = rows(hm.rnea(put(tq), put(tqd), put(a32.contiguous()), g, layout=layout))
+    rt_err = (back - ttau).abs().max().item()
+    record_parity(rt_err, 2 * f32_aba_backward_tol(n) * scale, f"fp32 round trip RNEA(ABA(tau)) {layout_name} 131072")
+    assert rt_err <= 2 * f32_aba_backward_tol(n) * scale, (rt_err, scale)
+
+
+def test_config4_at_full_size_on_one_gpu(torch_cuda):
+    """BASELINE.json configs[3] unsharded: forward dynamics of 262 144 configurations of the humanoid on ONE GPU (what `bench.py --config 4
+    --gpus 1` times): the device-filling plan of the tree-split kernels (persistent workgroups looping over the batch).  512 sampled rows
+    against the oracle at the absolute 1e-10, and on every row the round trip RNEA(ABA(tau)) = tau."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    d = sys_.toModelDesc()
+    B, base = 262144, 16384
+    q, qd, _, tau = rt.nextState(np.random.default_rng(2342), sys_, base)
+    g = (0.0, 0.0, -9.81)
+    hm = HipModel(d)
+    tq, tqd, ttau = (dev(torch, x).repeat(B // base, 1) for x in (q, qd, tau))
+    qdd = hm.aba(tq, tqd, ttau, g)
+    idx = np.arange(0, B, 512)
+    src = idx % base
+    close(qdd[torch.as_tensor(idx, device="cuda")].cpu().numpy(), OracleModel(d).aba(q[src], qd[src], tau[src], g), 1e-10, absolute=True,
+          label="aba 262144")
+    back = hm.rnea(tq, tqd, qdd, g)
+    assert (back - ttau).abs().max().item() <= 1e-9
+    assert torch.equal(qdd.reshape(B // base, base, d.nv)[0], qdd.reshape(B // base, base, d.nv)[-1])

@@ -169,8 +169,8 @@ def test_regressor_humanoid_first_moments_and_fp32(torch_cuda):
     assert Y32.dtype == torch.float32
     scale = float(Y[:2048].abs().max())
     err = float((Y32.double() - Y[:2048]).abs().max())
-    bound = 64 * d.n_joints * 2.0 ** -24 * scale
-    from helpers import record_parity
+    from helpers import f32_forward_tol, record_parity
+    bound = f32_forward_tol(d.n_joints) * scale
     record_parity(err, bound, "fp32 Y")
     assert err <= bound, (err, bound)
 

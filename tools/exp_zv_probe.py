@@ -40,6 +40,9 @@ for job in (0, 1):
 print("wait for the flag (flag_seen - root), wave 0: median %.2f us, max %.2f us" % (np.median(st[:, 1, 0, 5] - st[:, 1, 0, 4]) / 100, (st[:, 1, 0, 5] - st[:, 1, 0, 4]).max() / 100))
 print("flag stored -> flag seen (same group): median %.2f us" % (np.median(st[:, 1, 0, 5] - st[:, 0, 0, 7]) / 100))
 print("entry skew: bias job %.2f..%.2f us, inertia job %.2f..%.2f us" % ((st[:, 0, 0, 0] - t0).min() / 100, (st[:, 0, 0, 0] - t0).max() / 100, (st[:, 1, 0, 0] - t0).min() / 100, (st[:, 1, 0, 0] - t0).max() / 100))
+if (st[:, 1, :, 12] > 0).all():
+    for w in range(4):
+        print(f"inward limb phase, wave {w}: first pass (cold instruction cache) {np.median(st[:, 1, w, 12] - st[:, 1, w, 1]) / 100:.2f} us, second pass (warm) {np.median(st[:, 1, w, 2] - st[:, 1, w, 13]) / 100:.2f} us")
 print("after the prologue (before the scalar-cache warm-up), median: bias %.2f, inertia %.2f us" % (np.median(st[:, 0, :, 14] - t0) / 100, np.median(st[:, 1, :, 14] - t0) / 100))
 print("kernel entry (first instruction) relative to t0: bias %.2f..%.2f, inertia %.2f..%.2f us" % ((st[:, 0, :, 15].min() - t0) / 100, (st[:, 0, :, 15].max() - t0) / 100, (st[:, 1, :, 15].min() - t0) / 100, (st[:, 1, :, 15].max() - t0) / 100))
 if what == "pair":
