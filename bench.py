@@ -96,6 +96,32 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, jobs, target_s=10.0):
                       f"oracle/mecano_oracle.c (C restatement in fp64, not Mecano/JVM), {cores} threads, {dt:.1f} s; one thread alone: {single:.0f} configs/s"}
 
 
+def mecano_jvm_baseline(iterations=50000):
+    """the REAL Mecano calculators timed on one host core by java/us/ihmc/mecano/hip/tools/MecanoGoldenVectorHarness.java
+    (InverseDynamicsCalculatorTest.java:124-158's protocol on the 30-DoF humanoid).  Needs `java` / `javac` >= 17 on PATH and the Mecano,
+    Euclid and EJML jars in $MECANO_CLASSPATH; returns None otherwise (this repository's image and its GPU box have no JVM)."""
+    import shutil, subprocess, tempfile
+    cp = os.environ.get("MECANO_CLASSPATH")
+    if not (cp and shutil.which("java") and shutil.which("javac")):
+        return None
+    out = tempfile.mkdtemp(prefix="mh_mecano_")
+    try:
+        src = os.path.join(ROOT, "java", "us", "ihmc", "mecano", "hip", "tools", "MecanoGoldenVectorHarness.java")
+        subprocess.run(["javac", "-cp", cp, "-d", out, src], check=True, timeout=300)
+        p = subprocess.run(["java", "-cp", out + os.pathsep + cp, "us.ihmc.mecano.hip.tools.MecanoGoldenVectorHarness",
+                            os.path.join(ROOT, "mecano_amd", "models", "humanoid30.json"), os.path.join(ROOT, "tests", "golden", "states_humanoid30.json"),
+                            os.path.join(out, "mecano_humanoid30.json"), str(iterations)], check=True, timeout=600, capture_output=True, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith('{"mecano_cpu_baseline"')][-1]
+        b = json.loads(line)["mecano_cpu_baseline"]
+        return {"value": b["rnea_aba_pair_including_frame_update"], "unit": "configs/s", "cores": 1, "kind": "reference",
+                "sample": f"{iterations} fresh states of the 30-DoF humanoid, one thread, us.ihmc.mecano InverseDynamicsCalculator + ForwardDynamicsCalculator "
+                          f"+ updateFramesRecursively per configuration (rnea alone {b['rnea']:.0f}/s, aba alone {b['aba']:.0f}/s)"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def committed_traffic(fused_launch, B):
     """Fallback for `roofline.traffic`: the rocprofv3 PMC passes committed under profiles/ (same workload, same correction); only quoted
     for the configuration they were collected on, else null."""
@@ -454,7 +480,10 @@ def main():
         "check": check,
     }
     # CPU baseline beside it: rank 0 at N = 1 only (a reported baseline, not the optimisation target)
-    line["cpu_baseline"] = cpu_baseline(desc, q, qd, qdd, tau_in, gravity, jobs) if (world == 1 and not args.no_cpu_baseline) else None
+    line["cpu_baseline"] = None
+    if world == 1 and not args.no_cpu_baseline:
+        jvm = mecano_jvm_baseline() if cfg == 0 else None  # the true Mecano figure when a JVM and the jars are on the box ...
+        line["cpu_baseline"] = jvm or cpu_baseline(desc, q, qd, qdd, tau_in, gravity, jobs)  # ... else the C restatement ("port")
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

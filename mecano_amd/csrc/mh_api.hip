@@ -9,6 +9,11 @@
 #include "mh_split_kernels.h"
 
 #include <dlfcn.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <cerrno>
+extern char **environ;
 #include <unistd.h>
 
 #include <algorithm>
@@ -220,6 +225,7 @@ struct mh_model
    int use_fused = 1;       // MH_DISABLE_FUSED=1: mh_rnea_aba_f64 always issues two launches
    int fused_factor = 4;    // one launch for RNEA + ABA while 2 * ceil(B / 64) workgroups <= cu_count * factor (MH_FUSED_FACTOR)
    int use_spec = 1;        // MH_DISABLE_SPEC=1 in the environment forces the generic kernels (A/B measurements)
+   bool spec_minimal = false; // the loaded code object is a minimal (fast) build
    int lds_wave_factor = 1; // ABA hand-over in LDS while waves <= cu_count * factor (MH_ABA_LDS_FACTOR)
    int ident_maps = 0;      // the engine-order index maps are the identity
    int dense_maps = 0;      // nq / nv equal the joints' totals (no unused matrix rows): rows can be staged as dense blocks
@@ -1362,8 +1368,14 @@ void try_load_spec(mh_model *m, const Plan &P)
    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
    if (const char *e = getenv("MH_SPEC_DIR")) // experiment builds of the specialised code objects live elsewhere (tools/isa.py)
       dir = e;
-   const std::string path = dir + "/libmecano_hip_topo_" + P.key + ".so";
+   // the full code object, else a minimal one (mh_build_code_object's fast form: tree-split RNEA / ABA / pair for AoS + identity maps)
+   std::string path = dir + "/libmecano_hip_topo_" + P.key + ".so";
    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+   if (!h)
+   {
+      path = dir + "/libmecano_hip_topo_" + P.key + ".min.so";
+      h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+   }
    if (!h)
       return;
    auto f_n = (int (*)(void))dlsym(h, "mh_spec_n");
@@ -1416,6 +1428,10 @@ void try_load_spec(mh_model *m, const Plan &P)
    }
    m->spec = s;
    m->variant = "topo:" + P.key;
+   auto f_min = (int (*)(void))dlsym(h, "mh_spec_minimal");
+   m->spec_minimal = f_min && f_min() != 0;
+   if (m->spec_minimal)
+      m->variant += " (minimal build: tree-split RNEA / ABA / pair kernels only, every other plan on the run-time-topology kernels)";
 }
 // Mass matrix + Coriolis matrix (CompositeRigidBodyMassMatrixCalculator with the Coriolis calculation enabled): run-time-topology kernel
 template <typename T>
@@ -2028,9 +2044,17 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    if (m->use_split_rt != 0)
       split_rt_plan(m);
    try_load_spec(m, P);
-   if (const char *ab = getenv("MH_AUTO_BUILD"); ab && atoi(ab) != 0 && !m->spec.handle && m->use_spec && m->variant == "generic")
-   { // no code object for this tree yet: build one now (hipcc on the box; fast form: seconds; MH_AUTO_BUILD=2: the full set, minutes)
+   // MH_AUTO_BUILD: no usable code object for this tree (none there, or one refused for its ABI stamp / tree) -> build one now (hipcc on the
+   // box; 1: the fast form, seconds; 2: the full set, minutes -- also when only a minimal object was found)
+   if (const char *ab = getenv("MH_AUTO_BUILD"); ab && atoi(ab) != 0 && m->use_spec
+                                                 && ((!m->spec.handle && m->variant.compare(0, 7, "generic") == 0) || (atoi(ab) == 2 && m->spec.handle && m->spec_minimal)))
+   {
       char built[1024];
+      if (m->spec.handle)
+      { // a minimal object is loaded and the full set was asked for
+         dlclose(m->spec.handle);
+         m->spec = SpecLib{};
+      }
       if (build_code_object(d, getenv("MH_SPEC_DIR"), built, sizeof built, atoi(ab) != 2) == MH_OK)
          try_load_spec(m, P);
       else
@@ -2158,36 +2182,98 @@ static mh_status build_code_object(const mh_model_desc *desc, const char *out_di
       fclose(f);
    else
       return fail(MH_ERR_INVALID_ARGUMENT, "%s not found: the kernel sources must sit next to the library (csrc/)", src.c_str());
+   // The compiler is clang++ itself, not the hipcc wrapper: hipcc assembles a command line of its own and hands it to a shell, so a
+   // directory name with shell syntax in it would be interpreted there (seen in tests/test_abi.py).  MH_HIPCC overrides the choice.
    const char *hipcc = getenv("MH_HIPCC");
    std::string cc = hipcc ? hipcc : "";
    if (cc.empty())
    {
-      if (FILE *f = fopen("/opt/rocm/bin/hipcc", "r"))
-      {
-         fclose(f);
-         cc = "/opt/rocm/bin/hipcc";
-      }
-      else
-         cc = "hipcc";
+      for (const char *candidate : {"/opt/rocm/lib/llvm/bin/clang++", "/opt/rocm/llvm/bin/clang++"})
+         if (FILE *f = fopen(candidate, "r"))
+         {
+            fclose(f);
+            cc = candidate;
+            break;
+         }
+      if (cc.empty())
+         cc = "amdclang++";
    }
+   const size_t base = cc.find_last_of('/');
+   const bool wrapper = cc.compare(base == std::string::npos ? 0 : base + 1, std::string::npos, "hipcc") == 0; // a user's MH_HIPCC=hipcc: its own driver flags
    std::string parents, kinds;
    for (int e = 0; e < n; e++)
    {
       parents += (e ? "," : "") + std::to_string(P.eparent[e]);
       kinds += (e ? "," : "") + std::to_string(P.etype[e]);
    }
-   const std::string out = std::string(out_dir ? out_dir : dir.c_str()) + "/libmecano_hip_topo_" + P.key + ".so";
+   // A fast build (-DMH_SPEC_MINIMAL: tree-split RNEA / ABA / pair kernels for AoS matrices with identity index maps only) gets a name of
+   // its own, so that it can neither be taken for the full object by mecano_amd.build (which would never build the full set then) nor
+   // replace a full object; the loader prefers the full object and falls back to the minimal one.
+   const std::string out = std::string(out_dir ? out_dir : dir.c_str()) + "/libmecano_hip_topo_" + P.key + (fast ? ".min.so" : ".so");
    const std::string tmp = out + ".tmp" + std::to_string((long)getpid());
-   const char *extra = getenv("MH_HIPCC_FLAGS"); // appended to the compiler flags
-   // MH_BUILD_FAST=1: only the tree-split RNEA / ABA / fused kernels for AoS matrices with identity index maps (what a simulation or a
-   // controller calls) -- seconds instead of minutes; every other plan of the model keeps running on the run-time-topology kernels
-   const std::string cmd = cc + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-signed-zeros -ffinite-math-only -fno-slp-vectorize "
-                           + std::string(fast ? "-DMH_SPEC_MINIMAL " : "") + std::string(extra ? extra : "") + " -DMH_TOPO_N="
-                           + std::to_string(n) + " \"-DMH_TOPO_PARENTS=" + parents + "\" \"-DMH_TOPO_TYPES=" + kinds + "\" -o \"" + tmp + "\" \"" + src
-                           + "\" && mv \"" + tmp + "\" \"" + out + "\""; // (rename is atomic: a concurrent build of the same tree cannot leave a torn file)
-   const int rc = system(cmd.c_str());
-   if (rc != 0)
-      return fail(MH_ERR_HIP, "building the code object failed (exit status %d): %s", rc, cmd.c_str());
+   // hipcc is started WITHOUT a shell (posix_spawn with an argument vector): a directory name or flag handed in by an application cannot
+   // be interpreted as shell syntax.  MH_HIPCC_FLAGS is split at white space into separate arguments.
+   std::vector<std::string> argv_s = {cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only",
+                                      "-fno-slp-vectorize"};
+   if (!wrapper)
+   {
+      argv_s.push_back("--driver-mode=g++");
+      argv_s.push_back("--hip-link");
+   }
+   if (fast)
+      argv_s.push_back("-DMH_SPEC_MINIMAL");
+   if (const char *extra = getenv("MH_HIPCC_FLAGS"))
+   {
+      std::string word;
+      for (const char *c = extra;; c++)
+      {
+         if (*c == 0 || *c == ' ' || *c == '\t' || *c == '\n')
+         {
+            if (!word.empty())
+               argv_s.push_back(word);
+            word.clear();
+            if (*c == 0)
+               break;
+         }
+         else
+            word += *c;
+      }
+   }
+   argv_s.push_back("-DMH_TOPO_N=" + std::to_string(n));
+   argv_s.push_back("-DMH_TOPO_PARENTS=" + parents);
+   argv_s.push_back("-DMH_TOPO_TYPES=" + kinds);
+   argv_s.push_back("-o");
+   argv_s.push_back(tmp);
+   if (!wrapper)
+   {
+      argv_s.push_back("-x");
+      argv_s.push_back("hip");
+   }
+   argv_s.push_back(src);
+   std::vector<char *> argv;
+   for (std::string &a : argv_s)
+      argv.push_back(const_cast<char *>(a.c_str()));
+   argv.push_back(nullptr);
+   pid_t pid = 0;
+   const int sp = posix_spawnp(&pid, cc.c_str(), nullptr, nullptr, argv.data(), environ);
+   if (sp != 0)
+      return fail(MH_ERR_HIP, "cannot start %s: %s", cc.c_str(), strerror(sp));
+   int status = 0;
+   while (waitpid(pid, &status, 0) < 0)
+      if (errno != EINTR)
+         return fail(MH_ERR_HIP, "waiting for %s failed: %s", cc.c_str(), strerror(errno));
+   if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
+   {
+      (void)unlink(tmp.c_str());
+      if (WIFEXITED(status))
+         return fail(MH_ERR_HIP, "building the code object failed: %s exited with status %d", cc.c_str(), WEXITSTATUS(status));
+      return fail(MH_ERR_HIP, "building the code object failed: %s was ended by signal %d", cc.c_str(), WIFSIGNALED(status) ? WTERMSIG(status) : -1);
+   }
+   if (rename(tmp.c_str(), out.c_str()) != 0) // atomic: a concurrent build of the same tree cannot leave a torn file
+   {
+      (void)unlink(tmp.c_str());
+      return fail(MH_ERR_HIP, "cannot move the code object to %s: %s", out.c_str(), strerror(errno));
+   }
    if (path_out && path_cap)
       snprintf(path_out, path_cap, "%s", out.c_str());
    return MH_OK;

@@ -329,6 +329,15 @@ int mh_spec_split_plan(int *out, int cap)
 }
 // everything this object shares with libmecano_hip.so beyond its own entry points (argument structs, record strides, frame convention)
 unsigned long long mh_spec_abi(void) { return mh::spec_abi_stamp(); }
+// 1: built with -DMH_SPEC_MINIMAL (mh_build_code_object's fast form, tools/isa.py): only the tree-split RNEA / ABA / pair kernels
+int mh_spec_minimal(void)
+{
+#ifdef MH_SPEC_MINIMAL
+   return 1;
+#else
+   return 0;
+#endif
+}
 int mh_spec_n(void) { return TP::N; }
 const int *mh_spec_parents(void) { return kParents; }
 const int *mh_spec_types(void) { return kTypes; }

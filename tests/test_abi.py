@@ -209,3 +209,47 @@ def test_code_objects_can_be_built_through_the_c_abi(hip_lib, tmp_path, monkeypa
     assert hip_lib.mh_build_code_object(ctypes.byref(deep), str(tmp_path).encode(), path, 1024) == 5 and b"joints deep" in hip_lib.mh_last_error()
     sph, keep3 = c_desc(MultiBodySystem.toMultiBodySystemInput(rt.nextJointTree(rng, 4, ("spherical",))[0].getPredecessor()).toModelDesc())
     assert hip_lib.mh_build_code_object(ctypes.byref(sph), str(tmp_path).encode(), path, 1024) == 3
+
+
+def test_code_object_build_runs_hipcc_without_a_shell(hip_lib, tmp_path, monkeypatch):
+    """mh_build_code_object assembled a shell command from its out_dir argument and MH_HIPCC_FLAGS; `$(...)`, back-ticks and
+    quotes in a directory name reached /bin/sh.  It now starts hipcc with an argument vector (posix_spawn): a directory whose NAME is shell
+    syntax is just a directory, the fast build lands in it under a name of its own (.min.so), and nothing else is executed.  (Cross-compiles
+    here without a GPU; the three-finger hand builds in a few seconds.)"""
+    import ctypes
+    import shutil
+    import numpy as np
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.multibody import MultiBodySystem, RigidBody
+    rng = np.random.default_rng(515)
+    root = RigidBody("root")
+    for k in range(3):
+        rt.nextJointChain(rng, 2, ("revolute",), rootBody=root, prefix=f"finger{k}_")
+    desc = MultiBodySystem.toMultiBodySystemInput(root).toModelDesc()
+    keep, d = [], _lib.MhModelDesc()
+    d.n_joints, d.nq, d.nv = int(desc.n_joints), int(desc.nq), int(desc.nv)
+    for k, dt in (("parent", np.int32), ("joint_type", np.int32), ("dof_indices", np.int32), ("cfg_indices", np.int32), ("axis", np.float64),
+                  ("X_before", np.float64), ("X_com", np.float64), ("inertia_J", np.float64), ("inertia_mass", np.float64), ("inertia_com", np.float64)):
+        a = np.ascontiguousarray(getattr(desc, k), dtype=dt)
+        keep.append(a)
+        setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
+    marker = tmp_path / "INJECTED"
+    evil = tmp_path / "out $(touch INJECTED) `touch INJECTED` \"; touch INJECTED; \""  # cwd = tmp_path below: the marker would land there
+    evil.mkdir()
+    monkeypatch.setenv("MH_BUILD_FAST", "1")
+    monkeypatch.setenv("MH_HIPCC_FLAGS", f"-DMH_UNUSED_A=1   -DMH_UNUSED_B=2")
+    monkeypatch.chdir(tmp_path)
+    path = ctypes.create_string_buffer(2048)
+    rc = hip_lib.mh_build_code_object(ctypes.byref(d), str(evil).encode(), path, 2048)
+    assert rc == 0, hip_lib.mh_last_error()
+    assert not marker.exists(), "the out_dir argument was interpreted by a shell"
+    built = path.value.decode()
+    assert built.endswith(".min.so") and os.path.dirname(built) == str(evil) and os.path.getsize(built) > 0
+    assert sorted(os.listdir(evil)) == [os.path.basename(built)]  # no temporaries left behind
+    # a compiler that fails: the exit status is decoded, the temporary is removed
+    monkeypatch.setenv("MH_HIPCC_FLAGS", "--no-such-compiler-flag")  # the compiler refuses to start the build
+    rc = hip_lib.mh_build_code_object(ctypes.byref(d), str(evil).encode(), path, 2048)
+    assert rc != 0 and b"exited with status" in hip_lib.mh_last_error()
+    assert sorted(os.listdir(evil)) == [os.path.basename(built)]

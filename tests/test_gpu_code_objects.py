@@ -170,9 +170,11 @@ def test_fast_code_object_built_on_the_box_serves_what_it_has_and_falls_back_for
             setattr(d, k, a.ctypes.data_as(ctypes.c_void_p))
     path = ctypes.create_string_buffer(1024)
     assert hip_lib.mh_build_code_object(ctypes.byref(d), str(tmp_path).encode(), path, 1024) == 0, hip_lib.mh_last_error()
+    assert path.value.decode().endswith(".min.so")  # a fast build never takes the full object's name
     monkeypatch.setenv("MH_SPEC_DIR", str(tmp_path))
     hm = HipModel(desc)
     assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant  # stamp and self-check passed
+    assert "minimal build" in hm.kernel_variant
     om = OracleModel(desc)
     g = (0.0, 0.0, -9.81)
     B = 300

@@ -25,7 +25,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for f in glob.glob(f"{out}/{tag}_pmc_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "fused_split" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            if ("fused_split" in r["Kernel_Name"] or "zv_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == c and int(r["Grid_Size"]) >= 128 * 256:
                 vals.append(float(r["Counter_Value"]))
     if vals:
         res[f"{c}_KB_per_launch_mean"] = sum(vals) / len(vals)
