@@ -614,7 +614,7 @@ struct Ctx
    {
       if constexpr (OUTMODE == 1)
          v = in3(k) - v;
-      if constexpr (IO_LDS)
+      if constexpr (IO_LDS && OUTMODE != 2) // OUTMODE 2: results go straight to the caller's matrix although the inputs are staged in LDS
          lo[di(k)] = v;
       else
          orow[di(k) * v_es] = v;

@@ -197,7 +197,8 @@ struct ZvIn
 };
 
 // ---- the bias fold: pA' = sum over the children of X* pa'_c;  u = tau' - S^T pA';  pa' = pA' + U D^-1 u  (:1224-1235 with c = 0).
-//      Returns pa' in the parent's frame.  MODE 0: whole subtree; 1: trunk pass, limb roots come from the exchange area.
+//      Returns pa' in the parent's frame.  MODE 0: whole subtree; 1: trunk pass, limb roots come from the exchange area; 2: the root
+//      body alone of a staged fold (sub-trunks come from the exchange area too).
 template <class TP, int J, typename T, class CX, int MODE = 0>
 struct ZvFold
 {
@@ -208,8 +209,10 @@ struct ZvFold
       {
          constexpr int C = Tree<TP>::child(J, K);
          SV<T> c;
-         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+         if constexpr ((MODE == 1 || MODE == 2) && !Split<TP>::is_trunk(C))
             c = x_get6<Split<TP>::limb_index(C), ZV_XW, 0, CX, T>(cx);
+         else if constexpr (MODE == 2) // staged fold: the sub-trunk below the root was folded by one wave (zv_subtrunks_fold_of)
+            c = x_get6<Split<TP>::sub_slot(C), ZV_XW, 6, CX, T>(cx);
          else
             c = ZvFold<TP, C, T, CX, MODE>::run(cx);
          if constexpr (K == 0)
@@ -449,6 +452,174 @@ MH_DEV void zv_limbs_fold(const CX &cx)
    }
 }
 
+// ---- which trunk bodies a wave has to walk in the outward sweep: those above a limb it owns (it needs their accelerations), plus the
+//      ones it WRITES the accelerations of -- for every trunk body the lowest-numbered wave that walks it anyway
+template <class TP>
+struct ZvWalk
+{
+   using S = Split<TP>;
+   static constexpr bool below(int j, int top)
+   { // is body j in the subtree of (or equal to) body top
+      for (int a = j; a >= 0; a = TP::parent[a])
+         if (a == top)
+            return true;
+      return false;
+   }
+   static constexpr bool needs(int W, int J)
+   {
+      for (int k = 0; k < S::n_limbs(); k++)
+         if (S::owner(k) == W && below(S::limb_root(k), J))
+            return true;
+      return false;
+   }
+   static constexpr int writer(int J)
+   {
+      for (int w = 0; w < 4; w++)
+         if (needs(w, J))
+            return w;
+      return 0;
+   }
+};
+// outward sweep of wave W over the trunk (MODE 1 of ZvOut with the subtrees pruned in which W owns nothing), then W's limbs
+template <class TP, int J, int W, typename T, class CX>
+struct ZvOutW
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx, const SV<T> &a)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         constexpr int C = Tree<TP>::child(J, K);
+         if constexpr (!Split<TP>::is_trunk(C))
+         {
+            if constexpr (Split<TP>::owner(Split<TP>::limb_index(C)) == W)
+               ZvOut<TP, C, T, CX, 0>::run(cx, a);
+         }
+         else if constexpr (ZvWalk<TP>::needs(W, C))
+            ZvOutW<TP, C, W, T, CX>::run(cx, a);
+         children<K + 1>(cx, a);
+      }
+   }
+   static MH_DEV void run(const CX &cx, const SV<T> &ap)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr bool HAS_PARENT = TP::parent[J] >= 0;
+      constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
+      constexpr int RS = Tree<TP>::zv_result_slot(J, false);
+      constexpr bool WRITES = ZvWalk<TP>::writer(J) == W;
+      const T *cp = cx.C + J * MC_STRIDE;
+      asm volatile("" : "+s"(cp));
+      const CRef<T, false> c{cp};
+      const V3<T> Z{T(0), T(0), T(0)};
+      SV<T> a{Z, Z};
+      if constexpr (HAS_PARENT)
+      {
+         JX<T> jx;
+         jx.c = T(1), jx.s = T(0), jx.d = T(0);
+         if constexpr (TYPE == JT_REVOLUTE)
+            jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>();
+         else if constexpr (TYPE != JT_FIXED)
+            jx = spec_joint<TYPE, CO, CX, T>(cx);
+         a = motion_down(TYPE, jx, load_xb_j<TP, J, T>(c), ap);
+      }
+      if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
+      {
+         const V3<T> sa{cx.st.template get<J, 0>(), cx.st.template get<J, 1>(), cx.st.template get<J, 2>()};
+         const V3<T> sl{cx.st.template get<J, 3>(), cx.st.template get<J, 4>(), cx.st.template get<J, 5>()};
+         const T qdd = cx.st.template get<J, RS>() - (dot(sa, a.a) + dot(sl, a.l));
+         if constexpr (WRITES)
+            cx.out(DO, qdd);
+         if constexpr (TYPE == JT_REVOLUTE)
+            a.a.z += qdd;
+         else
+            a.l.z += qdd;
+      }
+      else if constexpr (TYPE == JT_SIXDOF)
+      {
+         const SV<T> x{V3<T>{cx.st.template get<J, RS + 0>(), cx.st.template get<J, RS + 1>(), cx.st.template get<J, RS + 2>()},
+                       V3<T>{cx.st.template get<J, RS + 3>(), cx.st.template get<J, RS + 4>(), cx.st.template get<J, RS + 5>()}};
+         if constexpr (WRITES)
+            spec_write<TYPE, DO, CX, T>(cx, x - a);
+         a = x;
+      }
+      MH_BODY_FENCE();
+      children<0>(cx, a);
+   }
+};
+template <class TP, int W, typename T, class CX, int K = 0>
+MH_DEV void zv_roots_out_wave(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      const V3<T> Z{T(0), T(0), T(0)};
+      constexpr int R = Tree<TP>::child(-1, K);
+      if constexpr (ZvWalk<TP>::needs(W, R) || ZvWalk<TP>::writer(R) == W)
+         ZvOutW<TP, R, W, T, CX>::run(cx, SV<T>{Z, Z});
+      zv_roots_out_wave<TP, W, T, CX, K + 1>(cx);
+   }
+}
+// limbs of wave W in the bias fold: LATE = -1 all, 0 / 1 the early / late ones of a staged trunk
+template <class TP, int W, int K, int LATE, typename T, class CX>
+MH_DEV void zv_limbs_fold_sel(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if constexpr (S::owner(K) == W && (LATE < 0 || (S::is_late(K) ? 1 : 0) == LATE))
+         x_put6<K, ZV_XW, 0, CX, T>(cx, ZvFold<TP, S::limb_root(K), T, CX, 0>::run(cx));
+      zv_limbs_fold_sel<TP, W, K + 1, LATE, T, CX>(cx);
+   }
+}
+// the sub-trunks wave W folds between the fold's two barriers: bias wrench handed up in the SECOND record of the exchange slot the
+// sub-trunk's inertia travelled in (its first record holds that early limb's own bias wrench, which this very fold consumes)
+template <class TP, int W, int I, typename T, class CX>
+MH_DEV void zv_subtrunks_fold_of(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (I < S::n_sub())
+   {
+      constexpr int ST = S::sub_top(I);
+      if constexpr (S::sub_owner(ST) == W)
+         x_put6<S::sub_slot(ST), ZV_XW, 6, CX, T>(cx, ZvFold<TP, ST, T, CX, 1>::run(cx));
+      zv_subtrunks_fold_of<TP, W, I + 1, T, CX>(cx);
+   }
+}
+// Bias fold and outward sweep of wave W.  Staged trunk: early limbs | barrier | late limbs and, on the waves that own them, the sub-trunks
+// (their results go to the trunk's LDS slots) | barrier | the root body alone on every wave | the outward sweep over the part of the
+// trunk W needs.  The serial chain is max(early limbs + sub-trunk, late limbs) + root instead of (all limbs of a wave) + (whole trunk).
+// Plain split: limbs | barrier | whole trunk on every wave | pruned outward sweep.  Every wave passes the same number of barriers.
+template <class TP, int W, typename T, class CX>
+MH_DEV void zv_fold_out(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+      {
+         if constexpr (S::staged())
+         {
+            zv_limbs_fold_sel<TP, W, 0, 0, T, CX>(cx);
+            __syncthreads();
+            zv_limbs_fold_sel<TP, W, 0, 1, T, CX>(cx);
+            zv_subtrunks_fold_of<TP, W, 0, T, CX>(cx);
+            __syncthreads();
+            (void)ZvFold<TP, S::root(), T, CX, 2>::run(cx);
+         }
+         else
+         {
+            zv_limbs_fold_sel<TP, W, 0, -1, T, CX>(cx);
+            __syncthreads();
+            zv_roots_fold<TP, T, CX>(cx);
+         }
+         asm volatile("" ::: "memory");
+         zv_roots_out_wave<TP, W, T, CX>(cx);
+      }
+      else
+         zv_fold_out<TP, W + 1, T, CX>(cx);
+   }
+}
+
 // rows of one matrix, global -> LDS, all NT threads of the workgroup (N entries per configuration, `rows` configurations)
 template <typename T, int N, int NT>
 MH_DEV void zv_stage_rows(lds_ptr<T> dst, const T *src, int rows)
@@ -571,7 +742,10 @@ template <class TP, typename T, bool IDENT>
 MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup, const ZvSync &sy)
 {
    using S = Split<TP>;
-   using CX = Ctx<T, true, IDENT, ZvStore<TP>>;
+#ifndef MH_ZV_DIRECT_OUT
+#define MH_ZV_DIRECT_OUT 0 // experiment knob: 1 = accelerations stored per lane as they are formed instead of LDS rows + one coalesced copy
+#endif
+   using CX = Ctx<T, true, IDENT, ZvStore<TP>, false, MH_ZV_DIRECT_OUT ? 2 : 0>;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
    const int nq = A.m.nq, nv = A.m.nv;
@@ -619,6 +793,10 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    if (active)
       zv_roots_in<TP, T, CX, (S::staged() ? 2 : 1)>(cx);
    ZV_STAMP(1, 4);
+   // (Polling from a spare wave WHILE the others run the root body's step was measured: the flag is then seen ~0.7 us LATER -- a poll that
+   // reaches memory before the flag store leaves the old line behind for the polls after it -- 17.6 against 16.1 us per step.  Publishing
+   // the limbs' rows ahead of the trunk's entries, fetched by the least-loaded wave during the limb phase: 19.6 us, every extra
+   // store -> flag -> poll -> load chain through memory costs ~3 us.  The plain form below is the fastest of the three.)
    if (wave == 0)
       zv_wait(sy, k);
    __syncthreads(); // the polling wave has seen the flag: now every wave may load the rows
@@ -627,21 +805,14 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    __syncthreads(); // bias rows staged; nobody reads the exchange area's inertias any more
    ZV_STAMP(1, 6);
    asm volatile("" ::: "memory");
-   if (active)
-      zv_limbs_fold<TP, 0, T, CX>(cx);
-   ZV_STAMP(1, 7);
-   __syncthreads(); // every limb's bias wrench is in the exchange area
-   ZV_STAMP(1, 8);
-   if (active)
-   {
-      zv_roots_fold<TP, T, CX>(cx);
-      ZV_STAMP(1, 9);
-      asm volatile("" ::: "memory");
-      zv_roots_out<TP, T, CX>(cx);
-   }
+   if (active) // (lane 0 of every wave is active: each wave reaches the barriers the fold carries in here)
+      zv_fold_out<TP, 0, T, CX>(cx);
    ZV_STAMP(1, 10);
-   __syncthreads();
-   wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
+   if constexpr (!MH_ZV_DIRECT_OUT)
+   {
+      __syncthreads();
+      wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
+   }
    ZV_STAMP(1, 11);
 }
 
