@@ -1653,3 +1653,76 @@ def test_config4_at_full_size_on_one_gpu(torch_cuda):
     back = hm.rnea(tq, tqd, qdd, g)
     assert (back - ttau).abs().max().item() <= 1e-9
     assert torch.equal(qdd.reshape(B // base, base, d.nv)[0], qdd.reshape(B // base, base, d.nv)[-1])
+
+
+def test_reference_signatures_on_one_configuration(torch_cuda):
+    """The calculators' OWN signatures (VERDICT r2 missing 2; BASELINE configs[0] is exactly this plumbing): compute() reading q, qd, qdd /
+    tau from the joints, compute(matrix), setExternalWrench(body, wrench) / getExternalWrench, getComputedJointTau,
+    writeComputedJointWrench(es), getComputedJointAcceleration, writeComputedJointAcceleration(s) and the 6-D setRootAcceleration
+    (InverseDynamicsCalculator.java:413-501, 567-653; ForwardDynamicsCalculator.java:330-381, 475-520, 556-708) -- one configuration
+    through the HIP path, results shaped and written back like the reference's, against the oracle."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.calculators import ForwardDynamicsCalculator, InverseDynamicsCalculator
+    from mecano_amd.multibody import JointStateType, MultiBodySystemTools
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(77)
+    for sys_ in (system_of(rt.nextJointChain(rng, 7, ("revolute",))), rt.nextHumanoid(rng), system_of(families()["onedof_tree"](rng, 9))):
+        d = sys_.toModelDesc()
+        om = OracleModel(d)
+        joints = sys_.getJointMatrixIndexProvider().getIndexedJointsInOrder()
+        provider = sys_.getJointMatrixIndexProvider()
+        q, qd, qdd, tau = rt.nextState(rng, sys_, 1)
+        for kind, row in ((JointStateType.CONFIGURATION, q), (JointStateType.VELOCITY, qd), (JointStateType.ACCELERATION, qdd), (JointStateType.EFFORT, tau)):
+            MultiBodySystemTools.insertJointsState(joints, kind, row.reshape(-1, 1))
+        idc, fdc = InverseDynamicsCalculator(sys_), ForwardDynamicsCalculator(sys_)
+        idc.setGravitationalAcceleration(-9.81), fdc.setGravitationalAcceleration(-9.81)
+        g = (0.0, 0.0, -9.81)
+        # compute(): everything from the joints
+        idc.compute()
+        t_ref = om.rnea(q, qd, qdd, g)
+        assert idc.getJointTauMatrix().shape == (d.nv, 1)
+        close(idc.getJointTauMatrix()[:, 0], t_ref[0])
+        fdc.compute()
+        a_ref = om.aba(q, qd, tau, g)
+        assert fdc.getJointAccelerationMatrix().shape == (d.nv, 1)
+        close(fdc.getJointAccelerationMatrix()[:, 0], a_ref[0], 1e-9)
+        # compute(matrix): the accelerations / efforts given explicitly, column vectors like DMatrixRMaj
+        qdd2, tau2 = rng.uniform(-1, 1, (d.nv, 1)), rng.uniform(-1, 1, (d.nv, 1))
+        idc.compute(qdd2)
+        close(idc.getJointTauMatrix()[:, 0], om.rnea(q, qd, qdd2.T, g)[0])
+        fdc.compute(tau2)
+        close(fdc.getJointAccelerationMatrix()[:, 0], om.aba(q, qd, tau2.T, g)[0], 1e-9)
+        with pytest.raises(Exception):
+            idc.compute(np.zeros((d.nv + 1, 1)))  # MatrixDimensionException in the reference
+        # external wrenches per body, a rotating base, and the write-back into the joints
+        body = joints[-1].getSuccessor()
+        w = rng.uniform(-2, 2, 6)
+        idc.setExternalWrench(body, w), fdc.setExternalWrench(body, w)
+        assert np.array_equal(idc.getExternalWrench(body), w)
+        fext = np.zeros((1, d.n_joints, 6))
+        fext[0, len(joints) - 1] = w
+        a0 = rng.uniform(-1, 1, 6)
+        idc.setRootAcceleration(a0), fdc.setRootAcceleration(a0)
+        idc.compute(), fdc.compute()
+        t_ref, a_ref = om.rnea(q, qd, qdd, a0, fext), om.aba(q, qd, tau, a0, fext)
+        close(idc.getJointTauMatrix()[:, 0], t_ref[0])
+        close(fdc.getJointAccelerationMatrix()[:, 0], a_ref[0], 1e-9)
+        j = joints[min(3, len(joints) - 1)]
+        rows = provider.getJointDoFIndices(j)
+        assert idc.getComputedJointTau(j).shape == (len(rows), 1) and np.array_equal(idc.getComputedJointTau(j)[:, 0], idc.getJointTauMatrix()[rows, 0])
+        assert np.array_equal(fdc.getComputedJointAcceleration(j)[:, 0], fdc.getJointAccelerationMatrix()[rows, 0])
+        idc.writeComputedJointWrenches(joints)
+        fdc.writeComputedJointAccelerations(joints)
+        back_t, back_a = np.zeros((d.nv, 1)), np.zeros((d.nv, 1))
+        MultiBodySystemTools.extractJointsState(joints, JointStateType.EFFORT, back_t)
+        MultiBodySystemTools.extractJointsState(joints, JointStateType.ACCELERATION, back_a)
+        assert np.array_equal(back_t, np.asarray(idc.getJointTauMatrix())) and np.array_equal(back_a, np.asarray(fdc.getJointAccelerationMatrix()))
+        idc.setExternalWrenchesToZero()
+        idc.compute()
+        close(idc.getJointTauMatrix()[:, 0], om.rnea(q, qd, back_a.T, a0)[0])  # (the joints now hold the accelerations written back)
+        # a batched call afterwards is a batched call again
+        qb, qdb, qddb, _ = rt.nextState(rng, sys_, 5)
+        assert np.asarray(idc.compute(qb, qdb, qddb)).shape == (5, d.nv)
+        with pytest.raises(ValueError):
+            idc.writeComputedJointWrench(j)

@@ -149,3 +149,32 @@ def test_committed_humanoid_model_is_what_the_generator_produces():
     assert (a.n_joints, a.nq, a.nv) == (b.n_joints, b.nq, b.nv) == (25, 31, 30)
     for f in ("parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices"):
         assert np.array_equal(np.asarray(getattr(a, f)).reshape(-1), np.asarray(getattr(b, f)).reshape(-1)), f
+
+
+def test_joint_state_and_extract_insert_follow_the_reference():
+    """JointBasics.setJointConfiguration / ...Velocity / ...Acceleration / ...Tau (multiBodySystem/interfaces/JointBasics.java:150-224) and
+    MultiBodySystemTools.extractJointsState / insertJointsState (tools/MultiBodySystemTools.java:1433-1491, 1578-1637): joints in index
+    provider order, each consuming getConfigurationMatrixSize() / getDegreesOfFreedom() rows; a fresh floating joint sits at the identity."""
+    import numpy as np
+    from mecano_amd import random_tools as rt
+    from mecano_amd.multibody import JointStateType, MultiBodySystemTools
+    sys_ = rt.nextHumanoid(np.random.default_rng(1))
+    joints = sys_.getJointMatrixIndexProvider().getIndexedJointsInOrder()
+    nq, nv = sys_.getConfigurationSize(), sys_.getNumberOfDoFs()
+    q0 = np.zeros((nq, 1))
+    assert MultiBodySystemTools.extractJointsState(joints, JointStateType.CONFIGURATION, q0) == nq
+    assert q0[3, 0] == 1.0 and np.count_nonzero(q0) == 1  # identity quaternion (x, y, z, s) of the pelvis, everything else zero
+    q, qd, qdd, tau = rt.nextState(np.random.default_rng(2), sys_, 1)
+    for kind, row, size in ((JointStateType.CONFIGURATION, q[0], nq), (JointStateType.VELOCITY, qd[0], nv),
+                            (JointStateType.ACCELERATION, qdd[0], nv), (JointStateType.EFFORT, tau[0], nv)):
+        assert MultiBodySystemTools.insertJointsState(joints, kind, row.reshape(-1, 1)) == size
+        back = np.zeros((size, 1))
+        assert MultiBodySystemTools.extractJointsState(joints, kind, back) == size
+        assert np.array_equal(back[:, 0], row)
+    # per-joint access with a row offset, and the one-DoF convenience setters
+    provider = sys_.getJointMatrixIndexProvider()
+    knee = joints[4]
+    assert knee.getDegreesOfFreedom() == 1 and knee.getQd() == qd[0, provider.getJointDoFIndices(knee)[0]]
+    knee.setQdd(0.25)
+    m = np.zeros(5)
+    assert knee.getJointAcceleration(3, m) == 4 and m[3] == 0.25
