@@ -24,7 +24,7 @@ SOURCES = [os.path.join(CSRC, "mh_api.hip")]
 HEADERS = [os.path.join(CSRC, "mh_kernels.h"), os.path.join(CSRC, "mh_device.h"), os.path.join(ROOT, "include", "mecano_hip.h")]
 LIB_HEADERS = HEADERS + [os.path.join(CSRC, "mh_dfs_kernels.h"), os.path.join(CSRC, "mh_split_kernels.h")]  # the library's own kernels
 SPEC_SOURCE = os.path.join(CSRC, "mh_spec.hip")
-SPEC_HEADERS = HEADERS + [os.path.join(CSRC, "mh_spec_kernels.h")]
+SPEC_HEADERS = HEADERS + [os.path.join(CSRC, "mh_spec_kernels.h"), os.path.join(CSRC, "mh_zv_kernels.h")]
 # -fno-signed-zeros -ffinite-math-only: lets the compiler drop the multiplications by the structural zeros of the canonical
 # joint frames (S = e_z); no reassociation is enabled, products and sums keep their written order.
 # -fno-slp-vectorize: hipcc 7.2 packs adjacent fp32 operations into v_pk_* instructions; in crba_kernel<float> that came with a wrong

@@ -802,6 +802,11 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    __syncthreads(); // the polling wave has seen the flag: now every wave may load the rows
    ZV_STAMP(1, 5);
    zv_fetch_rows<T, Tree<TP>::total_dofs(), 256>(lx, taup + cfg0 * nv, rows);
+   // The flag goes back to zero once its rows have been consumed: a captured launch is replayed with the SAME epoch (hipGraph), and a flag
+   // left standing from the previous replay would let this job read the previous replay's rows.  (Stream order puts the reset before the
+   // next launch's bias job; the rows' loads were issued above and this store cannot pass the flag poll it depends on.)
+   if (threadIdx.x == 0)
+      __hip_atomic_store(sy.flags + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    __syncthreads(); // bias rows staged; nobody reads the exchange area's inertias any more
    ZV_STAMP(1, 6);
    asm volatile("" ::: "memory");

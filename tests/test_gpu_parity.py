@@ -1356,6 +1356,17 @@ def test_entry_points_are_graph_capturable(torch_cuda, monkeypatch, spec):
     torch.cuda.synchronize()
     assert torch.equal(t_out, t_ref) and torch.equal(a_out, a_ref) and torch.equal(t2_out, t2_ref) and torch.equal(H_out, H_ref)
     assert torch.equal(qs, qn_ref) and torch.equal(qds, qdn_ref)
+    # replayed on NEW inputs (written into the captured buffers): a replay re-issues the launch with the arguments of the capture -- the
+    # bias-split launch's epoch among them -- so nothing of the previous replay may be taken for this one's (flags reset by their consumer)
+    q2, qd2, qdd2, tau2 = (dev(torch, x) for x in rt.nextState(rng, sys_, B))
+    t_ref2, a_ref2 = hm.rnea_aba(q2, qd2, qdd2, tau2, g)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        q.copy_(q2), qd.copy_(qd2), qdd.copy_(qdd2), tau.copy_(tau2), qs.copy_(q2), qds.copy_(qd2)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(t_out, t_ref2) and torch.equal(a_out, a_ref2)
 
 
 def test_host_pointer_pipeline(torch_cuda, monkeypatch):
