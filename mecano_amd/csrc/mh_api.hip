@@ -1055,10 +1055,9 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             return s3;
          T *t_q = (T *)model->tr.ptr, *t_qd = t_q + (size_t)B * nq, *t_in3 = t_qd + (size_t)B * nv;
          t_out = t_in3 + (size_t)B * nv;
-         const dim3 gq((unsigned)(((B + 63) / 64) * ((nq + 63) / 64))), gv((unsigned)(((B + 63) / 64) * ((nv + 63) / 64)));
-         hipLaunchKernelGGL((mh::transpose_kernel<T>), gq, dim3(256), 0, stream, q, t_q, (long)B, (long)nq);
-         hipLaunchKernelGGL((mh::transpose_kernel<T>), gv, dim3(256), 0, stream, qd, t_qd, (long)B, (long)nv);
-         hipLaunchKernelGGL((mh::transpose_kernel<T>), gv, dim3(256), 0, stream, in3, t_in3, (long)B, (long)nv);
+         mh::transpose_rows<T>(q, t_q, (long)B, (long)nq, true, stream);
+         mh::transpose_rows<T>(qd, t_qd, (long)B, (long)nv, true, stream);
+         mh::transpose_rows<T>(in3, t_in3, (long)B, (long)nv, true, stream);
          A.q = t_q, A.qd = t_qd, A.in3 = t_in3, A.out = t_out;
          A.q_bs = 1, A.q_es = B, A.v_bs = 1, A.v_es = B;
       }
@@ -1131,8 +1130,7 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    }
    if (t_out)
    {
-      const dim3 go((unsigned)(((model->nv + 63) / 64) * ((B + 63) / 64)));
-      hipLaunchKernelGGL((mh::transpose_kernel<T>), go, dim3(256), 0, stream, (const T *)t_out, out, (long)model->nv, (long)B);
+      mh::transpose_rows<T>((const T *)t_out, out, (long)B, (long)model->nv, false, stream);
    }
    HIP_TRY(hipGetLastError());
    return MH_OK;

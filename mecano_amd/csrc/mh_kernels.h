@@ -505,6 +505,91 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T *__restrict__ sr
          dst[(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
+// Wide matrices (the 128-body tree: n = 323 / 362, not a multiple of anything): the AoS side of a 64 x 64 tile is 64 pieces of 256 bytes
+// at odd alignments, and the tile kernel reaches 3.4 TB/s (read + write) there.  But R consecutive ROWS of an AoS matrix are one
+// contiguous block of R * n entries: with R = 128 / sizeof(T) it starts on a 128-byte boundary whatever n is, so a workgroup moves it with
+// aligned 16-byte accesses and the other side sees whole 128-byte lines (R entries of one column).  The block passes through LDS as it
+// lies in memory ([R][n], 128 n bytes); the transposition is the LDS gather / scatter.
+// Needs B % V == 0 (V = 16 / sizeof(T): every column segment is then 16-byte aligned), 16-byte aligned bases and 128 n bytes of LDS.
+template <typename T>
+struct RowBlock
+{
+   static constexpr int V = 16 / (int)sizeof(T), R = 128 / (int)sizeof(T), LPC = R / V; // LPC lanes per column segment (8)
+   typedef T VT __attribute__((ext_vector_type(V)));
+};
+// src [B][n] (AoS) -> dst [n][B] (SoA)
+template <typename T>
+__global__ void __launch_bounds__(256) rows_to_columns_kernel(const T *__restrict__ src, T *__restrict__ dst, long B, int n)
+{
+   using RB = RowBlock<T>;
+   using VT = typename RB::VT;
+   constexpr int V = RB::V, R = RB::R, LPC = RB::LPC;
+   extern __shared__ double lds_raw[];
+   T *const blk = (T *)lds_raw;
+   const long r0 = (long)blockIdx.x * R;
+   const int rows = (int)(B - r0 < R ? B - r0 : R), len = rows * n; // rows % V == 0, hence len % V == 0
+   const T *const flat = src + r0 * n;
+   for (int i = threadIdx.x * V; i + V <= len; i += 256 * V)
+      *(VT *)(blk + i) = *(const VT *)(flat + i);
+   __syncthreads();
+   const int rb = (threadIdx.x % LPC) * V, jl = threadIdx.x / LPC;
+   if (rb < rows)
+      for (int j = jl; j < n; j += 256 / LPC)
+      {
+         VT w;
+#pragma unroll
+         for (int k = 0; k < V; k++)
+            w[k] = blk[(rb + k) * n + j];
+         *(VT *)(dst + (long)j * B + r0 + rb) = w;
+      }
+}
+// src [n][B] (SoA) -> dst [B][n] (AoS)
+template <typename T>
+__global__ void __launch_bounds__(256) columns_to_rows_kernel(const T *__restrict__ src, T *__restrict__ dst, long B, int n)
+{
+   using RB = RowBlock<T>;
+   using VT = typename RB::VT;
+   constexpr int V = RB::V, R = RB::R, LPC = RB::LPC;
+   extern __shared__ double lds_raw[];
+   T *const blk = (T *)lds_raw;
+   const long r0 = (long)blockIdx.x * R;
+   const int rows = (int)(B - r0 < R ? B - r0 : R), len = rows * n;
+   const int rb = (threadIdx.x % LPC) * V, jl = threadIdx.x / LPC;
+   if (rb < rows)
+      for (int j = jl; j < n; j += 256 / LPC)
+      {
+         const VT w = *(const VT *)(src + (long)j * B + r0 + rb);
+#pragma unroll
+         for (int k = 0; k < V; k++)
+            blk[(rb + k) * n + j] = w[k];
+      }
+   __syncthreads();
+   T *const flat = dst + r0 * n;
+   for (int i = threadIdx.x * V; i + V <= len; i += 256 * V)
+      *(VT *)(flat + i) = *(const VT *)(blk + i);
+}
+// [B][n] -> [n][B] (to_columns) or [n][B] -> [B][n] on `stream`: row blocks for wide matrices, 64 x 64 tiles otherwise
+template <typename T>
+inline void transpose_rows(const T *src, T *dst, long B, long n, bool to_columns, hipStream_t stream)
+{
+   using RB = RowBlock<T>;
+   const size_t lds = (size_t)128 * (size_t)n;
+   if (B % RB::V == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && lds >= 16 * 1024 && lds <= 64 * 1024)
+   {
+      const dim3 grid((unsigned)((B + RB::R - 1) / RB::R));
+      if (to_columns)
+         hipLaunchKernelGGL((rows_to_columns_kernel<T>), grid, dim3(256), lds, stream, src, dst, B, (int)n);
+      else
+         hipLaunchKernelGGL((columns_to_rows_kernel<T>), grid, dim3(256), lds, stream, src, dst, B, (int)n);
+      return;
+   }
+   const dim3 grid((unsigned)(((B + 63) / 64) * ((n + 63) / 64)));
+   if (to_columns)
+      hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, stream, src, dst, B, n);
+   else
+      hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, stream, src, dst, n, B);
+}
+
 // ============================================================================================ RNEA
 template <typename T, bool LDSC, bool BODIES = false>
 __global__ void __launch_bounds__(256) rnea_kernel(Args<T> A)

@@ -255,6 +255,14 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
     assert torch.equal(hm.aba(fq, fqd, ftau, g), hm.aba(T(fq), T(fqd), T(ftau), g, layout=_lib.LAYOUT_SOA).t())
     assert torch.equal(hm.rnea(fq, fqd, fqdd, g), hm.rnea(T(fq), T(fqd), T(fqdd), g, layout=_lib.LAYOUT_SOA).t())
     close(hm.rnea(fq, fqd, fqdd, g).cpu().numpy().astype(np.float64)[idx], om.rnea(q[idx], qd[idx], qdd[idx], g), f32_forward_tol(d.n_joints), label="rnea_f32 big batch")
+    # a batch size the row-block transposers take (B % 4 == 0: 16-byte column segments) with a ragged last block (8228 = 257 * 32 + 4
+    # rows in fp32, 514 * 16 + 4 in fp64); 8229 above is served by the 64 x 64 tile kernel.  Same bits as the SoA call either way.
+    B3 = 8192 + 36
+    for dt in (f32, torch.float64):
+        cq, cqd, ctau = (dev(torch, x[:B3], dt) for x in (q, qd, tau))
+        out = hm.aba(cq, cqd, ctau, g)
+        assert torch.equal(out, hm.aba(T(cq), T(cqd), T(ctau), g, layout=_lib.LAYOUT_SOA).t())
+        assert torch.equal(out[:4096], hm.aba(cq[:4096].contiguous(), cqd[:4096].contiguous(), ctau[:4096].contiguous(), g))  # direct AoS reads
 
 
 def test_layouts_soa_equals_aos(torch_cuda):
