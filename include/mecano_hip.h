@@ -427,6 +427,33 @@ mh_status mh_copy_to_device(void *dst_device, const void *src_host, size_t bytes
 mh_status mh_copy_to_host(void *dst_host, const void *src_device, size_t bytes, void *stream);
 mh_status mh_stream_synchronize(void *stream);
 
+/*
+ * ---- multi-GPU: one process per GPU, the batch sharded by rows, RCCL over xGMI ----
+ * The reference is single-threaded Java (InverseDynamicsCalculatorTest.java:124-158 times one calculator on one thread) and has no
+ * counterpart.  Every configuration is independent and the model is read-only, so the compute entry points above need no collective:
+ * each rank calls them on its own rows.  What a host without torch.distributed needs around that (mecano_amd/distributed.py is the
+ * same for the Python host) is
+ *   mh_shard_range          which rows of a batch a rank owns (contiguous; sizes differ by at most one);
+ *   mh_comm_broadcast_host  the robot description (the arrays of mh_model_desc, packed by the host) from the rank that has it;
+ *   mh_comm_all_gather_rows the ranks' output rows side by side on every rank, once, after the steps.
+ * Rank 0 calls mh_comm_unique_id and carries the MH_COMM_ID_BYTES bytes to the other processes by its own means (a file, a socket, the
+ * launcher's environment); every process then calls mh_comm_create on the device it computes on.  librccl.so.1 is opened at the first
+ * of these calls (MH_RCCL_LIBRARY overrides the name): MH_ERR_NO_DEVICE when it cannot be.  A communicator is used by one thread at a time.
+ */
+#define MH_COMM_ID_BYTES 128
+typedef struct mh_comm *mh_comm_t;
+mh_status mh_shard_range(int64_t B, int32_t rank, int32_t world, int64_t *lo_out, int64_t *hi_out);
+mh_status mh_comm_unique_id(void *id_out); /* MH_COMM_ID_BYTES bytes */
+mh_status mh_comm_create(const void *id, int32_t rank, int32_t world, mh_comm_t *comm_out); /* collective: every rank, same id */
+mh_status mh_comm_destroy(mh_comm_t comm);
+mh_status mh_comm_size(mh_comm_t comm, int32_t *rank_out, int32_t *world_out); /* as the communicator itself counted them */
+mh_status mh_comm_broadcast(mh_comm_t comm, void *device_buf, size_t bytes, int32_t root, void *stream); /* in place, asynchronous */
+mh_status mh_comm_broadcast_host(mh_comm_t comm, void *host_buf, size_t bytes, int32_t root); /* staged through the device, synchronous */
+/* local_rows: [hi - lo][row_bytes] of mh_shard_range(B_total, rank, world), device; all_rows_out: [B_total][row_bytes], device, on every
+ * rank.  Asynchronous on `stream`.  Ragged shards travel as they are (one grouped operation, no padding). */
+mh_status mh_comm_all_gather_rows(mh_comm_t comm, const void *local_rows, int64_t B_total, size_t row_bytes, void *all_rows_out, void *stream);
+mh_status mh_comm_barrier(mh_comm_t comm, void *stream); /* every rank has arrived and `stream` has drained */
+
 /* ---- measurement helper: HIP-event timing of launches on a stream (bench.py, §8d timing protocol) ---- */
 typedef struct mh_timer *mh_timer_t;
 mh_status mh_timer_create(mh_timer_t *timer_out);

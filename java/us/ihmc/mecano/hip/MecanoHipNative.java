@@ -115,6 +115,19 @@ public final class MecanoHipNative
    static final MethodHandle COPY_TO_HOST = handle("mh_copy_to_host", status(ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
    static final MethodHandle STREAM_SYNCHRONIZE = handle("mh_stream_synchronize", status(ADDRESS));
 
+   // ---- multi-GPU: one JVM per GPU, the batch sharded by rows, RCCL over xGMI (HipCommunicator)
+   static final int COMM_ID_BYTES = 128;
+   static final MethodHandle SET_DEVICE = handle("mh_set_device", status(JAVA_INT));
+   static final MethodHandle SHARD_RANGE = handle("mh_shard_range", status(JAVA_LONG, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+   static final MethodHandle COMM_UNIQUE_ID = handle("mh_comm_unique_id", status(ADDRESS));
+   static final MethodHandle COMM_CREATE = handle("mh_comm_create", status(ADDRESS, JAVA_INT, JAVA_INT, ADDRESS));
+   static final MethodHandle COMM_DESTROY = handle("mh_comm_destroy", status(ADDRESS));
+   static final MethodHandle COMM_SIZE = handle("mh_comm_size", status(ADDRESS, ADDRESS, ADDRESS));
+   static final MethodHandle COMM_BROADCAST = handle("mh_comm_broadcast", status(ADDRESS, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS));
+   static final MethodHandle COMM_BROADCAST_HOST = handle("mh_comm_broadcast_host", status(ADDRESS, ADDRESS, JAVA_LONG, JAVA_INT));
+   static final MethodHandle COMM_ALL_GATHER_ROWS = handle("mh_comm_all_gather_rows", status(ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, ADDRESS));
+   static final MethodHandle COMM_BARRIER = handle("mh_comm_barrier", status(ADDRESS, ADDRESS));
+
    /** An mh_options in `arena`: the calculators' switches, AoS layout (rows = configurations), the null stream, gravity as the root acceleration. */
    static MemorySegment options(Arena arena, boolean considerCoriolis, boolean considerAccelerations)
    {

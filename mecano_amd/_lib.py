@@ -21,6 +21,8 @@ ABI_SYMBOLS = [
     "mh_topology_key", "mh_build_code_object", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64", "mh_rnea_crba_f64", "mh_regressor_f64", "mh_regressor_f32",
     "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_rnea_joint_wrenches_f64", "mh_aba_joint_wrenches_f64", "mh_relative_acceleration_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_bodies_f32", "mh_aba_bodies_f32", "mh_aba_locked_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_rnea_f32_host", "mh_aba_f32_host", "mh_crba_f32_host", "mh_rnea_aba_f64_host", "mh_host_alloc", "mh_host_free", "mh_host_register", "mh_host_unregister", "mh_device_alloc", "mh_device_free", "mh_copy_to_device", "mh_copy_to_host", "mh_stream_synchronize", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
     "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
+    "mh_shard_range", "mh_comm_unique_id", "mh_comm_create", "mh_comm_destroy", "mh_comm_size", "mh_comm_broadcast", "mh_comm_broadcast_host",
+    "mh_comm_all_gather_rows", "mh_comm_barrier",
 ]
 
 
@@ -146,6 +148,15 @@ def _load_locked():
     lib.mh_timer_start.argtypes = [P, P]
     lib.mh_timer_stop.argtypes = [P, P]
     lib.mh_timer_elapsed_ms.argtypes = [P, ctypes.POINTER(ctypes.c_float)]
+    lib.mh_shard_range.argtypes = [I64, I32, I32, ctypes.POINTER(I64), ctypes.POINTER(I64)]
+    lib.mh_comm_unique_id.argtypes = [P]
+    lib.mh_comm_create.argtypes = [P, I32, I32, ctypes.POINTER(P)]
+    lib.mh_comm_destroy.argtypes = [P]
+    lib.mh_comm_size.argtypes = [P, ctypes.POINTER(I32), ctypes.POINTER(I32)]
+    lib.mh_comm_broadcast.argtypes = [P, P, ctypes.c_size_t, I32, P]
+    lib.mh_comm_broadcast_host.argtypes = [P, P, ctypes.c_size_t, I32]
+    lib.mh_comm_all_gather_rows.argtypes = [P, P, I64, ctypes.c_size_t, P, P]
+    lib.mh_comm_barrier.argtypes = [P, P]
     _lib = lib
     return lib
 

@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libmecano_hip.so")
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, "mh_api.hip")]
+SOURCES = [os.path.join(CSRC, "mh_api.hip"), os.path.join(CSRC, "mh_comm.hip")]
 HEADERS = [os.path.join(CSRC, "mh_kernels.h"), os.path.join(CSRC, "mh_device.h"), os.path.join(ROOT, "include", "mecano_hip.h")]
 LIB_HEADERS = HEADERS + [os.path.join(CSRC, "mh_dfs_kernels.h"), os.path.join(CSRC, "mh_split_kernels.h")]  # the library's own kernels
 SPEC_SOURCE = os.path.join(CSRC, "mh_spec.hip")

@@ -1660,6 +1660,8 @@ extern "C" {
 int32_t mh_abi_version(void) { return MH_ABI_VERSION; }
 uint64_t mh_spec_abi_stamp(void) { return mh::spec_abi_stamp(); }
 const char *mh_last_error(void) { return g_err; }
+// the library's other translation units (mh_comm.hip) report through the same thread-local message
+mh_status mh_internal_fail(mh_status code, const char *message) { return fail(code, "%s", message); }
 
 mh_status mh_device_count(int32_t *count)
 {

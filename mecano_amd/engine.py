@@ -565,3 +565,77 @@ class HipTimer:
                 self._h = None
         except Exception:
             pass
+
+
+class HipCommunicator:
+    """The C-ABI's RCCL communicator (mh_comm_*, include/mecano_hip.h): what a host without torch.distributed uses around the sharded
+    compute calls -- shard_range, one broadcast of the robot description, one all-gather of the output rows.  mecano_amd/distributed.py
+    does the same over torch.distributed; bench.py keeps that transport (the driver launches it under torch.distributed.run)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(HipCommunicator.ID_BYTES)
+        _lib.check(_lib.load().mh_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def shard_range(B: int, rank: int, world: int):
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.load().mh_shard_range(B, rank, world, ctypes.byref(lo), ctypes.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError(f"a communicator id has {self.ID_BYTES} bytes")
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().mh_comm_create(ctypes.create_string_buffer(unique_id, self.ID_BYTES), rank, world, ctypes.byref(self._h)))
+        r, w = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(_lib.load().mh_comm_size(self._h, ctypes.byref(r), ctypes.byref(w)))
+        self.rank, self.world = int(r.value), int(w.value)
+
+    def broadcast_bytes(self, payload: Optional[bytes], nbytes: int, root: int = 0) -> bytes:
+        """`root` passes the payload, the others None; everybody returns the same nbytes bytes."""
+        buf = ctypes.create_string_buffer(payload if self.rank == root else b"", nbytes)
+        _lib.check(_lib.load().mh_comm_broadcast_host(self._h, buf, nbytes, root))
+        return buf.raw
+
+    def broadcast_model_desc(self, desc, root: int = 0):
+        """The robot description from `root` (the others pass None): header of two lengths, then the packed integer and real arrays."""
+        from .distributed import pack_desc, unpack_desc
+        if self.rank == root:
+            ints, f64 = pack_desc(desc)
+            head = np.array([len(ints), len(f64)], dtype=np.int64).tobytes()
+        else:
+            ints = f64 = None
+            head = None
+        ni, nf = (int(x) for x in np.frombuffer(self.broadcast_bytes(head, 16, root), dtype=np.int64))
+        raw = self.broadcast_bytes(ints.tobytes() + f64.tobytes() if self.rank == root else None, 8 * (ni + nf), root)
+        return unpack_desc(np.frombuffer(raw[:8 * ni], dtype=np.int64).copy(), np.frombuffer(raw[8 * ni:], dtype=np.float64).copy())
+
+    def all_gather_rows(self, local, B_total: int, stream=None):
+        """local: this rank's rows of shard_range(B_total, rank, world), a contiguous CUDA tensor [rows, ...]; returns [B_total, ...]."""
+        import torch
+        lo, hi = self.shard_range(B_total, self.rank, self.world)
+        if local.shape[0] != hi - lo or not local.is_contiguous():
+            raise ValueError(f"rank {self.rank} owns rows [{lo}, {hi}) of {B_total}: pass exactly those, contiguous")
+        out = torch.empty((B_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        row_bytes = local.element_size() * int(np.prod(local.shape[1:], dtype=np.int64))
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().mh_comm_all_gather_rows(self._h, local.data_ptr(), B_total, row_bytes, out.data_ptr(), s))
+        return out
+
+    def barrier(self, stream=None):
+        _lib.check(_lib.load().mh_comm_barrier(self._h, stream))
+
+    def close(self):
+        if self._h:
+            _lib.check(_lib.load().mh_comm_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -73,6 +73,33 @@ def test_shard_range_partitions_the_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_c_abi_shard_range_is_the_python_one_and_rejects_bad_arguments():
+    """mh_shard_range (what a host without torch calls, include/mecano_hip.h) against mecano_amd.distributed.shard_range, including more
+    ranks than rows; the communicator entry points refuse NULL handles without touching RCCL or a device."""
+    import ctypes
+    from mecano_amd import _lib
+    from mecano_amd.distributed import shard_range
+    from mecano_amd.engine import HipCommunicator
+    for B in (0, 1, 3, 7, 4096, 4099, 262144, 1000003):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert HipCommunicator.shard_range(B, r, world) == shard_range(B, r, world)
+    lib = _lib.load()
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    for B, r, w in ((-1, 0, 1), (8, 2, 2), (8, -1, 2), (8, 0, 0)):
+        assert lib.mh_shard_range(B, r, w, ctypes.byref(lo), ctypes.byref(hi)) == 1  # MH_ERR_INVALID_ARGUMENT
+        assert b"mh_shard_range" in lib.mh_last_error()
+    assert lib.mh_shard_range(8, 0, 2, None, ctypes.byref(hi)) == 1
+    out = ctypes.c_void_p()
+    assert lib.mh_comm_create(None, 0, 1, ctypes.byref(out)) == 1
+    assert lib.mh_comm_unique_id(None) == 1
+    assert lib.mh_comm_barrier(None, None) == 1
+    assert lib.mh_comm_all_gather_rows(None, None, 8, 8, None, None) == 1
+    assert lib.mh_comm_destroy(None) == _lib.MH_OK
+    with pytest.raises(ValueError):
+        HipCommunicator(b"short", 0, 1)
+
+
 def test_pack_unpack_roundtrip():
     from mecano_amd import distributed as mdist
     from mecano_amd import random_tools as rt

@@ -1461,6 +1461,39 @@ def test_two_ranks_sharing_one_gpu_reproduce_the_single_rank_result(torch_cuda, 
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def test_c_abi_communicator_on_one_rank(torch_cuda, monkeypatch):
+    """mh_comm_* (RCCL behind the C-ABI, for hosts without torch.distributed) on the one rank this box has: the id, the communicator's own
+    count, the robot description through mh_comm_broadcast_host, the rows through both all-gather paths (equal shards: ncclAllGather;
+    ragged shards: grouped broadcasts, forced here with MH_COMM_RAGGED=1), the barrier.  More ranks need more GPUs (RCCL refuses two
+    ranks on one device); the N > 1 logic that does not depend on RCCL (shard_range) is covered on CPU."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipCommunicator, HipModel
+    uid = HipCommunicator.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = HipCommunicator(uid, 0, 1)
+    assert (comm.rank, comm.world) == (0, 1)
+    assert comm.broadcast_bytes(b"mecano", 6) == b"mecano"
+    sys_ = rt.nextHumanoid(np.random.default_rng(11))
+    d = sys_.toModelDesc()
+    d2 = comm.broadcast_model_desc(d)
+    for f in ("parent", "joint_type", "axis", "X_before", "X_com", "inertia_J", "inertia_mass", "inertia_com", "dof_indices", "cfg_indices"):
+        assert np.array_equal(np.asarray(getattr(d2, f)), np.asarray(getattr(d, f)))
+    B = 4099
+    q, qd, qdd, tau = rt.nextState(np.random.default_rng(12), sys_, B)
+    out = HipModel(d2).rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), (0.0, 0.0, -9.81))
+    lo, hi = comm.shard_range(B, comm.rank, comm.world)
+    assert (lo, hi) == (0, B)
+    for ragged in ("0", "1"):
+        monkeypatch.setenv("MH_COMM_RAGGED", ragged)
+        everything = comm.all_gather_rows(out[lo:hi].contiguous(), B)
+        comm.barrier(torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(everything, out)
+    with pytest.raises(ValueError):
+        comm.all_gather_rows(out[:5].contiguous(), B)
+    comm.close()
+
+
 def test_bench_launches_its_own_ranks(torch_cuda):
     """`python3 bench.py --gpus 2` with no external launcher: a GPU-free parent starts two fresh rank processes (here both on the box's one
     GPU, gloo as the transport), relays rank 0's line and returns its exit code -- ONE JSON line with n_gpus = 2, both ranks counted by
