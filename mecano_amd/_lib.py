@@ -7,7 +7,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmecano_hip.so")
+LIB_PATH = os.environ.get("MECANO_HIP_LIBRARY") or os.path.join(HERE, "libmecano_hip.so")  # (the override: A/B runs of two builds)
 
 MH_OK = 0
 STATUS_NAMES = {0: "MH_OK", 1: "MH_ERR_INVALID_ARGUMENT", 2: "MH_ERR_BAD_DIMENSION", 3: "MH_ERR_UNSUPPORTED_JOINT", 4: "MH_ERR_LOOP_CLOSURE",
