@@ -334,8 +334,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        t_all.start(stream)  # (instrumentation, ahead of the host clock: the event pair then brackets a superset of the K launches)
         t0 = time.perf_counter()
-        t_all.start(stream)
         for k in range(K):
             if fused:
                 fused_step()
@@ -389,10 +389,10 @@ def main():
         return
 
     # ---- the outputs of the launches that were timed, against the CPU oracle on a strided sample (outside the timed regions).
-    # fp64: ABSOLUTE 1e-10 on every entry (north_star's bar; what tests/test_gpu_parity.py asserts on configs 2-4).  fp32: forward bound
-    # 64 n u max|ref| for RNEA / CRBA; forward dynamics by its backward error, as the tests do: the fp64 inverse dynamics of the fp32
-    # answer must reproduce the given efforts within 64 n u max(1, |tau|, |RNEA bias|) (its forward error is conditioning-bound and
-    # reported only).
+    # fp64: ABSOLUTE 1e-10 on every entry (north_star's bar; what tests/test_gpu_parity.py asserts on configs 2-4).  fp32: the bounds of
+    # tests/helpers.py (u = 2^-24, rounding errors of ~8 n operations adding up like a random walk): forward 4 sqrt(8 n) u max(1, |ref|)
+    # for RNEA / CRBA; forward dynamics by its backward error, as the tests do: the fp64 inverse dynamics of the fp32 answer must
+    # reproduce the given efforts within 16 sqrt(8 n) u (|tau| + |RNEA bias|) (its forward error is conditioning-bound and reported only).
     idx = np.arange(0, B, max(1, B // 64))[:64]
     check = {"rows": int(len(idx)), "tol": 1e-10 if word == 8 else None}
     got = {"rnea": tau if fused else outs.get("rnea"), "aba": acc if fused else outs.get("aba"), "crba": Hm if fused else outs.get("crba")}
@@ -416,10 +416,10 @@ def main():
                 back = om.rnea(q64, qd64, mine, gravity)
                 bias = om.rnea(q64, qd64, np.zeros_like(mine), gravity)
                 check["backward_err_aba"] = float(np.abs(back - tau64).max())
-                check["bound_aba"] = 64 * desc.n_joints * u32 * max(1.0, float(np.abs(tau64).max()), float(np.abs(bias).max()))
+                check["bound_aba"] = 16 * (8 * desc.n_joints) ** 0.5 * u32 * (float(np.abs(tau64).max()) + float(np.abs(bias).max()))
                 ok = ok and np.isfinite(err) and check["backward_err_aba"] <= check["bound_aba"]
             else:
-                check[f"bound_{job}"] = 64 * desc.n_joints * u32 * max(1.0, float(np.abs(ref).max()))
+                check[f"bound_{job}"] = 4 * (8 * desc.n_joints) ** 0.5 * u32 * max(1.0, float(np.abs(ref).max()))
                 ok = ok and err <= check[f"bound_{job}"]
         check["ok"] = bool(ok)
 
