@@ -27,10 +27,15 @@ def region(mode):
         ev.record()
         while not ev.query():
             pass
-    torch.cuda.synchronize()
+    if mode == "event":  # wait on the stop event the timer has recorded anyway, then the (now idle) device synchronize
+        t.elapsed_ms()
+    if mode == "nosync_after_event":
+        t.elapsed_ms()
+    else:
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return dt * 1e6, t.elapsed_ms() * 1e3
-for mode in ("sync", "spin"):
+for mode in ("sync", "event", "nosync_after_event", "sync"):
     rs = [region(mode) for _ in range(15)]
     print("HSA_ENABLE_INTERRUPT=%s %s: host %.1f us (min %.1f) for %d steps, events %.1f us -> %.2f / %.2f us per step" % (
         os.environ.get("HSA_ENABLE_INTERRUPT"), mode, np.median([r[0] for r in rs]), min(r[0] for r in rs), K, np.median([r[1] for r in rs]),
