@@ -761,7 +761,51 @@ mh_status launch_split_rt(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A,
    const void *kern = nullptr;
 #define MH_SPLIT_KERN(NAME) (mode == 0 ? (const void *)&mh::NAME<T, 0> : (mode == 1 ? (const void *)&mh::NAME<T, 1> : (const void *)&mh::NAME<T, 2>))
    kern = algo == ALGO_RNEA ? MH_SPLIT_KERN(rnea_split_kernel) : (algo == ALGO_ABA ? MH_SPLIT_KERN(aba_split_kernel) : MH_SPLIT_KERN(crba_split_kernel));
+   if constexpr (sizeof(T) == 8)
+      if (algo == ALGO_ABA)
+      { // the machine code the pair call runs (mh::pair_split_kernel): the two calls then agree bit for bit
+         P.roles = 2;
+         kern = MH_SPLIT_KERN(pair_split_kernel);
+      }
 #undef MH_SPLIT_KERN
+   if (lds > 64 * 1024 && model->lds_attr[kern] < lds)
+   {
+      HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      model->lds_attr[kern] = lds;
+   }
+   void *args[] = {(void *)&A, (void *)&P};
+   HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(256), args, lds, stream));
+   return MH_OK;
+}
+
+// The pair call of a model without a code object at small batches: both algorithms in ONE launch of the run-time tree split
+// (mh::pair_split_kernel): A.in3 = qdd, A.out = tau, A.in3b = tau, A.outb = qdd.  2 * groups workgroups, one per CU.
+mh_status launch_split_rt_pair(mh_model *model, int64_t B, mh::Args<double> &A, hipStream_t stream)
+{
+   using T = double;
+   const mh_model::SplitRt &S = model->split_rt;
+   const long groups = (B + 63) / 64;
+   const int grid = (int)(2 * groups);
+   // the record set (hence the kernel instantiation) the single calls of this batch take (launch_split_rt): the pair call and the two
+   // single calls then run the same machine code and agree bit for bit
+   int k = 1;
+   if (S.lds_slots[k] < S.slots && (size_t)S.slots * 64 * sizeof(T) * ((size_t)groups / 8 + 1) <= (size_t)3 << 20)
+      k = 2;
+   if (model->split_rt_lds >= 0)
+      k = model->split_rt_lds ? 1 : 2;
+   const int mode = S.lds_slots[k] >= S.slots ? 0 : (S.lds_slots[k] == 0 ? 1 : 2);
+   mh_status st = ensure_bytes(model->ws, (size_t)S.slots * (size_t)grid * 64 * sizeof(T));
+   if (st != MH_OK)
+      return st;
+   A.ws = (T *)model->ws.ptr;
+   mh::SplitDev P{};
+   P.meta = S.d_meta[k], P.trunk = S.d_trunk, P.seg = S.d_seg, P.xl_ofs = S.d_xl_ofs, P.xl = S.d_xl[k];
+   P.n_trunk = S.n_trunk, P.slots = S.slots;
+   for (int w = 0; w < mh::SPLIT_WAVES; w++)
+      P.n_seg[w] = S.n_seg[w];
+   const size_t lds = mode == 1 ? 0 : (size_t)std::min(S.slots, S.lds_slots[k] + mh::SPLIT_LDS_MARGIN) * 64 * sizeof(T);
+   const void *kern = mode == 0 ? (const void *)&mh::pair_split_kernel<T, 0>
+                                : (mode == 1 ? (const void *)&mh::pair_split_kernel<T, 1> : (const void *)&mh::pair_split_kernel<T, 2>);
    if (lds > 64 * 1024 && model->lds_attr[kern] < lds)
    {
       HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2551,6 +2595,23 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    // object, B = 4096: 63 + 112 us one after the other, ~115 us together).
    auto two_calls = [&]() -> mh_status {
       hipStream_t s = (hipStream_t)opts.stream;
+      // no code object would serve either call and the run-time tree split serves both: one launch, half the grid each
+      const bool no_spec = !model->use_spec || !model->spec.launch_split || !model->spec.split_usable || !model->spec.split_usable();
+      if (no_spec && model->use_pair && model->split_rt.usable && model->n_locked == 0 && model->use_split_rt != 0 && 2 * waves <= (long)model->cu_count)
+      {
+         mh::Args<double> P{};
+         P.m = dev_model<double>(model);
+         P.B = B;
+         P.q = q, P.qd = qd, P.in3 = qdd, P.fext = f_ext, P.out = tau_out;
+         P.in3b = tau, P.outb = qdd_out;
+         const bool soa = opts.layout == MH_LAYOUT_SOA;
+         P.q_bs = soa ? 1 : model->nq, P.q_es = soa ? B : 1;
+         P.v_bs = soa ? 1 : model->nv, P.v_es = soa ? B : 1;
+         P.f_bs = soa ? 1 : (long)model->n * 6, P.f_es = soa ? B : 1;
+         set_root_acceleration(P, opts, gravity);
+         P.coriolis = opts.consider_coriolis, P.accel = opts.consider_accelerations;
+         return launch_split_rt_pair(model, B, P, s);
+      }
       if (!model->use_pair || waves > (long)model->cu_count) // measured: pays up to one wave per CU (profiles/r02_generic_pair_side_by_side.txt)
       {
          mh_status r = mh_rnea_f64(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);

@@ -115,11 +115,14 @@ struct SplitDev
    const int *xl;
    int n_trunk, slots; // workspace slots of one workgroup block: the sweep kernels' + the exchange records
    int n_seg[SPLIT_WAVES];
+   int roles;          // pair_split_kernel: 0 = first half of the grid inverse dynamics, second half forward dynamics; 2 = forward dynamics only
 };
 
 // ============================================================================================ RNEA
+// (a device function so that one launch can run it next to the other algorithm's: pair_split_kernel below.  blk / nblk: this
+// workgroup's first group of 64 configurations and the stride to its next; ws_blk: its block of the workspace)
 template <typename T, int MODE>
-__global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
+MH_DEV void rnea_split_body(const Args<T> &A, const SplitDev &P, long blk, long nblk, long ws_blk)
 {
    const DevModel &m = A.m;
    const T *CB = (const T *)m.consts;
@@ -127,12 +130,12 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
    const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
    const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    extern __shared__ double lds_raw[];
-   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid};
+   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + ws_blk * ((long)P.slots * 64) + tid};
    const V3<T> Z{T(0), T(0), T(0)};
    const int n_seg = P.n_seg[wave];
    const long groups = (A.B + 63) / 64;
 
-   for (long grp = blockIdx.x; grp < groups; grp += gridDim.x)
+   for (long grp = blk; grp < groups; grp += nblk)
    {
       const long cfg0 = grp * 64 + tid;
       const bool active = cfg0 < A.B;
@@ -273,8 +276,10 @@ __global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
 }
 
 // ============================================================================================ ABA
+// (a device function so that one launch can run it next to the other algorithm's: pair_split_kernel below.  blk / nblk: this
+// workgroup's first group of 64 configurations and the stride to its next; ws_blk: its block of the workspace)
 template <typename T, int MODE>
-__global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
+MH_DEV void aba_split_body(const Args<T> &A, const SplitDev &P, long blk, long nblk, long ws_blk)
 {
    const DevModel &m = A.m;
    const T *CB = (const T *)m.consts;
@@ -282,12 +287,12 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
    const ciptr trunk = as_const(P.trunk), seg = as_const(P.seg), xl_ofs = as_const(P.xl_ofs), xl = as_const(P.xl);
    const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    extern __shared__ double lds_raw[];
-   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + (long)blockIdx.x * ((long)P.slots * 64) + tid};
+   const DStack<T, MODE> S{(dfs_lds_ptr<T>)lds_raw + tid, A.ws + ws_blk * ((long)P.slots * 64) + tid};
    const V3<T> Z{T(0), T(0), T(0)};
    const int n_seg = P.n_seg[wave];
    const long groups = (A.B + 63) / 64;
 
-   for (long grp = blockIdx.x; grp < groups; grp += gridDim.x)
+   for (long grp = blk; grp < groups; grp += nblk)
    {
       const long cfg0 = grp * 64 + tid;
       const bool active = cfg0 < A.B;
@@ -585,6 +590,38 @@ __global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
       __syncthreads(); // the next group of configurations re-uses the block
    }
 }
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) rnea_split_kernel(Args<T> A, SplitDev P)
+{
+   rnea_split_body<T, MODE>(A, P, blockIdx.x, gridDim.x, blockIdx.x);
+}
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) aba_split_kernel(Args<T> A, SplitDev P)
+{
+   aba_split_body<T, MODE>(A, P, blockIdx.x, gridDim.x, blockIdx.x);
+}
+// tau = RNEA(q, qd, A.in3) -> A.out and qdd = ABA(q, qd, A.in3b) -> A.outb of the same configurations in ONE launch: the first half of
+// the grid runs the inverse dynamics, the second half the forward dynamics, each workgroup on a CU and a workspace block of its own.
+// For small batches of a model without a code object (2 * groups <= CUs): two launches side by side on two streams cost their
+// fork / join events (~15 us against kernels of 30 and 48 us on the humanoid at B = 4096).
+// P.roles == 2: forward dynamics alone (A.in3 -> A.out) on the whole grid -- the fp64 mh_aba_f64 runs through THIS kernel too, so that
+// the pair call and the single call execute the same machine code (two instantiations of the body differ in which products the
+// compiler contracts into FMAs: last-bit differences between the two calls otherwise).
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) pair_split_kernel(Args<T> A, SplitDev P)
+{
+   const long half = P.roles == 2 ? 0 : gridDim.x / 2;
+   if ((long)blockIdx.x < half)
+      rnea_split_body<T, MODE>(A, P, blockIdx.x, half, blockIdx.x);
+   else
+   {
+      Args<T> A2 = A;
+      if (P.roles != 2)
+         A2.in3 = A.in3b, A2.out = A.outb;
+      aba_split_body<T, MODE>(A2, P, (long)blockIdx.x - half, (long)gridDim.x - half, blockIdx.x);
+   }
+}
+
 // ============================================================================================ CRBA
 // CompositeRigidBodyMassMatrixCalculator.java:588-707, 770-798.  The columns of a limb body need the joint transforms of its ancestors,
 // not their composite inertias: every wave finishes ALL columns of its limbs' bodies (walking up through the trunk with the trunk's

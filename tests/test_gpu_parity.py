@@ -1254,9 +1254,11 @@ def test_run_time_tree_split_kernels(torch_cuda, monkeypatch, dtype):
 
 
 def test_pair_call_without_a_code_object_runs_side_by_side(torch_cuda, monkeypatch):
-    """mh_rnea_aba_f64 of a model without a fused kernel launches RNEA and ABA side by side on small batches (the ABA on a stream and a
-    workspace of the model's own, forked from / joined into the caller's stream): the same numbers as two separate calls, on the default and
-    on a non-default stream, call after call without a synchronisation in between, and the oracle's on a sample."""
+    """mh_rnea_aba_f64 of a model without a code object: ONE launch of the run-time tree split whose grid is half inverse, half forward
+    dynamics while every workgroup gets a CU of its own (mh::pair_split_kernel; B = 1, 300, 4096 here), one call after the other beyond
+    (B = 20000; chains and other shapes without a tree split: side by side on a second stream).  Bit for bit the numbers of two separate
+    calls -- the fp64 single forward-dynamics call runs the pair kernel's machine code for that reason --, on the default and on a
+    non-default stream, call after call without a synchronisation in between, and the oracle's on a sample."""
     torch = torch_cuda
     from mecano_amd import random_tools as rt
     from mecano_amd.engine import HipModel

@@ -32,7 +32,9 @@ while time.time() - t0 < budget:
     t2, a2 = hm.rnea_aba(q, qd, qdd, tau, g, f_ext=fx)
     t3, H3 = hm.rnea_crba(q, qd, qdd, g, f_ext=fx)
     H1 = hm.crba(q)
-    assert torch.equal(t1, t2) and torch.equal(a1, a2) and torch.equal(t1, t3) and torch.equal(H1, H3), B
+    assert torch.equal(t1, t2) and torch.equal(t1, t3) and torch.equal(H1, H3), B
+    # (forward dynamics: the bias split serves the single call up to 128 groups, the pair call up to 85 -- same q̈ to rounding in between)
+    assert float((a2 - a1).abs().max()) <= 1e-10 * max(1.0, float(a1.abs().max())), B
     idx = np.unique(np.concatenate([[0, B - 1], rng.integers(0, B, 4)]))
     ti = torch.as_tensor(idx, device="cuda")
     sq, sqd, sqdd, stau = (x[ti].cpu().numpy() for x in (q, qd, qdd, tau))
@@ -41,6 +43,7 @@ while time.time() - t0 < budget:
     chk("aba", a1[ti].cpu().numpy(), om.aba(sq, sqd, stau, g, sf), B)
     chk("crba", H1[ti].cpu().numpy(), om.crba(sq), B)
     qn, vn, acc = hm.step(1e-3, q, qd, tau, g, f_ext=fx)
-    assert torch.equal(acc, a1), B
+    # (the fused step runs the one-job tree-split forward dynamics, mh_aba_f64 the bias split at small batches: same q̈ to rounding)
+    assert float((acc - a1).abs().max()) <= 1e-10 * max(1.0, float(a1.abs().max())), B
     n += 1
 print(f"{n} random batches in {time.time() - t0:.0f} s, worst scaled error {worst:.2e}  [{hm.kernel_variant[:30]}]")
