@@ -27,6 +27,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     fext = torch.tensor(rng.uniform(-1, 1, (B, d.n_joints, 6)), device="cuda")
     t, t0 = on.rnea(q, qd, qdd, g, fext), off.rnea(q, qd, qdd, g, fext)
     a, a0 = on.aba(q, qd, tau, g, fext), off.aba(q, qd, tau, g, fext)
+    tp, ap = on.rnea_aba(q, qd, qdd, tau, g, fext)  # one launch while 2 * groups <= CUs (pair_split_kernel): bit for bit the two single calls
+    assert torch.equal(tp, t) and torch.equal(ap, a), (it, d.n_joints, B, float((tp - t).abs().max()), float((ap - a).abs().max()))
     et = float((t - t0).abs().max() / max(1.0, float(t0.abs().max()))); ea = float((a - a0).abs().max() / max(1.0, float(a0.abs().max())))
     back = float((on.rnea(q, qd, a, g, fext) - tau).abs().max() / max(1.0, float(tau.abs().max())))  # ABA then RNEA returns the efforts
     worst_t, worst_a = max(worst_t, et), max(worst_a, back)
