@@ -298,10 +298,10 @@ def main():
 
     # caller-owned output buffers, as the C-ABI prescribes (Mecano's calculators also write into pre-allocated matrices)
     tau, acc = torch.empty_like(tqd), torch.empty_like(tqd)
-    fused = cfg in (0, 3) and not args.separate
-    fused_key = {0: "rnea_aba", 3: "rnea_crba"}.get(cfg)
+    fused = cfg in (0, 3, 5) and not args.separate
+    fused_key = {0: "rnea_aba", 3: "rnea_crba", 5: "rnea_aba"}.get(cfg)
     Hm = torch.empty((B, nv, nv), dtype=tdt, device="cuda") if (fused and cfg == 3) else None
-    fused_step = (model.bind_rnea_aba(tq, tqd, tqdd, ttau, tau, acc, gravity) if cfg == 0 else model.bind_rnea_crba(tq, tqd, tqdd, tau, Hm, gravity)) if fused else None
+    fused_step = (model.bind_rnea_aba(tq, tqd, tqdd, ttau, tau, acc, gravity) if cfg != 3 else model.bind_rnea_crba(tq, tqd, tqdd, tau, Hm, gravity)) if fused else None
     jobs = {0: ("rnea", "aba"), 3: ("rnea", "crba"), 4: ("aba",), 5: ("rnea", "aba")}[cfg]
     outs = {}
 
@@ -466,7 +466,7 @@ def main():
         "ms_per_step": elapsed / K * 1e3 if K else None, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": workloads[cfg],
-                   "entry_point": f"mh_{fused_key}_f64" if fused else " + ".join(f"mh_{j}_{dtype}" for j in jobs),
+                   "entry_point": f"mh_{fused_key}_{dtype}" if fused else " + ".join(f"mh_{j}_{dtype}" for j in jobs),
                    "batch_per_gpu": B, "global_batch": B_total, "nq": nq, "nv": nv, "bodies": desc.n_joints,
                    "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
                    "model_seed": MODEL_SEED if cfg != 5 else 128, "state_seed": STATE_SEED},

@@ -372,6 +372,10 @@ mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *
 mh_status mh_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau,
                      const double gravity[3], const float *f_ext, const mh_options *opts, float *qdd_out);
 mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_options *opts, float *H_out);
+/* mh_rnea_aba_f64 in fp32 (BASELINE.json configs[4] evaluates both per step): big AoS batches of wide matrices share the transposed
+ * scratch copies of q and qd between the two algorithms; otherwise mh_rnea_f32 followed by mh_aba_f32.  Same results as those two. */
+mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const float *tau,
+                          const double gravity[3], const float *f_ext, const mh_options *opts, float *tau_out, float *qdd_out);
 /* fp32 forms of the per-body outputs and of forward dynamics with acceleration-source joints (run-time-topology kernels) */
 mh_status mh_rnea_bodies_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const double gravity[3],
                              const float *f_ext, const mh_options *opts, float *tau_out, float *body_acc_out, float *body_twist_out);

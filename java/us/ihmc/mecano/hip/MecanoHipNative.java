@@ -86,6 +86,8 @@ public final class MecanoHipNative
    static final MethodHandle RNEA = handle("mh_rnea_f64", DYNAMICS);
    static final MethodHandle ABA = handle("mh_aba_f64", DYNAMICS);
    static final MethodHandle RNEA_ABA = handle("mh_rnea_aba_f64", PAIR);
+   /** the same in fp32 (float matrices on the device) */
+   static final MethodHandle RNEA_ABA_F32 = handle("mh_rnea_aba_f32", PAIR);
    /** (model, B, q, qd, qdd, gravity, f_ext|NULL, opts|NULL, tau_out, H_out): inverse dynamics and the mass matrix of the same state, one launch */
    static final MethodHandle RNEA_CRBA = handle("mh_rnea_crba_f64", DYNAMICS_2);
    /** (model, B, q, qd, qdd, gravity, opts|NULL, first_moment_columns, Y_out): JointTorqueRegressorCalculator.compute for B configurations */

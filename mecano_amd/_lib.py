@@ -19,7 +19,7 @@ LAYOUT_AOS, LAYOUT_SOA = 0, 1
 ABI_SYMBOLS = [
     "mh_abi_version", "mh_spec_abi_stamp", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
     "mh_topology_key", "mh_build_code_object", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64", "mh_rnea_crba_f64", "mh_regressor_f64", "mh_regressor_f32",
-    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_rnea_joint_wrenches_f64", "mh_aba_joint_wrenches_f64", "mh_relative_acceleration_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_bodies_f32", "mh_aba_bodies_f32", "mh_aba_locked_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_rnea_f32_host", "mh_aba_f32_host", "mh_crba_f32_host", "mh_rnea_aba_f64_host", "mh_host_alloc", "mh_host_free", "mh_host_register", "mh_host_unregister", "mh_device_alloc", "mh_device_free", "mh_copy_to_device", "mh_copy_to_host", "mh_stream_synchronize", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
+    "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_rnea_joint_wrenches_f64", "mh_aba_joint_wrenches_f64", "mh_relative_acceleration_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_aba_f32", "mh_rnea_bodies_f32", "mh_aba_bodies_f32", "mh_aba_locked_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_rnea_f32_host", "mh_aba_f32_host", "mh_crba_f32_host", "mh_rnea_aba_f64_host", "mh_host_alloc", "mh_host_free", "mh_host_register", "mh_host_unregister", "mh_device_alloc", "mh_device_free", "mh_copy_to_device", "mh_copy_to_host", "mh_stream_synchronize", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
     "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
     "mh_shard_range", "mh_comm_unique_id", "mh_comm_create", "mh_comm_destroy", "mh_comm_size", "mh_comm_broadcast", "mh_comm_broadcast_host",
     "mh_comm_all_gather_rows", "mh_comm_barrier",
@@ -112,6 +112,7 @@ def _load_locked():
     for f in ("mh_crba_f64", "mh_crba_f32", "mh_crba_f64_host", "mh_crba_f32_host"):
         getattr(lib, f).argtypes = [P, I64, P, opt, P]
     lib.mh_rnea_aba_f64.argtypes = [P, I64, P, P, P, P, P, P, opt, P, P]
+    lib.mh_rnea_aba_f32.argtypes = [P, I64, P, P, P, P, P, P, opt, P, P]
     lib.mh_rnea_crba_f64.argtypes = [P, I64, P, P, P, P, P, opt, P, P]
     lib.mh_regressor_f64.argtypes = [P, I64, P, P, P, P, opt, ctypes.c_int32, P]
     lib.mh_regressor_f32.argtypes = [P, I64, P, P, P, P, opt, ctypes.c_int32, P]

@@ -2769,6 +2769,54 @@ mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_opti
 {
    return launch<float>(ALGO_CRBA, model, B, q, nullptr, nullptr, nullptr, nullptr, opts, H_out);
 }
+// tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) of the same configurations, fp32 (BASELINE.json configs[4]: both per step on
+// the 128-body tree).  Where the forward dynamics of a big AoS batch would go through transposed scratch copies anyway (launch<T>), the
+// copies of q and qd are made ONCE and serve both algorithms -- the inverse dynamics then runs on SoA strides instead of reading its
+// rows through LDS windows (468 against 742 us at B = 131 072 on that tree) -- and both results are transposed back.  Same numbers as
+// mh_rnea_f32 followed by mh_aba_f32 (the two layouts of the depth-first kernels agree bit for bit).
+mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const float *tau,
+                          const double gravity[3], const float *f_ext, const mh_options *opts_in, float *tau_out, float *qdd_out)
+{
+   mh_options opts;
+   if (opts_in)
+      opts = *opts_in;
+   else
+      mh_options_default(&opts);
+   const bool shared = model && B >= 8192 && q && qd && qdd && tau && tau_out && qdd_out && !f_ext && opts.layout == MH_LAYOUT_AOS
+                       && model->use_dfs && model->n_locked == 0 && model->use_transpose < 0 && model->dfs_transpose < 0
+                       && model->nq + model->nv >= 64 && opts.consider_coriolis && opts.consider_accelerations;
+   if (!shared)
+   {
+      const mh_status r = mh_rnea_f32(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
+      return r != MH_OK ? r : mh_aba_f32(model, B, q, qd, tau, gravity, f_ext, &opts, qdd_out);
+   }
+   mh_status st = check_common(model, B, &opts);
+   if (st != MH_OK)
+      return st;
+   const size_t nq = model->nq, nv = model->nv, Bz = (size_t)B;
+   st = ensure_bytes(model->tr_pair, Bz * (nq + 5 * nv) * sizeof(float));
+   if (st != MH_OK)
+      return st;
+   float *t_q = (float *)model->tr_pair.ptr, *t_qd = t_q + Bz * nq, *t_qdd = t_qd + Bz * nv, *t_tau = t_qdd + Bz * nv, *t_o1 = t_tau + Bz * nv,
+         *t_o2 = t_o1 + Bz * nv;
+   hipStream_t stream = (hipStream_t)opts.stream;
+   mh::transpose_rows<float>(q, t_q, (long)B, (long)nq, true, stream);
+   mh::transpose_rows<float>(qd, t_qd, (long)B, (long)nv, true, stream);
+   mh::transpose_rows<float>(qdd, t_qdd, (long)B, (long)nv, true, stream);
+   mh::transpose_rows<float>(tau, t_tau, (long)B, (long)nv, true, stream);
+   HIP_TRY(hipGetLastError());
+   mh_options so = opts;
+   so.layout = MH_LAYOUT_SOA;
+   st = launch<float>(ALGO_RNEA, model, B, t_q, t_qd, t_qdd, gravity, nullptr, &so, t_o1);
+   if (st == MH_OK)
+      st = launch<float>(ALGO_ABA, model, B, t_q, t_qd, t_tau, gravity, nullptr, &so, t_o2);
+   if (st != MH_OK)
+      return st;
+   mh::transpose_rows<float>(t_o1, tau_out, (long)B, (long)nv, false, stream);
+   mh::transpose_rows<float>(t_o2, qdd_out, (long)B, (long)nv, false, stream);
+   HIP_TRY(hipGetLastError());
+   return MH_OK;
+}
 
 mh_status mh_rnea_f64_host(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double gravity[3],
                            const double *f_ext, const mh_options *opts, double *tau_out)

@@ -349,17 +349,17 @@ class HipModel:
             return tau_out, qdd_out
         import torch
         for t in (q, qd, qdd, tau) + ((f_ext,) if f_ext is not None else ()):
-            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
-                raise ValueError("rnea_aba needs contiguous float64 tensors on the HIP device")
+            if not t.is_cuda or t.dtype not in (torch.float64, torch.float32) or t.dtype != q.dtype or not t.is_contiguous():
+                raise ValueError("rnea_aba needs contiguous float64 (or float32) tensors of one dtype on the HIP device")
         B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
         if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         g, ra = self._root(gravity)
         opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         tau_out, qdd_out = torch.empty_like(qd), torch.empty_like(qd)
-        _lib.check(lib.mh_rnea_aba_f64(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), tau.data_ptr(), g,
-                                       f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts), tau_out.data_ptr(),
-                                       qdd_out.data_ptr()))
+        fn = lib.mh_rnea_aba_f64 if q.dtype == torch.float64 else lib.mh_rnea_aba_f32
+        _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), tau.data_ptr(), g,
+                      f_ext.data_ptr() if f_ext is not None else None, ctypes.byref(opts), tau_out.data_ptr(), qdd_out.data_ptr()))
         return tau_out, qdd_out
 
     def rnea_crba(self, q, qd, qdd, gravity=(0.0, 0.0, -9.81), f_ext=None):
@@ -382,14 +382,15 @@ class HipModel:
         return tau_out, H
 
     def bind_rnea_aba(self, q, qd, qdd, tau, tau_out, qdd_out, gravity=(0.0, 0.0, -9.81), f_ext=None):
-        """Returns a zero-argument callable that issues mh_rnea_aba_f64 on the given (caller-owned, device-resident) buffers.
+        """Returns a zero-argument callable that issues mh_rnea_aba_f64 (float32 tensors: mh_rnea_aba_f32) on the given (caller-owned,
+        device-resident) buffers.
         All argument marshalling is done once here: a steady-state caller (a simulation loop, bench.py) pays one C call per step."""
         import torch
         lib = _lib.load()
         tensors = (q, qd, qdd, tau, tau_out, qdd_out) + ((f_ext,) if f_ext is not None else ())
         for t in tensors:
-            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
-                raise ValueError("bind_rnea_aba needs contiguous float64 tensors on the HIP device")
+            if not t.is_cuda or t.dtype not in (torch.float64, torch.float32) or t.dtype != q.dtype or not t.is_contiguous():
+                raise ValueError("bind_rnea_aba needs contiguous float64 (or float32) tensors of one dtype on the HIP device")
         B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
         if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau, tau_out, qdd_out)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
@@ -398,7 +399,7 @@ class HipModel:
         args = (self._h, ctypes.c_int64(B), ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(qd.data_ptr()), ctypes.c_void_p(qdd.data_ptr()),
                 ctypes.c_void_p(tau.data_ptr()), g, ctypes.c_void_p(f_ext.data_ptr()) if f_ext is not None else None, ctypes.byref(opts),
                 ctypes.c_void_p(tau_out.data_ptr()), ctypes.c_void_p(qdd_out.data_ptr()))
-        fn = lib.mh_rnea_aba_f64
+        fn = lib.mh_rnea_aba_f64 if q.dtype == torch.float64 else lib.mh_rnea_aba_f32
         keep = (tensors, g, opts)
 
         def call(_fn=fn, _args=args, _keep=keep):

@@ -255,6 +255,13 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
     assert torch.equal(hm.aba(fq, fqd, ftau, g), hm.aba(T(fq), T(fqd), T(ftau), g, layout=_lib.LAYOUT_SOA).t())
     assert torch.equal(hm.rnea(fq, fqd, fqdd, g), hm.rnea(T(fq), T(fqd), T(fqdd), g, layout=_lib.LAYOUT_SOA).t())
     close(hm.rnea(fq, fqd, fqdd, g).cpu().numpy().astype(np.float64)[idx], om.rnea(q[idx], qd[idx], qdd[idx], g), f32_forward_tol(d.n_joints), label="rnea_f32 big batch")
+    # mh_rnea_aba_f32: one set of transposed copies of q and qd for both algorithms on big AoS batches (B3 below is big enough), the two
+    # single calls otherwise (4096; external wrenches) -- bit for bit the single calls either way
+    for nb, wrench in ((8192 + 36, False), (4096, False), (8192 + 36, True)):
+        cq, cqd, cqdd, ctau = (dev(torch, x[:nb], f32) for x in (q, qd, qdd, tau))
+        cf = dev(torch, fext[:nb], f32) if wrench else None
+        tp, ap = hm.rnea_aba(cq, cqd, cqdd, ctau, g, cf)
+        assert tp.dtype == f32 and torch.equal(tp, hm.rnea(cq, cqd, cqdd, g, cf)) and torch.equal(ap, hm.aba(cq, cqd, ctau, g, cf))
     # a batch size the row-block transposers take (B % 4 == 0: 16-byte column segments) with a ragged last block (8228 = 257 * 32 + 4
     # rows in fp32, 514 * 16 + 4 in fp64); 8229 above is served by the 64 x 64 tile kernel.  Same bits as the SoA call either way.
     B3 = 8192 + 36
