@@ -378,12 +378,11 @@ mh_status zv_check_error(mh_model *m)
    }
    return MH_OK;
 }
-// jobs = 2: A.in3b = tau, A.outb = qdd.  jobs = 3: additionally A.in3 = qdd, A.out = tau.  Returns hipErrorNotSupported (as int) in *rc
-// when the code object lacks the plan.
-mh_status zv_launch(mh_model *m, mh::Args<double> &A, int jobs, hipStream_t stream, int *rc)
+// scratch of the bias-split launches for batches up to B: the bias rows, the flags (zeroed on `stream`), the mapped error word
+mh_status zv_prepare(mh_model *m, int64_t B, hipStream_t stream)
 {
-   const size_t groups = (size_t)((A.B + 63) / 64);
-   mh_status st = ensure_bytes(m->zv_tau, (size_t)A.B * m->nv * sizeof(double));
+   const size_t groups = (size_t)((B + 63) / 64);
+   mh_status st = ensure_bytes(m->zv_tau, (size_t)B * m->nv * sizeof(double));
    if (st != MH_OK)
       return st;
    if (m->zv_flags.bytes < groups * sizeof(int))
@@ -402,6 +401,15 @@ mh_status zv_launch(mh_model *m, mh::Args<double> &A, int jobs, hipStream_t stre
       *m->zv_error_host = 0;
       HIP_TRY(hipHostGetDevicePointer((void **)&m->zv_error_dev, m->zv_error_host, 0));
    }
+   return MH_OK;
+}
+// jobs = 2: A.in3b = tau, A.outb = qdd.  jobs = 3: additionally A.in3 = qdd, A.out = tau.  Returns hipErrorNotSupported (as int) in *rc
+// when the code object lacks the plan.
+mh_status zv_launch(mh_model *m, mh::Args<double> &A, int jobs, hipStream_t stream, int *rc)
+{
+   mh_status st = zv_prepare(m, A.B, stream);
+   if (st != MH_OK)
+      return st;
    if (m->zv_epoch == 0x7fffffff)
    { // the flags have seen every positive value: start over
       HIP_TRY(hipDeviceSynchronize());
@@ -2374,6 +2382,19 @@ mh_status mh_reserve(mh_model_t m, int64_t max_batch)
       st = ensure_bytes(m->ws, dfs_bytes);
    if (st == MH_OK && m->use_pair && (max_batch + 63) / 64 <= (long)m->cu_count)
       st = ensure_bytes(m->ws_pair, m->ws.bytes);
+   // round 3's plans: the bias-split launches (their scratch for the largest batch they serve: two jobs on every group of 64 within the
+   // CUs), the one-launch pair of the run-time tree split (twice the workgroups of a single call), the shared transposed copies of
+   // mh_rnea_aba_f32 -- a call right after mh_reserve may be captured into a graph, where an allocation is an error
+   if (st == MH_OK && m->spec.launch_zv && m->use_zv)
+   {
+      st = zv_prepare(m, std::min<int64_t>(max_batch, m->use_zv == 2 ? max_batch : 32L * m->cu_count), nullptr);
+      if (st == MH_OK)
+         HIP_TRY(hipStreamSynchronize(nullptr)); // the flags are zero before any stream's first launch looks at them
+   }
+   if (st == MH_OK && m->split_rt.usable)
+      st = ensure_bytes(m->ws, (size_t)m->split_rt.slots * (size_t)std::min<long>(2 * ((max_batch + 63) / 64), (long)m->cu_count) * 64 * sizeof(double));
+   if (st == MH_OK && transposes && m->use_dfs)
+      st = ensure_bytes(m->tr_pair, (size_t)max_batch * ((size_t)m->nq + 5 * (size_t)m->nv) * sizeof(float));
    return st;
 }
 
