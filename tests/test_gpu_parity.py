@@ -1386,6 +1386,38 @@ def test_entry_points_are_graph_capturable(torch_cuda, monkeypatch, spec):
         assert torch.equal(t_out, t_ref2) and torch.equal(a_out, a_ref2)
 
 
+def test_first_pair_call_after_reserve_is_capturable(torch_cuda):
+    """mh_reserve allocates what the bias-split launch needs (bias rows, flags, the mapped error word): the FIRST mh_rnea_aba_f64 and
+    mh_aba_f64 of a model may already sit inside a stream capture, where an allocation would be an error."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    rng = np.random.default_rng(32)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    B = 2048
+    q, qd, qdd, tau = (dev(torch, x) for x in rt.nextState(rng, sys_, B))
+    g = (0.0, 0.0, -9.81)
+    t_ref, a_ref = HipModel(d).rnea_aba(q, qd, qdd, tau, g)  # another handle of the same robot: the reference values
+    hm = HipModel(d)
+    assert hm.kernel_variant.startswith("topo:")
+    hm.reserve(B)
+    t_out, a_out, a2_out = torch.empty_like(qd), torch.empty_like(qd), torch.empty_like(qd)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        pair = hm.bind_rnea_aba(q, qd, qdd, tau, t_out, a_out, g)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            pair()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        t_out.zero_(), a_out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(t_out, t_ref) and torch.equal(a_out, a_ref)
+
+
 def test_host_pointer_pipeline(torch_cuda, monkeypatch):
     """The host-pointer entry points (what a Java shim calls): batches above 1024 configurations travel in chunks through three streams.
     Pageable and pinned (mh_host_alloc) matrices, a chunk size that leaves a ragged last chunk and re-uses every ring slot, external
