@@ -137,7 +137,7 @@ struct SpecLib
    // bias-split forward dynamics (mh_zv_kernels.h)
    int (*zv_usable)(void) = nullptr;
    long (*zv_lds_bytes)(int nq, int nv) = nullptr;
-   int (*launch_zv)(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, void *stream) = nullptr;
+   int (*launch_zv)(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, int same_l2, void *stream) = nullptr;
 };
 enum : int
 {
@@ -198,6 +198,7 @@ struct mh_model
    Workspace zv_tau, zv_flags;
    int zv_epoch = 0;
    int *zv_error_host = nullptr, *zv_error_dev = nullptr;
+   int zv_same_l2 = 1;    // MH_ZV_SAME_L2=0: bias rows always written through to memory (zv_bias_group)
    int use_zv = 1;        // MH_ZV=0: never; 1: while every job's workgroup gets a CU of its own (default); 2: whenever the call qualifies
    // run-time tree split (mh_split_kernels.h): plan made at creation, device copies, workspace blocks
    struct SplitRt
@@ -385,9 +386,9 @@ mh_status zv_prepare(mh_model *m, int64_t B, hipStream_t stream)
    mh_status st = ensure_bytes(m->zv_tau, (size_t)B * m->nv * sizeof(double));
    if (st != MH_OK)
       return st;
-   if (m->zv_flags.bytes < groups * sizeof(int))
+   if (m->zv_flags.bytes < groups * mh::ZV_SYNC_STRIDE * sizeof(int))
    {
-      st = ensure_bytes(m->zv_flags, std::max<size_t>(groups, 1024) * sizeof(int));
+      st = ensure_bytes(m->zv_flags, std::max<size_t>(groups, 1024) * mh::ZV_SYNC_STRIDE * sizeof(int));
       if (st != MH_OK)
          return st;
       // zeroed ON THE LAUNCH STREAM: a plain hipMemset is not ordered against kernels of other streams (seen here as a rare refusal by the
@@ -418,7 +419,7 @@ mh_status zv_launch(mh_model *m, mh::Args<double> &A, int jobs, hipStream_t stre
    }
    const int epoch = ++m->zv_epoch;
    int flags = SPEC_IO_LDS | (m->ident_maps ? SPEC_IDENT : 0);
-   *rc = m->spec.launch_zv(flags, &A, m->zv_tau.ptr, (int *)m->zv_flags.ptr, m->zv_error_dev, epoch, jobs, (void *)stream);
+   *rc = m->spec.launch_zv(flags, &A, m->zv_tau.ptr, (int *)m->zv_flags.ptr, m->zv_error_dev, epoch, jobs, m->zv_same_l2, (void *)stream);
    if (*rc != 0 && *rc != (int)hipErrorNotSupported)
       return fail(MH_ERR_HIP, "bias-split kernel launch failed: %s", hipGetErrorString((hipError_t)*rc));
    return MH_OK;
@@ -2051,6 +2052,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_fused = atoi(e) ? 0 : 1;
    if (const char *e = getenv("MH_ZV"))
       m->use_zv = atoi(e);
+   if (const char *e = getenv("MH_ZV_SAME_L2"))
+      m->zv_same_l2 = atoi(e) ? 1 : 0;
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
       m->lds_wave_factor = atoi(e);
    if (const char *e = getenv("MH_SPEC_IO"))

@@ -2386,6 +2386,10 @@ __global__ void __launch_bounds__(256) regressor_kernel(Args<T> A)
    }
 }
 
+// ints of synchronisation state per 64 configurations of a bias-split launch (mh_zv_kernels.h): two 128-byte lines, so that no line
+// mixes words stored by workgroups behind different L2s
+constexpr int ZV_SYNC_STRIDE = 64;
+
 // ---- stamp of everything a topology-specialised code object shares with the library beyond the C-ABI: the argument structs it
 // reinterprets, the strides of the per-joint records, the canonical-frame convention.  mh_model_create refuses a code object whose stamp
 // differs (a stale libmecano_hip_topo_<key>.so would otherwise read a mis-laid-out struct or fold zeros that are not there).
@@ -2394,7 +2398,8 @@ constexpr unsigned long long spec_abi_stamp()
    unsigned long long h = 1469598103934665603ull;
    const unsigned long long parts[] = {sizeof(Args<double>), sizeof(CentArgs<double>), (unsigned long long)MC_STRIDE, (unsigned long long)MI_STRIDE,
                                        (unsigned long long)MH_FRAME_CONVENTION, (unsigned long long)offsetof(Args<double>, joint_wrench),
-                                       (unsigned long long)offsetof(Args<double>, q_next)};
+                                       (unsigned long long)offsetof(Args<double>, q_next), (unsigned long long)ZV_SYNC_STRIDE,
+                                       2ull /* revision of the mh_spec_* entry points' signatures: 2 = mh_spec_launch_zv(..., same_l2, stream) */};
    for (unsigned long long v : parts)
       h = (h ^ v) * 1099511628211ull;
    return h;

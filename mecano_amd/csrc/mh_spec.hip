@@ -272,8 +272,8 @@ int mh_spec_zv_usable(void) { return SPL::usable() ? 1 : 0; }
 int mh_spec_zv_probe_read(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mh::zv_probe), bytes); }
 #endif
 // jobs = 2: qdd = ABA(q, qd, tau) with args->in3b = tau, args->outb = qdd.  jobs = 3: additionally args->out = RNEA(q, qd, args->in3).
-// taup: scratch [B][nv]; sync_flags: ceil(B / 64) ints that never held `epoch` before; error: one int, set when a wait timed out.
-int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, void *stream)
+// taup: scratch [B][nv]; sync_flags: ceil(B / 64) * ZV_SYNC_STRIDE ints that never held `epoch` before; same_l2: rows may stay in a shared L2; error: one int, set when a wait timed out.
+int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, int same_l2, void *stream)
 {
    if constexpr (SPL::usable())
    {
@@ -284,7 +284,7 @@ int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, 
       if (lds > 160 * 1024)
          return (int)hipErrorNotSupported;
       const long groups = (A.B + 63) / 64, padded = (groups + 7) / 8 * 8;
-      const mh::ZvSync sy{sync_flags, error, epoch, jobs};
+      const mh::ZvSync sy{sync_flags, error, epoch, jobs, same_l2 ? 1 : 0};
       hipStream_t s = (hipStream_t)stream;
       if (flags & F_IDENT)
       {

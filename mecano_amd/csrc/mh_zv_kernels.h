@@ -104,6 +104,33 @@ MH_DEV LDL6<T> st_get_ldl(const CX &cx)
 // ---- inward sweep without bias terms (ForwardDynamicsCalculator.java:1146-1235 with p = c = 0): returns the articulated inertia the
 //      subtree hands to its parent, in the parent's frame.  MODE as in AbaIn: 0 whole subtree, 1 trunk pass (limb roots come from the
 //      exchange area), 2 the root body alone of a staged trunk, 3 a late limb carrying the workgroup's first barrier.
+// (cos, sin) of every revolute joint below and including J, into the store slots ZvIn leaves them in anyway.  A body step of the
+// inward walk begins with the sincos of its joint angle -- a long dependent chain with ONE wave per SIMD and nothing to fill its gaps --
+// while the joints of a limb need nothing from each other: formed together, up front, the evaluations interleave (leg of the humanoid:
+// inward walk 7.6 -> 5.45 us, profiles/r03_presincos_experiment.txt).
+template <class TP, int J, typename T, class CX>
+struct ZvPre
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         ZvPre<TP, Tree<TP>::child(J, K), T, CX>::run(cx);
+         children<K + 1>(cx);
+      }
+   }
+   static MH_DEV void run(const CX &cx)
+   {
+      children<0>(cx);
+      if constexpr (TP::type[J] == JT_REVOLUTE)
+      {
+         const JX<T> jx = spec_joint<JT_REVOLUTE, Tree<TP>::cfg_ofs(J), CX, T>(cx);
+         cx.st.template put<J, 7>(jx.c);
+         cx.st.template put<J, 8>(jx.s);
+      }
+   }
+};
 template <class TP, int J, typename T, class CX, int MODE = 0>
 struct ZvIn
 {
@@ -154,7 +181,11 @@ struct ZvIn
       // the kernel's arguments, more than the file has, and every use became a v_readlane from a spill lane (15 % of the instructions of
       // this chain); the sincos and the rank-1 downdate in front of its first use cover the latency
       const XF<T> Xb = load_xb_j<TP, J, T>(c);
-      const JX<T> jx = spec_joint_from<TYPE, T>(jq);
+      JX<T> jx;
+      if constexpr (TYPE == JT_REVOLUTE && !Split<TP>::is_trunk(J) && (MODE == 0 || MODE == 3)) // a limb: ZvPre ran (zv_limbs_in_of)
+         jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>(), jx.d = T(0);
+      else
+         jx = spec_joint_from<TYPE, T>(jq);
       ABI<T> out = abi_zero<T>();
       if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
       {
@@ -389,7 +420,10 @@ MH_DEV void zv_limbs_in_of(const CX &cx)
    if constexpr (K < S::n_limbs())
    {
       if constexpr (S::owner(K) == W && (LATE < 0 || (S::is_late(K) ? 1 : 0) == LATE))
+      {
+         ZvPre<TP, S::limb_root(K), T, CX>::run(cx);
          x_put_ia<K, CX, T>(cx, ZvIn<TP, S::limb_root(K), T, CX, (LATE >= 0 && S::cut_limb(W) == K ? 3 : 0)>::run(cx));
+      }
       zv_limbs_in_of<TP, W, K + 1, LATE, T, CX>(cx);
    }
 }
@@ -638,11 +672,16 @@ MH_DEV void zv_stage_rows(lds_ptr<T> dst, const T *src, int rows)
 
 struct ZvSync
 {
-   int *flags;     // one per 64 configurations; the bias job stores `epoch` there once its rows are in memory
+   int *flags;     // per 64 configurations ZV_SYNC_STRIDE ints (two 128-byte lines): [0] the flag -- the bias job stores `epoch` there once
+                   // its rows can be read --, [32] the mailbox the inertia job leaves its XCD's id in
    int *error;     // set to 1 when an inertia job gave up waiting (wall-clock limit): the host turns it into MH_ERR_HIP
    int epoch;
    int jobs;       // 2: bias + inertia (mh_aba_f64); 3: + the inverse dynamics of mh_rnea_aba_f64
+   int same_l2;    // 1: a bias job that finds its inertia job behind the SAME L2 (both read HW_REG_XCC_ID) leaves rows and flag in that L2
 };
+// id of the XCD this wave runs on (HW_REG_XCC_ID, register 20, bits 3:0)
+MH_DEV int zv_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf); }
+MH_DEV int zv_mail_key(int epoch, int xcc) { return (int)(((unsigned)epoch & 0x03ffffffu) << 5) | 16 | xcc; }
 constexpr unsigned long long ZV_WAIT_TICKS = 20000000ull; // 0.2 s of the 100 MHz real-time counter
 
 // The hand-off follows the one form MI355X_MICROARCH.md lists as valid without agent-scope fences (a release fence writes back the whole
@@ -652,7 +691,7 @@ constexpr unsigned long long ZV_WAIT_TICKS = 20000000ull; // 0.2 s of the 100 MH
 // Returns once the flag of group k holds this launch's epoch, or after the wall-clock limit.
 MH_DEV void zv_wait(const ZvSync &sy, long k)
 {
-   const int *f = sy.flags + k;
+   const int *f = sy.flags + k * ZV_SYNC_STRIDE;
    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sy.epoch)
       return;
    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -671,10 +710,14 @@ MH_DEV void zv_wait(const ZvSync &sy, long k)
 }
 // rows of one matrix, LDS -> global, write-through (sc1), all NT threads
 template <typename T, int NT>
-MH_DEV void zv_publish_rows(T *dst, lds_ptr<T> src, int n)
-{
-   for (int i = threadIdx.x; i < n; i += NT)
-      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+MH_DEV void zv_publish_rows(T *dst, lds_ptr<T> src, int n, bool same_l2)
+{ // same_l2: the reader is known to sit behind this L2 -- workgroup-scope stores (sc0) leave the lines there, where its sc1 loads are served
+   if (same_l2)
+      for (int i = threadIdx.x; i < n; i += NT)
+         __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+   else
+      for (int i = threadIdx.x; i < n; i += NT)
+         __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // rows of one matrix, global -> LDS, every load sc1 (past the L1), all NT threads
 template <typename T, int N, int NT>
@@ -706,6 +749,7 @@ MH_DEV void zv_bias_group(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, con
    const long cfg0 = k * 64;
    const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
    const bool active = lane < rows;
+   __shared__ int zv_same_l2;
    ZV_STAMP(0, 0);
    wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
    __syncthreads();
@@ -721,19 +765,38 @@ MH_DEV void zv_bias_group(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, con
    if (active)
       split_rnea_limbs<TP, 0, T, CX>(cx);
    ZV_STAMP(0, 2);
+   if (threadIdx.x == 64)
+      zv_same_l2 = sy.same_l2 && __hip_atomic_load(sy.flags + k * ZV_SYNC_STRIDE + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == zv_mail_key(sy.epoch, zv_xcc_id());
    __syncthreads();
    ZV_STAMP(0, 3);
+   const bool same = zv_same_l2 != 0;
    if (active && wave == 0)
       rnea_trunk_roots<TP, T, CX>(cx);
+   // (Which L2 the rows will be read from was looked up before the barrier above.)  The inertia job of these configurations started
+   // together with this one and left the id of its XCD in the mailbox.  The same id as this workgroup's own: one L2 serves both,
+   // and rows and flag left there (stores that are NOT write-through) are what that job's sc1 polls and loads find: flag stored -> seen
+   // 0.24 us and the rows fetched in 0.67 us, against 0.36 and 0.85 us through memory.  Anything else in the mailbox (not started,
+   // another XCD, same_l2 off): write-through.  The inertia job empties its mailbox when it has consumed the rows, so that a replay
+   // of a captured launch (same epoch) never finds the previous replay's.
+   // (The flags of 32 groups shared a 128-byte line at first.  A consumer that arrives BEFORE the flag then saw it 1.6-1.9 us after its
+   // store -- the line bounced between 32 pollers and 32 writers -- which is why speeding up the inertia job alone made the step
+   // slower; with a line per group a waiting consumer sees it as fast as a late one: profiles/r03_presincos_experiment.txt.)
    ZV_STAMP(0, 4);
    __syncthreads();
-   zv_publish_rows<T, 256>(taup + cfg0 * nv, lx, rows * nv);
+   // (Publishing the limbs' entries from the idle waves while wave 0 runs the trunk was measured: the masked 8-byte stores write every
+   // line in pieces -- 1.4 + 1.1 us for the two parts against 0.55 us for whole rows.)
+   zv_publish_rows<T, 256>(taup + cfg0 * nv, lx, rows * nv, same);
    ZV_STAMP(0, 5);
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have been acknowledged ...
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its stores have been acknowledged by the L2 / by memory ...
    ZV_STAMP(0, 6);
    __syncthreads();
-   if (threadIdx.x == 0) // ... so the flag, stored behind the barrier, is never seen ahead of them
-      __hip_atomic_store(sy.flags + k, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   if (threadIdx.x == 0) // ... so the flag, stored behind the barrier (the same way as the rows), is never seen ahead of them
+   {
+      if (same)
+         __hip_atomic_store(sy.flags + k * ZV_SYNC_STRIDE, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else
+         __hip_atomic_store(sy.flags + k * ZV_SYNC_STRIDE, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
    ZV_STAMP(0, 7);
 }
 
@@ -759,6 +822,8 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
    const bool active = lane < rows;
    ZV_STAMP(1, 0);
+   if (sy.same_l2 && threadIdx.x == 0) // where this job runs, for the bias job of the same configurations (see there)
+      __hip_atomic_store(sy.flags + k * ZV_SYNC_STRIDE + 32, zv_mail_key(sy.epoch, zv_xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    zv_stage_rows<T, Tree<TP>::total_cfgs(), 256>(lq, A.q + cfg0 * nq, rows);
    __syncthreads();
    ZV_STAMP(1, 1);
@@ -808,7 +873,11 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    // left standing from the previous replay would let this job read the previous replay's rows.  (Stream order puts the reset before the
    // next launch's bias job; the rows' loads were issued above and this store cannot pass the flag poll it depends on.)
    if (threadIdx.x == 0)
-      __hip_atomic_store(sy.flags + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   {
+      __hip_atomic_store(sy.flags + k * ZV_SYNC_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sy.same_l2)
+         __hip_atomic_store(sy.flags + k * ZV_SYNC_STRIDE + 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
    __syncthreads(); // bias rows staged; nobody reads the exchange area's inertias any more
    ZV_STAMP(1, 6);
    asm volatile("" ::: "memory");
