@@ -633,12 +633,18 @@ MH_DEV void zv_fold_out(const CX &cx)
       {
          if constexpr (S::staged())
          {
+#ifdef MH_ZV_PROBE
+            const long k = (long)cx.own; // (the group, for the stamps: zv_aba_group leaves it there in probe builds)
+#endif
             zv_limbs_fold_sel<TP, W, 0, 0, T, CX>(cx);
+            ZV_STAMP(1, 7);
             __syncthreads();
             zv_limbs_fold_sel<TP, W, 0, 1, T, CX>(cx);
             zv_subtrunks_fold_of<TP, W, 0, T, CX>(cx);
+            ZV_STAMP(1, 8);
             __syncthreads();
             (void)ZvFold<TP, S::root(), T, CX, 2>::run(cx);
+            ZV_STAMP(1, 9);
          }
          else
          {
@@ -834,6 +840,9 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    cx.xbase = lxc + lane;
    cx.st.lbase = lst + lane;
    cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+#ifdef MH_ZV_PROBE
+   cx.own = (unsigned long long)k;
+#endif
 #ifdef MH_ZV_TWICE // experiment: the inward limb phase a second time, through a warm instruction cache (stamps 12 = first pass done)
 #pragma unroll 1
    for (int rep = 0; rep < 2; rep++)

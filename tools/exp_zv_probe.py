@@ -32,7 +32,7 @@ G = min((B + 63) // 64, 4096)
 st = buf.reshape(4096, 3, 4, 16)[:G].astype(np.int64)
 t0 = st[:, :, :, 15].min()  # first instruction of the launch
 names = {0: ["entry", "staged", "limbs", "barrier", "trunk", "copied", "fenced", "flag"],
-         1: ["entry", "staged(q)", "limbs_in", "barrier2", "root", "flag_seen", "tau_staged", "limb_fold", "barrier", "trunk_fold", "out", "copied"]}
+         1: ["entry", "staged(q)", "limbs_in", "barrier2", "root", "flag_seen", "tau_staged", "early_fold", "late_fold+sub", "root_fold", "out", "copied"]}
 print("B", B, what, "variant", hm.kernel_variant, "(times in us relative to the first entry; median over groups)")
 for job in (0, 1):
     for w in range(4):
