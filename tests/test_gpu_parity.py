@@ -442,8 +442,9 @@ def test_every_specialised_variant(torch_cuda, B):
             off = {"MH_SPEC_SPLIT": "0"}
             for env in ({"MH_DISABLE_SPEC": "1"}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "0", "MH_SPEC_ST": "1", **off},
                         {"MH_SPEC_IO": "1", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "1", "MH_SPEC_ST": "1", **off}, {"MH_SPEC_SPLIT": "1"}, {},
-                        {"MH_ZV": "0"}, {"MH_ZV": "2"}):  # bias-split forward dynamics never / at every batch size (default: small batches)
-                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV"):
+                        {"MH_ZV": "0"}, {"MH_ZV": "2"},  # bias-split forward dynamics never / at every batch size (default: small batches)
+                        {"MH_ZV": "2", "MH_ZV_SAME_L2": "0"}):  # ... its hand-off always written through to memory (no shared-L2 form)
+                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2"):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 hm = HipModel(d)
@@ -456,7 +457,7 @@ def test_every_specialised_variant(torch_cuda, B):
                 close(t2.cpu().numpy()[idx], t_ref)
                 close(a2.cpu().numpy()[idx], a_ref)
         finally:
-            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV"):
+            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2"):
                 os.environ.pop(k, None)
         assert any(v.startswith("generic") for v in seen) and any(v.startswith("topo:") for v in seen), seen
 
