@@ -125,7 +125,7 @@ def mecano_jvm_baseline(iterations=50000):
 def committed_traffic(fused_launch, B):
     """Fallback for `roofline.traffic`: the rocprofv3 PMC passes committed under profiles/ (same workload, same correction); only quoted
     for the configuration they were collected on, else null."""
-    for name in ("r02_fused_split_b4096_hbm_pmc.json", "r01_fused_split_b4096_hbm_pmc.json"):
+    for name in ("r03_final_zv_b4096_hbm_pmc.json",):  # (the bias-split launch that serves this call since round 3)
         path = os.path.join(ROOT, "profiles", name)
         if fused_launch and B == BATCH and os.path.exists(path):
             pmc = json.load(open(path))
