@@ -693,7 +693,9 @@ constexpr unsigned long long ZV_WAIT_TICKS = 20000000ull; // 0.2 s of the 100 MH
 // The hand-off follows the one form MI355X_MICROARCH.md lists as valid without agent-scope fences (a release fence writes back the whole
 // L2: 7-11 us measured here; an acquire fence invalidates it): every byte of the bias rows is stored sc1 (write-through) and loaded sc1
 // (served past the L1), every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier behind which ONE lane
-// stores the flag sc1, and the consumer's polling wave joins a workgroup barrier before any wave loads the rows.
+// stores the flag sc1, and the consumer's polling wave joins a workgroup barrier before any wave loads the rows.  Where the two jobs of
+// a group have PROVED to run behind the same L2 (mailbox, zv_bias_group) the stores are workgroup-scope (sc0) instead: rows and flag
+// stay in that L2, which is where the consumer's sc1 polls and loads are served from; everything else is the same.
 // Returns once the flag of group k holds this launch's epoch, or after the wall-clock limit.
 MH_DEV void zv_wait(const ZvSync &sy, long k)
 {
@@ -714,7 +716,7 @@ MH_DEV void zv_wait(const ZvSync &sy, long k)
       }
    }
 }
-// rows of one matrix, LDS -> global, write-through (sc1), all NT threads
+// rows of one matrix, LDS -> global, all NT threads: write-through (sc1), or left in the L2 the reader shares (sc0)
 template <typename T, int NT>
 MH_DEV void zv_publish_rows(T *dst, lds_ptr<T> src, int n, bool same_l2)
 { // same_l2: the reader is known to sit behind this L2 -- workgroup-scope stores (sc0) leave the lines there, where its sc1 loads are served
