@@ -39,10 +39,24 @@
  *     JointMatrixIndexProvider contract
  *     (multiBodySystem/interfaces/JointMatrixIndexProvider.java:71-123).
  *
- * Threading: like the reference's calculators (one per thread), a model handle is to be used by one host thread at a time AND on one
- * stream at a time -- compute calls share its device workspace and scratch buffers, so two calls on the same handle issued on different
- * streams would race on them (also from a single host thread).  Create one handle per thread / stream (models are a few KB) or serialise
- * the calls (an event wait between streams); different handles are independent.  Calls are asynchronous on opts->stream.
+ * Threading: a model handle is READ-ONLY after mh_model_create and may be shared by any number of host threads and streams.  What
+ * compute calls write besides their outputs -- device workspace, scratch matrices, staging buffers, the hand-off flags and the error word
+ * of the bias-split forward dynamics -- belongs to a CONTEXT: mh_context_create(model) makes one per host thread / per stream, and a call
+ * names it in opts->context.  Calls that leave opts->context NULL use the model's built-in default context and are then subject to the
+ * rule of the reference's calculators (one per thread: their scratch fields, InverseDynamicsCalculator.java:706-707): one host thread
+ * and one stream at a time per context.  Contexts of one model are independent of each other; so are different models.
+ *
+ * Calls with device pointers are ASYNCHRONOUS on opts->stream: they return once the work is enqueued.  A failure that shows only while
+ * the work runs is therefore reported later: by mh_model_check (synchronises the stream and reports for one context), by
+ * mh_stream_synchronize (reports for every context), by the *_host entry points (synchronous: they check before they return) and at the
+ * latest by the context's next forward-dynamics call.  One such failure exists: a bias-split forward dynamics launch (small batches of a
+ * model with a tree-split code object, mh_aba_f64 / mh_rnea_aba_f64) whose consumer workgroup waited longer than MH_ZV_WAIT_MS
+ * (environment, default 2000) for its producer; the accelerations of those 64 configurations are then written as NaN, never as numbers.
+ *
+ * Last bits: mh_aba_f64 / mh_rnea_aba_f64 choose the formulation of forward dynamics by batch size (bias split while every job gets a CU
+ * of its own, one-job tree split up to one group of 64 configurations per CU, two launches beyond; MH_ZV / MH_ZVB in the environment force
+ * either).  The formulations agree to about 1e-13 relative, not bit for bit: the same configuration evaluated inside batches of different
+ * sizes -- e.g. in shards of different sizes on different ranks -- may differ in its last bits.  MH_ZV=0 MH_ZVB=0 pins the one-job form.
  *
  * No function throws or aborts; every entry point returns an mh_status and
  * mh_last_error() gives a thread-local message.  The library never falls back
@@ -59,7 +73,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 3
+#define MH_ABI_VERSION 4
 
 /* ---- status codes (the Java shim maps them back to Mecano's exception types) ---- */
 typedef enum mh_status
@@ -136,9 +150,12 @@ typedef struct mh_options
                                     * ForwardDynamicsCalculator.setRootAcceleration (java:330-343): spatial acceleration of the root body
                                     * (angular x y z, then linear x y z), expressed in the root body's frame, of the root body's frame
                                     * relative to an inertial frame -- what a moving / rotating base contributes; (0, 0, 0, -g) is gravity */
+   void *context;                  /* mh_context_t the call's workspace, scratch and flags come from; NULL (default) = the model's own
+                                    * default context (then: one host thread and one stream at a time on this model) */
 } mh_options;
 
 typedef struct mh_model *mh_model_t;
+typedef struct mh_context *mh_context_t;
 
 /* ---- library / device ---- */
 int32_t mh_abi_version(void);
@@ -181,6 +198,20 @@ mh_status mh_topology_key(const mh_model_desc *desc, char key_out[17], int32_t *
  * itself for a tree it finds no code object for, into MH_SPEC_DIR or next to the library.
  */
 mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap);
+
+/*
+ * ---- contexts (see "Threading" at the top) ----
+ * A context owns everything a compute call writes besides its outputs; the model handle it was made from stays read-only.  Make one per
+ * host thread or stream, pass it in opts->context; destroy it before its model.  mh_context_reserve is mh_reserve for a context.
+ * While contexts of a model exist mh_model_set_joint_source_modes is refused (the contexts hold copies of the joint records' host side).
+ */
+mh_status mh_context_create(mh_model_t model, mh_context_t *ctx_out);
+void mh_context_destroy(mh_context_t ctx);
+mh_status mh_context_reserve(mh_context_t ctx, int64_t max_batch);
+/* Synchronises `stream` (NULL = the null stream) and reports failures of the asynchronous calls issued through `ctx` (NULL = the model's
+ * default context) that only showed on the device -- see "Calls with device pointers are ASYNCHRONOUS" at the top.  MH_OK: the outputs
+ * of every call of this context enqueued on `stream` so far are valid. */
+mh_status mh_model_check(mh_model_t model, mh_context_t ctx, void *stream);
 
 /* Pre-allocate device workspace for batches up to max_batch so that compute calls allocate nothing.  After it (and one first call of
  * each entry point, which sets kernel attributes once) the device-pointer entry points only enqueue work on opts->stream -- kernels,
@@ -456,6 +487,19 @@ mh_status mh_comm_broadcast_host(mh_comm_t comm, void *host_buf, size_t bytes, i
 /* local_rows: [hi - lo][row_bytes] of mh_shard_range(B_total, rank, world), device; all_rows_out: [B_total][row_bytes], device, on every
  * rank.  Asynchronous on `stream`.  Ragged shards travel as they are (one grouped operation, no padding). */
 mh_status mh_comm_all_gather_rows(mh_comm_t comm, const void *local_rows, int64_t B_total, size_t row_bytes, void *all_rows_out, void *stream);
+/* The operations mh_comm_all_gather_rows issues on `rank` of `world`, without issuing them (host-only: no RCCL, no device).  Step k is a
+ * broadcast of `bytes` bytes from rank `root` into [recv_offset, recv_offset + bytes) of every rank's output, in place except on the root
+ * (send_local = 1: the bytes come from its local rows); equal shards give ONE step with root = -1, the plain all-gather.  Every rank gets
+ * the same list (roots, sizes, offsets, order).  steps may be NULL with cap = 0 to ask for the count only (at most world steps). */
+typedef struct mh_gather_step
+{
+   int32_t root;
+   int32_t send_local;
+   int64_t recv_offset;
+   int64_t bytes;
+} mh_gather_step;
+mh_status mh_comm_gather_plan(int64_t B_total, size_t row_bytes, int32_t rank, int32_t world, int32_t force_ragged, mh_gather_step *steps,
+                              int32_t cap, int32_t *n_steps_out);
 mh_status mh_comm_barrier(mh_comm_t comm, void *stream); /* every rank has arrived and `stream` has drained */
 
 /* ---- measurement helper: HIP-event timing of launches on a stream (bench.py, §8d timing protocol) ---- */

@@ -14,12 +14,19 @@ import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
  * (forward dynamics + integration per step, mh_aba_integrate_f64) or a controller that chains inverse dynamics, mass matrix and forward
  * dynamics never crosses PCIe between calls; upload(...) / download(...) move a matrix when the host wants to see it.
  * Row b of every matrix is the column vector Mecano's MultiBodySystemTools.extractJointsState produces for configuration b.
+ * <p>
+ * A batch owns an mh_context: the calculators' device-side calls on it name that context in their options, so every batch brings its own
+ * workspace, scratch and hand-off flags and two threads may drive two batches of one shared (read-only) HipMultiBodyModel at the same
+ * time -- the restriction of Mecano's calculators (scratch fields, one calculator per thread: InverseDynamicsCalculator.java:706-707)
+ * does not carry over.  {@link #check()} synchronises and surfaces failures of asynchronous calls before their outputs are read.
  */
 public final class HipDeviceBatch implements AutoCloseable
 {
    final HipMultiBodyModel model;
    final int batchSize;
    final MemorySegment q, qd, qdd, tau, fExt, bodyAcceleration, bodyTwist, jointWrench, pairOutput;
+   /** mh_context_t of this batch: pass it as the last argument of MecanoHipNative.options(...) for every call on this batch's buffers */
+   final MemorySegment context;
    /** doubles each device buffer holds, in the order of {@link #buffers()}: every copy is checked against it */
    private final long[] capacity;
 
@@ -32,19 +39,29 @@ public final class HipDeviceBatch implements AutoCloseable
       long B = batchSize, wrenches = B * 6 * model.numberOfJoints;
       capacity = new long[] {B * model.nq, B * model.nv, B * model.nv, B * model.nv, wrenches, wrenches, wrenches, wrenches, B * 6};
       MemorySegment[] made = new MemorySegment[capacity.length];
+      MemorySegment madeContext = MemorySegment.NULL;
       try
       {
          for (int i = 0; i < made.length; i++)
             made[i] = allocate(capacity[i]);
-         MecanoHipNative.invoke(() -> (int) MecanoHipNative.RESERVE.invokeExact(model.handle, (long) batchSize));
+         try (Arena arena = Arena.ofConfined())
+         {
+            MemorySegment out = arena.allocate(ADDRESS);
+            MecanoHipNative.invoke(() -> (int) MecanoHipNative.CONTEXT_CREATE.invokeExact(model.handle, out));
+            madeContext = out.get(ADDRESS, 0);
+         }
+         final MemorySegment c = madeContext;
+         MecanoHipNative.invoke(() -> (int) MecanoHipNative.CONTEXT_RESERVE.invokeExact(c, (long) batchSize));
       }
       catch (RuntimeException | Error e)
       { // a later allocation failed: the earlier ones must not leak
          for (MemorySegment buffer : made)
             if (buffer != null)
                free(buffer);
+         destroyContext(madeContext);
          throw e;
       }
+      context = madeContext;
       q = made[0];
       qd = made[1];
       qdd = made[2];
@@ -69,6 +86,29 @@ public final class HipDeviceBatch implements AutoCloseable
          if (all[i].address() == deviceBuffer.address())
             return capacity[i];
       throw new IllegalArgumentException("not a buffer of this batch");
+   }
+
+   private static void destroyContext(MemorySegment context)
+   {
+      if (context.address() == 0)
+         return;
+      try
+      {
+         MecanoHipNative.CONTEXT_DESTROY.invokeExact(context);
+      }
+      catch (Throwable t)
+      {
+         // best effort on the error path
+      }
+   }
+
+   /**
+    * mh_model_check: waits for the null stream and throws if a call on this batch failed on the device after it had returned (the compute
+    * calls with device pointers are asynchronous).  download(...) calls it before it copies, so values never reach the host unchecked.
+    */
+   public void check()
+   {
+      MecanoHipNative.invoke(() -> (int) MecanoHipNative.MODEL_CHECK.invokeExact(model.handle, context, MemorySegment.NULL));
    }
 
    private static void free(MemorySegment buffer)
@@ -115,6 +155,7 @@ public final class HipDeviceBatch implements AutoCloseable
       if ((long) rows * columns > capacityOf(deviceBuffer))
          throw new IllegalArgumentException(rows + " x " + columns + " exceeds the " + capacityOf(deviceBuffer) + " doubles of the device buffer");
       matrixToPack.reshape(rows, columns);
+      check();
       try (Arena arena = Arena.ofConfined())
       {
          long count = (long) rows * columns;
@@ -176,5 +217,6 @@ public final class HipDeviceBatch implements AutoCloseable
    {
       for (MemorySegment buffer : buffers())
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.DEVICE_FREE.invokeExact(buffer));
+      destroyContext(context);
    }
 }

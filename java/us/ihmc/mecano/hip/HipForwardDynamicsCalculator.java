@@ -286,7 +286,7 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
    {
       try (Arena arena = Arena.ofConfined())
       {
-         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true, rootAcceleration);
+         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true, rootAcceleration, batch.context);
          MemorySegment f = withExternalWrenches ? batch.fExt : MemorySegment.NULL;
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.ABA_BODIES.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.qd, batch.tau, g, f,
                                                                                   options, batch.qdd, batch.bodyAcceleration, batch.bodyTwist));
@@ -304,7 +304,7 @@ public class HipForwardDynamicsCalculator implements AutoCloseable
    {
       try (Arena arena = Arena.ofConfined())
       {
-         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true, rootAcceleration);
+         MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), options = MecanoHipNative.options(arena, true, true, rootAcceleration, batch.context);
          MemorySegment f = withExternalWrenches ? batch.fExt : MemorySegment.NULL;
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.ABA_INTEGRATE.invokeExact(model.handle, (long) batch.batchSize, dt, batch.q, batch.qd, batch.tau, g, f,
                                                                                      options, batch.qdd, batch.q, batch.qd));

@@ -238,7 +238,7 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
       {
          MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity);
          MemorySegment f = withExternalWrenches ? batch.fExt : MemorySegment.NULL;
-         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration);
+         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration, batch.context);
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.RNEA_BODIES.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.qd, batch.qdd, g, f,
                                                                                    options, batch.tau, batch.bodyAcceleration, batch.bodyTwist));
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.RNEA_JOINT_WRENCHES.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.qd,
@@ -307,7 +307,7 @@ public class HipInverseDynamicsCalculator implements AutoCloseable
       try (Arena arena = Arena.ofConfined())
       {
          MemorySegment g = arena.allocateFrom(JAVA_DOUBLE, gravity), bases = arena.allocateFrom(JAVA_INT, baseIndex), bodies = arena.allocateFrom(JAVA_INT, bodyIndex);
-         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration);
+         MemorySegment options = MecanoHipNative.options(arena, considerCoriolisAndCentrifugalForces, considerJointAccelerations, rootAcceleration, batch.context);
          MemorySegment twist = considerCoriolisAndCentrifugalForces ? batch.bodyTwist : MemorySegment.NULL;
          MecanoHipNative.invoke(() -> (int) MecanoHipNative.RELATIVE_ACCELERATION.invokeExact(model.handle, (long) batch.batchSize, batch.q, batch.bodyAcceleration,
                                                                                              twist, g, 1, bases, bodies, options, batch.pairOutput));

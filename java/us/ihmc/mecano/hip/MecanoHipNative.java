@@ -15,7 +15,7 @@ import static java.lang.foreign.ValueLayout.JAVA_INT;
 import static java.lang.foreign.ValueLayout.JAVA_LONG;
 
 /**
- * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h, ABI version 3.  NOT compiled in this repository's image (no JVM
+ * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h, ABI version 4.  NOT compiled in this repository's image (no JVM
  * there); it is the reference-side stub a Mecano maintainer adds.  One downcall handle per C entry point the shim classes use; every
  * entry point returns an mh_status int which {@link #check(int)} maps back to the exception types Mecano itself throws.
  * <p>
@@ -37,15 +37,16 @@ public final class MecanoHipNative
    }
 
    /** the ABI version this binding was written against (include/mecano_hip.h: MH_ABI_VERSION); checked when the class loads */
-   static final int ABI = 3;
+   static final int ABI = 4;
 
    /**
     * struct mh_options { int32 consider_coriolis, consider_accelerations, layout, use_root_acceleration; void *stream; double
-    * root_acceleration[6]; }
+    * root_acceleration[6]; void *context; }
     */
    static final StructLayout OPTIONS = MemoryLayout.structLayout(JAVA_INT.withName("consider_coriolis"), JAVA_INT.withName("consider_accelerations"),
                                                                 JAVA_INT.withName("layout"), JAVA_INT.withName("use_root_acceleration"),
-                                                                ADDRESS.withName("stream"), MemoryLayout.sequenceLayout(6, JAVA_DOUBLE).withName("root_acceleration"));
+                                                                ADDRESS.withName("stream"), MemoryLayout.sequenceLayout(6, JAVA_DOUBLE).withName("root_acceleration"),
+                                                                ADDRESS.withName("context"));
 
    static final MethodHandle ABI_VERSION = handle("mh_abi_version", FunctionDescriptor.of(JAVA_INT));
    static final MethodHandle LAST_ERROR = handle("mh_last_error", FunctionDescriptor.of(ADDRESS));
@@ -55,6 +56,15 @@ public final class MecanoHipNative
    /** (desc, out_dir|NULL, path_out, path_cap): runs hipcc on the kernel sources next to the library; minutes; once per robot. */
    static final MethodHandle BUILD_CODE_OBJECT = handle("mh_build_code_object", status(ADDRESS, ADDRESS, ADDRESS, JAVA_LONG));
    static final MethodHandle RESERVE = handle("mh_reserve", status(ADDRESS, JAVA_LONG));
+   /**
+    * Contexts: the model handle is read-only and shared; what compute calls write besides their outputs (workspace, scratch, hand-off flags,
+    * error word) belongs to a context, one per thread / stream, named in mh_options.context (HipDeviceBatch owns one).
+    */
+   static final MethodHandle CONTEXT_CREATE = handle("mh_context_create", status(ADDRESS, ADDRESS));
+   static final MethodHandle CONTEXT_DESTROY = handle("mh_context_destroy", FunctionDescriptor.ofVoid(ADDRESS));
+   static final MethodHandle CONTEXT_RESERVE = handle("mh_context_reserve", status(ADDRESS, JAVA_LONG));
+   /** (model, context|NULL, stream|NULL): synchronises the stream and reports failures of asynchronous calls that only showed on the device */
+   static final MethodHandle MODEL_CHECK = handle("mh_model_check", status(ADDRESS, ADDRESS, ADDRESS));
    static final MethodHandle SET_JOINT_SOURCE_MODES = handle("mh_model_set_joint_source_modes", status(ADDRESS, ADDRESS));
 
    /* (model, B, q, qd, qdd|tau, gravity[3] (host), f_ext|NULL, opts|NULL, out) */
@@ -142,6 +152,12 @@ public final class MecanoHipNative
     */
    static MemorySegment options(Arena arena, boolean considerCoriolis, boolean considerAccelerations, double[] rootAcceleration)
    {
+      return options(arena, considerCoriolis, considerAccelerations, rootAcceleration, MemorySegment.NULL);
+   }
+
+   /** The same for calls made through a context (HipDeviceBatch.context); MemorySegment.NULL is the model's default context. */
+   static MemorySegment options(Arena arena, boolean considerCoriolis, boolean considerAccelerations, double[] rootAcceleration, MemorySegment context)
+   {
       MemorySegment options = arena.allocate(OPTIONS);
       options.set(JAVA_INT, 0, considerCoriolis ? 1 : 0);
       options.set(JAVA_INT, 4, considerAccelerations ? 1 : 0);
@@ -150,6 +166,7 @@ public final class MecanoHipNative
       options.set(ADDRESS, 16, MemorySegment.NULL);
       for (int k = 0; k < 6; k++)
          options.set(JAVA_DOUBLE, 24 + 8L * k, rootAcceleration == null ? 0.0 : rootAcceleration[k]);
+      options.set(ADDRESS, 72, context);
       return options;
    }
 

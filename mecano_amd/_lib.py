@@ -18,11 +18,12 @@ LAYOUT_AOS, LAYOUT_SOA = 0, 1
 # every symbol include/mecano_hip.h declares (tests/test_abi.py checks the library exports each one)
 ABI_SYMBOLS = [
     "mh_abi_version", "mh_spec_abi_stamp", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
+    "mh_context_create", "mh_context_destroy", "mh_context_reserve", "mh_model_check",
     "mh_topology_key", "mh_build_code_object", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64", "mh_rnea_crba_f64", "mh_regressor_f64", "mh_regressor_f32",
     "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_rnea_joint_wrenches_f64", "mh_aba_joint_wrenches_f64", "mh_relative_acceleration_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_aba_f32", "mh_rnea_bodies_f32", "mh_aba_bodies_f32", "mh_aba_locked_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_rnea_f32_host", "mh_aba_f32_host", "mh_crba_f32_host", "mh_rnea_aba_f64_host", "mh_host_alloc", "mh_host_free", "mh_host_register", "mh_host_unregister", "mh_device_alloc", "mh_device_free", "mh_copy_to_device", "mh_copy_to_host", "mh_stream_synchronize", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
     "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
     "mh_shard_range", "mh_comm_unique_id", "mh_comm_create", "mh_comm_destroy", "mh_comm_size", "mh_comm_broadcast", "mh_comm_broadcast_host",
-    "mh_comm_all_gather_rows", "mh_comm_barrier",
+    "mh_comm_all_gather_rows", "mh_comm_gather_plan", "mh_comm_barrier",
 ]
 
 
@@ -35,7 +36,12 @@ class MhModelDesc(ctypes.Structure):
 
 class MhOptions(ctypes.Structure):
     _fields_ = [("consider_coriolis", ctypes.c_int32), ("consider_accelerations", ctypes.c_int32), ("layout", ctypes.c_int32),
-                ("use_root_acceleration", ctypes.c_int32), ("stream", ctypes.c_void_p), ("root_acceleration", ctypes.c_double * 6)]
+                ("use_root_acceleration", ctypes.c_int32), ("stream", ctypes.c_void_p), ("root_acceleration", ctypes.c_double * 6),
+                ("context", ctypes.c_void_p)]
+
+
+class MhGatherStep(ctypes.Structure):
+    _fields_ = [("root", ctypes.c_int32), ("send_local", ctypes.c_int32), ("recv_offset", ctypes.c_int64), ("bytes", ctypes.c_int64)]
 
 
 CENTROIDAL_FRAME_FIXED, CENTROIDAL_FRAME_AT_COM = 0, 1
@@ -106,6 +112,11 @@ def _load_locked():
     lib.mh_topology_key.argtypes = [ctypes.POINTER(MhModelDesc), ctypes.c_char_p, P, P]
     lib.mh_build_code_object.argtypes = [ctypes.POINTER(MhModelDesc), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     lib.mh_reserve.argtypes = [P, I64]
+    lib.mh_context_create.argtypes = [P, ctypes.POINTER(P)]
+    lib.mh_context_destroy.argtypes = [P]
+    lib.mh_context_destroy.restype = None
+    lib.mh_context_reserve.argtypes = [P, I64]
+    lib.mh_model_check.argtypes = [P, P, P]
     opt = ctypes.POINTER(MhOptions)
     for f in ("mh_rnea_f64", "mh_aba_f64", "mh_rnea_f32", "mh_aba_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_rnea_f32_host", "mh_aba_f32_host"):
         getattr(lib, f).argtypes = [P, I64, P, P, P, P, P, opt, P]
@@ -158,6 +169,7 @@ def _load_locked():
     lib.mh_comm_broadcast_host.argtypes = [P, P, ctypes.c_size_t, I32]
     lib.mh_comm_all_gather_rows.argtypes = [P, P, I64, ctypes.c_size_t, P, P]
     lib.mh_comm_barrier.argtypes = [P, P]
+    lib.mh_comm_gather_plan.argtypes = [I64, ctypes.c_size_t, I32, I32, I32, ctypes.POINTER(MhGatherStep), I32, ctypes.POINTER(I32)]
     _lib = lib
     return lib
 

@@ -137,7 +137,12 @@ struct SpecLib
    // bias-split forward dynamics (mh_zv_kernels.h)
    int (*zv_usable)(void) = nullptr;
    long (*zv_lds_bytes)(int nq, int nv) = nullptr;
-   int (*launch_zv)(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, int same_l2, void *stream) = nullptr;
+   int (*launch_zv)(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, int same_l2, unsigned wait_ticks, void *stream) = nullptr;
+   // forward dynamics of device-filling batches as two launches (mh_zv_kernels.h, spec_zvb_*)
+   int (*zvb_usable)(void) = nullptr;
+   int (*zvb_cs_rows)(void) = nullptr;
+   long (*zvb_lds_bytes)(int which, int nq, int nv) = nullptr;
+   int (*launch_zvb)(int flags, const void *args, void *taup, void *cs, long cs_stride, int groups, int which, void *stream) = nullptr;
 };
 enum : int
 {
@@ -171,8 +176,17 @@ struct mh_model
       int algo, budget, lds_slots, glb_slots, glb_frames;
       int *d_meta;
    };
-   std::deque<DfsPlan> dfs_plans; // references stay valid across push_back
-   std::mutex dfs_mutex;
+   std::deque<DfsPlan> dfs_plans; // references stay valid across push_back; kept by the model itself (a context uses its model's: dfs_plan)
+   struct PlainMutex : std::mutex
+   { // a context starts as a copy of its model (context_clone): the copy gets a mutex of its own
+      PlainMutex() = default;
+      PlainMutex(const PlainMutex &) : std::mutex() {}
+      PlainMutex &operator=(const PlainMutex &) { return *this; }
+   } dfs_mutex;
+   // mh_context_create: a context is a copy of the model's host-side description that SHARES its device records (parent owns them) and
+   // owns everything compute calls write -- workspace, scratch matrices, staging buffers, streams, hand-off flags, the error word
+   mh_model *parent = nullptr;
+   int n_contexts = 0; // live contexts of this model (guarded by g_context_mutex)
    int use_win = 1;       // MH_DFS_WIN=0: AoS rows are read per lane instead of through LDS windows (A/B measurements)
    int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
    int dfs_budget = -1;   // MH_DFS_BUDGET: cap of the stack's LDS budget in slots per wave (measurements)
@@ -196,9 +210,14 @@ struct mh_model
    // bias-split forward dynamics (mh_zv_kernels.h): tau - h(q, qd) rows, one flag per 64 configurations (a launch stores its epoch there),
    // an error word in mapped host memory that a timed-out wait sets (read at the next call of the model)
    Workspace zv_tau, zv_flags;
+   Workspace zvb_cs;      // two-launch forward dynamics: (cos, sin) of the revolute joints, [2 n_rev][B rounded up to 64]
+   int use_zvb = 1;       // MH_ZVB=0: never; 1: batches of two or more groups of 64 configurations per CU (default); 2: whenever the call qualifies; MH_ZVB_WHICH = 1 | 2: one of the two launches only (timing)
+   int zvb_which = 3;
    int zv_epoch = 0;
    int *zv_error_host = nullptr, *zv_error_dev = nullptr;
-   int zv_same_l2 = 1;    // MH_ZV_SAME_L2=0: bias rows always written through to memory (zv_bias_group)
+   int zv_same_l2 = 0;    // MH_ZV_SAME_L2=1 (experiment, off by default): bias rows and flag of a group whose two jobs prove to sit behind the same L2
+                          // stay in that L2 (workgroup-scope stores) -- cache behaviour the memory model does not promise, for no measured gain
+   unsigned zv_wait_ticks = 200000000u; // MH_ZV_WAIT_MS: how long an inertia job waits for its bias rows (100 MHz ticks; default 2 s)
    int use_zv = 1;        // MH_ZV=0: never; 1: while every job's workgroup gets a CU of its own (default); 2: whenever the call qualifies
    // run-time tree split (mh_split_kernels.h): plan made at creation, device copies, workspace blocks
    struct SplitRt
@@ -236,8 +255,13 @@ struct mh_model
    int waves_per_cu = 8;    // resident waves per CU the run-time-topology kernels are launched with (MH_WAVES_PER_CU)
 };
 
+struct mh_context
+{
+   mh_model *m; // the context's copy of the handle (parent = the model it was created from)
+};
 namespace
 {
+std::mutex g_context_mutex;
 mh_status ensure_bytes(Workspace &w, size_t bytes)
 {
    if (w.bytes >= bytes)
@@ -317,10 +341,19 @@ void set_root_acceleration(ARGS &A, const mh_options &o, const double *gravity)
    }
 }
 
-mh_status check_common(mh_model_t model, int64_t B, const mh_options *opts)
+// Also resolves opts->context: a compute call made with a context runs on the context's copy of the handle (its own workspace, scratch,
+// streams, flags); `model` is switched to it here, before the entry point touches anything mutable.
+mh_status check_common(mh_model_t &model, int64_t B, const mh_options *opts)
 {
    if (!model)
       return fail(MH_ERR_INVALID_ARGUMENT, "model is NULL");
+   if (opts && opts->context)
+   {
+      mh_model *c = ((mh_context *)opts->context)->m;
+      if (c->parent != (model->parent ? model->parent : model))
+         return fail(MH_ERR_INVALID_ARGUMENT, "opts->context belongs to another model");
+      model = c;
+   }
    if (B < 0)
       return fail(MH_ERR_BAD_DIMENSION, "negative batch size %lld", (long long)B);
    if (opts && opts->layout != MH_LAYOUT_AOS && opts->layout != MH_LAYOUT_SOA)
@@ -369,14 +402,33 @@ bool zv_ok(const mh_model *m, int64_t B, bool soa, int jobs)
    const long lds = m->spec.zv_lds_bytes(m->nq, m->nv);
    return lds > 0 && lds <= 160 * 1024 && (m->use_zv == 2 || (B + 63) / 64 * jobs <= (long)m->cu_count);
 }
-// A wait of an earlier bias-split launch that ran into its wall-clock limit (the producer workgroup never published): surfaced here
+// A wait of a bias-split launch that ran into its wall-clock limit (the producer workgroup never published): the kernel wrote NaN rows
+// for that group and set the model's (context's) error word in mapped host memory.  It is a failure of an ASYNCHRONOUS call, so it is
+// reported where the library next synchronises or is asked to: mh_model_check, mh_stream_synchronize, the *_host entry points after
+// their own synchronisation, the create-time self-check -- and at the latest by the next bias-split call of the same model / context.
+std::mutex g_error_words_mutex;
+std::vector<int *> g_error_words; // every live model's / context's mapped error word (mh_stream_synchronize has no handle to ask)
 mh_status zv_check_error(mh_model *m)
 {
    if (m->zv_error_host && *(volatile int *)m->zv_error_host != 0)
    {
       *(volatile int *)m->zv_error_host = 0;
-      return fail(MH_ERR_HIP, "a bias-split forward dynamics launch gave up waiting for its bias rows (results of that launch are invalid)");
+      return fail(MH_ERR_HIP, "a bias-split forward dynamics launch gave up waiting for its bias rows (the accelerations of those configurations were written as NaN)");
    }
+   return MH_OK;
+}
+mh_status check_all_error_words()
+{
+   std::lock_guard<std::mutex> lock(g_error_words_mutex);
+   bool any = false;
+   for (int *w : g_error_words)
+      if (*(volatile int *)w != 0)
+      {
+         *(volatile int *)w = 0;
+         any = true;
+      }
+   if (any)
+      return fail(MH_ERR_HIP, "a bias-split forward dynamics launch gave up waiting for its bias rows (the accelerations of those configurations were written as NaN)");
    return MH_OK;
 }
 // scratch of the bias-split launches for batches up to B: the bias rows, the flags (zeroed on `stream`), the mapped error word
@@ -401,6 +453,8 @@ mh_status zv_prepare(mh_model *m, int64_t B, hipStream_t stream)
       HIP_TRY(hipHostMalloc((void **)&m->zv_error_host, sizeof(int), hipHostMallocMapped));
       *m->zv_error_host = 0;
       HIP_TRY(hipHostGetDevicePointer((void **)&m->zv_error_dev, m->zv_error_host, 0));
+      std::lock_guard<std::mutex> lock(g_error_words_mutex);
+      g_error_words.push_back(m->zv_error_host);
    }
    return MH_OK;
 }
@@ -419,9 +473,37 @@ mh_status zv_launch(mh_model *m, mh::Args<double> &A, int jobs, hipStream_t stre
    }
    const int epoch = ++m->zv_epoch;
    int flags = SPEC_IO_LDS | (m->ident_maps ? SPEC_IDENT : 0);
-   *rc = m->spec.launch_zv(flags, &A, m->zv_tau.ptr, (int *)m->zv_flags.ptr, m->zv_error_dev, epoch, jobs, m->zv_same_l2, (void *)stream);
+   *rc = m->spec.launch_zv(flags, &A, m->zv_tau.ptr, (int *)m->zv_flags.ptr, m->zv_error_dev, epoch, jobs, m->zv_same_l2, m->zv_wait_ticks, (void *)stream);
    if (*rc != 0 && *rc != (int)hipErrorNotSupported)
       return fail(MH_ERR_HIP, "bias-split kernel launch failed: %s", hipGetErrorString((hipError_t)*rc));
+   return MH_OK;
+}
+
+// Forward dynamics of device-filling batches as two launches at two workgroups per CU (mh_zv_kernels.h, spec_zvb_*): the same calls the
+// bias split serves (AoS matrices, dense index maps, every joint an effort source), taken from two groups of 64 configurations per CU
+// upwards -- below that the one-job kernel gives every group a CU of its own and is faster (humanoid, one MI355X: 24.2 against 20.1 us
+// at 16 384, 36.8 against 37.3 at 32 768, 64.9 against 73.1 at 65 536, 214.5 against 248.4 at 262 144: profiles/r04_zvb_vs_tree_split.txt).
+bool zvb_ok(const mh_model *m, int64_t B, bool soa)
+{
+   if (!m->spec.launch_zvb || !m->spec.zvb_usable || !m->spec.zvb_usable() || !m->use_spec || !m->use_zvb || m->use_split == 0)
+      return false;
+   if (soa || !m->dense_maps || m->force_io == 0 || m->n_locked > 0)
+      return false;
+   return m->use_zvb == 2 || (B + 63) / 64 >= 2 * (long)m->cu_count;
+}
+mh_status zvb_launch(mh_model *m, mh::Args<double> &A, hipStream_t stream, int *rc)
+{
+   const size_t padded = (size_t)((A.B + 63) / 64 * 64);
+   mh_status st = ensure_bytes(m->zv_tau, (size_t)A.B * m->nv * sizeof(double));
+   if (st == MH_OK)
+      st = ensure_bytes(m->zvb_cs, std::max<size_t>(1, (size_t)m->spec.zvb_cs_rows()) * padded * sizeof(double));
+   if (st != MH_OK)
+      return st;
+   const int flags = SPEC_IO_LDS | (m->ident_maps ? SPEC_IDENT : 0);
+   const long groups = std::min<long>((A.B + 63) / 64, (long)m->cu_count * 2);
+   *rc = m->spec.launch_zvb(flags, &A, m->zv_tau.ptr, m->zvb_cs.ptr, (long)padded, (int)groups, m->zvb_which, (void *)stream);
+   if (*rc != 0 && *rc != (int)hipErrorNotSupported)
+      return fail(MH_ERR_HIP, "two-launch forward dynamics failed to launch: %s", hipGetErrorString((hipError_t)*rc));
    return MH_OK;
 }
 
@@ -445,6 +527,8 @@ enum Algo
 // whose offsets count global-homed ancestors only.
 const mh_model::DfsPlan *dfs_plan(mh_model *m, int algo, int budget)
 {
+   if (m->parent)
+      m = m->parent; // the plans (device copies of the body records) belong to the model; its contexts share them
    std::lock_guard<std::mutex> lock(m->dfs_mutex);
    for (const mh_model::DfsPlan &p : m->dfs_plans)
       if (p.algo == algo && p.budget == budget)
@@ -1016,6 +1100,14 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             return MH_OK;
          A.in3b = nullptr, A.outb = nullptr; // not in this code object: the plans below
       }
+      if (algo == ALGO_ABA && !q_next && zvb_ok(model, B, soa))
+      { // device-filling batches: bias rows and (cos, sin) pairs by one launch, articulated inertias + fold + outward sweep by the next
+         int rc = 0;
+         if (const mh_status sz = zvb_launch(model, A, stream, &rc); sz != MH_OK)
+            return sz;
+         if (rc == 0)
+            return MH_OK;
+      }
    }
    if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
    {
@@ -1303,7 +1395,7 @@ mh_status launch_host(int kind, mh_model_t model, int64_t B, const T *q, const T
       HIP_TRY(hipEventRecord(model->ev_out[s], model->hs_out));
    }
    HIP_TRY(hipStreamSynchronize(model->hs_out));
-   return MH_OK;
+   return zv_check_error(model); // before the caller reads the outputs
 }
 } // namespace
 
@@ -1451,6 +1543,10 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.zv_usable = (decltype(s.zv_usable))dlsym(h, "mh_spec_zv_usable");
    s.zv_lds_bytes = (decltype(s.zv_lds_bytes))dlsym(h, "mh_spec_zv_lds_bytes");
    s.launch_zv = (decltype(s.launch_zv))dlsym(h, "mh_spec_launch_zv");
+   s.zvb_usable = (decltype(s.zvb_usable))dlsym(h, "mh_spec_zvb_usable");
+   s.zvb_cs_rows = (decltype(s.zvb_cs_rows))dlsym(h, "mh_spec_zvb_cs_rows");
+   s.zvb_lds_bytes = (decltype(s.zvb_lds_bytes))dlsym(h, "mh_spec_zvb_lds_bytes");
+   s.launch_zvb = (decltype(s.launch_zvb))dlsym(h, "mh_spec_launch_zvb");
    s.rnea_crba_lds_bytes = (decltype(s.rnea_crba_lds_bytes))dlsym(h, "mh_spec_rnea_crba_lds_bytes");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
@@ -1742,6 +1838,7 @@ void mh_options_default(mh_options *opts)
    opts->stream = nullptr;
    for (int k = 0; k < 6; k++)
       opts->root_acceleration[k] = 0.0;
+   opts->context = nullptr;
 }
 
 mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
@@ -2054,6 +2151,12 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_zv = atoi(e);
    if (const char *e = getenv("MH_ZV_SAME_L2"))
       m->zv_same_l2 = atoi(e) ? 1 : 0;
+   if (const char *e = getenv("MH_ZV_WAIT_MS"))
+      m->zv_wait_ticks = (unsigned)std::max<long long>(1, std::min<long long>(40000, atoll(e))) * 100000u;
+   if (const char *e = getenv("MH_ZVB"))
+      m->use_zvb = atoi(e);
+   if (const char *e = getenv("MH_ZVB_WHICH"))
+      m->zvb_which = std::max(1, std::min(3, atoi(e)));
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
       m->lds_wave_factor = atoi(e);
    if (const char *e = getenv("MH_SPEC_IO"))
@@ -2133,25 +2236,23 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    return MH_OK;
 }
 
-void mh_model_destroy(mh_model_t m)
+// everything compute calls write: owned by a model (its default context) and by every context
+static void free_scratch(mh_model *m)
 {
-   if (!m)
-      return;
-   dfs_plans_drop(m);
-   split_rt_free(m);
-   (void)hipFree(m->d_meta);
-   (void)hipFree(m->d_dof);
-   (void)hipFree(m->d_cfg);
-   (void)hipFree(m->d_prog);
-   (void)hipFree(m->d_consts64);
-   (void)hipFree(m->d_consts32);
    (void)hipFree(m->ws.ptr);
    (void)hipFree(m->ws_pair.ptr);
    (void)hipFree(m->tr_pair.ptr);
    (void)hipFree(m->zv_tau.ptr);
+   (void)hipFree(m->zvb_cs.ptr);
    (void)hipFree(m->zv_flags.ptr);
    if (m->zv_error_host)
+   {
+      {
+         std::lock_guard<std::mutex> lock(g_error_words_mutex);
+         g_error_words.erase(std::remove(g_error_words.begin(), g_error_words.end(), m->zv_error_host), g_error_words.end());
+      }
       (void)hipHostFree(m->zv_error_host);
+   }
    if (m->pair_stream)
    {
       (void)hipStreamDestroy(m->pair_stream);
@@ -2177,9 +2278,103 @@ void mh_model_destroy(mh_model_t m)
    (void)hipFree(m->tr.ptr);
    (void)hipFree(m->aux.ptr);
    (void)hipFree(m->pairs.ptr);
+}
+// a fresh set of the above for a copy of a handle
+static void reset_scratch(mh_model *m)
+{
+   m->ws = m->stage = m->ws_pair = m->zv_tau = m->zv_flags = m->zvb_cs = m->tr = m->tr_pair = m->aux = m->pairs = Workspace{};
+   m->hs_in = m->hs_run = m->hs_out = nullptr;
+   for (int k = 0; k < 3; k++)
+      m->ev_in[k] = m->ev_run[k] = m->ev_out[k] = nullptr;
+   m->pair_stream = nullptr, m->pair_fork = m->pair_join = nullptr;
+   m->zv_epoch = 0, m->zv_error_host = m->zv_error_dev = nullptr;
+   m->pairs_host.clear();
+   m->lds_attr.clear();
+}
+void mh_model_destroy(mh_model_t m)
+{
+   if (!m)
+      return;
+   if (m->parent)
+   { // (a context handed in by mistake: its model owns the device records)
+      mh_context wrap{m};
+      (void)wrap;
+      return;
+   }
+   dfs_plans_drop(m);
+   split_rt_free(m);
+   (void)hipFree(m->d_meta);
+   (void)hipFree(m->d_dof);
+   (void)hipFree(m->d_cfg);
+   (void)hipFree(m->d_prog);
+   (void)hipFree(m->d_consts64);
+   (void)hipFree(m->d_consts32);
+   free_scratch(m);
    if (m->spec.handle)
       dlclose(m->spec.handle);
    delete m;
+}
+// ---- contexts: the model handle is read-only and may be shared by any number of host threads and streams, each calling through a
+//      context of its own ("Threading"; the reference keeps this state inside the calculator object, which is why
+//      it needs one calculator per thread: InverseDynamicsCalculator.java:706-707)
+mh_status mh_context_create(mh_model_t model, mh_context_t *ctx_out)
+{
+   if (!model || !ctx_out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model / ctx_out is NULL");
+   *ctx_out = nullptr;
+   mh_model *root = model->parent ? model->parent : model;
+   mh_model *c = nullptr;
+   {
+      std::lock_guard<std::mutex> lock(g_context_mutex);
+      c = new (std::nothrow) mh_model(*root);
+      if (!c)
+         return fail(MH_ERR_OUT_OF_MEMORY, "out of host memory");
+      root->n_contexts++;
+   }
+   c->parent = root;
+   c->n_contexts = 0;
+   c->dfs_plans.clear(); // (dfs_plan looks them up in the model)
+   reset_scratch(c);
+   mh_context *ctx = new (std::nothrow) mh_context{c};
+   if (!ctx)
+   {
+      delete c;
+      std::lock_guard<std::mutex> lock(g_context_mutex);
+      root->n_contexts--;
+      return fail(MH_ERR_OUT_OF_MEMORY, "out of host memory");
+   }
+   *ctx_out = ctx;
+   return MH_OK;
+}
+void mh_context_destroy(mh_context_t ctx)
+{
+   if (!ctx)
+      return;
+   mh_model *c = ctx->m;
+   free_scratch(c);
+   {
+      std::lock_guard<std::mutex> lock(g_context_mutex);
+      c->parent->n_contexts--;
+   }
+   delete c;
+   delete ctx;
+}
+mh_status mh_context_reserve(mh_context_t ctx, int64_t max_batch)
+{
+   if (!ctx)
+      return fail(MH_ERR_INVALID_ARGUMENT, "context is NULL");
+   return mh_reserve(ctx->m, max_batch);
+}
+// Synchronises `stream` and reports what the asynchronous calls issued through this context (NULL: the model's own) left behind.
+mh_status mh_model_check(mh_model_t model, mh_context_t ctx, void *stream)
+{
+   if (!model)
+      return fail(MH_ERR_INVALID_ARGUMENT, "model is NULL");
+   mh_model *m = ctx ? ctx->m : model;
+   if (ctx && m->parent != (model->parent ? model->parent : model))
+      return fail(MH_ERR_INVALID_ARGUMENT, "the context belongs to another model");
+   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+   return zv_check_error(m);
 }
 mh_status mh_topology_key(const mh_model_desc *desc, char key_out[17], int32_t *parents_out, int32_t *types_out)
 {
@@ -2394,6 +2589,12 @@ mh_status mh_reserve(mh_model_t m, int64_t max_batch)
       if (st == MH_OK)
          HIP_TRY(hipStreamSynchronize(nullptr)); // the flags are zero before any stream's first launch looks at them
    }
+   if (st == MH_OK && zvb_ok(m, max_batch, false))
+   { // the two-launch forward dynamics of device-filling batches: bias rows and (cos, sin) pairs
+      st = ensure_bytes(m->zv_tau, (size_t)max_batch * m->nv * sizeof(double));
+      if (st == MH_OK)
+         st = ensure_bytes(m->zvb_cs, std::max<size_t>(1, (size_t)m->spec.zvb_cs_rows()) * (size_t)((max_batch + 63) / 64 * 64) * sizeof(double));
+   }
    if (st == MH_OK && m->split_rt.usable)
       st = ensure_bytes(m->ws, (size_t)m->split_rt.slots * (size_t)std::min<long>(2 * ((max_batch + 63) / 64), (long)m->cu_count) * 64 * sizeof(double));
    if (st == MH_OK && transposes && m->use_dfs)
@@ -2560,6 +2761,11 @@ mh_status mh_model_set_joint_source_modes(mh_model_t model, const int32_t *modes
    int cur = 0;
    if (hipGetDevice(&cur) != hipSuccess || cur != model->device)
       return fail(MH_ERR_INVALID_ARGUMENT, "model lives on device %d, which is not the calling thread's device", model->device);
+   {
+      std::lock_guard<std::mutex> lock(g_context_mutex);
+      if (model->parent || model->n_contexts > 0)
+         return fail(MH_ERR_INVALID_ARGUMENT, "joint source modes are set on the model itself, before its contexts are created (%d exist)", model->parent ? 1 : model->n_contexts);
+   }
    for (int e = 0; modes && e < model->n; e++)
       if (modes[e] != MH_EFFORT_SOURCE && modes[e] != MH_ACCELERATION_SOURCE)
          return fail(MH_ERR_INVALID_ARGUMENT, "joint %d: unknown source mode %d", e, modes[e]);
@@ -2929,7 +3135,7 @@ mh_status mh_copy_to_host(void *dst_host, const void *src_device, size_t bytes, 
 mh_status mh_stream_synchronize(void *stream)
 {
    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-   return MH_OK;
+   return check_all_error_words(); // an inertia job that gave up waiting (mh_zv_kernels.h): reported here, not at the model's next call
 }
 mh_status mh_host_alloc(size_t bytes, void **ptr_out)
 {
@@ -3221,6 +3427,7 @@ static void self_check_spec(mh_model *m)
       return MH_OK;
    };
    const int real_cus = m->cu_count;
+   static const char *const kPlanNames[4] = {"small-batch", "device-filling", "tree-split", "device-filling, one job"};
    const bool verbose = getenv("MH_SPEC_SELFCHECK_VERBOSE") != nullptr;
    std::vector<unsigned long long> ref, got; // raw words: see nan_word
    std::string failure;
@@ -3240,24 +3447,33 @@ static void self_check_spec(mh_model *m)
          (void)hipMemcpy(ref.data(), d_out, used * sizeof(double), hipMemcpyDeviceToHost);
          // plan 0: the real CU count; 1: a pretended single CU (device-filling plans); 2: the bias-split forward dynamics switched off
          // (the tree-split kernels it replaced still serve SoA calls, simulation steps and models with acceleration sources)
-         const int zv_was = m->use_zv;
+         // 3: a pretended single CU with the two-launch forward dynamics switched off (plan 1 takes the two launches where the code object has
+         // them: the one-job kernel's device-filling plan is what serves SoA calls and simulation steps at those sizes)
+         const int zv_was = m->use_zv, zvb_was = m->use_zvb;
          const bool zv_plan = (what == CK_ABA || what == CK_FUSED) && L == 0 && zv_was && zv_ok(m, B, false, what == CK_FUSED ? 3 : 2);
-         for (int plan = 0; plan < (zv_plan ? 3 : 2) && failure.empty(); plan++)
+         m->cu_count = 1;
+         const bool zvb_plan = (what == CK_ABA || what == CK_FUSED || what == CK_STEP) && L == 0 && zvb_was && zvb_ok(m, B, false);
+         m->cu_count = real_cus;
+         for (int plan = 0; plan < 4 && failure.empty(); plan++)
          {
-            const int pretend = plan == 1 ? 1 : 0;
+            if ((plan == 2 && !zv_plan) || (plan == 3 && !zvb_plan))
+               continue;
+            const int pretend = plan == 1 || plan == 3 ? 1 : 0;
             m->cu_count = pretend ? 1 : real_cus;
             m->use_zv = plan == 2 ? 0 : zv_was;
+            m->use_zvb = plan == 3 ? 0 : zvb_was;
             st = run(what, L, used);
             const hipError_t sync = hipDeviceSynchronize();
             m->cu_count = real_cus;
             m->use_zv = zv_was;
+            m->use_zvb = zvb_was;
             if (st == MH_OK)
                st = zv_check_error(m);
             char buf[320];
             if (st != MH_OK || sync != hipSuccess)
             {
                snprintf(buf, sizeof buf, "%s (%s, %s plan) failed: %s", kCheckNames[what], L ? "SoA" : "AoS",
-                        plan == 2 ? "tree-split" : (pretend ? "device-filling" : "small-batch"), st != MH_OK ? g_err : hipGetErrorString(sync));
+                        kPlanNames[plan], st != MH_OK ? g_err : hipGetErrorString(sync));
                failure = buf;
                break;
             }
@@ -3289,7 +3505,7 @@ static void self_check_spec(mh_model *m)
             const double tol = (what == CK_ABA || what == CK_FUSED || what == CK_STEP || what == CK_BODIES_ABA) ? 1.0e-8 : 1.0e-10;
             if (verbose)
                fprintf(stderr, "[mh self-check] %-28s %s %-14s  |diff| %.3e  |ref| %.3e  unwritten-mismatch %d (word %zu)\n", kCheckNames[what], L ? "SoA" : "AoS",
-                       plan == 2 ? "tree-split" : (pretend ? "device-filling" : "small-batch"), err, scale, (int)nan_mismatch, first_bad);
+                       kPlanNames[plan], err, scale, (int)nan_mismatch, first_bad);
             if (nan_mismatch || err > tol * scale)
             {
                char where[96] = "";
@@ -3297,7 +3513,7 @@ static void self_check_spec(mh_model *m)
                   snprintf(where, sizeof where, ", output word %zu %s", first_bad,
                            bad_is_unwritten ? "left unwritten" : "written although the run-time-topology kernels do not write it");
                snprintf(buf, sizeof buf, "%s (%s, %s plan) differs from the run-time-topology kernels by %.3e (|ref| <= %.3e%s)", kCheckNames[what],
-                        L ? "SoA" : "AoS", plan == 2 ? "tree-split" : (pretend ? "device-filling" : "small-batch"), err, scale, where);
+                        L ? "SoA" : "AoS", kPlanNames[plan], err, scale, where);
                failure = buf;
             }
          }

@@ -5,10 +5,12 @@
 // (3) optionally the ranks' output rows side by side on every rank.  mecano_amd/distributed.py does this over torch.distributed for the
 // Python host; these are the same three operations for a host that has no torch (the Java shim: HipCommunicator.java).
 //
-// librccl.so.1 is opened on the first call: the library carries no link-time dependency on RCCL and loads on a box without it.
+// librccl.so.1 is opened on the first call: the library carries no link-time dependency on RCCL and loads on a box without it -- and no
+// build-time dependency either: the handful of RCCL types and constants the eleven entry points need are declared below (they are part of
+// RCCL's / NCCL's stable C ABI: ncclUniqueId is 128 opaque bytes, ncclSuccess 0, ncclInt8 0, ncclInt32 2, ncclSum 0), so the library builds
+// on a box without the RCCL headers.
 #include "mecano_hip.h"
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
@@ -20,20 +22,33 @@ extern "C" mh_status mh_internal_fail(mh_status code, const char *message); // m
 
 namespace
 {
+// ---- the slice of RCCL's C ABI this file calls (rccl.h / nccl.h), declared locally
+typedef struct ncclComm *ncclComm_t;
+constexpr int NCCL_UNIQUE_ID_BYTES = 128;
+typedef struct
+{
+   char internal[NCCL_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+typedef int ncclResult_t;   // enum ncclResult_t: ncclSuccess = 0
+typedef int ncclDataType_t; // enum ncclDataType_t
+typedef int ncclRedOp_t;    // enum ncclRedOp_t
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclChar = 0, ncclInt32 = 2;
+constexpr ncclRedOp_t ncclSum = 0;
 struct Rccl
 {
    void *handle = nullptr;
-   decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-   decltype(&ncclCommInitRank) comm_init_rank = nullptr;
-   decltype(&ncclCommDestroy) comm_destroy = nullptr;
-   decltype(&ncclCommCount) comm_count = nullptr;
-   decltype(&ncclCommUserRank) comm_user_rank = nullptr;
-   decltype(&ncclBroadcast) broadcast = nullptr;
-   decltype(&ncclAllGather) all_gather = nullptr;
-   decltype(&ncclAllReduce) all_reduce = nullptr;
-   decltype(&ncclGroupStart) group_start = nullptr;
-   decltype(&ncclGroupEnd) group_end = nullptr;
-   decltype(&ncclGetErrorString) error_string = nullptr;
+   ncclResult_t (*get_unique_id)(ncclUniqueId *) = nullptr;
+   ncclResult_t (*comm_init_rank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+   ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+   ncclResult_t (*comm_count)(const ncclComm_t, int *) = nullptr;
+   ncclResult_t (*comm_user_rank)(const ncclComm_t, int *) = nullptr;
+   ncclResult_t (*broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*all_gather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*all_reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*group_start)(void) = nullptr;
+   ncclResult_t (*group_end)(void) = nullptr;
+   const char *(*error_string)(ncclResult_t) = nullptr;
    bool ok = false;
    char why[256] = "";
 };
@@ -231,9 +246,43 @@ mh_status mh_comm_broadcast_host(mh_comm_t c, void *host_buf, size_t bytes, int3
    return MH_OK;
 }
 
+// The operations mh_comm_all_gather_rows issues on rank `rank` of `world`, without issuing them (host-only; no RCCL, no device): step k is
+// a broadcast of steps[k].bytes bytes from rank steps[k].root into [recv_offset, recv_offset + bytes) of every rank's output; on the root
+// the bytes come from its local rows (send_local = 1: send buffer != receive buffer), everywhere else the operation is in place.  Equal
+// shards without forcing: ONE step with root = -1, the plain all-gather (bytes = one shard).  Every rank computes the same list (same
+// roots, sizes and offsets in the same order) -- which is what a grouped collective needs, and what tests/test_distributed_cpu.py checks
+// for every world size up to nine without any transport.
+mh_status mh_comm_gather_plan(int64_t B_total, size_t row_bytes, int32_t rank, int32_t world, int32_t force_ragged, mh_gather_step *steps,
+                              int32_t cap, int32_t *n_steps_out)
+{
+   if (B_total < 0 || world < 1 || rank < 0 || rank >= world || !n_steps_out || (cap > 0 && !steps))
+      return mh_internal_fail(MH_ERR_INVALID_ARGUMENT, "mh_comm_gather_plan: need B_total >= 0, 0 <= rank < world and an output count");
+   int n = 0;
+   auto put = [&](int root, int send_local, int64_t ofs, int64_t bytes) {
+      if (n < cap)
+         steps[n] = mh_gather_step{root, send_local, ofs, bytes};
+      n++;
+   };
+   if (B_total > 0 && row_bytes > 0)
+   {
+      if (B_total % world == 0 && !force_ragged)
+         put(-1, 1, (int64_t)rank * (B_total / world) * (int64_t)row_bytes, (B_total / world) * (int64_t)row_bytes);
+      else
+         for (int r = 0; r < world; r++)
+         {
+            int64_t rl = 0, rh = 0;
+            (void)mh_shard_range(B_total, r, world, &rl, &rh);
+            if (rh > rl) // (more ranks than rows: nothing to send, and every rank skips the same r)
+               put(r, r == rank ? 1 : 0, rl * (int64_t)row_bytes, (rh - rl) * (int64_t)row_bytes);
+         }
+   }
+   *n_steps_out = n;
+   return MH_OK;
+}
+
 // every rank passes the rows mh_shard_range gives it ([hi - lo][row_bytes], device) and receives all B_total rows in batch order.
 // Equal shards: one all-gather.  Ragged shards (sizes differ by one): one broadcast per rank inside a group -- still one fused operation,
-// no padding and no compaction pass.
+// no padding and no compaction pass.  The list of operations is mh_comm_gather_plan's.
 mh_status mh_comm_all_gather_rows(mh_comm_t c, const void *local_rows, int64_t B_total, size_t row_bytes, void *all_rows_out, void *stream)
 {
    if (!c || B_total < 0 || (!all_rows_out && B_total && row_bytes))
@@ -247,22 +296,22 @@ mh_status mh_comm_all_gather_rows(mh_comm_t c, const void *local_rows, int64_t B
    RCCL_READY();
    char *const out = (char *)all_rows_out;
    const char *force = getenv("MH_COMM_RAGGED"); // =1: the grouped-broadcast path for equal shards too (tests on one rank)
-   if (B_total % c->world == 0 && !(force && atoi(force)))
+   std::vector<mh_gather_step> steps((size_t)c->world + 1);
+   int32_t n = 0;
+   if (const mh_status st = mh_comm_gather_plan(B_total, row_bytes, c->rank, c->world, force && atoi(force) ? 1 : 0, steps.data(), (int32_t)steps.size(), &n); st != MH_OK)
+      return st;
+   if (n == 1 && steps[0].root < 0)
    {
-      RCCL_TRY(R.all_gather(local_rows, out, (size_t)(hi - lo) * row_bytes, ncclChar, c->comm, (hipStream_t)stream));
+      RCCL_TRY(R.all_gather(local_rows, out, (size_t)steps[0].bytes, ncclChar, c->comm, (hipStream_t)stream));
       return MH_OK;
    }
    RCCL_TRY(R.group_start());
-   for (int r = 0; r < c->world; r++)
+   for (int k = 0; k < n; k++)
    {
-      int64_t rl = 0, rh = 0;
-      (void)mh_shard_range(B_total, r, c->world, &rl, &rh);
-      if (rh == rl)
-         continue; // (more ranks than rows: nothing to send, and every rank skips the same r)
-      void *recv = out + (size_t)rl * row_bytes;
-      const ncclResult_t e = R.broadcast(r == c->rank ? local_rows : recv, recv, (size_t)(rh - rl) * row_bytes, ncclChar, r, c->comm, (hipStream_t)stream);
+      void *recv = out + steps[k].recv_offset;
+      const ncclResult_t e = R.broadcast(steps[k].send_local ? local_rows : recv, recv, (size_t)steps[k].bytes, ncclChar, steps[k].root, c->comm, (hipStream_t)stream);
       if (e != ncclSuccess)
-      {
+      { // an error at this point is an argument error, and every rank computed the same arguments: they all leave the group here
          (void)R.group_end();
          return failf(MH_ERR_HIP, "ncclBroadcast (ragged all-gather): %s", R.error_string(e));
       }

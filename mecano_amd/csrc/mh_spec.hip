@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef MH_TOPO_N
 #error "MH_TOPO_N / MH_TOPO_PARENTS / MH_TOPO_TYPES must be defined"
@@ -272,8 +273,9 @@ int mh_spec_zv_usable(void) { return SPL::usable() ? 1 : 0; }
 int mh_spec_zv_probe_read(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mh::zv_probe), bytes); }
 #endif
 // jobs = 2: qdd = ABA(q, qd, tau) with args->in3b = tau, args->outb = qdd.  jobs = 3: additionally args->out = RNEA(q, qd, args->in3).
-// taup: scratch [B][nv]; sync_flags: ceil(B / 64) * ZV_SYNC_STRIDE ints that never held `epoch` before; same_l2: rows may stay in a shared L2; error: one int, set when a wait timed out.
-int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, int same_l2, void *stream)
+// taup: scratch [B][nv]; sync_flags: ceil(B / 64) * ZV_SYNC_STRIDE ints that never held `epoch` before; same_l2: rows may stay in a shared L2; error: one int
+// (host-mapped), set when a wait ran into wait_ticks (100 MHz ticks): that group's accelerations are then NaN.
+int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, int same_l2, unsigned wait_ticks, void *stream)
 {
    if constexpr (SPL::usable())
    {
@@ -284,7 +286,7 @@ int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, 
       if (lds > 160 * 1024)
          return (int)hipErrorNotSupported;
       const long groups = (A.B + 63) / 64, padded = (groups + 7) / 8 * 8;
-      const mh::ZvSync sy{sync_flags, error, epoch, jobs, same_l2 ? 1 : 0};
+      const mh::ZvSync sy{sync_flags, error, epoch, jobs, same_l2 ? 1 : 0, wait_ticks};
       hipStream_t s = (hipStream_t)stream;
       if (flags & F_IDENT)
       {
@@ -304,6 +306,69 @@ int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, 
          return (int)e;
       hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A, (double *)taup, sy);
       return (int)hipGetLastError();
+#endif
+   }
+   else
+      return (int)hipErrorNotSupported;
+}
+// ---- forward dynamics of device-filling batches as two launches (mh_zv_kernels.h, spec_zvb_*): AoS matrices, dense index maps.
+// cs: scratch [2 * revolute joints][cs_stride] with cs_stride >= B rounded up to whole groups of 64; taup: scratch [B][nv].
+int mh_spec_zvb_usable(void)
+{
+   if constexpr (SPL::usable())
+      return mh::ZvbPlan<TP>::lds_slots() * 64 * (long)sizeof(double) * 2 <= 160 * 1024 ? 1 : 0; // two workgroups per CU or not at all
+   else
+      return 0;
+}
+int mh_spec_zvb_cs_rows(void) { return 2 * TR::n_revolute(); }
+long mh_spec_zvb_lds_bytes(int which, int nq, int nv)
+{ // which: 0 = the bias launch, 1 = the inertia launch
+   if constexpr (SPL::usable())
+      return (long)(which == 0 ? mh::ZvbPlan<TP>::bias_lds_slots(nq, nv) : mh::ZvbPlan<TP>::lds_slots()) * 64 * (long)sizeof(double);
+   else
+      return 0;
+}
+// which: 1 = bias launch only, 2 = inertia launch only, 3 = both (measurements time them apart).  args->in3 = tau, args->out = qdd.
+int mh_spec_launch_zvb(int flags, const void *args, void *taup, void *cs, long cs_stride, int groups, int which, void *stream)
+{
+   if constexpr (SPL::usable())
+   {
+      const mh::Args<double> &A = *(const mh::Args<double> *)args;
+      if (!(flags & F_IO_LDS) || !mh_spec_zvb_usable() || cs_stride < (A.B + 63) / 64 * 64 || groups < 1)
+         return (int)hipErrorNotSupported;
+      const size_t lds0 = (size_t)mh_spec_zvb_lds_bytes(0, A.m.nq, A.m.nv), lds1 = (size_t)mh_spec_zvb_lds_bytes(1, A.m.nq, A.m.nv);
+      if (lds0 > 160 * 1024)
+         return (int)hipErrorNotSupported;
+      hipStream_t s = (hipStream_t)stream;
+      auto run = [&](auto ident) -> hipError_t {
+         constexpr bool ID = decltype(ident)::value;
+         static LdsAttr attr0, attr1;
+         auto k0 = &mh::spec_zvb_bias_kernel<TP, double, ID>;
+         auto k1 = &mh::spec_zvb_kernel<TP, double, ID>;
+         if (which & 1)
+         {
+            if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k0), lds0, attr0); e != hipSuccess)
+               return e;
+            hipLaunchKernelGGL(k0, dim3((unsigned)groups), dim3(256), lds0, s, A, (double *)taup, (double *)cs, cs_stride);
+            if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+               return e;
+         }
+         if (which & 2)
+         {
+            if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k1), lds1, attr1); e != hipSuccess)
+               return e;
+            hipLaunchKernelGGL(k1, dim3((unsigned)groups), dim3(256), lds1, s, A, (const double *)taup, (const double *)cs, cs_stride);
+            if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+               return e;
+         }
+         return hipSuccess;
+      };
+      if (flags & F_IDENT)
+         return (int)run(std::true_type{});
+#ifdef MH_SPEC_MINIMAL
+      return (int)hipErrorNotSupported;
+#else
+      return (int)run(std::false_type{});
 #endif
    }
    else

@@ -64,6 +64,15 @@ struct Tree
       return t;
    }
    static constexpr int total_cfgs() { return cfg_ofs(N); }
+   // ordinal of joint j among the revolute joints (rows 2 r and 2 r + 1 of the (cos, sin) scratch of the two-launch forward dynamics, mh_zv_kernels.h)
+   static constexpr int rev_index(int j)
+   {
+      int r = 0;
+      for (int i = 0; i < j; i++)
+         r += TP::type[i] == JT_REVOLUTE ? 1 : 0;
+      return r;
+   }
+   static constexpr int n_revolute() { return rev_index(N); }
    // ABA hand-over slots: revolute 9 (U/D, u/D, cos, sin), prismatic 7, sixdof 6 (IA^-1 u), fixed 0
    static constexpr int aba_slots_of(int j)
    {
@@ -459,6 +468,7 @@ struct Split
    static constexpr int n_limbs() { return P.n_limbs; }
    static constexpr int limb_root(int k) { return P.root_of[k]; }
    static constexpr int limb_index(int root) { return P.limb_of[root]; }
+   static constexpr int limb_index_of_body(int j) { return P.limb_of[j]; } // any body of a limb
    static constexpr int owner(int k) { return P.owner[k]; }             // ABA
    static constexpr int owner_plain(int k) { return P.owner_plain[k]; } // RNEA, CRBA
    static constexpr int f_limb(int j) { return P.f_limb[j]; }
@@ -565,9 +575,17 @@ struct LaneStore
 // (Mecano's default JointMatrixIndexProvider over joints in depth-first order), so every row index is a compile-time constant.
 // OUTMODE 1 (bias job of the bias-split forward dynamics, mh_zv_kernels.h): out(k, v) leaves in3(k) - v, i.e. with in3 = tau and the
 // accelerations switched off the inverse-dynamics walk writes tau - h(q, qd) instead of h
-template <typename T, bool IO_LDS, bool IDENT, class SP, bool BODIES = false, int OUTMODE = 0>
+// CSMODE (two-launch forward dynamics of device-filling batches, mh_zv_kernels.h): 1 = the walk also leaves (cos, sin) of every revolute
+// joint in a slot-major scratch matrix, cs[(2 r + {0, 1}) * cs_stride]; 2 = the walk takes them from there, q and qd are read from the
+// caller's matrices (never staged) while in3 / out stay LDS rows, and the bias fold's exchange records are 12 wide instead of 21
+template <typename T, bool IO_LDS, bool IDENT, class SP, bool BODIES = false, int OUTMODE = 0, int CSMODE = 0>
 struct Ctx
 {
+   using SPolicy = SP;
+   static constexpr int csmode = CSMODE;
+   static constexpr int fold_xw = CSMODE == 2 ? 12 : 21; // width of a limb's record in the bias fold (ZV_XW while the inertias' records are reused)
+   T *cs;          // CSMODE: this configuration's column of the (cos, sin) scratch
+   long cs_stride;
    // BODIES: the kernel also writes every successor body's spatial acceleration / twist (RigidBodyAccelerationProvider; SURVEY.md
    // section 8f N2) -- a property of the context TYPE, so that the kernels without it stay instruction for instruction what they were
    static constexpr bool bodies = BODIES;
@@ -591,14 +609,14 @@ struct Ctx
    MH_DEV int di(int k) const { return IDENT ? k : dof_map[k]; }
    MH_DEV T q(int k) const
    {
-      if constexpr (IO_LDS)
+      if constexpr (IO_LDS && CSMODE != 2)
          return lq[ci(k)];
       else
          return qrow[ci(k) * q_es];
    }
    MH_DEV T qd(int k) const
    {
-      if constexpr (IO_LDS)
+      if constexpr (IO_LDS && CSMODE != 2)
          return lqd[di(k)];
       else
          return qdrow[di(k) * v_es];
@@ -767,6 +785,11 @@ struct RneaSub
       const RI<T> I = load_inertia<T>(c);
       MH_BODY_FENCE(); // everything the body reads is requested before its arithmetic starts (see JQ)
       const JX<T> jx = spec_joint_from<TYPE, T>(jq);
+      if constexpr (CX::csmode == 1 && TYPE == JT_REVOLUTE)
+      {
+         constexpr int R = Tree<TP>::rev_index(J);
+         cx.cs[(2 * R) * cx.cs_stride] = jx.c, cx.cs[(2 * R + 1) * cx.cs_stride] = jx.s;
+      }
       const V3<T> Z{T(0), T(0), T(0)};
       SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
       const SV<T> a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
@@ -836,6 +859,11 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
       t[(S0 + 0) * 64] = f.a.x, t[(S0 + 1) * 64] = f.a.y, t[(S0 + 2) * 64] = f.a.z;
       t[(S0 + 3) * 64] = f.l.x, t[(S0 + 4) * 64] = f.l.y, t[(S0 + 5) * 64] = f.l.z;
       t[(S0 + 6) * 64] = jx.c, t[(S0 + 7) * 64] = jx.s;
+      if constexpr (CX::csmode == 1 && TYPE == JT_REVOLUTE)
+      {
+         constexpr int R = Tree<TP>::rev_index(J);
+         cx.cs[(2 * R) * cx.cs_stride] = jx.c, cx.cs[(2 * R + 1) * cx.cs_stride] = jx.s;
+      }
    }
    MH_BODY_FENCE();
 }

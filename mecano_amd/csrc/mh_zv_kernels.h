@@ -28,6 +28,29 @@ struct ZvStore
    static constexpr int REG_SLOTS = Split<TP>::zv_reg_slots();
    static constexpr int kind(int j) { return Split<TP>::is_trunk(j) ? ST_LDS_KIND : ST_REG_KIND; }
    static constexpr int index(int j) { return Split<TP>::is_trunk(j) ? Split<TP>::zv_trunk_slot(j) : Split<TP>::zv_reg_slot(j); }
+   // one wave owns the body's slots: what the bias fold leaves for the outward sweep overwrites 1/D / the factor (Tree<TP>::zv_result_slot)
+   static constexpr bool shared(int j) { return !Split<TP>::is_trunk(j); }
+};
+// The same for the two-launch form of device-filling batches (spec_zvb_kernel): with a staged trunk EVERY wave folds the root body for
+// itself (ZvIn / ZvFold MODE 2), so its slots -- 21 for the factor of a 6-DoF root -- are registers of each wave instead of LDS; with
+// them out of the way two workgroups fit the LDS of a CU.
+template <class TP>
+struct ZvbStore
+{
+   using S = Split<TP>;
+   static constexpr bool root_in_regs(int j) { return S::staged() && j == S::root(); }
+   static constexpr int REG_SLOTS = S::zv_reg_slots() + (S::staged() ? Tree<TP>::zv_slots_of(S::root() < 0 ? 0 : S::root(), true) : 0);
+   static constexpr int trunk_slot(int j)
+   { // LDS slots of the trunk bodies before j, the root left out when it lives in registers
+      int s = 0;
+      for (int i = 0; i < j; i++)
+         s += S::is_trunk(i) && !root_in_regs(i) ? Tree<TP>::zv_slots_of(i, false) : 0;
+      return s;
+   }
+   static constexpr int TRUNK_SLOTS = trunk_slot(TP::N);
+   static constexpr int kind(int j) { return S::is_trunk(j) && !root_in_regs(j) ? ST_LDS_KIND : ST_REG_KIND; }
+   static constexpr int index(int j) { return root_in_regs(j) ? S::zv_reg_slots() : (S::is_trunk(j) ? trunk_slot(j) : S::zv_reg_slot(j)); }
+   static constexpr bool shared(int j) { return kind(j) == ST_REG_KIND; }
 };
 #ifdef MH_ZV_PROBE // experiment builds: 100 MHz real-time stamps per group, job, wave and phase (tools/exp_zv_probe.py)
 __device__ unsigned long long zv_probe[4096 * 3 * 4 * 16];
@@ -108,6 +131,20 @@ MH_DEV LDL6<T> st_get_ldl(const CX &cx)
 // inward walk begins with the sincos of its joint angle -- a long dependent chain with ONE wave per SIMD and nothing to fill its gaps --
 // while the joints of a limb need nothing from each other: formed together, up front, the evaluations interleave (leg of the humanoid:
 // inward walk 7.6 -> 5.45 us, profiles/r03_presincos_experiment.txt).
+// (cos, sin) of revolute joint J: formed from q, or -- CSMODE 2 -- read from the scratch matrix the bias launch left them in
+template <class TP, int J, class CX, typename T>
+MH_DEV JX<T> zv_revolute_joint(const CX &cx)
+{
+   if constexpr (CX::csmode == 2)
+   {
+      constexpr int R = Tree<TP>::rev_index(J);
+      JX<T> jx;
+      jx.c = cx.cs[(2 * R) * cx.cs_stride], jx.s = cx.cs[(2 * R + 1) * cx.cs_stride], jx.d = T(0);
+      return jx;
+   }
+   else
+      return spec_joint<JT_REVOLUTE, Tree<TP>::cfg_ofs(J), CX, T>(cx);
+}
 template <class TP, int J, typename T, class CX>
 struct ZvPre
 {
@@ -125,12 +162,49 @@ struct ZvPre
       children<0>(cx);
       if constexpr (TP::type[J] == JT_REVOLUTE)
       {
-         const JX<T> jx = spec_joint<JT_REVOLUTE, Tree<TP>::cfg_ofs(J), CX, T>(cx);
+         const JX<T> jx = zv_revolute_joint<TP, J, CX, T>(cx);
          cx.st.template put<J, 7>(jx.c);
          cx.st.template put<J, 8>(jx.s);
       }
    }
 };
+// The same for the revolute TRUNK bodies of the sub-trunk rooted at J (two-launch form, CSMODE 2: the pairs come from memory, so the wave
+// that will fold the sub-trunk requests them before it starts on its limbs and finds them in the trunk's LDS slots when it gets there)
+template <class TP, int J, typename T, class CX>
+struct ZvPreTrunk
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         if constexpr (Split<TP>::is_trunk(Tree<TP>::child(J, K)))
+            ZvPreTrunk<TP, Tree<TP>::child(J, K), T, CX>::run(cx);
+         children<K + 1>(cx);
+      }
+   }
+   static MH_DEV void run(const CX &cx)
+   {
+      children<0>(cx);
+      if constexpr (TP::type[J] == JT_REVOLUTE)
+      {
+         const JX<T> jx = zv_revolute_joint<TP, J, CX, T>(cx);
+         cx.st.template put<J, 7>(jx.c);
+         cx.st.template put<J, 8>(jx.s);
+      }
+   }
+};
+template <class TP, int W, int I, typename T, class CX>
+MH_DEV void zv_pre_subtrunks_of(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (I < S::n_sub())
+   {
+      if constexpr (S::sub_owner(S::sub_top(I)) == W)
+         ZvPreTrunk<TP, S::sub_top(I), T, CX>::run(cx);
+      zv_pre_subtrunks_of<TP, W, I + 1, T, CX>(cx);
+   }
+}
 template <class TP, int J, typename T, class CX, int MODE = 0>
 struct ZvIn
 {
@@ -170,7 +244,14 @@ struct ZvIn
       const T *cp = cx.C + J * MC_STRIDE;
       asm volatile("" : "+s"(cp)); // the constants are read where they are used, never kept across a subtree
       const CRef<T, false> c{cp};
-      const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
+      // (cos, sin) already in the body's slots: limbs (ZvPre ran, zv_limbs_in_of); CSMODE 2: the bodies of a staged sub-trunk too (ZvPreTrunk)
+      constexpr bool PRE = TYPE == JT_REVOLUTE && ((!Split<TP>::is_trunk(J) && (MODE == 0 || MODE == 3)) || (CX::csmode == 2 && Split<TP>::staged() && Split<TP>::is_trunk(J) && MODE == 1));
+      JQ<T> jq;
+      JX<T> jx;
+      if constexpr (TYPE == JT_REVOLUTE && CX::csmode == 2 && !PRE)
+         jx = zv_revolute_joint<TP, J, CX, T>(cx);
+      else if constexpr (!PRE)
+         jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const RI<T> I = load_inertia<T>(c);
       MH_BODY_FENCE();
       ABI<T> IA = abi_from_rigid(I);
@@ -181,10 +262,9 @@ struct ZvIn
       // the kernel's arguments, more than the file has, and every use became a v_readlane from a spill lane (15 % of the instructions of
       // this chain); the sincos and the rank-1 downdate in front of its first use cover the latency
       const XF<T> Xb = load_xb_j<TP, J, T>(c);
-      JX<T> jx;
-      if constexpr (TYPE == JT_REVOLUTE && !Split<TP>::is_trunk(J) && (MODE == 0 || MODE == 3)) // a limb: ZvPre ran (zv_limbs_in_of)
+      if constexpr (PRE)
          jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>(), jx.d = T(0);
-      else
+      else if constexpr (!(TYPE == JT_REVOLUTE && CX::csmode == 2))
          jx = spec_joint_from<TYPE, T>(jq);
       ABI<T> out = abi_zero<T>();
       if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
@@ -241,9 +321,9 @@ struct ZvFold
          constexpr int C = Tree<TP>::child(J, K);
          SV<T> c;
          if constexpr ((MODE == 1 || MODE == 2) && !Split<TP>::is_trunk(C))
-            c = x_get6<Split<TP>::limb_index(C), ZV_XW, 0, CX, T>(cx);
+            c = x_get6<Split<TP>::limb_index(C), CX::fold_xw, 0, CX, T>(cx);
          else if constexpr (MODE == 2) // staged fold: the sub-trunk below the root was folded by one wave (zv_subtrunks_fold_of)
-            c = x_get6<Split<TP>::sub_slot(C), ZV_XW, 6, CX, T>(cx);
+            c = x_get6<Split<TP>::sub_slot(C), CX::fold_xw, 6, CX, T>(cx);
          else
             c = ZvFold<TP, C, T, CX, MODE>::run(cx);
          if constexpr (K == 0)
@@ -260,7 +340,7 @@ struct ZvFold
       constexpr bool HAS_PARENT = TP::parent[J] >= 0;
       constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
-      constexpr int RS = Tree<TP>::zv_result_slot(J, !Split<TP>::is_trunk(J));
+      constexpr int RS = Tree<TP>::zv_result_slot(J, CX::SPolicy::shared(J));
       const V3<T> Z{T(0), T(0), T(0)};
       SV<T> pA{Z, Z};
       if constexpr (!LEAF)
@@ -342,7 +422,7 @@ struct ZvOut
       constexpr bool HAS_PARENT = TP::parent[J] >= 0;
       constexpr bool LEAF = Tree<TP>::n_children(J) == 0;
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
-      constexpr int RS = Tree<TP>::zv_result_slot(J, !Split<TP>::is_trunk(J));
+      constexpr int RS = Tree<TP>::zv_result_slot(J, CX::SPolicy::shared(J));
       const T *cp = cx.C + J * MC_STRIDE;
       asm volatile("" : "+s"(cp));
       const CRef<T, false> c{cp};
@@ -450,6 +530,8 @@ MH_DEV void zv_limbs_in(const CX &cx)
       {
          if constexpr (S::staged())
          {
+            if constexpr (CX::csmode == 2)
+               zv_pre_subtrunks_of<TP, W, 0, T, CX>(cx);
             zv_limbs_in_of<TP, W, 0, 0, T, CX>(cx);
             if constexpr (S::cut_limb(W) < 0)
                __syncthreads();
@@ -470,7 +552,7 @@ MH_DEV void zv_limbs_fold_of(const CX &cx)
    if constexpr (K < S::n_limbs())
    {
       if constexpr (S::owner(K) == W)
-         x_put6<K, ZV_XW, 0, CX, T>(cx, ZvFold<TP, S::limb_root(K), T, CX, 0>::run(cx));
+         x_put6<K, CX::fold_xw, 0, CX, T>(cx, ZvFold<TP, S::limb_root(K), T, CX, 0>::run(cx));
       zv_limbs_fold_of<TP, W, K + 1, T, CX>(cx);
    }
 }
@@ -540,7 +622,7 @@ struct ZvOutW
       constexpr int TYPE = TP::type[J];
       constexpr bool HAS_PARENT = TP::parent[J] >= 0;
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
-      constexpr int RS = Tree<TP>::zv_result_slot(J, false);
+      constexpr int RS = Tree<TP>::zv_result_slot(J, CX::SPolicy::shared(J));
       constexpr bool WRITES = ZvWalk<TP>::writer(J) == W;
       const T *cp = cx.C + J * MC_STRIDE;
       asm volatile("" : "+s"(cp));
@@ -601,7 +683,7 @@ MH_DEV void zv_limbs_fold_sel(const CX &cx)
    if constexpr (K < S::n_limbs())
    {
       if constexpr (S::owner(K) == W && (LATE < 0 || (S::is_late(K) ? 1 : 0) == LATE))
-         x_put6<K, ZV_XW, 0, CX, T>(cx, ZvFold<TP, S::limb_root(K), T, CX, 0>::run(cx));
+         x_put6<K, CX::fold_xw, 0, CX, T>(cx, ZvFold<TP, S::limb_root(K), T, CX, 0>::run(cx));
       zv_limbs_fold_sel<TP, W, K + 1, LATE, T, CX>(cx);
    }
 }
@@ -615,7 +697,7 @@ MH_DEV void zv_subtrunks_fold_of(const CX &cx)
    {
       constexpr int ST = S::sub_top(I);
       if constexpr (S::sub_owner(ST) == W)
-         x_put6<S::sub_slot(ST), ZV_XW, 6, CX, T>(cx, ZvFold<TP, ST, T, CX, 1>::run(cx));
+         x_put6<S::sub_slot(ST), CX::fold_xw, 6, CX, T>(cx, ZvFold<TP, ST, T, CX, 1>::run(cx));
       zv_subtrunks_fold_of<TP, W, I + 1, T, CX>(cx);
    }
 }
@@ -652,6 +734,10 @@ MH_DEV void zv_fold_out(const CX &cx)
             __syncthreads();
             zv_roots_fold<TP, T, CX>(cx);
          }
+         // CSMODE 2 writes the accelerations IN PLACE over the bias rows (no LDS left for rows of their own at two workgroups per CU): no
+         // wave may start writing while another still folds the trunk, whose efforts it reads from those rows
+         if constexpr (CX::csmode == 2)
+            __syncthreads();
          asm volatile("" ::: "memory");
          zv_roots_out_wave<TP, W, T, CX>(cx);
       }
@@ -684,11 +770,11 @@ struct ZvSync
    int epoch;
    int jobs;       // 2: bias + inertia (mh_aba_f64); 3: + the inverse dynamics of mh_rnea_aba_f64
    int same_l2;    // 1: a bias job that finds its inertia job behind the SAME L2 (both read HW_REG_XCC_ID) leaves rows and flag in that L2
+   unsigned wait_ticks; // how long an inertia job waits for its flag, in ticks of the 100 MHz real-time counter (MH_ZV_WAIT_MS; default 2 s)
 };
 // id of the XCD this wave runs on (HW_REG_XCC_ID, register 20, bits 3:0)
 MH_DEV int zv_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf); }
 MH_DEV int zv_mail_key(int epoch, int xcc) { return (int)(((unsigned)epoch & 0x03ffffffu) << 5) | 16 | xcc; }
-constexpr unsigned long long ZV_WAIT_TICKS = 20000000ull; // 0.2 s of the 100 MHz real-time counter
 
 // The hand-off follows the one form MI355X_MICROARCH.md lists as valid without agent-scope fences (a release fence writes back the whole
 // L2: 7-11 us measured here; an acquire fence invalidates it): every byte of the bias rows is stored sc1 (write-through) and loaded sc1
@@ -696,23 +782,25 @@ constexpr unsigned long long ZV_WAIT_TICKS = 20000000ull; // 0.2 s of the 100 MH
 // stores the flag sc1, and the consumer's polling wave joins a workgroup barrier before any wave loads the rows.  Where the two jobs of
 // a group have PROVED to run behind the same L2 (mailbox, zv_bias_group) the stores are workgroup-scope (sc0) instead: rows and flag
 // stay in that L2, which is where the consumer's sc1 polls and loads are served from; everything else is the same.
-// Returns once the flag of group k holds this launch's epoch, or after the wall-clock limit.
-MH_DEV void zv_wait(const ZvSync &sy, long k)
+// Returns true once the flag of group k holds this launch's epoch; false after the wall-clock limit, with the error word set (the caller
+// then writes NaN rows instead of accelerations: zv_aba_group).  The limit is generous (seconds): the real-time counter keeps counting
+// while a queue is preempted, and a producer that has not even been dispatched yet (HIP promises no dispatch order) needs a CU to free up.
+MH_DEV bool zv_wait(const ZvSync &sy, long k)
 {
    const int *f = sy.flags + k * ZV_SYNC_STRIDE;
    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sy.epoch)
-      return;
+      return true;
    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
    for (;;)
    {
       __builtin_amdgcn_s_sleep(1);
       if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sy.epoch)
-         return;
-      if (__builtin_amdgcn_s_memrealtime() - t0 > ZV_WAIT_TICKS)
+         return true;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)sy.wait_ticks)
       {
          if ((threadIdx.x & 63) == 0)
-            __hip_atomic_store(sy.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         return;
+            __hip_atomic_store(sy.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+         return false;
       }
    }
 }
@@ -795,9 +883,15 @@ MH_DEV void zv_bias_group(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, con
    // line in pieces -- 1.4 + 1.1 us for the two parts against 0.55 us for whole rows.)
    zv_publish_rows<T, 256>(taup + cfg0 * nv, lx, rows * nv, same);
    ZV_STAMP(0, 5);
+#ifdef MH_ZV_TEST_FLAG_BEFORE_DRAIN // tests/test_handoff_isa.py compiles this ONCE, to ISA text only, to prove that its checks catch a flag
+                                    // that can overtake its rows; it is never linked into anything
+   if (threadIdx.x == 0)
+      __hip_atomic_store(sy.flags + k * ZV_SYNC_STRIDE, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its stores have been acknowledged by the L2 / by memory ...
    ZV_STAMP(0, 6);
    __syncthreads();
+#ifndef MH_ZV_TEST_FLAG_BEFORE_DRAIN
    if (threadIdx.x == 0) // ... so the flag, stored behind the barrier (the same way as the rows), is never seen ahead of them
    {
       if (same)
@@ -805,6 +899,7 @@ MH_DEV void zv_bias_group(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, con
       else
          __hip_atomic_store(sy.flags + k * ZV_SYNC_STRIDE, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    }
+#endif
    ZV_STAMP(0, 7);
 }
 
@@ -875,9 +970,26 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    // store -> flag -> poll -> load chain through memory costs ~3 us.  Rows and flag kept in the L2 by sc0 stores where both jobs prove to sit
    // behind the same one (HW_REG_XCC_ID through a mailbox; 64 of 64 groups did): fetch 0.67 instead of 0.85 us, step time unchanged -- the
    // flag is up before the root step ends.  The plain form below is the fastest of the four.)
+   __shared__ int zv_gave_up;
    if (wave == 0)
-      zv_wait(sy, k);
+   {
+      const bool seen = zv_wait(sy, k);
+      if (lane == 0)
+         zv_gave_up = seen ? 0 : 1;
+   }
    __syncthreads(); // the polling wave has seen the flag: now every wave may load the rows
+   if (zv_gave_up)
+   { // (the whole workgroup takes this branch) the bias rows never came: NaN instead of accelerations formed from whatever the scratch
+     // matrix holds, and no fold; the error word is set, the host reports MH_ERR_HIP at its next synchronisation point (mh_api.hip)
+      for (int i = threadIdx.x; i < rows * nv; i += 256) // (as a bit pattern: the build's -ffinite-math-only knows no NaN values)
+      {
+         if constexpr (sizeof(T) == 8)
+            reinterpret_cast<unsigned long long *>(A.out)[cfg0 * nv + i] = 0x7ff8000000000000ull;
+         else
+            reinterpret_cast<unsigned *>(A.out)[cfg0 * nv + i] = 0x7fc00000u;
+      }
+      return;
+   }
    ZV_STAMP(1, 5);
    zv_fetch_rows<T, Tree<TP>::total_dofs(), 256>(lx, taup + cfg0 * nv, rows);
    // The flag goes back to zero once its rows have been consumed: a captured launch is replayed with the SAME epoch (hipGraph), and a flag
@@ -936,5 +1048,183 @@ __global__ void __launch_bounds__(256) MH_ZV_KERNEL_ATTR spec_zv_kernel(Args<T> 
       split_group<TP, T, 0, IDENT, true>(A, k, (A.B + 63) / 64, (lds_ptr<T>)lds_raw);
       ZV_STAMP(2, 1);
    }
+}
+
+// ============================================================================================ device-filling batches: two launches
+// Beyond one workgroup per CU and job the two jobs stop running side by side, and the one-job forward dynamics of mh_spec_kernels.h holds
+// a SIMD with ONE wave (446 registers).  The inertia job fits 256 registers; what kept it at one workgroup per CU was 129 KB of LDS.  Here
+// the bias job is a launch of its own that runs first and leaves, for every configuration, the rows tau - h(q, qd) and (cos, sin) of every
+// revolute joint; the inertia job then needs no q, no sincos and no flag, and its LDS shrinks to the limbs' exchange records plus the
+// trunk's hand-over slots (ZvbStore: the root body in registers): the bias rows are staged into the exchange area once the inward sweep
+// has consumed it, the fold's records sit behind them and the accelerations are written in place -- 69 KB for the humanoid, two
+// workgroups per CU, two waves per SIMD.
+template <class TP>
+struct ZvbPlan
+{
+   using S = Split<TP>;
+   static constexpr int NV = Tree<TP>::total_dofs();
+   static constexpr int x_slots()
+   { // exchange area: the limbs' inertia records during the inward sweep; afterwards [64][nv] bias rows | 12 slots per limb for the fold
+      const int in = S::n_limbs() * ZV_XW, fold = NV + S::n_limbs() * 12;
+      return in > fold ? in : fold;
+   }
+   static constexpr int lds_slots() { return x_slots() + ZvbStore<TP>::TRUNK_SLOTS; }
+   static constexpr int bias_lds_slots(int nq, int nv) { return S::n_limbs() * 6 + S::RNEA_TRUNK_SLOTS + nq + 2 * nv; }
+};
+
+// The rows of the NEXT group a workgroup will work on, requested while the current one is being finished and held in registers until the
+// LDS rows are free (both launches loop over groups with two workgroups per CU: a wave that sits waiting for its rows is a quarter of what
+// the SIMD has to run).  Stamps at B = 262 144 (profiles/r04_zvb_phase_stamps.txt): staging q, qd, tau took 3.2 of the bias launch's 11.3 us
+// per group, the (cos, sin) pairs and the bias rows ~2 of the inertia launch's 11.4.
+template <typename T, int N, int NT>
+struct RowRegs
+{
+   static constexpr int U = (64 * N + NT - 1) / NT;
+   T r[U];
+   MH_DEV void issue(const T *src, int rows)
+   {
+      const int n = rows * N, t = threadIdx.x;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+         r[u] = t + NT * u < n ? src[t + NT * u] : T(0);
+   }
+   MH_DEV void commit(lds_ptr<T> dst) const
+   {
+      const int t = threadIdx.x;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+         if (t + NT * u < 64 * N)
+            dst[t + NT * u] = r[u];
+   }
+};
+
+// first launch: rows tau - RNEA(q, qd, 0) (A.in3 = tau) to taup [B][nv], (cos, sin) of the revolute joints to cs [2 n_rev][cs_stride]
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(256, 2) spec_zvb_bias_kernel(Args<T> A, T *taup, T *cs, long cs_stride)
+{
+   extern __shared__ double lds_raw[];
+   using S = Split<TP>;
+   using CX = Ctx<T, true, IDENT, SplitStore<TP>, false, 1, 1>;
+   constexpr int NQ = Tree<TP>::total_cfgs(), NV = Tree<TP>::total_dofs();
+   const lds_ptr<T> lds = (lds_ptr<T>)lds_raw;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const int nq = A.m.nq, nv = A.m.nv;
+   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * 6 * 64, lq = lst + S::RNEA_TRUNK_SLOTS * 64, lqd = lq + 64 * nq, lx = lqd + 64 * nv;
+   RowRegs<T, NQ, 256> rq;
+   RowRegs<T, NV, 256> rd, rx;
+   auto request = [&](long k) {
+      const long cfg0 = k * 64;
+      const int rows = (int)(A.B - cfg0 < 64 ? (A.B - cfg0 > 0 ? A.B - cfg0 : 0) : 64);
+      rq.issue(A.q + cfg0 * nq, rows), rd.issue(A.qd + cfg0 * nv, rows), rx.issue(A.in3 + cfg0 * nv, rows);
+   };
+   const long ngroups = (A.B + 63) / 64;
+   request(blockIdx.x);
+   for (long k = blockIdx.x; k < ngroups; k += gridDim.x)
+   {
+      const long cfg0 = k * 64;
+      const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+      const bool active = lane < rows;
+      ZV_STAMP(0, 0);
+      rq.commit(lq), rd.commit(lqd), rx.commit(lx);
+      __syncthreads();
+      ZV_STAMP(0, 1);
+      CX cx;
+      fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+      cx.coriolis = 1, cx.accel = 0;
+      cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = cx.lx;
+      cx.wave = wave;
+      cx.xbase = lxc + lane;
+      cx.st.lbase = lst + lane;
+      cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+      cx.cs = cs + cfg0 + lane, cx.cs_stride = cs_stride; // (the scratch is padded to whole groups; inactive lanes never store)
+      if (active)
+         split_rnea_limbs<TP, 0, T, CX>(cx);
+      ZV_STAMP(0, 2);
+      __syncthreads();
+      ZV_STAMP(0, 3);
+      // the next group's rows: in flight during the trunk pass and the copy-out.  (Unconditionally -- the last turn asks for its own group
+      // again: under a condition the registers would have to keep the OLD rows alive through the whole loop body, 48 more live registers.)
+      request(k + gridDim.x < ngroups ? k + gridDim.x : k);
+      if (active && wave == 0)
+         rnea_trunk_roots<TP, T, CX>(cx);
+      ZV_STAMP(0, 4);
+      __syncthreads();
+      wave_copy_out<T, 256>(taup + cfg0 * nv, lx, rows * nv);
+      ZV_STAMP(0, 5);
+      __syncthreads(); // the LDS rows are free for the next group
+      ZV_STAMP(0, 6);
+   }
+}
+
+// second launch, group k: qdd rows (A.out) from the bias rows and the (cos, sin) pairs.
+// (Requesting the NEXT group's pairs during the fold and carrying them in registers to the next turn was built and measured: the kernel
+// sits at 231 of 256 registers, the carried pairs cost 156-184 bytes of scratch per lane and the step got slower, not faster.)
+template <class TP, typename T, bool IDENT>
+MH_DEV void zvb_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup, const T *cs, long cs_stride)
+{
+   using S = Split<TP>;
+   using PL = ZvbPlan<TP>;
+   using CX = Ctx<T, true, IDENT, ZvbStore<TP>, false, 0, 2>;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const int nv = A.m.nv;
+   // LDS map: exchange area [x_slots][64] | the trunk's hand-over slots [TRUNK_SLOTS][64].  Exchange area, inward sweep: one inertia record
+   // of ZV_XW slots per limb; afterwards: [64][nv] bias rows, overwritten by the accelerations | CX::fold_xw slots per limb for the fold.
+   const lds_ptr<T> lxc = lds, lst = lxc + PL::x_slots() * 64, lx = lxc, lfold = lxc + 64 * nv;
+   const long cfg0 = k * 64;
+   const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+   const bool active = lane < rows;
+   CX cx;
+   fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+   cx.lq = lxc, cx.lqd = lxc; // (never read: CSMODE 2 takes q from the caller's matrix)
+   cx.lx = lx + lane * nv, cx.lo = cx.lx;
+   cx.wave = wave;
+   cx.xbase = lxc + lane;
+   cx.st.lbase = lst + lane;
+   cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+   cx.cs = const_cast<T *>(cs) + cfg0 + lane, cx.cs_stride = cs_stride; // padded to whole groups: inactive lanes read what nobody uses
+#ifdef MH_ZV_PROBE
+   cx.own = (unsigned long long)k;
+#endif
+   ZV_STAMP(1, 0);
+   if (active) // (lane 0 of every wave is active, so each wave reaches the barrier a staged trunk carries in here)
+      zv_limbs_in<TP, 0, T, CX>(cx);
+   ZV_STAMP(1, 2);
+   __syncthreads(); // every limb's (and sub-trunk's) articulated inertia is in the exchange area
+   ZV_STAMP(1, 3);
+#ifndef MH_ZVB_ROWS_EARLY
+#define MH_ZVB_ROWS_EARLY 1 // the bias rows are requested before the root body's step and held in registers across it (231 -> 247 registers, no scratch; 219.7 -> 214.5 us at B = 262 144); 0: requested when the exchange area is free
+#endif
+   RowRegs<T, Tree<TP>::total_dofs(), 256> rt;
+   if constexpr (MH_ZVB_ROWS_EARLY)
+      rt.issue(taup + cfg0 * nv, rows);
+   if (active)
+      zv_roots_in<TP, T, CX, (S::staged() ? 2 : 1)>(cx);
+   ZV_STAMP(1, 4);
+   __syncthreads(); // nobody reads the exchange area's inertias any more
+   ZV_STAMP(1, 5);
+   if constexpr (!MH_ZVB_ROWS_EARLY)
+      rt.issue(taup + cfg0 * nv, rows);
+   rt.commit(lx);
+   __syncthreads();
+   ZV_STAMP(1, 6);
+   cx.xbase = lfold + lane;
+   asm volatile("" ::: "memory");
+   if (active) // (lane 0 of every wave is active: each wave reaches the barriers the fold carries in here)
+      zv_fold_out<TP, 0, T, CX>(cx);
+   ZV_STAMP(1, 10);
+   __syncthreads();
+   wave_copy_out<T, 256>(A.out + cfg0 * nv, lx, rows * nv);
+   ZV_STAMP(1, 11);
+   __syncthreads(); // the exchange area is written again by the next group of this workgroup
+   ZV_STAMP(1, 12);
+}
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(256, 2) spec_zvb_kernel(Args<T> A, const T *taup, const T *cs, long cs_stride)
+{
+   extern __shared__ double lds_raw[];
+   for (long k = blockIdx.x; k * 64 < A.B; k += gridDim.x)
+      zvb_aba_group<TP, T, IDENT>(A, k, (lds_ptr<T>)lds_raw, taup, cs, cs_stride);
 }
 } // namespace mh

@@ -37,9 +37,33 @@ class HipModel:
         handle = ctypes.c_void_p()
         _lib.check(lib.mh_model_create(ctypes.byref(d), ctypes.byref(handle)))
         self._h = handle
+        self._ctx = None       # mh_context_t of a view made by context(); None: the model's default context
+        self._parent = None    # the HipModel a context view was made from (kept alive: it owns the handle)
         self.nq, self.nv, self.n_joints = desc.nq, desc.nv, desc.n_joints
 
+    def context(self) -> "HipModel":
+        """A view of this model with a context of its own (mh_context_create): the handle is read-only and shared, everything compute
+        calls write besides their outputs -- workspace, scratch, staging buffers, hand-off flags, error word -- belongs to the view.  One
+        view per host thread / per stream; views and the model itself may then be used at the same time (include/mecano_hip.h, Threading)."""
+        import copy
+        ctx = ctypes.c_void_p()
+        _lib.check(_lib.load().mh_context_create(self._h, ctypes.byref(ctx)))
+        view = copy.copy(self)
+        view._ctx, view._parent = ctx, (self._parent or self)
+        return view
+
+    def check(self, stream=None):
+        """mh_model_check: synchronises `stream` and raises what this model's (view's) asynchronous calls left behind on the device."""
+        _lib.check(_lib.load().mh_model_check(self._h, self._ctx, stream))
+
     def close(self):
+        if getattr(self, "_ctx", None):
+            _lib.load().mh_context_destroy(self._ctx)
+            self._ctx = None
+            self._h = None  # (a view: the handle belongs to the model it was made from)
+            return
+        if getattr(self, "_parent", None) is not None:
+            return
         if getattr(self, "_h", None):
             _lib.load().mh_model_destroy(self._h)
             self._h = None
@@ -55,12 +79,15 @@ class HipModel:
         return _lib.load().mh_model_kernel_variant(self._h).decode()
 
     def reserve(self, max_batch: int):
-        _lib.check(_lib.load().mh_reserve(self._h, int(max_batch)))
+        if self._ctx:
+            _lib.check(_lib.load().mh_context_reserve(self._ctx, int(max_batch)))
+        else:
+            _lib.check(_lib.load().mh_reserve(self._h, int(max_batch)))
 
     # ------------------------------------------------------------------ helpers
-    @staticmethod
-    def _options(layout, consider_coriolis=True, consider_accelerations=True, stream=None, root_acceleration=None):
+    def _options(self, layout, consider_coriolis=True, consider_accelerations=True, stream=None, root_acceleration=None):
         o = _lib.MhOptions()
+        o.context = self._ctx
         o.consider_coriolis = int(bool(consider_coriolis))
         o.consider_accelerations = int(bool(consider_accelerations))
         o.layout = int(layout)

@@ -151,6 +151,29 @@ def humanoid30Desc():
                      np.array(d["inertia_com"]), np.array(d["dof_indices"], dtype=np.int32), np.array(d["cfg_indices"], dtype=np.int32))
 
 
+def modelDescFromJson(name: str):
+    """A committed model of mecano_amd/models/ (flat mh_model_desc form) as a ModelDesc: "humanoid30", "arm7", "tree128"."""
+    import json
+    import os
+    from .multibody import ModelDesc
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", name + ".json")))
+    return ModelDesc(d["n_joints"], d["nq"], d["nv"], np.array(d["parent"], dtype=np.int32), np.array(d["joint_type"], dtype=np.int32),
+                     np.array(d["axis"]), np.array(d["X_before"]), np.array(d["X_com"]), np.array(d["inertia_J"]), np.array(d["inertia_mass"]),
+                     np.array(d["inertia_com"]), np.array(d["dof_indices"], dtype=np.int32), np.array(d["cfg_indices"], dtype=np.int32))
+
+
+def committedBenchmarkSystems():
+    """The three mechanisms BASELINE.json's configs name, as this repository generates them (model seeds fixed here; the committed JSON files
+    under mecano_amd/models/ are their flattened form, tests/golden/make_model_fixtures.py):
+      humanoid30  configs 3 / 4 and the metric: nextHumanoid(default_rng(43))
+      arm7        configs 1 / 2: a 7-joint revolute chain, nextJointChain(default_rng(43), 7)
+      tree128     config 5: nextJointTree(default_rng(128), 128, revolute / prismatic / 6-DoF) -- the tree bench.py --config 5 times"""
+    return {"humanoid30": nextHumanoid(np.random.default_rng(43)),
+            "arm7": MultiBodySystem.toMultiBodySystemInput(nextJointChain(np.random.default_rng(43), 7)[0].getPredecessor()),
+            "tree128": MultiBodySystem.toMultiBodySystemInput(
+                nextJointTree(np.random.default_rng(128), 128, ("revolute", "prismatic", "sixdof"))[0].getPredecessor())}
+
+
 def referenceBenchmarkSystems(seed: int = 43, numberOfJoints: int = 30):
     """The four systems of the reference's own (disabled) RNEA benchmarks, InverseDynamicsCalculatorTest.java:24-158: a 30-joint random
     1-DoF chain and tree on a fixed base, and the same below a SixDoF root joint; seed 43 each (the reference's seed; the RNG is numpy's,

@@ -191,7 +191,7 @@ static void xf_motion_inv(const xf_t *X, const double in[6], double out[6])
 
 /* ------------------------------------------------------------------ joint kinematics */
 /* Joint transform afterJoint -> beforeJoint.
- * revolute : tools/MecanoFactories.java:231-260 (axis-angle; the X/Y/Z shortcuts are the same rotation)
+ * revolute : tools/MecanoFactories.java:231-260 (axis-angle; within 1e-7 of X / Y / Z the roll / pitch / yaw closed forms, i.e. the exact coordinate axis)
  * prismatic: multiBodySystem/interfaces/PrismaticJointReadOnly.java:18-22
  * sixdof   : multiBodySystem/interfaces/FloatingJointReadOnly.java:34-37 (quaternion x,y,z,s then position) */
 static void joint_transform(const mo_model *m, int i, const double *qrow, xf_t *X)
@@ -206,6 +206,19 @@ static void joint_transform(const mo_model *m, int i, const double *qrow, xf_t *
          const double *a = m->axis[i];
          double nrm = sqrt(v3_dot(a, a));
          double ux = a[0] / nrm, uy = a[1] / nrm, uz = a[2] / nrm;
+         /* tools/MecanoFactories.java:51, 237-248: an axis that geometricallyEquals X, Y or Z within TRANSFORM_UPDATER_EPSILON = 1e-7 gets the
+          * closed-form roll / pitch / yaw matrix -- a rotation about EXACTLY that coordinate axis -- while the joint's unit twist keeps the
+          * axis as given (multiBodySystem/OneDoFJoint.java:170).  (Euclid's geometricallyEquals for vectors, un-vendored: norm of the
+          * difference <= epsilon.)  An axis exactly on X / Y / Z gives the same matrix either way. */
+         for (int k = 0; k < 3; k++)
+         {
+            double d[3] = {a[0] - (k == 0), a[1] - (k == 1), a[2] - (k == 2)};
+            if (sqrt(v3_dot(d, d)) <= 1.0e-7)
+            {
+               ux = k == 0, uy = k == 1, uz = k == 2;
+               break;
+            }
+         }
          double c = cos(q), s = sin(q), t = 1.0 - c;
          X->R[0] = t * ux * ux + c, X->R[1] = t * ux * uy - s * uz, X->R[2] = t * ux * uz + s * uy;
          X->R[3] = t * ux * uy + s * uz, X->R[4] = t * uy * uy + c, X->R[5] = t * uy * uz - s * ux;

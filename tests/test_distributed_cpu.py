@@ -62,6 +62,76 @@ def test_world_size_2_gloo(tmp_path, B):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def test_world_size_8_gloo_ragged_config4_total(tmp_path):
+    """Eight ranks -- the node size the driver's scaling run uses -- over gloo with a ragged total (8 does not divide 262 144 + 5 scaled down to
+    what the oracle evaluates in seconds: 1024 + 5): shard sizes 129, 129, 129, 129, 129, 128, 128, 128; broadcast of the model, sharded
+    compute, padded all-gather, every row equal to the unsharded result."""
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, 1029, str(tmp_path)), nprocs=8, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(8))
+
+
+def test_gather_plan_is_the_same_on_every_rank_and_tiles_the_output():
+    """mh_comm_all_gather_rows issues what mh_comm_gather_plan lists (mecano_amd/csrc/mh_comm.hip).  RCCL cannot put two ranks on one GPU and
+    the builder's box has one, so the ragged schedule -- a group of broadcasts, send != receive on the root, in place elsewhere -- had only
+    ever run with world = 1.  The plan is a pure function: here it is evaluated for every rank of every world size up to nine and EXECUTED
+    on host buffers standing in for the ranks' device memory: all ranks list the same operations in the same order (a grouped collective
+    deadlocks otherwise), the received ranges tile the output exactly, and every rank ends with all rows in batch order."""
+    import ctypes
+    from mecano_amd import _lib
+    from mecano_amd.distributed import shard_range
+    lib = _lib.load()
+
+    def plan(B, row_bytes, rank, world, force):
+        n = ctypes.c_int32()
+        steps = (_lib.MhGatherStep * (world + 1))()
+        assert lib.mh_comm_gather_plan(B, row_bytes, rank, world, force, steps, world + 1, ctypes.byref(n)) == _lib.MH_OK
+        count_only = ctypes.c_int32()
+        assert lib.mh_comm_gather_plan(B, row_bytes, rank, world, force, None, 0, ctypes.byref(count_only)) == _lib.MH_OK
+        assert count_only.value == n.value <= world
+        return [(s.root, s.send_local, s.recv_offset, s.bytes) for s in steps[:n.value]]
+
+    row = 24  # bytes per row
+    for world in range(1, 10):
+        for B in (0, 1, 5, world, 8 * world, 8 * world + 1, 9 * world - 1, 4099, 262144 + 5):
+            for force in (0, 1):
+                plans = [plan(B, row, r, world, force) for r in range(world)]
+                # same operations, same order, on every rank (send_local differs: it marks the root's own step)
+                for r in range(1, world):
+                    if plans[0] and plans[0][0][0] == -1:  # the plain all-gather: one step everywhere, same size; the offset is where the rank's own shard lands
+                        assert [(a, d) for a, _, _, d in plans[r]] == [(a, d) for a, _, _, d in plans[0]], (world, B, force, r)
+                    else:
+                        assert [(a, c, d) for a, _, c, d in plans[r]] == [(a, c, d) for a, _, c, d in plans[0]], (world, B, force, r)
+                if B == 0:
+                    assert plans[0] == []
+                    continue
+                full = np.random.default_rng(B + world).integers(0, 255, size=B * row, dtype=np.uint8)
+                shards = [full[shard_range(B, r, world)[0] * row:shard_range(B, r, world)[1] * row] for r in range(world)]
+                outs = [np.zeros(B * row, dtype=np.uint8) for _ in range(world)]
+                covered = np.zeros(B * row, dtype=np.int32)
+                if len(plans[0]) == 1 and plans[0][0][0] == -1:  # equal shards: the plain all-gather, every rank's shard at rank * bytes
+                    assert B % world == 0 and not force
+                    for r in range(world):
+                        root, send_local, ofs, nbytes = plans[r][0]
+                        assert (send_local, ofs, nbytes) == (1, r * (B // world) * row, (B // world) * row)
+                        for o in outs:
+                            o[ofs:ofs + nbytes] = shards[r]
+                        covered[ofs:ofs + nbytes] += 1
+                else:
+                    for k, (root, _, ofs, nbytes) in enumerate(plans[0]):
+                        assert 0 <= root < world and nbytes == len(shards[root]) > 0 and ofs == shard_range(B, root, world)[0] * row
+                        for r in range(world):
+                            assert plans[r][k][1] == (1 if r == root else 0)  # the root sends its local rows, everybody else receives in place
+                            outs[r][ofs:ofs + nbytes] = shards[root]
+                        covered[ofs:ofs + nbytes] += 1
+                assert (covered == 1).all(), (world, B, force)
+                assert all(np.array_equal(o, full) for o in outs)
+    n = ctypes.c_int32()
+    for bad in ((-1, 8, 0, 1), (8, 8, 2, 2), (8, 8, -1, 2), (8, 8, 0, 0)):
+        assert lib.mh_comm_gather_plan(bad[0], bad[1], bad[2], bad[3], 0, None, 0, ctypes.byref(n)) == 1
+    assert lib.mh_comm_gather_plan(8, 8, 0, 2, 0, None, 0, None) == 1
+
+
 def test_shard_range_partitions_the_batch():
     from mecano_amd.distributed import shard_range
     for B in (0, 1, 7, 4096, 262144, 1000003):

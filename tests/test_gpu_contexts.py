@@ -1,0 +1,127 @@
+"""SURVEY.md section 8(b), "Threading": the model handle is read-only and shareable.  Everything a compute call writes besides its outputs
+(workspace, scratch matrices, staging buffers, the hand-off flags and the error word of the bias-split forward dynamics) belongs to a
+context (mh_context_create); the reference keeps the same state inside the calculator object, which is why Mecano needs one calculator per
+thread (InverseDynamicsCalculator.java:706-707).  Here: two host threads, each with two contexts on two streams of its own, all on ONE
+handle and all at once, bit for bit equal to the same calls made one after the other."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(hip_lib):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def dev(torch, x):
+    return torch.tensor(np.ascontiguousarray(x), device="cuda", dtype=torch.float64)
+
+
+# batch sizes that take the three formulations of forward dynamics: bias split (hand-off flags, scratch rows), one job, two launches
+BATCHES = (4096, 20000, 40000)
+
+
+def _inputs(torch, sys_, seed):
+    from mecano_amd import random_tools as rt
+    out = {}
+    for B in BATCHES:
+        q, qd, qdd, tau = rt.nextState(np.random.default_rng(seed + B), sys_, B)
+        out[B] = tuple(dev(torch, x) for x in (q, qd, qdd, tau))
+    return out
+
+
+def _evaluate(torch, hm, inputs, g, stream, rounds):
+    """rounds x (RNEA, ABA, pair, CRBA on the small batch) on `stream`; returns the results of the LAST round (earlier rounds only keep
+    the scratch buffers busy while the other contexts use theirs)."""
+    res = {}
+    with torch.cuda.stream(stream):
+        for _ in range(rounds):
+            for B, (q, qd, qdd, tau) in inputs.items():
+                res[("rnea", B)] = hm.rnea(q, qd, qdd, g)
+                res[("aba", B)] = hm.aba(q, qd, tau, g)
+                t2, a2 = hm.rnea_aba(q, qd, qdd, tau, g)
+                res[("pair_tau", B)], res[("pair_qdd", B)] = t2, a2
+            q = inputs[BATCHES[0]][0]
+            res[("crba", BATCHES[0])] = hm.crba(q)
+        hm.check(stream.cuda_stream)  # mh_model_check: synchronises the stream, reports asynchronous failures of this context
+    return res
+
+
+def test_two_threads_two_streams_each_on_one_shared_handle(torch_cuda):
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    desc = sys_.toModelDesc()
+    hm = HipModel(desc)
+    assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant
+    g = (0.2, -0.1, -9.81)
+    jobs = [(_inputs(torch, sys_, 1000 * (k + 1)), hm.context(), torch.cuda.Stream()) for k in range(4)]
+    torch.cuda.synchronize()
+    # serial: one context after the other, on the default stream, through the model's own default context
+    serial = [_evaluate(torch, hm, inputs, g, torch.cuda.current_stream(), 1) for inputs, _, _ in jobs]
+    torch.cuda.synchronize()
+    # concurrent: thread t drives contexts 2 t and 2 t + 1, each on a stream of its own, several rounds so that the calls really overlap
+    results, errors = [None] * 4, []
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            for k in (2 * t, 2 * t + 1):
+                inputs, view, stream = jobs[k]
+                results[k] = _evaluate(torch, view, inputs, g, stream, 6)
+        except Exception as e:  # noqa: BLE001 (reported below, on the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k in range(4):
+        for key, ref in serial[k].items():
+            assert torch.equal(results[k][key], ref), (k, key, (results[k][key] - ref).abs().max().item())
+    # ... and the serial results are the oracle's
+    om = OracleModel(desc)
+    q, qd, qdd, tau = (x[:64].cpu().numpy() for x in jobs[0][0][BATCHES[0]])
+    assert np.abs(serial[0][("aba", BATCHES[0])][:64].cpu().numpy() - om.aba(q, qd, tau, g)).max() < 1e-10
+    assert np.abs(serial[0][("rnea", BATCHES[0])][:64].cpu().numpy() - om.rnea(q, qd, qdd, g)).max() < 1e-9
+    for _, view, _ in jobs:
+        view.close()
+    hm.close()
+
+
+def test_context_misuse_is_refused(torch_cuda):
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    lib = _lib.load()
+    a = HipModel(rt.nextHumanoid(np.random.default_rng(1)).toModelDesc())
+    b = HipModel(rt.nextQuadruped(np.random.default_rng(2)).toModelDesc())
+    view = a.context()
+    q, qd, qdd, tau = (dev(torch, x) for x in rt.nextState(np.random.default_rng(3), rt.nextQuadruped(np.random.default_rng(2)), 8))
+    # a context of model a handed to a call on model b
+    stolen = b.context()
+    lib.mh_context_destroy(stolen._ctx)
+    stolen._ctx = view._ctx
+    with pytest.raises(_lib.MecanoHipError) as e:
+        stolen.rnea(q, qd, qdd, (0, 0, -9.81))
+    assert e.value.status == 1 and "another model" in str(e.value)
+    stolen._ctx = None
+    # mh_model_check with a foreign context
+    assert lib.mh_model_check(b._h, view._ctx, None) == 1
+    # joint source modes are set on the model, before its contexts are created
+    modes = (ctypes.c_int32 * a.n_joints)(*([0] * a.n_joints))
+    assert lib.mh_model_set_joint_source_modes(a._h, modes) == 1
+    view.close()
+    assert lib.mh_model_set_joint_source_modes(a._h, modes) == 0
+    assert lib.mh_model_check(a._h, None, None) == 0

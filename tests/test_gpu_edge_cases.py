@@ -1,0 +1,246 @@
+"""Edge cases of the hot path the reference's code distinguishes and the random-state tests never reach, HIP path
+against the oracle (paths relative to /root/reference/src/main/java/us/ihmc/mecano/):
+
+* revolute angles far outside (-pi, pi]: |q| >= 2^19 takes the library sincos on the device (mh_device.h: sincos_slow), below it the
+  Cody-Waite reduction -- both sides of the switch and |q| up to 1e7;
+* quaternions that are not unit (Euclid's Quaternion.set normalises: the engine normalises on input, include/mecano_hip.h);
+* revolute axes within 1e-7 of X / Y / Z (tools/MecanoFactories.java:51, 237-248) -- exactly on a coordinate axis, just inside the
+  threshold and just outside it;
+* bodies with |m| < 1e-7 (spatial/interfaces/FixedFrameSpatialInertiaBasics.java:174-175);
+* zero-length batches on every entry point.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import close
+
+pytestmark = pytest.mark.gpu
+G = (0.3, -0.2, -9.81)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(hip_lib):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def dev(torch, x, dtype=None):
+    return torch.tensor(np.ascontiguousarray(x), device="cuda", dtype=dtype or torch.float64)
+
+
+def system_of(joints):
+    from mecano_amd.multibody import MultiBodySystem
+    return MultiBodySystem.toMultiBodySystemInput(joints[0].getPredecessor())
+
+
+def _against_oracle(torch, desc, q, qd, qdd, tau, label, tol=1e-10, crba=True):
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    hm, om = HipModel(desc), OracleModel(desc)
+    close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), G).cpu().numpy(), om.rnea(q, qd, qdd, G), tol, label=label + " rnea")
+    close(hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), G).cpu().numpy(), om.aba(q, qd, tau, G), tol, label=label + " aba")
+    if crba:
+        close(hm.crba(dev(torch, q)).cpu().numpy(), om.crba(q), tol, label=label + " crba")
+    t2, a2 = hm.rnea_aba(dev(torch, q), dev(torch, qd), dev(torch, qdd), dev(torch, tau), G)
+    close(t2.cpu().numpy(), om.rnea(q, qd, qdd, G), tol, label=label + " pair tau")
+    close(a2.cpu().numpy(), om.aba(q, qd, tau, G), tol, label=label + " pair qdd")
+    return hm, om
+
+
+@pytest.mark.parametrize("which", ["humanoid", "arm7", "tree12"])
+def test_revolute_angles_far_outside_one_turn(torch_cuda, which):
+    """q on both sides of the device's 2^19 switch between its own range reduction and the library's, and up to 1e7 (a joint that has been
+    integrated for a long time without wrapping: MultiBodySystemStateIntegrator never wraps q, tools/MultiBodySystemStateIntegrator.java:433-441)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    rng = np.random.default_rng(5)
+    sys_ = {"humanoid": lambda: rt.nextHumanoid(rng), "arm7": lambda: system_of(rt.nextJointChain(rng, 7)),
+            "tree12": lambda: system_of(rt.nextJointTree(rng, 12, ("revolute", "prismatic")))}[which]()
+    desc = sys_.toModelDesc()
+    B = 256
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    rev = [int(desc.cfg_indices[k]) for k in _revolute_cfg_slots(desc)]
+    special = np.array([2.0 ** 19, -(2.0 ** 19), np.nextafter(2.0 ** 19, 0), -np.nextafter(2.0 ** 19, 0), 2.0 ** 19 + 0.5, 1.0e7, -1.0e7, 12345678.9,
+                        -9876543.21, 1.0e6 * np.pi, 524287.99999, 3.0e5])
+    for b in range(B):
+        for k, c in enumerate(rev):
+            if b < 64:
+                q[b, c] = special[(b + k) % len(special)] + (0.01 * b if b % 2 else 0.0)
+            elif b < 160:
+                q[b, c] = rng.uniform(-1.0e7, 1.0e7)
+            # (the rest keeps its draw from (-pi, pi]: both paths inside one wave)
+    _against_oracle(torch, desc, q, qd, qdd, tau, f"large angles {which}")
+
+
+def _revolute_cfg_slots(desc):
+    """positions in desc.cfg_indices (concatenated joint by joint) that belong to revolute joints"""
+    out, pos = [], 0
+    for t in desc.joint_type:
+        n = {0: 1, 1: 1, 2: 7, 3: 0, 4: 3, 5: 4}[int(t)]
+        if int(t) == 0:
+            out.append(pos)
+        pos += n
+    return out
+
+
+def test_quaternions_that_are_not_unit(torch_cuda):
+    """SixDoF and spherical joints: quaternions scaled by 1e-3 ... 1e3 (and the same unit quaternion beside them): identical outputs, and the
+    oracle's (which normalises where Euclid's Quaternion.set does)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    rng = np.random.default_rng(6)
+    for sys_ in (rt.nextHumanoid(rng), system_of(rt.nextJointTree(rng, 9, ("revolute", "spherical", "sixdof")))):
+        desc = sys_.toModelDesc()
+        B = 192
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        q_unit = q.copy()
+        pos = 0
+        for t in desc.joint_type:
+            n = {0: 1, 1: 1, 2: 7, 3: 0, 4: 3, 5: 4}[int(t)]
+            if int(t) in (2, 5):
+                cols = [int(c) for c in desc.cfg_indices[pos:pos + 4]]
+                scale = 10.0 ** rng.uniform(-3, 3, size=B)
+                scale[::7] = 1.0
+                q[:, cols] *= scale[:, None]
+            pos += n
+        hm, om = _against_oracle(torch, desc, q, qd, qdd, tau, "non-unit quaternions", crba=True)
+        # the scaled and the unit quaternion are the same rotation: same efforts to rounding
+        a = hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), G)
+        b = hm.rnea(dev(torch, q_unit), dev(torch, qd), dev(torch, qdd), G)
+        assert (a - b).abs().max().item() <= 1e-10 * max(1.0, b.abs().max().item())
+
+
+def _chain_with_axes(rng, axes, tiny_mass_bodies=()):
+    from mecano_amd import random_tools as rt
+    from mecano_amd.multibody import RigidBody, RevoluteJoint
+    root = RigidBody("root")
+    pred, joints = root, []
+    for i, axis in enumerate(axes):
+        j = RevoluteJoint(f"j{i}", pred, None if pred.isRootBody() else rt.nextRigidBodyTransform(rng), axis)
+        J = rt.nextSymmetricPositiveDefiniteMatrix3D(rng)
+        mass = 0.1 + rng.uniform()
+        if i in tiny_mass_bodies:
+            mass, J = 5.0e-8, J * 5.0e-8
+        pred = RigidBody(f"b{i}", j, J, mass, centerOfMassOffset=rt.nextVector3D(rng))
+        joints.append(j)
+    return system_of(joints)
+
+
+def _unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return v / np.linalg.norm(v)
+
+
+def test_revolute_axes_at_and_around_the_coordinate_axes(torch_cuda):
+    """tools/MecanoFactories.java:237-248: an axis that geometricallyEquals X, Y or Z within 1e-7 gets the roll / pitch / yaw closed form.
+    Exactly on the axis and outside the threshold the closed form and the axis-angle form are the same rotation about the same axis: 1e-10.
+    INSIDE the threshold but not on the axis the reference rotates about the exact coordinate axis while its unit twist keeps the axis as
+    given -- a model that is inconsistent with itself at the 1e-7 level; the oracle reproduces it, the device keeps ONE axis for both
+    (conscious divergences): the two then differ by at most the axis error times the scale of the result, asserted as such."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    rng = np.random.default_rng(8)
+    exact = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (-1, 0, 0), (0, -1, 0), (0, 0, -1), (1, 0, 0)]
+    outside = [_unit((1, 3e-7, 0)), _unit((0, 1, -2.5e-7)), _unit((2e-7, 2e-7, 1)), _unit((1, 0, 1.5e-7)), _unit((1e-6, 1, 0)), _unit((0, 4e-7, 1)),
+               _unit((1, 1e-3, 0))]
+    inside = [_unit((1, 3e-8, -4e-8)), _unit((5e-8, 1, 0)), _unit((0, -6e-8, 1)), _unit((1, 0, 9e-8)), _unit((2e-8, 1, 2e-8)), _unit((7e-8, 0, 1)),
+              _unit((1, -5e-8, 5e-8))]
+    for label, axes, tol in (("axes exactly on X / Y / Z", exact, 1e-10), ("axes just outside 1e-7", outside, 1e-10)):
+        sys_ = _chain_with_axes(rng, axes)
+        q, qd, qdd, tau = rt.nextState(rng, sys_, 128)
+        _against_oracle(torch, sys_.toModelDesc(), q, qd, qdd, tau, label, tol)
+    sys_ = _chain_with_axes(rng, inside)
+    desc = sys_.toModelDesc()
+    q, qd, qdd, tau = rt.nextState(rng, sys_, 128)
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    hm, om = HipModel(desc), OracleModel(desc)
+    t_dev, t_ref = hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), G).cpu().numpy(), om.rnea(q, qd, qdd, G)
+    gap = np.abs(t_dev - t_ref).max() / max(1.0, np.abs(t_ref).max())
+    assert gap <= 4.0e-7, gap          # the axis error (<= 1e-7) times a handful of transforms
+    # ... and it IS that divergence, nothing else: with the axes snapped onto the coordinate axes both sides agree to 1e-10
+    snapped = _chain_with_axes(np.random.default_rng(8), [np.round(a) for a in inside])
+    # (same random stream as a chain built with `inside` would have used is not needed: a fresh consistent model is compared on both sides)
+    q, qd, qdd, tau = rt.nextState(rng, snapped, 128)
+    _against_oracle(torch, snapped.toModelDesc(), q, qd, qdd, tau, "axes snapped", 1e-10)
+
+
+def test_bodies_with_tiny_mass(torch_cuda):
+    """|m| < 1e-7.  RNEA and ABA never add inertias: 1e-10 against the oracle whatever the masses.  CRBA: SpatialInertia.add renormalises the
+    centre of mass only if |m| >= 1e-7 (FixedFrameSpatialInertiaBasics.java:174-175) -- a guard against 0 / 0 that leaves m c in the place
+    of c when a COMPOSITE mass stays under the threshold; a light body under an ordinary one never triggers it (1e-10), two light bodies at
+    the end of a chain do: there the device keeps (m, m c, I) and stays physically consistent (H e_j = RNEA(q, 0, e_j) at zero gravity, to
+    1e-10), the oracle follows the reference, and the two differ by less than the masses involved (conscious divergences)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(9)
+    axes = [rt.nextUnitVector3D(rng) for _ in range(6)]
+    # a light body in the middle and a light leaf under an ordinary body: no composite under the threshold
+    sys_ = _chain_with_axes(rng, axes, tiny_mass_bodies=(2, 5))
+    q, qd, qdd, tau = rt.nextState(rng, sys_, 128)
+    tau[:, 5] *= 1e-7  # (efforts on a 5e-8 kg leaf: keep its acceleration finite-sized)
+    _against_oracle(torch, sys_.toModelDesc(), q, qd, qdd, tau, "light bodies, ordinary composites", 1e-10, crba=False)
+    hm, om = HipModel(sys_.toModelDesc()), OracleModel(sys_.toModelDesc())
+    close(hm.crba(dev(torch, q)).cpu().numpy(), om.crba(q), 1e-10, label="light leaf crba")
+    # two light bodies at the end: the composite of the last two is 1e-7 exactly at the threshold's wrong side
+    sys2 = _chain_with_axes(rng, axes, tiny_mass_bodies=(4, 5))
+    desc2 = sys2.toModelDesc()
+    hm2, om2 = HipModel(desc2), OracleModel(desc2)
+    q, qd, qdd, tau = rt.nextState(rng, sys2, 64)
+    close(hm2.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), G).cpu().numpy(), om2.rnea(q, qd, qdd, G), 1e-10, label="two light bodies rnea")
+    H = hm2.crba(dev(torch, q)).cpu().numpy()
+    zero = np.zeros_like(qd)
+    for j in range(desc2.nv):
+        e = zero.copy()
+        e[:, j] = 1.0
+        col = hm2.rnea(dev(torch, q), dev(torch, zero), dev(torch, e), (0.0, 0.0, 0.0)).cpu().numpy()
+        assert np.abs(H[:, :, j] - col).max() <= 1e-10 * max(1.0, np.abs(col).max()), j
+    assert np.abs(H - om2.crba(q)).max() <= 1e-6  # the reference's un-renormalised composite: differs by less than the masses it concerns
+
+
+def test_zero_length_batches_on_every_entry_point(torch_cuda):
+    """B = 0 is MH_OK and touches nothing, with NULL data pointers, on every compute entry point of include/mecano_hip.h (device- and
+    host-pointer forms, fp64 and fp32)."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    lib = _lib.load()
+    hm = HipModel(rt.nextHumanoid(np.random.default_rng(10)).toModelDesc())
+    h = hm._h
+    g = (ctypes.c_double * 3)(0.0, 0.0, -9.81)
+    N = None
+    calls = {
+        "mh_rnea_f64": (h, 0, N, N, N, g, N, N, N), "mh_aba_f64": (h, 0, N, N, N, g, N, N, N), "mh_crba_f64": (h, 0, N, N, N),
+        "mh_rnea_f32": (h, 0, N, N, N, g, N, N, N), "mh_aba_f32": (h, 0, N, N, N, g, N, N, N), "mh_crba_f32": (h, 0, N, N, N),
+        "mh_rnea_aba_f64": (h, 0, N, N, N, N, g, N, N, N, N), "mh_rnea_aba_f32": (h, 0, N, N, N, N, g, N, N, N, N),
+        "mh_rnea_crba_f64": (h, 0, N, N, N, g, N, N, N, N),
+        "mh_aba_locked_f64": (h, 0, N, N, N, N, g, N, N, N, N), "mh_aba_locked_f32": (h, 0, N, N, N, N, g, N, N, N, N),
+        "mh_rnea_bodies_f64": (h, 0, N, N, N, g, N, N, N, N, N), "mh_aba_bodies_f64": (h, 0, N, N, N, g, N, N, N, N, N),
+        "mh_rnea_bodies_f32": (h, 0, N, N, N, g, N, N, N, N, N), "mh_aba_bodies_f32": (h, 0, N, N, N, g, N, N, N, N, N),
+        "mh_rnea_joint_wrenches_f64": (h, 0, N, N, N, g, N, N, N, N), "mh_aba_joint_wrenches_f64": (h, 0, N, N, N, g, N, N, N, N),
+        "mh_crba_coriolis_f64": (h, 0, N, N, N, N, N), "mh_crba_coriolis_f32": (h, 0, N, N, N, N, N),
+        "mh_centroidal_f64": (h, 0, N, N, N, 0, N, N, N, N), "mh_centroidal_f32": (h, 0, N, N, N, 0, N, N, N, N),
+        "mh_integrate_f64": (h, 0, 1e-3, N, N, N, N, N, N, N), "mh_integrate_f32": (h, 0, 1e-3, N, N, N, N, N, N, N),
+        "mh_aba_integrate_f64": (h, 0, 1e-3, N, N, N, g, N, N, N, N, N),
+        "mh_regressor_f64": (h, 0, N, N, N, g, N, 0, N), "mh_regressor_f32": (h, 0, N, N, N, g, N, 0, N),
+        "mh_rnea_f64_host": (h, 0, N, N, N, g, N, N, N), "mh_aba_f64_host": (h, 0, N, N, N, g, N, N, N), "mh_crba_f64_host": (h, 0, N, N, N),
+        "mh_rnea_f32_host": (h, 0, N, N, N, g, N, N, N), "mh_aba_f32_host": (h, 0, N, N, N, g, N, N, N), "mh_crba_f32_host": (h, 0, N, N, N),
+        "mh_rnea_aba_f64_host": (h, 0, N, N, N, N, g, N, N, N, N),
+        "mh_crba_coriolis_f64_host": (h, 0, N, N, N, N, N), "mh_centroidal_f64_host": (h, 0, N, N, N, 0, N, N, N, N),
+    }
+    for name, args in calls.items():
+        assert getattr(lib, name)(*args) == _lib.MH_OK, (name, lib.mh_last_error())
+    base = np.zeros(4, dtype=np.int32)
+    assert lib.mh_relative_acceleration_f64(h, 0, N, N, N, g, 0, base.ctypes.data, base.ctypes.data, N, N) == _lib.MH_OK
+    # the Python mirror: empty tensors in, empty tensors out
+    e = lambda n: torch.empty((0, n), dtype=torch.float64, device="cuda")
+    assert hm.rnea(e(hm.nq), e(hm.nv), e(hm.nv), G).shape == (0, hm.nv)
+    assert hm.aba(e(hm.nq), e(hm.nv), e(hm.nv), G).shape == (0, hm.nv)
+    assert hm.crba(e(hm.nq)).shape == (0, hm.nv, hm.nv)
+    assert lib.mh_reserve(h, 0) == _lib.MH_OK and lib.mh_model_check(h, None, None) == _lib.MH_OK

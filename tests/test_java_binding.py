@@ -142,14 +142,15 @@ def test_options_helper_writes_at_the_struct_offsets():
     for name, kind, count in fields:
         offsets[name] = ofs
         ofs += (count if kind == "PAD" else SIZE[kind] * count)
-    body = re.search(r"static MemorySegment options\(Arena arena, boolean considerCoriolis, boolean considerAccelerations, double\[\] rootAcceleration\)\s*\{(.*?)\n   \}",
+    body = re.search(r"static MemorySegment options\(Arena arena, boolean considerCoriolis, boolean considerAccelerations, double\[\] rootAcceleration, MemorySegment context\)\s*\{(.*?)\n   \}",
                      NATIVE, flags=re.S).group(1)
     sets = re.findall(r"options\.set\((\w+),\s*([^,]+),", body)
     assert (("JAVA_INT", str(offsets["consider_coriolis"])) in sets and ("JAVA_INT", str(offsets["consider_accelerations"])) in sets
             and ("JAVA_INT", str(offsets["layout"])) in sets and ("JAVA_INT", str(offsets["use_root_acceleration"])) in sets
             and ("ADDRESS", str(offsets["stream"])) in sets), sets
     assert ("JAVA_DOUBLE", f"{offsets['root_acceleration']} + 8L * k") in sets, sets
-    assert size == 72
+    assert ("ADDRESS", str(offsets["context"])) in sets, sets  # mh_options.context (MH_ABI_VERSION 4): the calls of a HipDeviceBatch name its context
+    assert size == 80
 
 
 def test_abi_version_constants_agree():
