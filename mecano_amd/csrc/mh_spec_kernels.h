@@ -1828,14 +1828,27 @@ MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
       warm_scalar_cache(A.m.dof_map, nv * 4);
       warm_scalar_cache(A.m.cfg_map, nq * 4);
    }
+#ifdef MH_PROBE // experiment builds: 100 MHz real-time stamps per 64-configuration slice, written behind the B * nv results (tools/exp_c2_floor.py)
+#define MH_WSTAMP(k)                                                                                                                       \
+   do                                                                                                                                      \
+   {                                                                                                                                       \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                                      \
+      if (threadIdx.x == 0)                                                                                                                \
+         ((unsigned long long *)(A.out + A.B * nv))[(cfg0 / 64) * 32 + (k)] = t_;                                                          \
+   } while (0)
+#else
+#define MH_WSTAMP(k)
+#endif
    for (long cfg0 = wave * 64; cfg0 < A.B; cfg0 += nwaves * 64)
    {
       const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+      MH_WSTAMP(0);
       if constexpr (IO_LDS)
       {
          wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs()>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
          __syncthreads();
       }
+      MH_WSTAMP(1);
       if ((int)threadIdx.x < rows)
       {
          CX cx;
@@ -1852,6 +1865,7 @@ MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
          else
          {
             aba_roots_in<TP, T, CX>(cx);
+            MH_WSTAMP(4);
             // The hand-over store must really be memory, and the outward sweep must recompute the body velocities from
             // re-read inputs: if the compiler recognises values (or addresses) of the inward sweep it keeps them alive across
             // the turn-around -- 6 N velocities, N * 9 slot addresses -- and spills kilobytes per lane to scratch.
@@ -1860,12 +1874,14 @@ MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
             aba_roots_out<TP, T, CX>(cx);
          }
       }
+      MH_WSTAMP(2);
       if constexpr (IO_LDS)
       {
          __syncthreads();
          wave_copy_out<T>(A.out + cfg0 * nv, lx, rows * nv);
          __syncthreads();
       }
+      MH_WSTAMP(3);
    }
 }
 

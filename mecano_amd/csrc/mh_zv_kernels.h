@@ -1076,21 +1076,29 @@ struct ZvbPlan
 // LDS rows are free (both launches loop over groups with two workgroups per CU: a wave that sits waiting for its rows is a quarter of what
 // the SIMD has to run).  Stamps at B = 262 144 (profiles/r04_zvb_phase_stamps.txt): staging q, qd, tau took 3.2 of the bias launch's 11.3 us
 // per group, the (cos, sin) pairs and the bias rows ~2 of the inertia launch's 11.4.
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on gfx950 waits for
+// EVERY outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0)): loads requested ahead of time would be waited for at the
+// first barrier behind them.  Safe where no wave of the workgroup reads global memory another wave of it wrote.
+MH_DEV void zv_lds_barrier()
+{
+   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <typename T, int N, int NT>
 struct RowRegs
 {
    static constexpr int U = (64 * N + NT - 1) / NT;
    T r[U];
-   MH_DEV void issue(const T *src, int rows)
-   {
-      const int n = rows * N, t = threadIdx.x;
+   // t: this thread's number among the NT that take part (threadIdx.x when all 256 do; threadIdx.x - 64 when waves 1-3 load for the group)
+   MH_DEV void issue(const T *src, int rows, int t = threadIdx.x)
+   { // rows >= 1.  Entries past the last row are clamped onto it, not selected away: a select on the loaded value makes the load a
+     // synchronous one (the wave waits for it right here -- 1.4 us per group on the stamps), and nobody reads those LDS entries anyway
+      const int last = rows * N - 1;
 #pragma unroll
       for (int u = 0; u < U; u++)
-         r[u] = t + NT * u < n ? src[t + NT * u] : T(0);
+         r[u] = src[t + NT * u < last ? t + NT * u : last];
    }
-   MH_DEV void commit(lds_ptr<T> dst) const
+   MH_DEV void commit(lds_ptr<T> dst, int t = threadIdx.x) const
    {
-      const int t = threadIdx.x;
 #pragma unroll
       for (int u = 0; u < U; u++)
          if (t + NT * u < 64 * N)
@@ -1111,22 +1119,26 @@ __global__ void __launch_bounds__(256, 2) spec_zvb_bias_kernel(Args<T> A, T *tau
    const int lane = threadIdx.x & 63;
    const int nq = A.m.nq, nv = A.m.nv;
    const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * 6 * 64, lq = lst + S::RNEA_TRUNK_SLOTS * 64, lqd = lq + 64 * nq, lx = lqd + 64 * nv;
-   RowRegs<T, NQ, 256> rq;
-   RowRegs<T, NV, 256> rd, rx;
+   // waves 1-3 stage the rows (wave 0 folds the trunk while the next group's are requested: the workgroup waits for that pass)
+   RowRegs<T, NQ, 192> rq;
+   RowRegs<T, NV, 192> rd, rx;
+   const int loader = (int)threadIdx.x - 64;
    auto request = [&](long k) {
       const long cfg0 = k * 64;
-      const int rows = (int)(A.B - cfg0 < 64 ? (A.B - cfg0 > 0 ? A.B - cfg0 : 0) : 64);
-      rq.issue(A.q + cfg0 * nq, rows), rd.issue(A.qd + cfg0 * nv, rows), rx.issue(A.in3 + cfg0 * nv, rows);
+      const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64); // (k is a group of the batch: at least one row)
+      rq.issue(A.q + cfg0 * nq, rows, loader), rd.issue(A.qd + cfg0 * nv, rows, loader), rx.issue(A.in3 + cfg0 * nv, rows, loader);
    };
    const long ngroups = (A.B + 63) / 64;
-   request(blockIdx.x);
+   if (wave != 0)
+      request(blockIdx.x);
    for (long k = blockIdx.x; k < ngroups; k += gridDim.x)
    {
       const long cfg0 = k * 64;
       const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
       const bool active = lane < rows;
       ZV_STAMP(0, 0);
-      rq.commit(lq), rd.commit(lqd), rx.commit(lx);
+      if (wave != 0)
+         rq.commit(lq, loader), rd.commit(lqd, loader), rx.commit(lx, loader);
       __syncthreads();
       ZV_STAMP(0, 1);
       CX cx;
@@ -1145,14 +1157,15 @@ __global__ void __launch_bounds__(256, 2) spec_zvb_bias_kernel(Args<T> A, T *tau
       ZV_STAMP(0, 3);
       // the next group's rows: in flight during the trunk pass and the copy-out.  (Unconditionally -- the last turn asks for its own group
       // again: under a condition the registers would have to keep the OLD rows alive through the whole loop body, 48 more live registers.)
-      request(k + gridDim.x < ngroups ? k + gridDim.x : k);
-      if (active && wave == 0)
+      if (wave != 0)
+         request(k + gridDim.x < ngroups ? k + gridDim.x : k);
+      else if (active)
          rnea_trunk_roots<TP, T, CX>(cx);
       ZV_STAMP(0, 4);
-      __syncthreads();
+      zv_lds_barrier(); // (__syncthreads() would wait for the rows just requested: its release fence drains the vector-memory counter)
       wave_copy_out<T, 256>(taup + cfg0 * nv, lx, rows * nv);
       ZV_STAMP(0, 5);
-      __syncthreads(); // the LDS rows are free for the next group
+      zv_lds_barrier(); // the LDS rows are free for the next group
       ZV_STAMP(0, 6);
    }
 }

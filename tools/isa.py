@@ -4,10 +4,12 @@ import subprocess, sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from mecano_amd import build as b
 
-name = "humanoid30"
+name = os.environ.get("ISA_MODEL", "humanoid30")  # ISA_MODEL=arm7 ISA_FULL=1: the chain's whole-tree kernels (not in a minimal build)
 desc = b.registered_models()[name]
 key, parents, kinds = b.topology_of(desc)
-defs = [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents), "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-DMH_SPEC_MINIMAL"]
+defs = [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents), "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds)]
+if not os.environ.get("ISA_FULL"):
+    defs.append("-DMH_SPEC_MINIMAL")
 extra = [a for a in sys.argv[1:] if a != "--so"]
 t = time.time()
 if "--so" in sys.argv:
