@@ -31,6 +31,11 @@ SPEC_HEADERS = HEADERS + [os.path.join(CSRC, "mh_spec_kernels.h"), os.path.join(
 # component select for the first row of a multi-DoF joint's diagonal block (tools/diag_f32_crba2.py, DESIGN.md open issues), and packed
 # fp32 VALU is no faster on gfx950 anyway.  fp64 code is unaffected (there are no packed fp64 instructions).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize"]
+# the code objects only.  -disable-machine-licm: the kernels that loop over groups of 64 configurations (persistent workgroups at device-
+# filling batches) are a few thousand instructions of straight-line code per turn; the machine-level loop-invariant code motion lifts the
+# literal constants of that body (sincos coefficients, 1.0, ...) out of the loop into ~24 VGPRs that then live across every phase.  Without
+# it: fused forward dynamics 256 registers + 32 bytes of scratch -> 240 and none, tree-split RNEA 220 -> 190, tree-split CRBA 125 -> 98.
+SPEC_FLAGS = FLAGS + ["-mllvm", "-disable-machine-licm"]
 
 
 # deepest root-to-leaf path (in joints) a topology-specialised code object is built for: the humanoid is 9 deep; a 30-joint chain needs
@@ -106,7 +111,7 @@ def build_spec(desc, force: bool = False, verbose: bool = False) -> str:
     out = spec_path(key)
     if not force and not _stale(out, [SPEC_SOURCE] + SPEC_HEADERS):
         return out
-    cmd = [hipcc()] + FLAGS + [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
+    cmd = [hipcc()] + SPEC_FLAGS + [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
                                "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-o", out, SPEC_SOURCE]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")

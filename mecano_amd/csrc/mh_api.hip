@@ -143,6 +143,9 @@ struct SpecLib
    int (*zvb_cs_rows)(void) = nullptr;
    long (*zvb_lds_bytes)(int which, int nq, int nv) = nullptr;
    int (*launch_zvb)(int flags, const void *args, void *taup, void *cs, long cs_stride, int groups, int which, void *stream) = nullptr;
+   // ... as one launch, both jobs fused in a workgroup (spec_zvf_kernel)
+   int (*zvf_usable)(void) = nullptr;
+   int (*launch_zvf)(int flags, const void *args, int groups, void *stream) = nullptr;
 };
 enum : int
 {
@@ -213,6 +216,7 @@ struct mh_model
    Workspace zvb_cs;      // two-launch forward dynamics: (cos, sin) of the revolute joints, [2 n_rev][B rounded up to 64]
    int use_zvb = 1;       // MH_ZVB=0: never; 1: batches of two or more groups of 64 configurations per CU (default); 2: whenever the call qualifies; MH_ZVB_WHICH = 1 | 2: one of the two launches only (timing)
    int zvb_which = 3;
+   int use_zvf = 1;       // MH_ZVF=0: never the fused one-launch form; 1: where the two-launch form would be taken (default); 2: whenever the call qualifies
    int zv_epoch = 0;
    int *zv_error_host = nullptr, *zv_error_dev = nullptr;
    int zv_same_l2 = 0;    // MH_ZV_SAME_L2=1 (experiment, off by default): bias rows and flag of a group whose two jobs prove to sit behind the same L2
@@ -490,6 +494,17 @@ bool zvb_ok(const mh_model *m, int64_t B, bool soa)
    if (soa || !m->dense_maps || m->force_io == 0 || m->n_locked > 0)
       return false;
    return m->use_zvb == 2 || (B + 63) / 64 >= 2 * (long)m->cu_count;
+}
+// ... and as ONE launch where the code object has the fused kernel (joints below the root all revolute / fixed, identity index maps)
+bool zvf_ok(const mh_model *m, int64_t B, bool soa)
+{
+   if (!m->spec.launch_zvf || !m->spec.zvf_usable || !m->spec.zvf_usable() || !m->use_spec || !m->use_zvf || m->use_split == 0)
+      return false;
+   if (soa || !m->dense_maps || !m->ident_maps || m->force_io == 0 || m->n_locked > 0)
+      return false;
+   // measured (humanoid, one MI355X, profiles/r04_zvf_vs_others.txt): 20.5 us against the one-job kernel's 20.3 at 16 384 (one group per CU:
+   // a tie), 27.0 against 36.4 at 24 576, 28.4 against 37.8 at 32 768, 195.9 against 250.5 at 262 144
+   return m->use_zvf == 2 || (B + 63) / 64 > (long)m->cu_count;
 }
 mh_status zvb_launch(mh_model *m, mh::Args<double> &A, hipStream_t stream, int *rc)
 {
@@ -1100,8 +1115,17 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             return MH_OK;
          A.in3b = nullptr, A.outb = nullptr; // not in this code object: the plans below
       }
+      if (algo == ALGO_ABA && !q_next && zvf_ok(model, B, soa))
+      { // device-filling batches: bias efforts, articulated inertias, fold and outward sweep of a group of 64 configurations by ONE workgroup
+         const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
+         const int rc = model->spec.launch_zvf(SPEC_IO_LDS | SPEC_IDENT, &A, (int)groups, (void *)stream);
+         if (rc == 0)
+            return MH_OK;
+         if (rc != (int)hipErrorNotSupported)
+            return fail(MH_ERR_HIP, "fused forward dynamics failed to launch: %s", hipGetErrorString((hipError_t)rc));
+      }
       if (algo == ALGO_ABA && !q_next && zvb_ok(model, B, soa))
-      { // device-filling batches: bias rows and (cos, sin) pairs by one launch, articulated inertias + fold + outward sweep by the next
+      { // ... or as two launches: bias rows and (cos, sin) pairs by one, articulated inertias + fold + outward sweep by the next
          int rc = 0;
          if (const mh_status sz = zvb_launch(model, A, stream, &rc); sz != MH_OK)
             return sz;
@@ -1547,6 +1571,8 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.zvb_cs_rows = (decltype(s.zvb_cs_rows))dlsym(h, "mh_spec_zvb_cs_rows");
    s.zvb_lds_bytes = (decltype(s.zvb_lds_bytes))dlsym(h, "mh_spec_zvb_lds_bytes");
    s.launch_zvb = (decltype(s.launch_zvb))dlsym(h, "mh_spec_launch_zvb");
+   s.zvf_usable = (decltype(s.zvf_usable))dlsym(h, "mh_spec_zvf_usable");
+   s.launch_zvf = (decltype(s.launch_zvf))dlsym(h, "mh_spec_launch_zvf");
    s.rnea_crba_lds_bytes = (decltype(s.rnea_crba_lds_bytes))dlsym(h, "mh_spec_rnea_crba_lds_bytes");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
@@ -2155,6 +2181,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->zv_wait_ticks = (unsigned)std::max<long long>(1, std::min<long long>(40000, atoll(e))) * 100000u;
    if (const char *e = getenv("MH_ZVB"))
       m->use_zvb = atoi(e);
+   if (const char *e = getenv("MH_ZVF"))
+      m->use_zvf = atoi(e);
    if (const char *e = getenv("MH_ZVB_WHICH"))
       m->zvb_which = std::max(1, std::min(3, atoi(e)));
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
@@ -2463,8 +2491,9 @@ static mh_status build_code_object(const mh_model_desc *desc, const char *out_di
    const std::string tmp = out + ".tmp" + std::to_string((long)getpid());
    // hipcc is started WITHOUT a shell (posix_spawn with an argument vector): a directory name or flag handed in by an application cannot
    // be interpreted as shell syntax.  MH_HIPCC_FLAGS is split at white space into separate arguments.
+   // (the flags of mecano_amd/build.py's SPEC_FLAGS: see there for -disable-machine-licm)
    std::vector<std::string> argv_s = {cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only",
-                                      "-fno-slp-vectorize"};
+                                      "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm"};
    if (!wrapper)
    {
       argv_s.push_back("--driver-mode=g++");
@@ -2589,8 +2618,8 @@ mh_status mh_reserve(mh_model_t m, int64_t max_batch)
       if (st == MH_OK)
          HIP_TRY(hipStreamSynchronize(nullptr)); // the flags are zero before any stream's first launch looks at them
    }
-   if (st == MH_OK && zvb_ok(m, max_batch, false))
-   { // the two-launch forward dynamics of device-filling batches: bias rows and (cos, sin) pairs
+   if (st == MH_OK && zvb_ok(m, max_batch, false) && !zvf_ok(m, max_batch, false))
+   { // the two-launch forward dynamics of device-filling batches (models without the fused kernel): bias rows and (cos, sin) pairs
       st = ensure_bytes(m->zv_tau, (size_t)max_batch * m->nv * sizeof(double));
       if (st == MH_OK)
          st = ensure_bytes(m->zvb_cs, std::max<size_t>(1, (size_t)m->spec.zvb_cs_rows()) * (size_t)((max_batch + 63) / 64 * 64) * sizeof(double));
@@ -3427,7 +3456,7 @@ static void self_check_spec(mh_model *m)
       return MH_OK;
    };
    const int real_cus = m->cu_count;
-   static const char *const kPlanNames[4] = {"small-batch", "device-filling", "tree-split", "device-filling, one job"};
+   static const char *const kPlanNames[5] = {"small-batch", "device-filling", "tree-split", "device-filling, two launches", "device-filling, one job"};
    const bool verbose = getenv("MH_SPEC_SELFCHECK_VERBOSE") != nullptr;
    std::vector<unsigned long long> ref, got; // raw words: see nan_word
    std::string failure;
@@ -3447,26 +3476,31 @@ static void self_check_spec(mh_model *m)
          (void)hipMemcpy(ref.data(), d_out, used * sizeof(double), hipMemcpyDeviceToHost);
          // plan 0: the real CU count; 1: a pretended single CU (device-filling plans); 2: the bias-split forward dynamics switched off
          // (the tree-split kernels it replaced still serve SoA calls, simulation steps and models with acceleration sources)
-         // 3: a pretended single CU with the two-launch forward dynamics switched off (plan 1 takes the two launches where the code object has
-         // them: the one-job kernel's device-filling plan is what serves SoA calls and simulation steps at those sizes)
-         const int zv_was = m->use_zv, zvb_was = m->use_zvb;
+         // 3: a pretended single CU with the fused forward dynamics switched off (the one-job kernel's device-filling plan, plan 4, is what
+         // serves SoA calls and simulation steps at those sizes)
+         // 4: ... with the fused one-launch form switched off as well (plan 1 takes the fused kernel where the code object has it, plan 3 then
+         // the two launches, plan 4 the one-job kernel)
+         const int zv_was = m->use_zv, zvb_was = m->use_zvb, zvf_was = m->use_zvf;
          const bool zv_plan = (what == CK_ABA || what == CK_FUSED) && L == 0 && zv_was && zv_ok(m, B, false, what == CK_FUSED ? 3 : 2);
          m->cu_count = 1;
-         const bool zvb_plan = (what == CK_ABA || what == CK_FUSED || what == CK_STEP) && L == 0 && zvb_was && zvb_ok(m, B, false);
+         const bool fd_aos = (what == CK_ABA || what == CK_FUSED) && L == 0;
+         const bool zvf_plan = fd_aos && zvf_was && zvf_ok(m, B, false), zvb_plan = fd_aos && zvb_was && zvb_ok(m, B, false);
          m->cu_count = real_cus;
-         for (int plan = 0; plan < 4 && failure.empty(); plan++)
+         for (int plan = 0; plan < 5 && failure.empty(); plan++)
          {
-            if ((plan == 2 && !zv_plan) || (plan == 3 && !zvb_plan))
+            if ((plan == 2 && !zv_plan) || (plan == 3 && !(zvf_plan && zvb_plan)) || (plan == 4 && !(zvf_plan || zvb_plan)))
                continue;
-            const int pretend = plan == 1 || plan == 3 ? 1 : 0;
+            const int pretend = plan == 1 || plan >= 3 ? 1 : 0;
             m->cu_count = pretend ? 1 : real_cus;
             m->use_zv = plan == 2 ? 0 : zv_was;
-            m->use_zvb = plan == 3 ? 0 : zvb_was;
+            m->use_zvf = plan >= 3 ? 0 : zvf_was;
+            m->use_zvb = plan == 4 ? 0 : zvb_was;
             st = run(what, L, used);
             const hipError_t sync = hipDeviceSynchronize();
             m->cu_count = real_cus;
             m->use_zv = zv_was;
             m->use_zvb = zvb_was;
+            m->use_zvf = zvf_was;
             if (st == MH_OK)
                st = zv_check_error(m);
             char buf[320];

@@ -374,6 +374,35 @@ int mh_spec_launch_zvb(int flags, const void *args, void *taup, void *cs, long c
    else
       return (int)hipErrorNotSupported;
 }
+// ---- the same as ONE launch (spec_zvf_kernel: bias and inertia job fused in a workgroup); trees whose joints below the root are revolute / fixed
+int mh_spec_zvf_usable(void)
+{
+   if constexpr (SPL::usable())
+      return mh::ZvfPlan<TP>::usable() ? 1 : 0;
+   else
+      return 0;
+}
+long mh_spec_zvf_lds_bytes(void)
+{
+   if constexpr (SPL::usable())
+      return (long)mh::ZvfPlan<TP>::lds_slots() * 64 * (long)sizeof(double);
+   else
+      return 0;
+}
+// args->in3 = tau, args->out = qdd; groups = workgroups of the launch (each loops over the batch's groups of 64 configurations)
+int mh_spec_launch_zvf(int flags, const void *args, int groups, void *stream)
+{
+   if constexpr (SPL::usable())
+   {
+      const mh::Args<double> &A = *(const mh::Args<double> *)args;
+      if (!(flags & F_IO_LDS) || !(flags & F_IDENT) || !mh_spec_zvf_usable() || groups < 1 || A.m.nq != TR::total_cfgs() || A.m.nv != TR::total_dofs())
+         return (int)hipErrorNotSupported;
+      static LdsAttr attr;
+      return (int)launch_lds(&mh::spec_zvf_kernel<TP, double, true>, A, groups, (size_t)mh_spec_zvf_lds_bytes(), attr, (hipStream_t)stream);
+   }
+   else
+      return (int)hipErrorNotSupported;
+}
 // the tree-split plan of this topology, for tests and documentation: out[0] = usable, [1] = staged trunk, [2] = limbs, [3] = sub-trunks,
 // [4] = root trunk body, then per limb (root body, bodies, ABA owner wave, RNEA / CRBA owner wave, late) and per wave the body after
 // whose children its cut barrier sits (-1: explicit barrier).  Returns the number of ints written (<= cap).

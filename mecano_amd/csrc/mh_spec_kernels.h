@@ -193,6 +193,7 @@ struct Split
       // on its way to a limb (f_limb: that limb), and parked in LDS (8 slots per trunk body: wrench, cos, sin)
       int trunk_rank[N] = {};
       int f_limb[N] = {};
+      int f_limb_aba[N] = {}; // the same under the ABA's limb owners (the fused bias + inertia kernel walks its inverse dynamics with those)
       int n_trunk = 0;
       // ---- staged trunk (ABA): see make_stages()
       bool staged = false;
@@ -434,6 +435,35 @@ struct Split
       if (!P.staged)
          for (int k = 0; k < P.n_limbs; k++)
             P.owner[k] = P.owner_plain[k];
+      {  // f_limb under the final ABA owners (see the plain form above)
+         bool walks[N] = {};
+         int load[WAVES] = {}, last_parent[WAVES] = {};
+         for (int w = 0; w < WAVES; w++)
+            last_parent[w] = -2;
+         for (int k = 0; k < P.n_limbs; k++)
+         {
+            const int w = P.owner[k], par = TP::parent[P.root_of[k]];
+            walks[k] = par != last_parent[w] && par >= 0;
+            last_parent[w] = par;
+            load[w] += P.size_of[k];
+         }
+         for (int j = 0; j < N; j++)
+         {
+            P.f_limb_aba[j] = -1;
+            if (!P.trunk[j])
+               continue;
+            for (int k = 0; k < P.n_limbs; k++)
+            {
+               if (!walks[k])
+                  continue;
+               bool through = false;
+               for (int a = TP::parent[P.root_of[k]]; a >= 0; a = TP::parent[a])
+                  through = through || a == j;
+               if (through && (P.f_limb_aba[j] < 0 || load[P.owner[k]] < load[P.owner[P.f_limb_aba[j]]]))
+                  P.f_limb_aba[j] = k;
+            }
+         }
+      }
       // ABA hand-over placement: trunk bodies in LDS (all waves write the same values), limb bodies in the owner's registers
       int regs[WAVES] = {};
       for (int j = 0; j < N; j++)
@@ -472,6 +502,11 @@ struct Split
    static constexpr int owner(int k) { return P.owner[k]; }             // ABA
    static constexpr int owner_plain(int k) { return P.owner_plain[k]; } // RNEA, CRBA
    static constexpr int f_limb(int j) { return P.f_limb[j]; }
+   // OWN = 1: the inverse dynamics walks its limbs with the ABA's owners (fused bias + inertia kernel, mh_zv_kernels.h)
+   template <int OWN>
+   static constexpr int owner_sel(int k) { return OWN ? P.owner[k] : P.owner_plain[k]; }
+   template <int OWN>
+   static constexpr int f_limb_sel(int j) { return OWN ? P.f_limb_aba[j] : P.f_limb[j]; }
    static constexpr int rnea_trunk_slot(int j) { return 8 * P.trunk_rank[j]; }
    static constexpr int RNEA_TRUNK_SLOTS = 8 * P.n_trunk;
    static constexpr bool staged() { return P.staged; }
@@ -577,15 +612,18 @@ struct LaneStore
 // accelerations switched off the inverse-dynamics walk writes tau - h(q, qd) instead of h
 // CSMODE (two-launch forward dynamics of device-filling batches, mh_zv_kernels.h): 1 = the walk also leaves (cos, sin) of every revolute
 // joint in a slot-major scratch matrix, cs[(2 r + {0, 1}) * cs_stride]; 2 = the walk takes them from there, q and qd are read from the
-// caller's matrices (never staged) while in3 / out stay LDS rows, and the bias fold's exchange records are 12 wide instead of 21
+// caller's matrices (never staged) while in3 / out stay LDS rows, and the bias fold's exchange records are 12 wide instead of 21;
+// 3 = bias and inertia job fused in one workgroup (spec_zvf_kernel): the inverse-dynamics walk leaves the pairs and tau - h in the slots
+// of the hand-over store (registers of the limb's owner, LDS for the trunk), nothing travels through memory
 template <typename T, bool IO_LDS, bool IDENT, class SP, bool BODIES = false, int OUTMODE = 0, int CSMODE = 0>
 struct Ctx
 {
    using SPolicy = SP;
    static constexpr int csmode = CSMODE;
-   static constexpr int fold_xw = CSMODE == 2 ? 12 : 21; // width of a limb's record in the bias fold (ZV_XW while the inertias' records are reused)
-   T *cs;          // CSMODE: this configuration's column of the (cos, sin) scratch
+   static constexpr int fold_xw = CSMODE >= 2 ? 12 : 21; // width of a limb's record in the bias fold (ZV_XW while the inertias' records are reused)
+   T *cs;          // CSMODE 1, 2: this configuration's column of the (cos, sin) scratch
    long cs_stride;
+   lds_ptr<T> park; // CSMODE 3: where the inverse dynamics parks the trunk's wrenches (+ lane); see rnea_park
    // BODIES: the kernel also writes every successor body's spatial acceleration / twist (RigidBodyAccelerationProvider; SURVEY.md
    // section 8f N2) -- a property of the context TYPE, so that the kernels without it stay instruction for instruction what they were
    static constexpr bool bodies = BODIES;
@@ -712,6 +750,45 @@ MH_DEV void spec_write(const CX &cx, SV<T> w)
    }
 }
 
+// Fused bias + inertia kernel (CSMODE 3, mh_zv_kernels.h): tau - h of joint J, left by the inverse-dynamics walk where the bias fold of the
+// same workgroup reads it -- the owner's registers for a limb body, the trunk's LDS slots for a trunk body, LDS slots of their own for a
+// root body whose other slots are registers of every wave (the store policy says which: ZvfStore).
+template <class TP, int J, int K, class CX, typename T>
+MH_DEV void zvf_tau_put1(const CX &cx, T v)
+{
+   using SP = typename CX::SPolicy;
+   if constexpr (SP::root_in_regs(J))
+      cx.st.lbase[(SP::root_tau_slot() + K) * 64] = v;
+   else
+      cx.st.template put<J, SP::tau_slot(J) + K>(v);
+}
+template <class TP, int J, int K, class CX, typename T>
+MH_DEV T zvf_tau_get1(const CX &cx)
+{ // (what the bias fold reads: a late limb's entries have moved to LDS by then, zvf_park_late_tau)
+   using SP = typename CX::SPolicy;
+   if constexpr (SP::root_in_regs(J))
+      return cx.st.lbase[(SP::root_tau_slot() + K) * 64];
+   else if constexpr (SP::late_body(J))
+      return cx.st.lbase[(SP::late_tau_slot(J) + K) * 64];
+   else
+      return cx.st.template get<J, SP::tau_slot(J) + K>();
+}
+template <class TP, int J, class CX, typename T>
+MH_DEV void zvf_put_tau(const CX &cx, const SV<T> &h)
+{
+   constexpr int TYPE = TP::type[J], DO = Tree<TP>::dof_ofs(J);
+   if constexpr (TYPE == JT_REVOLUTE)
+      zvf_tau_put1<TP, J, 0, CX, T>(cx, cx.in3(DO) - h.a.z);
+   else if constexpr (TYPE == JT_PRISMATIC)
+      zvf_tau_put1<TP, J, 0, CX, T>(cx, cx.in3(DO) - h.l.z);
+   else if constexpr (TYPE == JT_SIXDOF)
+   {
+      zvf_tau_put1<TP, J, 0, CX, T>(cx, cx.in3(DO + 0) - h.a.x), zvf_tau_put1<TP, J, 1, CX, T>(cx, cx.in3(DO + 1) - h.a.y);
+      zvf_tau_put1<TP, J, 2, CX, T>(cx, cx.in3(DO + 2) - h.a.z), zvf_tau_put1<TP, J, 3, CX, T>(cx, cx.in3(DO + 3) - h.l.x);
+      zvf_tau_put1<TP, J, 4, CX, T>(cx, cx.in3(DO + 4) - h.l.y), zvf_tau_put1<TP, J, 5, CX, T>(cx, cx.in3(DO + 5) - h.l.z);
+   }
+}
+
 // per-body outputs of body J (canonical after-joint frame -> Mecano's body-fixed frame, row MI_EXT of the caller's joint listing)
 template <int J, class CX, typename T>
 MH_DEV void spec_body_outputs(const CX &cx, const SV<T> &acc, const SV<T> &twist)
@@ -790,6 +867,11 @@ struct RneaSub
          constexpr int R = Tree<TP>::rev_index(J);
          cx.cs[(2 * R) * cx.cs_stride] = jx.c, cx.cs[(2 * R + 1) * cx.cs_stride] = jx.s;
       }
+      if constexpr (CX::csmode == 3 && TYPE == JT_REVOLUTE)
+      { // fused kernel: the pair stays in this wave's registers, in the slots the inertia walk of the same limb reads it from
+         cx.st.template put<J, 7>(jx.c);
+         cx.st.template put<J, 8>(jx.s);
+      }
       const V3<T> Z{T(0), T(0), T(0)};
       SV<T> v = motion_down(TYPE, jx, Xb, vp) + vJ;
       const SV<T> a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
@@ -802,7 +884,10 @@ struct RneaSub
       MH_BODY_FENCE();
       children<0>(cx, v, a, f);
       MH_BODY_FENCE();
-      spec_write<TYPE, DO, CX, T>(cx, f);
+      if constexpr (CX::csmode == 3)
+         zvf_put_tau<TP, J, CX, T>(cx, f);
+      else
+         spec_write<TYPE, DO, CX, T>(cx, f);
       // the joint pose is read again rather than kept in 24 SGPRs per tree level across the subtree (which overflows the
       // SGPR file and turns every use into a v_readlane); the pointer is laundered so that the reload is not merged away
       const T *c2p = cx.C + J * MC_STRIDE;
@@ -822,11 +907,21 @@ MH_DEV void rnea_roots(const CX &cx)
       rnea_roots<TP, T, CX, MODE, K + 1>(cx);
    }
 }
+// where the tree-split inverse dynamics parks the trunk's Newton-Euler wrenches: the LDS block of the hand-over store, except in the fused
+// bias + inertia kernel (CSMODE 3), whose store holds the forward dynamics' hand-over there
+template <class CX, typename T>
+MH_DEV lds_ptr<T> rnea_park(const CX &cx)
+{
+   if constexpr (CX::csmode == 3)
+      return cx.park;
+   else
+      return cx.st.lbase;
+}
 // velocity and acceleration of trunk body J, walked down from the root (tree-split kernels: every wave needs them for its limbs)
 // FK = the limb this walk is for: the walk of limb Split<TP>::f_limb(J) also forms the body's own Newton-Euler wrench
 // f = I a + v x* I v - f_ext (InverseDynamicsCalculator.java:935-947) and parks it with (cos, sin) in the LDS trunk area, so that
 // the trunk pass after the barrier is a pure fold of 6-vectors (RneaTrunkUp) instead of a second full walk by one wave
-template <class TP, int J, typename T, class CX, int FK = -1>
+template <class TP, int J, typename T, class CX, int FK = -1, int OWN = 0>
 MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
 {
    constexpr int TYPE = TP::type[J];
@@ -834,7 +929,7 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
    const V3<T> Z{T(0), T(0), T(0)};
    SV<T> vp{Z, Z}, ap{cx.a0a, cx.a0l};
    if constexpr (TP::parent[J] >= 0)
-      trunk_va<TP, TP::parent[J], T, CX, FK>(cx, vp, ap);
+      trunk_va<TP, TP::parent[J], T, CX, FK, OWN>(cx, vp, ap);
    MH_BODY_FENCE();
    const CRef<T, false> c{cx.C + J * MC_STRIDE};
    const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
@@ -847,7 +942,7 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
    a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
    if (!cx.coriolis)
       v = SV<T>{Z, Z};
-   if constexpr (FK >= 0 && Split<TP>::f_limb(J) == FK)
+   if constexpr (FK >= 0 && Split<TP>::template f_limb_sel<OWN>(J) == FK)
    {
       spec_body_outputs<J, CX, T>(cx, a, v);
       const RI<T> I = load_inertia<T>(c);
@@ -855,7 +950,7 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
       if (cx.frow)
          f = f - load_fext<T>(c, cx.frow, cx.f_es, cx.meta[J * MI_STRIDE + MI_EXT]);
       constexpr int S0 = Split<TP>::rnea_trunk_slot(J);
-      const lds_ptr<T> t = cx.st.lbase;
+      const lds_ptr<T> t = rnea_park<CX, T>(cx);
       t[(S0 + 0) * 64] = f.a.x, t[(S0 + 1) * 64] = f.a.y, t[(S0 + 2) * 64] = f.a.z;
       t[(S0 + 3) * 64] = f.l.x, t[(S0 + 4) * 64] = f.l.y, t[(S0 + 5) * 64] = f.l.z;
       t[(S0 + 6) * 64] = jx.c, t[(S0 + 7) * 64] = jx.s;
@@ -890,7 +985,7 @@ struct RneaTrunkUp
       MH_BODY_FENCE();
       constexpr int TYPE = TP::type[J];
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J), S0 = Split<TP>::rnea_trunk_slot(J);
-      const lds_ptr<T> t = cx.st.lbase;
+      const lds_ptr<T> t = rnea_park<CX, T>(cx);
       SV<T> f{V3<T>{t[(S0 + 0) * 64], t[(S0 + 1) * 64], t[(S0 + 2) * 64]}, V3<T>{t[(S0 + 3) * 64], t[(S0 + 4) * 64], t[(S0 + 5) * 64]}};
       JX<T> jx;
       jx.c = t[(S0 + 6) * 64], jx.s = t[(S0 + 7) * 64], jx.d = T(0);
@@ -898,7 +993,17 @@ struct RneaTrunkUp
          jx = spec_joint_from<TYPE, T>(spec_joint_read<TYPE, CO, CX, T>(cx));
       children<0>(cx, f);
       MH_BODY_FENCE();
-      spec_write<TYPE, DO, CX, T>(cx, f);
+      if constexpr (CX::csmode == 3)
+      { // fused bias + inertia kernel: tau - h and (cos, sin) go where the forward dynamics of the same workgroup picks them up
+         zvf_put_tau<TP, J, CX, T>(cx, f);
+         if constexpr (TYPE == JT_REVOLUTE)
+         {
+            cx.st.template put<J, 7>(jx.c);
+            cx.st.template put<J, 8>(jx.s);
+         }
+      }
+      else
+         spec_write<TYPE, DO, CX, T>(cx, f);
       SV<T> up = f;
       if constexpr (TP::parent[J] >= 0)
          up = force_up(TYPE, jx, load_xb_j<TP, J, T>(CRef<T, false>{cx.C + J * MC_STRIDE}), f);
@@ -1919,13 +2024,13 @@ __global__ void __launch_bounds__(64) spec_fused_kernel(Args<T> A)
 // (trunk + its longest limb); the batch occupies 4x as many SIMDs.  Built for small batches, where latency is everything.
 // The limbs of one owner wave W, in limb order.  PC = trunk body whose velocity (and acceleration) the previous limb of this wave
 // hung from (-2: none yet): limbs sharing a parent -- an arm and the neck on the chest -- walk the trunk down to it once.
-template <class TP, int W, int K, int PC, typename T, class CX>
+template <class TP, int W, int K, int PC, typename T, class CX, int OWN = 0>
 MH_DEV void split_rnea_limbs_of(const CX &cx, SV<T> &vp, SV<T> &ap)
 {
    using S = Split<TP>;
    if constexpr (K < S::n_limbs())
    {
-      if constexpr (S::owner_plain(K) == W)
+      if constexpr (S::template owner_sel<OWN>(K) == W)
       {
          constexpr int R = S::limb_root(K), P = TP::parent[R];
          if constexpr (P != PC)
@@ -1933,13 +2038,13 @@ MH_DEV void split_rnea_limbs_of(const CX &cx, SV<T> &vp, SV<T> &ap)
             const V3<T> Z{T(0), T(0), T(0)};
             vp = SV<T>{Z, Z}, ap = SV<T>{cx.a0a, cx.a0l};
             if constexpr (P >= 0)
-               trunk_va<TP, P, T, CX, K>(cx, vp, ap);
+               trunk_va<TP, P, T, CX, K, OWN>(cx, vp, ap);
          }
          x_put6<K, 6, 0, CX, T>(cx, RneaSub<TP, R, T, CX, 0>::run(cx, vp, ap));
-         split_rnea_limbs_of<TP, W, K + 1, P, T, CX>(cx, vp, ap);
+         split_rnea_limbs_of<TP, W, K + 1, P, T, CX, OWN>(cx, vp, ap);
       }
       else
-         split_rnea_limbs_of<TP, W, K + 1, PC, T, CX>(cx, vp, ap);
+         split_rnea_limbs_of<TP, W, K + 1, PC, T, CX, OWN>(cx, vp, ap);
    }
 }
 template <class TP, int W, int K, int PC, typename T, class CX>
@@ -1965,7 +2070,7 @@ MH_DEV void split_aba_limbs_of(const CX &cx, SV<T> &vp)
          split_aba_limbs_of<TP, W, K + 1, PC, T, CX>(cx, vp);
    }
 }
-template <class TP, int W, typename T, class CX>
+template <class TP, int W, typename T, class CX, int OWN = 0>
 MH_DEV void split_rnea_limbs(const CX &cx)
 {
    if constexpr (W < 4)
@@ -1974,10 +2079,10 @@ MH_DEV void split_rnea_limbs(const CX &cx)
       {
          const V3<T> Z{T(0), T(0), T(0)};
          SV<T> vp{Z, Z}, ap{Z, Z};
-         split_rnea_limbs_of<TP, W, 0, -2, T, CX>(cx, vp, ap);
+         split_rnea_limbs_of<TP, W, 0, -2, T, CX, OWN>(cx, vp, ap);
       }
       else
-         split_rnea_limbs<TP, W + 1, T, CX>(cx);
+         split_rnea_limbs<TP, W + 1, T, CX, OWN>(cx);
    }
 }
 template <class TP, int W, typename T, class CX>

@@ -52,6 +52,71 @@ struct ZvbStore
    static constexpr int index(int j) { return root_in_regs(j) ? S::zv_reg_slots() : (S::is_trunk(j) ? trunk_slot(j) : S::zv_reg_slot(j)); }
    static constexpr bool shared(int j) { return kind(j) == ST_REG_KIND; }
 };
+// The store of the FUSED bias + inertia kernel (spec_zvf_kernel): as ZvbStore, plus room for tau - h of every joint -- the inverse dynamics
+// of the same workgroup leaves it there instead of in rows of a scratch matrix.  A limb body: ndof more registers of its owner behind its
+// bias-split slots.  A trunk body in LDS: ndof more slots (of their own: a plain split folds the trunk on every wave at its own pace, so
+// the result may not overwrite the effort it was formed from).  A root body kept in registers: its tau - h in ndof LDS slots behind the
+// trunk's (every wave folds the root, one wave computed the efforts).
+template <class TP>
+struct ZvfStore
+{
+   using S = Split<TP>;
+   using TR = Tree<TP>;
+   static constexpr bool root_in_regs(int j) { return S::staged() && j == S::root(); }
+   static constexpr int limb_slots(int j) { return TR::zv_slots_of(j, true) + TR::ndof(j); }
+   static constexpr int reg_slot(int j)
+   { // registers of the limb bodies before j that the same wave owns
+      int s = 0;
+      for (int i = 0; i < j; i++)
+         s += !S::is_trunk(i) && S::owner(S::limb_index_of_body(i)) == S::owner(S::limb_index_of_body(j)) ? limb_slots(i) : 0;
+      return s;
+   }
+   static constexpr int limb_reg_slots()
+   {
+      int best = 0;
+      for (int w = 0; w < 4; w++)
+      {
+         int n = 0;
+         for (int j = 0; j < TP::N; j++)
+            n += !S::is_trunk(j) && S::owner(S::limb_index_of_body(j)) == w ? limb_slots(j) : 0;
+         best = n > best ? n : best;
+      }
+      return best;
+   }
+   static constexpr int REG_SLOTS = limb_reg_slots() + (S::staged() ? TR::zv_slots_of(S::root() < 0 ? 0 : S::root(), true) : 0);
+   static constexpr int trunk_slot(int j)
+   {
+      int s = 0;
+      for (int i = 0; i < j; i++)
+         s += S::is_trunk(i) && !root_in_regs(i) ? TR::zv_slots_of(i, false) + TR::ndof(i) : 0;
+      return s;
+   }
+   static constexpr int root_tau_slot() { return trunk_slot(TP::N); }
+   static constexpr int ROOT_TAU_SLOTS = S::staged() ? TR::ndof(S::root() < 0 ? 0 : S::root()) : 0;
+   // tau - h of the bodies of a LATE limb (the long ones: the legs) leaves its owner's registers before the inertia walk of that limb --
+   // the walk that sets the kernel's register count -- and waits for the fold in LDS slots behind the trunk's (zvf_park_late_tau)
+   // (and of every other limb of a wave that owns a late one -- the neck beside a leg: the same wave's registers)
+   static constexpr bool owns_late(int w)
+   {
+      for (int k = 0; k < S::n_limbs(); k++)
+         if (S::is_late(k) && S::owner(k) == w)
+            return true;
+      return false;
+   }
+   static constexpr bool late_body(int j) { return S::staged() && !S::is_trunk(j) && owns_late(S::owner(S::limb_index_of_body(j))); }
+   static constexpr int late_tau_slot(int j)
+   {
+      int s = trunk_slot(TP::N) + ROOT_TAU_SLOTS;
+      for (int i = 0; i < j; i++)
+         s += late_body(i) ? TR::ndof(i) : 0;
+      return s;
+   }
+   static constexpr int TRUNK_SLOTS = late_tau_slot(TP::N); // trunk bodies | the root's tau - h | the late limbs' tau - h
+   static constexpr int tau_slot(int j) { return TR::zv_slots_of(j, !S::is_trunk(j)); } // (not for a root kept in registers: root_tau_slot)
+   static constexpr int kind(int j) { return S::is_trunk(j) && !root_in_regs(j) ? ST_LDS_KIND : ST_REG_KIND; }
+   static constexpr int index(int j) { return root_in_regs(j) ? limb_reg_slots() : (S::is_trunk(j) ? trunk_slot(j) : reg_slot(j)); }
+   static constexpr bool shared(int j) { return kind(j) == ST_REG_KIND; }
+};
 #ifdef MH_ZV_PROBE // experiment builds: 100 MHz real-time stamps per group, job, wave and phase (tools/exp_zv_probe.py)
 __device__ unsigned long long zv_probe[4096 * 3 * 4 * 16];
 #define ZV_STAMP(job, ph)                                                                                                                  \
@@ -64,6 +129,22 @@ __device__ unsigned long long zv_probe[4096 * 3 * 4 * 16];
 #else
 #define ZV_STAMP(job, ph)
 #endif
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on gfx950 waits for
+// EVERY outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0)): loads requested ahead of time would be waited for at the
+// first barrier behind them.  Safe where no wave of the workgroup reads global memory another wave of it wrote.
+MH_DEV void zv_lds_barrier()
+{
+   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// the barriers of the bias fold: the fused kernel (CSMODE 3) has the next group's rows in flight across them
+template <class CX>
+MH_DEV void zv_fold_barrier()
+{
+   if constexpr (CX::csmode == 3)
+      zv_lds_barrier();
+   else
+      __syncthreads();
+}
 constexpr int ZV_XW = 21; // limb -> trunk exchange record: the articulated inertia (A 6, L 6, C 9); the bias fold reuses its first 6 slots
 
 template <int LIMB, class CX, typename T>
@@ -244,8 +325,8 @@ struct ZvIn
       const T *cp = cx.C + J * MC_STRIDE;
       asm volatile("" : "+s"(cp)); // the constants are read where they are used, never kept across a subtree
       const CRef<T, false> c{cp};
-      // (cos, sin) already in the body's slots: limbs (ZvPre ran, zv_limbs_in_of); CSMODE 2: the bodies of a staged sub-trunk too (ZvPreTrunk)
-      constexpr bool PRE = TYPE == JT_REVOLUTE && ((!Split<TP>::is_trunk(J) && (MODE == 0 || MODE == 3)) || (CX::csmode == 2 && Split<TP>::staged() && Split<TP>::is_trunk(J) && MODE == 1));
+      // (cos, sin) already in the body's slots: limbs (ZvPre ran, zv_limbs_in_of); CSMODE 2: the bodies of a staged sub-trunk too (ZvPreTrunk); CSMODE 3: every body (left there by the inverse dynamics of the same workgroup)
+      constexpr bool PRE = TYPE == JT_REVOLUTE && ((!Split<TP>::is_trunk(J) && (MODE == 0 || MODE == 3)) || (CX::csmode == 2 && Split<TP>::staged() && Split<TP>::is_trunk(J) && MODE == 1) || (CX::csmode == 3 && Split<TP>::is_trunk(J)));
       JQ<T> jq;
       JX<T> jx;
       if constexpr (TYPE == JT_REVOLUTE && CX::csmode == 2 && !PRE)
@@ -352,7 +433,11 @@ struct ZvFold
       SV<T> up{Z, Z};
       if constexpr (TYPE == JT_REVOLUTE || TYPE == JT_PRISMATIC)
       {
-         const T tau = cx.in3(DO);
+         T tau;
+         if constexpr (CX::csmode == 3)
+            tau = zvf_tau_get1<TP, J, 0, CX, T>(cx);
+         else
+            tau = cx.in3(DO);
          JX<T> jx;
          jx.c = T(1), jx.s = T(0), jx.d = T(0);
          if constexpr (TYPE == JT_REVOLUTE)
@@ -373,7 +458,12 @@ struct ZvFold
       }
       else if constexpr (TYPE == JT_SIXDOF)
       {
-         const SV<T> tau = spec_vec<TYPE, DO, 1, CX, T>(cx, true);
+         SV<T> tau;
+         if constexpr (CX::csmode == 3)
+            tau = SV<T>{V3<T>{zvf_tau_get1<TP, J, 0, CX, T>(cx), zvf_tau_get1<TP, J, 1, CX, T>(cx), zvf_tau_get1<TP, J, 2, CX, T>(cx)},
+                        V3<T>{zvf_tau_get1<TP, J, 3, CX, T>(cx), zvf_tau_get1<TP, J, 4, CX, T>(cx), zvf_tau_get1<TP, J, 5, CX, T>(cx)}};
+         else
+            tau = spec_vec<TYPE, DO, 1, CX, T>(cx, true);
          const SV<T> x = spd6_solve(st_get_ldl<J, CX, T>(cx), tau - pA);
          cx.st.template put<J, RS + 0>(x.a.x), cx.st.template put<J, RS + 1>(x.a.y), cx.st.template put<J, RS + 2>(x.a.z);
          cx.st.template put<J, RS + 3>(x.l.x), cx.st.template put<J, RS + 4>(x.l.y), cx.st.template put<J, RS + 5>(x.l.z);
@@ -501,7 +591,8 @@ MH_DEV void zv_limbs_in_of(const CX &cx)
    {
       if constexpr (S::owner(K) == W && (LATE < 0 || (S::is_late(K) ? 1 : 0) == LATE))
       {
-         ZvPre<TP, S::limb_root(K), T, CX>::run(cx);
+         if constexpr (CX::csmode != 3) // (CSMODE 3: the inverse dynamics of this workgroup left the pairs in the slots)
+            ZvPre<TP, S::limb_root(K), T, CX>::run(cx);
          x_put_ia<K, CX, T>(cx, ZvIn<TP, S::limb_root(K), T, CX, (LATE >= 0 && S::cut_limb(W) == K ? 3 : 0)>::run(cx));
       }
       zv_limbs_in_of<TP, W, K + 1, LATE, T, CX>(cx);
@@ -519,6 +610,27 @@ MH_DEV void zv_subtrunks_of(const CX &cx)
       zv_subtrunks_of<TP, W, I + 1, T, CX>(cx);
    }
 }
+// fused kernel: wave W moves tau - h of its late limbs' joints from its registers to their LDS slots (ZvfStore::late_tau_slot)
+template <class TP, int W, int J, typename T, class CX>
+MH_DEV void zvf_park_late_tau(const CX &cx)
+{
+   using SP = typename CX::SPolicy;
+   if constexpr (J < TP::N)
+   {
+      if constexpr (SP::late_body(J) && Split<TP>::owner(Split<TP>::limb_index_of_body(J)) == W)
+      {
+         constexpr int TS = SP::tau_slot(J), L0 = SP::late_tau_slot(J);
+         cx.st.lbase[L0 * 64] = cx.st.template get<J, TS>();
+         if constexpr (Tree<TP>::ndof(J) == 6)
+         {
+            cx.st.lbase[(L0 + 1) * 64] = cx.st.template get<J, TS + 1>(), cx.st.lbase[(L0 + 2) * 64] = cx.st.template get<J, TS + 2>();
+            cx.st.lbase[(L0 + 3) * 64] = cx.st.template get<J, TS + 3>(), cx.st.lbase[(L0 + 4) * 64] = cx.st.template get<J, TS + 4>();
+            cx.st.lbase[(L0 + 5) * 64] = cx.st.template get<J, TS + 5>();
+         }
+      }
+      zvf_park_late_tau<TP, W, J + 1, T, CX>(cx);
+   }
+}
 // limb phases of the inward sweep, wave by wave; a staged trunk passes its first barrier in here exactly once per wave
 template <class TP, int W, typename T, class CX>
 MH_DEV void zv_limbs_in(const CX &cx)
@@ -528,6 +640,8 @@ MH_DEV void zv_limbs_in(const CX &cx)
    {
       if (cx.wave == W)
       {
+         if constexpr (CX::csmode == 3)
+            zvf_park_late_tau<TP, W, 0, T, CX>(cx);
          if constexpr (S::staged())
          {
             if constexpr (CX::csmode == 2)
@@ -705,8 +819,14 @@ MH_DEV void zv_subtrunks_fold_of(const CX &cx)
 // (their results go to the trunk's LDS slots) | barrier | the root body alone on every wave | the outward sweep over the part of the
 // trunk W needs.  The serial chain is max(early limbs + sub-trunk, late limbs) + root instead of (all limbs of a wave) + (whole trunk).
 // Plain split: limbs | barrier | whole trunk on every wave | pruned outward sweep.  Every wave passes the same number of barriers.
-template <class TP, int W, typename T, class CX>
-MH_DEV void zv_fold_out(const CX &cx)
+struct ZvNoHook
+{
+   MH_DEV void operator()() const {}
+};
+// HOOK: called by every wave between its fold and its outward sweep (the fused kernel requests the next group's rows there: the root's
+// factor and the fold's temporaries are dead, the request has the outward sweep and the copy-out to land)
+template <class TP, int W, typename T, class CX, class HOOK = ZvNoHook>
+MH_DEV void zv_fold_out(const CX &cx, const HOOK &hook = HOOK())
 {
    using S = Split<TP>;
    if constexpr (W < 4)
@@ -720,29 +840,31 @@ MH_DEV void zv_fold_out(const CX &cx)
 #endif
             zv_limbs_fold_sel<TP, W, 0, 0, T, CX>(cx);
             ZV_STAMP(1, 7);
-            __syncthreads();
+            zv_fold_barrier<CX>();
             zv_limbs_fold_sel<TP, W, 0, 1, T, CX>(cx);
             zv_subtrunks_fold_of<TP, W, 0, T, CX>(cx);
             ZV_STAMP(1, 8);
-            __syncthreads();
+            zv_fold_barrier<CX>();
             (void)ZvFold<TP, S::root(), T, CX, 2>::run(cx);
             ZV_STAMP(1, 9);
          }
          else
          {
             zv_limbs_fold_sel<TP, W, 0, -1, T, CX>(cx);
-            __syncthreads();
+            zv_fold_barrier<CX>();
             zv_roots_fold<TP, T, CX>(cx);
          }
          // CSMODE 2 writes the accelerations IN PLACE over the bias rows (no LDS left for rows of their own at two workgroups per CU): no
-         // wave may start writing while another still folds the trunk, whose efforts it reads from those rows
-         if constexpr (CX::csmode == 2)
-            __syncthreads();
+         // wave may start writing while another still folds the trunk, whose efforts it reads from those rows (CSMODE 3: its result rows
+         // lie over the fold's exchange records)
+         if constexpr (CX::csmode >= 2)
+            zv_fold_barrier<CX>();
+         hook();
          asm volatile("" ::: "memory");
          zv_roots_out_wave<TP, W, T, CX>(cx);
       }
       else
-         zv_fold_out<TP, W + 1, T, CX>(cx);
+         zv_fold_out<TP, W + 1, T, CX, HOOK>(cx, hook);
    }
 }
 
@@ -1076,13 +1198,6 @@ struct ZvbPlan
 // LDS rows are free (both launches loop over groups with two workgroups per CU: a wave that sits waiting for its rows is a quarter of what
 // the SIMD has to run).  Stamps at B = 262 144 (profiles/r04_zvb_phase_stamps.txt): staging q, qd, tau took 3.2 of the bias launch's 11.3 us
 // per group, the (cos, sin) pairs and the bias rows ~2 of the inertia launch's 11.4.
-// A workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on gfx950 waits for
-// EVERY outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0)): loads requested ahead of time would be waited for at the
-// first barrier behind them.  Safe where no wave of the workgroup reads global memory another wave of it wrote.
-MH_DEV void zv_lds_barrier()
-{
-   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 template <typename T, int N, int NT>
 struct RowRegs
 {
@@ -1239,5 +1354,140 @@ __global__ void __launch_bounds__(256, 2) spec_zvb_kernel(Args<T> A, const T *ta
    extern __shared__ double lds_raw[];
    for (long k = blockIdx.x; k * 64 < A.B; k += gridDim.x)
       zvb_aba_group<TP, T, IDENT>(A, k, (lds_ptr<T>)lds_raw, taup, cs, cs_stride);
+}
+
+// ============================================================================================ device-filling batches: ONE launch
+// Both jobs in the same workgroup, one after the other, two workgroups per CU.  The two-launch form pays for its seam: the bias rows and 48
+// (cos, sin) pairs per configuration travel through memory, each launch stages its inputs and copies its outputs, each loop turn has its
+// own barriers and tail (profiles/r04_zvb_phase_stamps.txt: 9.4 + 11.4 us per group, of which ~5 are the seam).  Fused, the inverse dynamics
+// of a group walks its limbs with the FORWARD dynamics' limb owners (Split<TP>::owner_sel<1>), so the pair of a limb joint and its
+// tau - h stay in the registers of the wave that needs them next; the trunk's go to the trunk's LDS slots; nothing is written to memory but
+// the accelerations.  LDS (slots of 64 doubles; humanoid): inverse dynamics [q 31 | qd 30 | tau 30 | limb wrenches 30 | parked trunk
+// wrenches 32] = 153; forward dynamics [trunk slots 39, written by wave 0's trunk pass over the rows of q, which nobody reads any more |
+// exchange area 105] = 144: 78 KB, two workgroups per CU.  Needs every joint below the root to be revolute or fixed (the later phases
+// would read q otherwise, whose rows are gone by then): the benchmark humanoid; other trees keep the two launches.
+template <class TP>
+struct ZvfPlan
+{
+   using S = Split<TP>;
+   using ST = ZvfStore<TP>;
+   static constexpr int NQ = Tree<TP>::total_cfgs(), NV = Tree<TP>::total_dofs();
+   static constexpr bool joints_ok()
+   {
+      for (int j = 0; j < TP::N; j++)
+         if (TP::parent[j] >= 0 && TP::type[j] != JT_REVOLUTE && TP::type[j] != JT_FIXED)
+            return false;
+      return true;
+   }
+   static constexpr int x_slots()
+   { // exchange area: the limbs' inertia records during the inward sweep; afterwards 12 slots per limb for the fold | [64][nv] result rows
+      const int in = S::n_limbs() * ZV_XW, fold = S::n_limbs() * 12 + NV;
+      return in > fold ? in : fold;
+   }
+   static constexpr int rnea_slots() { return NQ + 2 * NV + S::n_limbs() * 6 + S::RNEA_TRUNK_SLOTS; }
+   static constexpr int aba_slots() { return ST::TRUNK_SLOTS + x_slots(); }
+   static constexpr int lds_slots() { return rnea_slots() > aba_slots() ? rnea_slots() : aba_slots(); }
+   // the trunk slots are written while the inverse dynamics' exchange area and parking area are still being read: they must fit under
+   // the rows of q and qd, which are dead by then
+   static constexpr bool usable() { return S::usable() && joints_ok() && ST::TRUNK_SLOTS <= NQ + NV && lds_slots() * 64 * 8 * 2 <= 160 * 1024; }
+};
+template <typename T, int NQ, int NV>
+struct ZvfRows
+{ // the three input matrices' rows of the NEXT group (requested during the fold of the current one)
+   RowRegs<T, NQ, 256> q;
+   RowRegs<T, NV, 256> qd, x;
+   MH_DEV void request(const Args<T> &A, long k)
+   {
+      const long cfg0 = k * 64;
+      const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+      q.issue(A.q + cfg0 * A.m.nq, rows), qd.issue(A.qd + cfg0 * A.m.nv, rows), x.issue(A.in3 + cfg0 * A.m.nv, rows);
+   }
+};
+// one group of 64 configurations; `next`: the group whose rows are requested on the way (the same group again on the last turn)
+template <class TP, typename T, bool IDENT>
+MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRows<T, ZvfPlan<TP>::NQ, ZvfPlan<TP>::NV> &rows_ahead)
+{
+   using S = Split<TP>;
+   using CX = Ctx<T, true, IDENT, ZvfStore<TP>, false, 0, 3>;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const int nq = A.m.nq, nv = A.m.nv;
+   // inverse dynamics: rows | limb wrenches | parked trunk wrenches.  Forward dynamics: trunk slots (over the rows of q / qd) | exchange area.
+   const lds_ptr<T> lq = lds, lqd = lq + 64 * nq, lx = lqd + 64 * nv, lxc1 = lx + 64 * nv, lpark = lxc1 + S::n_limbs() * 6 * 64;
+   const lds_ptr<T> lst = lds, lxc2 = lst + ZvfStore<TP>::TRUNK_SLOTS * 64, lres = lxc2 + S::n_limbs() * 12 * 64;
+   const long cfg0 = k * 64;
+   const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+   const bool active = lane < rows;
+   ZV_STAMP(2, 0);
+#ifndef MH_ZVF_AHEAD
+#define MH_ZVF_AHEAD 1 // experiment knob: 0 = a group's rows are requested when its turn starts
+#endif
+   if constexpr (!MH_ZVF_AHEAD)
+      rows_ahead.request(A, k);
+   rows_ahead.q.commit(lq), rows_ahead.qd.commit(lqd), rows_ahead.x.commit(lx);
+   __syncthreads();
+   ZV_STAMP(2, 1);
+   CX cx;
+   fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+   cx.coriolis = 1, cx.accel = 0;
+   cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = lres + lane * nv;
+   cx.wave = wave;
+   cx.xbase = lxc1 + lane;
+   cx.park = lpark + lane;
+   cx.st.lbase = lst + lane;
+   cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+#ifdef MH_ZV_PROBE
+   cx.own = (unsigned long long)k;
+#endif
+   // ---- inverse dynamics at zero acceleration, limbs by the forward dynamics' owners: pairs and tau - h of the limb joints to registers
+   if (active)
+      split_rnea_limbs<TP, 0, T, CX, 1>(cx);
+   ZV_STAMP(2, 2);
+   __syncthreads(); // the limbs' wrenches are in the exchange area; nobody reads the rows of q and qd any more
+   ZV_STAMP(2, 3);
+   if (active && wave == 0)
+      rnea_trunk_roots<TP, T, CX>(cx); // the trunk's pairs and tau - h: to the trunk's slots (over the rows of q)
+   ZV_STAMP(2, 4);
+   __syncthreads();
+   // ---- articulated inertias
+   cx.xbase = lxc2 + lane;
+   asm volatile("" ::: "memory");
+   if (active) // (lane 0 of every wave is active, so each wave reaches the barrier a staged trunk carries in here)
+      zv_limbs_in<TP, 0, T, CX>(cx);
+   ZV_STAMP(2, 5);
+   __syncthreads(); // every limb's (and sub-trunk's) articulated inertia is in the exchange area
+   ZV_STAMP(2, 6);
+   if (active)
+      zv_roots_in<TP, T, CX, (S::staged() ? 2 : 1)>(cx);
+   ZV_STAMP(2, 7);
+   __syncthreads(); // nobody reads the exchange area's inertias any more
+   if constexpr (MH_ZVF_AHEAD == 1)
+      rows_ahead.request(A, next); // in flight during the fold, the outward sweep and the copy-out (unconditionally: see spec_zvb_bias_kernel)
+   ZV_STAMP(2, 8);
+   // ---- bias fold and outward sweep
+   asm volatile("" ::: "memory");
+   auto ahead = [&]() {
+      if constexpr (MH_ZVF_AHEAD == 2)
+         rows_ahead.request(A, next); // behind the fold: in flight during the outward sweep and the copy-out
+   };
+   if (active) // (lane 0 of every wave is active: each wave reaches the barriers the fold carries in here)
+      zv_fold_out<TP, 0, T, CX>(cx, ahead); // (a ragged group is the last one: what it would request is never committed)
+   ZV_STAMP(2, 10);
+   zv_lds_barrier();
+   wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
+   ZV_STAMP(2, 11);
+   zv_lds_barrier(); // the rows are committed over the result rows by the next turn
+   ZV_STAMP(2, 12);
+}
+template <class TP, typename T, bool IDENT>
+__global__ void __launch_bounds__(256, 2) spec_zvf_kernel(Args<T> A)
+{
+   extern __shared__ double lds_raw[];
+   ZvfRows<T, ZvfPlan<TP>::NQ, ZvfPlan<TP>::NV> rows_ahead;
+   const long ngroups = (A.B + 63) / 64;
+   if constexpr (MH_ZVF_AHEAD)
+      rows_ahead.request(A, blockIdx.x);
+   for (long k = blockIdx.x; k < ngroups; k += gridDim.x)
+      zvf_group<TP, T, IDENT>(A, k, k + gridDim.x < ngroups ? k + gridDim.x : k, (lds_ptr<T>)lds_raw, rows_ahead);
 }
 } // namespace mh

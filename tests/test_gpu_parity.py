@@ -444,9 +444,10 @@ def test_every_specialised_variant(torch_cuda, B):
                         {"MH_SPEC_IO": "1", "MH_SPEC_ST": "0", **off}, {"MH_SPEC_IO": "1", "MH_SPEC_ST": "1", **off}, {"MH_SPEC_SPLIT": "1"}, {},
                         {"MH_ZV": "0"}, {"MH_ZV": "2"},  # bias-split forward dynamics never / at every batch size (default: small batches)
                         {"MH_ZV": "2", "MH_ZV_SAME_L2": "1"},  # ... its hand-off left in a shared L2 where both jobs prove to sit behind one (opt-in)
-                        {"MH_ZV": "0", "MH_ZVB": "2"},  # forward dynamics as two launches at every batch size (default: device-filling batches)
-                        {"MH_ZV": "0", "MH_ZVB": "0"}):  # ... never: the one-job tree-split kernel at every size
-                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB"):
+                        {"MH_ZV": "0", "MH_ZVF": "2"},  # forward dynamics as ONE fused launch (bias + inertia job per workgroup) at every batch size
+                        {"MH_ZV": "0", "MH_ZVF": "0", "MH_ZVB": "2"},  # ... as two launches at every batch size (models without the fused kernel)
+                        {"MH_ZV": "0", "MH_ZVF": "0", "MH_ZVB": "0"}):  # ... never: the one-job tree-split kernel at every size
+                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB", "MH_ZVF"):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 hm = HipModel(d)
@@ -459,7 +460,7 @@ def test_every_specialised_variant(torch_cuda, B):
                 close(t2.cpu().numpy()[idx], t_ref)
                 close(a2.cpu().numpy()[idx], a_ref)
         finally:
-            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB"):
+            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB", "MH_ZVF"):
                 os.environ.pop(k, None)
         assert any(v.startswith("generic") for v in seen) and any(v.startswith("topo:") for v in seen), seen
 
@@ -1728,9 +1729,10 @@ def test_config5_at_its_full_per_gpu_shard(torch_cuda, layout_name):
 
 def test_config4_at_full_size_on_one_gpu(torch_cuda):
     """BASELINE.json configs[3] unsharded: forward dynamics of 262 144 configurations of the humanoid on ONE GPU (what `bench.py --config 4
-    --gpus 1` times): the device-filling plan -- two launches at two workgroups per CU (mh_zv_kernels.h, spec_zvb_*), persistent
-    workgroups looping over the batch.  512 sampled rows against the oracle at the absolute 1e-10, on every row the round trip
-    RNEA(ABA(tau)) = tau, and on every row the one-job tree-split kernel (MH_ZVB=0) to 1e-10."""
+    --gpus 1` times): the device-filling plan -- bias and inertia job fused in one workgroup, two workgroups per CU (mh_zv_kernels.h,
+    spec_zvf_kernel), persistent workgroups looping over the batch.  512 sampled rows against the oracle at the absolute 1e-10, on every
+    row the round trip RNEA(ABA(tau)) = tau, and on every row the two-launch form (MH_ZVF=0) and the one-job tree-split kernel
+    (MH_ZVF=0 MH_ZVB=0) to 1e-10."""
     torch = torch_cuda
     from mecano_amd import random_tools as rt
     from mecano_amd.engine import HipModel
@@ -1750,12 +1752,14 @@ def test_config4_at_full_size_on_one_gpu(torch_cuda):
     back = hm.rnea(tq, tqd, qdd, g)
     assert (back - ttau).abs().max().item() <= 1e-9
     assert torch.equal(qdd.reshape(B // base, base, d.nv)[0], qdd.reshape(B // base, base, d.nv)[-1])
-    os.environ["MH_ZVB"] = "0"
-    try:
-        one_job = HipModel(d).aba(tq, tqd, ttau, g)
-    finally:
-        os.environ.pop("MH_ZVB", None)
-    assert (one_job - qdd).abs().max().item() <= 1e-10
+    for env in ({"MH_ZVF": "0"}, {"MH_ZVF": "0", "MH_ZVB": "0"}):
+        os.environ.update(env)
+        try:
+            other = HipModel(d).aba(tq, tqd, ttau, g)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert (other - qdd).abs().max().item() <= 1e-10, env
 
 
 def test_reference_signatures_on_one_configuration(torch_cuda):

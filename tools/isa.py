@@ -15,9 +15,9 @@ t = time.time()
 if "--so" in sys.argv:
     out_dir = os.environ.get("EXP_DIR", "exp_build")
     os.makedirs(out_dir, exist_ok=True)  # never clobbers the shipped code object: run with MH_SPEC_DIR=exp_build
-    cmd = [b.hipcc()] + b.FLAGS + defs + extra + ["-o", os.path.join(out_dir, os.path.basename(b.spec_path(key))), b.SPEC_SOURCE]
+    cmd = [b.hipcc()] + b.SPEC_FLAGS + defs + extra + ["-o", os.path.join(out_dir, os.path.basename(b.spec_path(key))), b.SPEC_SOURCE]
 else:
     os.makedirs("gpurun_out/isa", exist_ok=True)
-    cmd = [b.hipcc()] + [f for f in b.FLAGS if f not in ("-shared", "-fPIC")] + defs + extra + ["--cuda-device-only", "-S", "-o", "gpurun_out/isa/min.s", b.SPEC_SOURCE]
+    cmd = [b.hipcc()] + [f for f in b.SPEC_FLAGS if f not in ("-shared", "-fPIC")] + defs + extra + ["--cuda-device-only", "-S", "-o", "gpurun_out/isa/min.s", b.SPEC_SOURCE]
 subprocess.check_call(cmd)
 print("built in %.0f s" % (time.time() - t))
