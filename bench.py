@@ -133,7 +133,7 @@ def committed_traffic(fused_launch, B):
     return None, None
 
 
-def _pmc_pass(counters, B, pick):
+def _pmc_pass(counters, B, pick, config=0):
     """One child process under `rocprofv3 --pmc <counters>` (nothing else enabled, the program directly after `--`) running a short form of
     this very command; returns {counter: mean value per launch} over the launches `pick(kernel_name, grid_size)` accepts, or None."""
     import csv, glob, shutil, subprocess, tempfile
@@ -144,7 +144,7 @@ def _pmc_pass(counters, B, pick):
     try:
         env = dict(os.environ, TMPDIR="/tmp", MH_BENCH_PMC_INNER="1")
         subprocess.run([exe, "--pmc"] + list(counters) + ["-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
-                        "--steps", "20", "--warmup", "5", "--regions", "1", "--no-cpu-baseline", "--batch", str(B)],
+                        "--steps", "20", "--warmup", "5", "--regions", "1", "--no-cpu-baseline", "--batch", str(B)] + (["--config", str(config)] if config else []),
                        cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
         vals = {c: [] for c in counters}
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -173,7 +173,14 @@ def headline_kernel_pick(B):
     return lambda name, grid: any(k in name and grid == g for k, g in grids.items())
 
 
-def live_traffic(B):
+def config4_kernel_pick(B):
+    """The launch mh_aba_f64 issues for a device-filling batch of the humanoid: the fused bias + inertia kernel, persistent workgroups (two per
+    CU) looping over the groups of 64 configurations."""
+    wgs = min((B + 63) // 64, 512)
+    return lambda name, grid: "spec_zvf_kernel" in name and grid == wgs * 256
+
+
+def live_traffic(B, config=0):
     """HBM bytes per launch of the dominant kernel, measured for THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, nothing else enabled) run a short form of this very command BEFORE this process touches the GPU; the
     launches of the benchmark's grid are picked out by kernel name and grid size (the create-time self-check launches the same kernel on
@@ -183,19 +190,19 @@ def live_traffic(B):
         return None
     kb = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        got = _pmc_pass([counter], B, headline_kernel_pick(B))
+        got = _pmc_pass([counter], B, config4_kernel_pick(B) if config == 4 else headline_kernel_pick(B), config)
         if got is None:
             return None
         kb[counter] = got[counter]
     return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
 
 
-def live_issue_counters(B):
+def live_issue_counters(B, config=0):
     """SQ counters of the dominant kernel for THIS run (one more child pass, same mechanism): wave-level VALU instructions, wave cycles and
     the cycles waves spent waiting, per launch.  None when unavailable."""
     if not _pmc_allowed():
         return None
-    return _pmc_pass(["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAVES"], B, headline_kernel_pick(B))
+    return _pmc_pass(["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAVES"], B, config4_kernel_pick(B) if config == 4 else headline_kernel_pick(B), config)
 
 
 def self_launch(n):
@@ -244,9 +251,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or unset WORLD_SIZE")
 
     # roofline.traffic measured for this run (N = 1, the metric's configuration), in child processes, before this one touches the GPU
-    headline = args.gpus == 1 and args.config == 0 and not args.separate
-    pmc_bytes = live_traffic(args.batch or BATCH) if headline else None
-    sq = live_issue_counters(args.batch or BATCH) if headline else None
+    headline = args.gpus == 1 and args.config in (0, 4) and not args.separate
+    pmc_batch = args.batch or (262144 if args.config == 4 else BATCH)
+    pmc_bytes = live_traffic(pmc_batch, args.config) if headline else None
+    sq = live_issue_counters(pmc_batch, args.config) if headline else None
 
     import torch
     import torch.distributed as dist
@@ -439,7 +447,8 @@ def main():
                  3: "30-DoF humanoid, RNEA and CRBA (30 x 30 mass matrix) of every configuration per step, fp64, AoS",
                  4: "30-DoF humanoid, ABA of every configuration per step, fp64, AoS, batch sharded over the GPUs",
                  5: "random 128-body tree (revolute / prismatic / 6-DoF joints), RNEA and ABA per step, fp32, AoS, batch sharded over the GPUs"}
-    if pmc_bytes is not None and fused_launch:
+    one_launch = fused_launch or (cfg == 4 and model.kernel_variant.startswith("topo:") and (B + 63) // 64 > 256)  # the counters were picked for that launch
+    if pmc_bytes is not None and one_launch:
         traffic, traffic_source = pmc_bytes, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, child processes of this run), 2 x FETCH + WRITE"
     else:
         traffic, traffic_source = committed_traffic(fused_launch and cfg == 0, B)
@@ -449,7 +458,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / MEASURED_COPY_GBS, "measured_copy": MEASURED_COPY_GBS,
                 "traffic": traffic, "traffic_source": traffic_source, "bytes_per_config": dom_bytes, "launch_ms": dom_ms}
-    if sq is not None and fused_launch and dom_ms > 0:
+    if sq is not None and one_launch and dom_ms > 0:
         simd_cycles = dom_ms * 1e-3 * CLOCK_HZ * N_SIMDS
         roofline.update({"valu_insts_per_launch": sq["SQ_INSTS_VALU"], "waves_per_launch": sq["SQ_WAVES"],
                          "valu_busy_frac": 4.0 * sq["SQ_INSTS_VALU"] / simd_cycles,
@@ -458,6 +467,8 @@ def main():
         few_waves = sq["SQ_WAVES"] <= N_SIMDS
         roofline["limited_by"] = ("instruction issue of single waves (at most one wave per SIMD, traffic far below the HBM roof)"
                                   if few_waves and roofline["frac"] < 0.25 else ("hbm" if roofline["frac"] >= 0.5 else "vector issue / latency"))
+        if cfg == 4:  # launch geometry: persistent workgroups of four waves, two per CU (240 registers, 78 KB of LDS each), resident for the whole launch
+            roofline["waves_per_simd"] = min((B + 63) // 64, 512) * 4 / N_SIMDS
     else:
         roofline["limited_by"] = None
     line = {

@@ -1420,7 +1420,9 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
    const bool active = lane < rows;
    ZV_STAMP(2, 0);
 #ifndef MH_ZVF_AHEAD
-#define MH_ZVF_AHEAD 1 // experiment knob: 0 = a group's rows are requested when its turn starts
+#define MH_ZVF_AHEAD 3 // when the NEXT group's rows are requested: 3 = behind the outward sweep (nothing else alive: 240 registers, no scratch;
+                       // in flight during the copy-out); 1 = before the fold and 2 = behind it (longer in flight, but 96-112 bytes of scratch per
+                       // lane, and with scratch the step is 40 % slower); 0 = when the group's own turn starts (no registers, fully exposed)
 #endif
    if constexpr (!MH_ZVF_AHEAD)
       rows_ahead.request(A, k);
@@ -1473,6 +1475,8 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
    if (active) // (lane 0 of every wave is active: each wave reaches the barriers the fold carries in here)
       zv_fold_out<TP, 0, T, CX>(cx, ahead); // (a ragged group is the last one: what it would request is never committed)
    ZV_STAMP(2, 10);
+   if constexpr (MH_ZVF_AHEAD == 3)
+      rows_ahead.request(A, next); // behind the outward sweep (nothing else is alive any more): in flight during the copy-out
    zv_lds_barrier();
    wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
    ZV_STAMP(2, 11);
