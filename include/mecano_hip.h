@@ -204,6 +204,8 @@ mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, c
  * A context owns everything a compute call writes besides its outputs; the model handle it was made from stays read-only.  Make one per
  * host thread or stream, pass it in opts->context; destroy it before its model.  mh_context_reserve is mh_reserve for a context.
  * While contexts of a model exist mh_model_set_joint_source_modes is refused (the contexts hold copies of the joint records' host side).
+ * A context must be destroyed BEFORE its model (it shares the model's device records); mh_stream_synchronize reports a pending
+ * asynchronous failure of ANY context and clears it -- use mh_model_check where the failing context matters.
  */
 mh_status mh_context_create(mh_model_t model, mh_context_t *ctx_out);
 void mh_context_destroy(mh_context_t ctx);

@@ -2324,10 +2324,12 @@ void mh_model_destroy(mh_model_t m)
    if (!m)
       return;
    if (m->parent)
-   { // (a context handed in by mistake: its model owns the device records)
-      mh_context wrap{m};
-      (void)wrap;
-      return;
+      return; // (the inner handle of a context cannot reach a caller; should one ever be passed here, its model owns the device records)
+   {
+      std::lock_guard<std::mutex> lock(g_context_mutex);
+      if (m->n_contexts > 0)
+         (void)fail(MH_ERR_INVALID_ARGUMENT, "mh_model_destroy: %d context(s) of this model are still alive; destroy them first (they share its device records)",
+                    m->n_contexts); // (void function: the message is left for mh_last_error; the model is destroyed all the same)
    }
    dfs_plans_drop(m);
    split_rt_free(m);

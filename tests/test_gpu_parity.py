@@ -1562,6 +1562,32 @@ def test_bench_launches_its_own_ranks(torch_cuda):
     assert len(line["per_rank"]) == 2
 
 
+def test_config4_strong_scaling_path_on_five_ranks_with_a_ragged_total(torch_cuda):
+    """Pre-flight of the driver's multi-GPU run of BASELINE.json configs[3] (no 8-GPU node is ever in the builder's hands; a GPU box admits six
+    of our processes on its card, so five ranks + their GPU-free parent): `bench.py --gpus 5 --config 4 --batch 262149` -- a total that five
+    does not divide, shards of 52 430 and 52 429 rows, each rank on the fused device-filling kernel, gloo as the transport, the outputs
+    all-gathered once after the timed regions (ragged: padded all-gather).  ONE JSON line: strong scaling, every rank counted, per-rank
+    kernel times, gather_ms, the timed outputs checked against the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MECANO_DIST_BACKEND="gloo", MH_BENCH_NO_PMC="1")
+    total = 262144 + 5
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "5", "--config", "4", "--batch", str(total), "--steps", "3", "--warmup", "1",
+                        "--regions", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 5 and line["scaling"] == "strong" and line["config"]["global_batch"] == total
+    assert line["rccl_ranks"] == {"world_size": 5, "ranks_counted": 5}
+    assert sorted(r["batch"] for r in line["per_rank"]) == [52429, 52430, 52430, 52430, 52430] and [r["rank"] for r in line["per_rank"]] == list(range(5))
+    assert all(r["kernels_ms"]["aba"] > 0 for r in line["per_rank"]) and line["gather_ms"] > 0
+    assert line["check"]["ok"] is True and line["config"]["kernel_variant"].startswith("topo:")
+
+
 @pytest.mark.parametrize("case", ["humanoid", "arm", "torso", "mixed_tree", "floating_onedof_tree", "planar_spherical"])
 def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
     """mh_options.root_acceleration: setRootAcceleration(SpatialAccelerationReadOnly) (InverseDynamicsCalculator.java:413-427,
@@ -1593,10 +1619,14 @@ def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
         cond = "mixed" in case or "planar" in case  # random mixed trees: forward dynamics conditioning (as in test_random_families_match_oracle)
         H_idx = om.crba(q[idx]) if cond else None
         tq, tqd, tqdd, ttau, tf = (dev(torch, x) for x in (q, qd, qdd, tau, fext))
-        for env in ({}, {"MH_DISABLE_SPEC": "1"}, {"MH_ZV": "0"}, {"MH_ZV": "2"}, {"MH_DISABLE_SPEC": "1", "MH_DFS": "0"}):
+        # (at 40 000 the default is the fused device-filling kernel where the code object has it, else the two launches; MH_ZVF=0 / MH_ZVB=0 step down)
+        for env in ({}, {"MH_DISABLE_SPEC": "1"}, {"MH_ZV": "0"}, {"MH_ZV": "2"}, {"MH_ZVF": "0"}, {"MH_ZVF": "0", "MH_ZVB": "0"},
+                    {"MH_DISABLE_SPEC": "1", "MH_DFS": "0"}):
             if B > 9000 and env.get("MH_DFS") == "0":
                 continue
-            for k in ("MH_DISABLE_SPEC", "MH_ZV", "MH_DFS"):
+            if B < 40000 and "MH_ZVF" in env:
+                continue
+            for k in ("MH_DISABLE_SPEC", "MH_ZV", "MH_DFS", "MH_ZVF", "MH_ZVB"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -1629,7 +1659,7 @@ def test_six_dimensional_root_acceleration(torch_cuda, monkeypatch, case):
             lin = np.concatenate([np.zeros(3), a0[3:]])
             assert torch.equal(hm.rnea(tq, tqd, tqdd, lin, tf), hm.rnea(tq, tqd, tqdd, -a0[3:], tf))
             assert torch.equal(hm.aba(tq, tqd, ttau, lin, tf), hm.aba(tq, tqd, ttau, -a0[3:], tf))
-    for k in ("MH_DISABLE_SPEC", "MH_ZV", "MH_DFS"):
+    for k in ("MH_DISABLE_SPEC", "MH_ZV", "MH_DFS", "MH_ZVF", "MH_ZVB"):
         monkeypatch.delenv(k, raising=False)
     # the calculators, as the reference's callers drive them: setRootAcceleration(six components) replaces the gravity term
     B = 64
