@@ -2849,7 +2849,10 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
    const long waves = (B + 63) / 64;
    const bool fusable = model->n_locked == 0 && model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
                         && opts.consider_coriolis && opts.consider_accelerations && 2 * waves <= (long)model->cu_count * model->fused_factor
-                        && model->spec.fused_lds_bytes(model->nq, model->nv) <= 160 * 1024;
+                        && model->spec.fused_lds_bytes(model->nq, model->nv) <= 160 * 1024
+                        // beyond one group per CU the fused forward-dynamics kernel behind mh_aba_f64 is worth more than one launch for both
+                        // (humanoid: 43.1 against 56.6 us at 32 768, 40.0 against 45.5 at 24 576; profiles/r04_pair_call_rates.txt)
+                        && !zvf_ok(model, B, false);
    // No fused kernel for this call (no code object, SoA, switches, ...).  While the batch leaves most of the device idle -- the
    // run-time-topology kernels put one wave per 64 configurations on it -- the two launches run SIDE BY SIDE: the ABA on a stream of the
    // model's own, forked from and joined back into the caller's stream with events, on a workspace of its own (humanoid without its code
