@@ -12,8 +12,10 @@ model is broadcast once over RCCL before timing and the outputs are all-gathered
   --config 5   configs[4]: random 128-body tree, RNEA + ABA, fp32, 1 048 576 sharded       (strong scaling)
   (no flag)    the metric: humanoid RNEA + ABA, fp64, 4096 per GPU                       (weak scaling)
 
-Timing: W warm-up steps, then R >= 5 timed REGIONS of exactly K steps each, every region bracketed by barrier + synchronize on both
-sides; `value` and `ms_per_step` come from the MEDIAN region (max over ranks per region), all regions are listed in `region_ms`.  After
+Timing: --ramp-ms (100) milliseconds of untimed steps for the device's clocks, W warm-up steps, then R >= 5 timed REGIONS of exactly K steps each, every region bracketed by barrier + synchronize on both
+sides; `value` and `ms_per_step` come from the MEDIAN region (max over ranks per region), all regions are listed in `region_ms`.  Each is
+followed by a region of the same K steps with HIP events recorded on the launch stream (`event_region_ms`): the roofline's kernel
+durations come from those, `value` from the regions that carry nothing but the steps.  After
 the timed regions the outputs the last step left in HBM are checked against the CPU oracle on a strided sample (`check`).
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), including
@@ -237,6 +239,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=0, choices=(0, 3, 4, 5), help="BASELINE.json configuration (1-based); default 0 = the metric")
     ap.add_argument("--batch", type=int, default=0, help="configurations per step: per GPU for the weak-scaling workloads, in total for --config 4 / 5")
+    ap.add_argument("--ramp-ms", type=float, default=100.0, help="untimed steps for this long before the W warm-up steps (device clocks; 0: none)")
     ap.add_argument("--regions", type=int, default=REGIONS, help="timed regions of --steps steps each; the median is reported (>= 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate", action="store_true", help="two calls per step (mh_rnea_f64, then mh_aba_f64 / mh_crba_f64) instead of mh_rnea_aba_f64 / mh_rnea_crba_f64")
@@ -328,31 +331,45 @@ def main():
             for job in jobs:
                 run(job)
 
+    # the device's clocks and caches first: the driver's five warm-up steps are 85 us of work, after which the regions still get faster
+    # from one to the next (20 steps: 347 -> 337 us over nine regions; 331 flat after 80 ms of steps: profiles/r04_bench_warmup_sweep.txt)
+    if args.ramp_ms > 0:
+        t_end = time.perf_counter() + args.ramp_ms * 1e-3
+        while time.perf_counter() < t_end:
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    # ---- timed regions: exactly K steps each between barrier + synchronize pairs; HIP events on the launch stream
+    # ---- timed regions: exactly K steps each between barrier + synchronize pairs.  They come in two kinds, interleaved: CLOCK regions carry
+    # nothing but the K steps (`value`, `ms_per_step`, `region_ms`); EVENT regions additionally carry the HIP events on the launch stream
+    # the roofline's kernel durations come from (`kernels_ms`, `event_region_ms`).  The events are instrumentation with a cost of their
+    # own inside a region -- an event pair around 20 steps of the headline: 7-8 us of 340 (profiles/r04_region_overhead.txt) -- so the
+    # figure the metric is quoted on is taken where they are absent, and the host clock of the event regions is printed beside it.
     K, R = args.steps, max(1, args.regions)
-    region_s, kernel_ms = [], {j: [] for j in ((fused_key,) if fused else jobs)}
-    for r in range(R):
+    region_s, event_region_s, kernel_ms = [], [], {j: [] for j in ((fused_key,) if fused else jobs)}
+
+    def region(with_events):
         # fused: ONE event pair brackets the K launches of a region (per-launch event pairs put ~5 us of markers between two ~25 us
         # kernels); average launch duration = elapsed / K, gaps included.  Otherwise one event pair per launch.
-        t_all = HipTimer()
-        per_launch = None if fused else [[HipTimer() for _ in range(K)] for _ in jobs]
+        t_all = HipTimer() if with_events else None
+        per_launch = [[HipTimer() for _ in range(K)] for _ in jobs] if with_events and not fused else None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t_all.start(stream)  # (instrumentation, ahead of the host clock: the event pair then brackets a superset of the K launches)
+        if with_events:
+            t_all.start(stream)  # (ahead of the host clock: the event pair then brackets a superset of the K launches)
         t0 = time.perf_counter()
         for k in range(K):
-            if fused:
-                fused_step()
+            if fused or not with_events:
+                step()
             else:
                 for i, job in enumerate(jobs):
                     per_launch[i][k].start(stream)
                     run(job)
                     per_launch[i][k].stop(stream)
-        t_all.stop(stream)
+        if with_events:
+            t_all.stop(stream)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0  # this rank's K steps, done; the closing barrier + synchronize follow, then the MAX over ranks
         if world > 1:
@@ -362,15 +379,21 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        region_s.append(elapsed)
+        if not with_events:
+            region_s.append(elapsed)
+            return
+        event_region_s.append(elapsed)
         if fused:
             kernel_ms[fused_key].append(t_all.elapsed_ms() / K if K else 0.0)
         else:
             for i, job in enumerate(jobs):
                 kernel_ms[job].append(float(np.mean([t.elapsed_ms() for t in per_launch[i]])) if K else 0.0)
-    order = np.argsort(region_s)
-    med = int(order[len(order) // 2])
-    elapsed = region_s[med]
+
+    for r in range(R):
+        region(False)
+        region(True)
+    elapsed = float(np.sort(region_s)[len(region_s) // 2])
+    med = int(np.argsort(event_region_s)[len(event_region_s) // 2])
     kernels_ms = {j: v[med] for j, v in kernel_ms.items()}
 
     # ---- after the timed regions: one all-gather of the outputs over xGMI (north_star: "a final gather"), per-rank kernel times
@@ -481,7 +504,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B_total, "nq": nq, "nv": nv, "bodies": desc.n_joints,
                    "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
                    "model_seed": MODEL_SEED if cfg != 5 else 128, "state_seed": STATE_SEED},
-        "regions": R, "region_ms": [s * 1e3 for s in region_s], "reported_region": "median",
+        "ramp_ms": args.ramp_ms, "regions": R, "region_ms": [s * 1e3 for s in region_s], "reported_region": "median",
+        "event_region_ms": [s * 1e3 for s in event_region_s],  # the same K steps with the HIP events of `kernels_ms` / `roofline` recorded around them
         "roofline": roofline,
         "kernels_ms": kernels_ms,
         "per_rank": per_rank,

@@ -146,6 +146,7 @@ struct SpecLib
    // ... as one launch, both jobs fused in a workgroup (spec_zvf_kernel)
    int (*zvf_usable)(void) = nullptr;
    int (*launch_zvf)(int flags, const void *args, int groups, void *stream) = nullptr;
+   int (*launch_rnea_ahead)(int flags, const void *args, int groups, void *stream) = nullptr;
 };
 enum : int
 {
@@ -214,6 +215,7 @@ struct mh_model
    // an error word in mapped host memory that a timed-out wait sets (read at the next call of the model)
    Workspace zv_tau, zv_flags;
    Workspace zvb_cs;      // two-launch forward dynamics: (cos, sin) of the revolute joints, [2 n_rev][B rounded up to 64]
+   int use_rnea_ahead = 1; // MH_RNEA_AHEAD (see rnea_ahead_ok)
    int use_zvb = 1;       // MH_ZVB=0: never; 1: batches of two or more groups of 64 configurations per CU (default); 2: whenever the call qualifies; MH_ZVB_WHICH = 1 | 2: one of the two launches only (timing)
    int zvb_which = 3;
    int use_zvf = 1;       // MH_ZVF=0: never the fused one-launch form; 1: where the two-launch form would be taken (default); 2: whenever the call qualifies
@@ -505,6 +507,17 @@ bool zvf_ok(const mh_model *m, int64_t B, bool soa)
    // measured (humanoid, one MI355X, profiles/r04_zvf_vs_others.txt): 20.5 us against the one-job kernel's 20.3 at 16 384 (one group per CU:
    // a tie), 27.0 against 36.4 at 24 576, 28.4 against 37.8 at 32 768, 195.9 against 250.5 at 262 144
    return m->use_zvf == 2 || (B + 63) / 64 > (long)m->cu_count;
+}
+// Inverse dynamics of device-filling batches in a persistent loop that requests the next group's rows behind the trunk pass
+// (spec_zvb_bias_kernel<.., BIAS = false>): AoS matrices, dense index maps; from three groups of 64 configurations per CU upwards, where
+// every workgroup of the launch takes a second turn.  MH_RNEA_AHEAD=0: never, 2: whenever the call qualifies.
+bool rnea_ahead_ok(const mh_model *m, int64_t B, bool soa)
+{
+   if (!m->spec.launch_rnea_ahead || !m->spec.zvb_usable || !m->spec.zvb_usable() || !m->use_spec || !m->use_rnea_ahead || m->use_split == 0)
+      return false;
+   if (soa || !m->dense_maps || m->force_io == 0)
+      return false;
+   return m->use_rnea_ahead == 2 || (B + 63) / 64 > 2 * (long)m->cu_count;
 }
 mh_status zvb_launch(mh_model *m, mh::Args<double> &A, hipStream_t stream, int *rc)
 {
@@ -1133,6 +1146,18 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             return MH_OK;
       }
    }
+   if constexpr (sizeof(T) == 8)
+   {
+      if (algo == ALGO_RNEA && rnea_ahead_ok(model, B, soa))
+      {
+         const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
+         const int rc = model->spec.launch_rnea_ahead(SPEC_IO_LDS | (model->ident_maps ? SPEC_IDENT : 0), &A, (int)groups, (void *)stream);
+         if (rc == 0)
+            return MH_OK;
+         if (rc != (int)hipErrorNotSupported)
+            return fail(MH_ERR_HIP, "inverse dynamics (rows requested ahead) failed to launch: %s", hipGetErrorString((hipError_t)rc));
+      }
+   }
    if (algo != ALGO_CRBA && sizeof(T) == 8 && split_ok(model, algo == ALGO_RNEA ? 0 : 1, B, soa))
    {
       int sf = split_flags(model, algo == ALGO_RNEA ? 0 : 1, soa);
@@ -1573,6 +1598,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.launch_zvb = (decltype(s.launch_zvb))dlsym(h, "mh_spec_launch_zvb");
    s.zvf_usable = (decltype(s.zvf_usable))dlsym(h, "mh_spec_zvf_usable");
    s.launch_zvf = (decltype(s.launch_zvf))dlsym(h, "mh_spec_launch_zvf");
+   s.launch_rnea_ahead = (decltype(s.launch_rnea_ahead))dlsym(h, "mh_spec_launch_rnea_ahead");
    s.rnea_crba_lds_bytes = (decltype(s.rnea_crba_lds_bytes))dlsym(h, "mh_spec_rnea_crba_lds_bytes");
    s.launch_coriolis = (decltype(s.launch_coriolis))dlsym(h, "mh_spec_launch_coriolis");
    s.launch_centroidal = (decltype(s.launch_centroidal))dlsym(h, "mh_spec_launch_centroidal");
@@ -2183,6 +2209,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_zvb = atoi(e);
    if (const char *e = getenv("MH_ZVF"))
       m->use_zvf = atoi(e);
+   if (const char *e = getenv("MH_RNEA_AHEAD"))
+      m->use_rnea_ahead = atoi(e);
    if (const char *e = getenv("MH_ZVB_WHICH"))
       m->zvb_which = std::max(1, std::min(3, atoi(e)));
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))
@@ -3280,7 +3308,10 @@ mh_status mh_timer_create(mh_timer_t *out)
    if (!out)
       return fail(MH_ERR_INVALID_ARGUMENT, "timer_out is NULL");
    mh_timer *t = new mh_timer();
-   if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess)
+   // timing only: without the system-scope fence (cache write-back) a default event performs when it becomes recorded -- measured on the
+   // headline's regions of 20 steps: 8 us per region with default events (profiles/r04_region_overhead.txt)
+   const unsigned flags = getenv("MH_TIMER_DEFAULT_EVENTS") ? hipEventDefault : hipEventDisableSystemFence;
+   if (hipEventCreateWithFlags(&t->start, flags) != hipSuccess || hipEventCreateWithFlags(&t->stop, flags) != hipSuccess)
    {
       delete t;
       return fail(MH_ERR_NO_DEVICE, "cannot create HIP events");
@@ -3485,27 +3516,31 @@ static void self_check_spec(mh_model *m)
          // serves SoA calls and simulation steps at those sizes)
          // 4: ... with the fused one-launch form switched off as well (plan 1 takes the fused kernel where the code object has it, plan 3 then
          // the two launches, plan 4 the one-job kernel)
-         const int zv_was = m->use_zv, zvb_was = m->use_zvb, zvf_was = m->use_zvf;
+         // (inverse dynamics: plan 1 takes the loop that requests rows ahead, plan 4 the tree-split kernel's own device-filling loop)
+         const int zv_was = m->use_zv, zvb_was = m->use_zvb, zvf_was = m->use_zvf, ahead_was = m->use_rnea_ahead;
          const bool zv_plan = (what == CK_ABA || what == CK_FUSED) && L == 0 && zv_was && zv_ok(m, B, false, what == CK_FUSED ? 3 : 2);
          m->cu_count = 1;
          const bool fd_aos = (what == CK_ABA || what == CK_FUSED) && L == 0;
          const bool zvf_plan = fd_aos && zvf_was && zvf_ok(m, B, false), zvb_plan = fd_aos && zvb_was && zvb_ok(m, B, false);
+         const bool ahead_plan = (what == CK_RNEA || what == CK_FUSED) && L == 0 && ahead_was && rnea_ahead_ok(m, B, false);
          m->cu_count = real_cus;
          for (int plan = 0; plan < 5 && failure.empty(); plan++)
          {
-            if ((plan == 2 && !zv_plan) || (plan == 3 && !(zvf_plan && zvb_plan)) || (plan == 4 && !(zvf_plan || zvb_plan)))
+            if ((plan == 2 && !zv_plan) || (plan == 3 && !(zvf_plan && zvb_plan)) || (plan == 4 && !(zvf_plan || zvb_plan || ahead_plan)))
                continue;
             const int pretend = plan == 1 || plan >= 3 ? 1 : 0;
             m->cu_count = pretend ? 1 : real_cus;
             m->use_zv = plan == 2 ? 0 : zv_was;
             m->use_zvf = plan >= 3 ? 0 : zvf_was;
             m->use_zvb = plan == 4 ? 0 : zvb_was;
+            m->use_rnea_ahead = plan >= 3 ? 0 : ahead_was;
             st = run(what, L, used);
             const hipError_t sync = hipDeviceSynchronize();
             m->cu_count = real_cus;
             m->use_zv = zv_was;
             m->use_zvb = zvb_was;
             m->use_zvf = zvf_was;
+            m->use_rnea_ahead = ahead_was;
             if (st == MH_OK)
                st = zv_check_error(m);
             char buf[320];

@@ -374,6 +374,39 @@ int mh_spec_launch_zvb(int flags, const void *args, void *taup, void *cs, long c
    else
       return (int)hipErrorNotSupported;
 }
+// ---- inverse dynamics of device-filling batches in the bias launch's persistent loop (spec_zvb_bias_kernel<.., BIAS = false>): AoS matrices,
+// dense index maps, no per-body outputs.  args->in3 = qdd, args->out = tau; groups = workgroups of the launch.
+int mh_spec_launch_rnea_ahead(int flags, const void *args, int groups, void *stream)
+{
+   if constexpr (SPL::usable())
+   {
+      const mh::Args<double> &A = *(const mh::Args<double> *)args;
+      if (!(flags & F_IO_LDS) || !mh_spec_zvb_usable() || groups < 1 || A.body_acc || A.body_twist || A.m.nq != TR::total_cfgs() || A.m.nv != TR::total_dofs())
+         return (int)hipErrorNotSupported;
+      const size_t lds = (size_t)mh_spec_zvb_lds_bytes(0, A.m.nq, A.m.nv);
+      if (lds * 2 > 160 * 1024)
+         return (int)hipErrorNotSupported;
+      hipStream_t s = (hipStream_t)stream;
+      auto run = [&](auto ident) -> hipError_t {
+         constexpr bool ID = decltype(ident)::value;
+         static LdsAttr attr;
+         auto k = &mh::spec_zvb_bias_kernel<TP, double, ID, false>;
+         if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k), lds, attr); e != hipSuccess)
+            return e;
+         hipLaunchKernelGGL(k, dim3((unsigned)groups), dim3(256), lds, s, A, A.out, (double *)nullptr, 0L);
+         return hipGetLastError();
+      };
+      if (flags & F_IDENT)
+         return (int)run(std::true_type{});
+#ifdef MH_SPEC_MINIMAL
+      return (int)hipErrorNotSupported;
+#else
+      return (int)run(std::false_type{});
+#endif
+   }
+   else
+      return (int)hipErrorNotSupported;
+}
 // ---- the same as ONE launch (spec_zvf_kernel: bias and inertia job fused in a workgroup); trees whose joints below the root are revolute / fixed
 int mh_spec_zvf_usable(void)
 {

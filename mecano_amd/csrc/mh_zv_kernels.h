@@ -1221,13 +1221,15 @@ struct RowRegs
    }
 };
 
-// first launch: rows tau - RNEA(q, qd, 0) (A.in3 = tau) to taup [B][nv], (cos, sin) of the revolute joints to cs [2 n_rev][cs_stride]
-template <class TP, typename T, bool IDENT>
+// first launch: rows tau - RNEA(q, qd, 0) (A.in3 = tau) to taup [B][nv], (cos, sin) of the revolute joints to cs [2 n_rev][cs_stride].
+// BIAS = false: the plain inverse dynamics of device-filling batches (A.in3 = qdd, rows RNEA(q, qd, qdd) to taup = A.out, cs unused) --
+// the tree-split walk of spec_split_kernel in this kernel's persistent loop, i.e. with the next group's rows in flight behind the trunk pass.
+template <class TP, typename T, bool IDENT, bool BIAS = true>
 __global__ void __launch_bounds__(256, 2) spec_zvb_bias_kernel(Args<T> A, T *taup, T *cs, long cs_stride)
 {
    extern __shared__ double lds_raw[];
    using S = Split<TP>;
-   using CX = Ctx<T, true, IDENT, SplitStore<TP>, false, 1, 1>;
+   using CX = Ctx<T, true, IDENT, SplitStore<TP>, false, BIAS ? 1 : 0, BIAS ? 1 : 0>;
    constexpr int NQ = Tree<TP>::total_cfgs(), NV = Tree<TP>::total_dofs();
    const lds_ptr<T> lds = (lds_ptr<T>)lds_raw;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1258,13 +1260,15 @@ __global__ void __launch_bounds__(256, 2) spec_zvb_bias_kernel(Args<T> A, T *tau
       ZV_STAMP(0, 1);
       CX cx;
       fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
-      cx.coriolis = 1, cx.accel = 0;
+      if constexpr (BIAS)
+         cx.coriolis = 1, cx.accel = 0;
       cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = cx.lx;
       cx.wave = wave;
       cx.xbase = lxc + lane;
       cx.st.lbase = lst + lane;
       cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
-      cx.cs = cs + cfg0 + lane, cx.cs_stride = cs_stride; // (the scratch is padded to whole groups; inactive lanes never store)
+      if constexpr (BIAS)
+         cx.cs = cs + cfg0 + lane, cx.cs_stride = cs_stride; // (the scratch is padded to whole groups; inactive lanes never store)
       if (active)
          split_rnea_limbs<TP, 0, T, CX>(cx);
       ZV_STAMP(0, 2);

@@ -446,8 +446,10 @@ def test_every_specialised_variant(torch_cuda, B):
                         {"MH_ZV": "2", "MH_ZV_SAME_L2": "1"},  # ... its hand-off left in a shared L2 where both jobs prove to sit behind one (opt-in)
                         {"MH_ZV": "0", "MH_ZVF": "2"},  # forward dynamics as ONE fused launch (bias + inertia job per workgroup) at every batch size
                         {"MH_ZV": "0", "MH_ZVF": "0", "MH_ZVB": "2"},  # ... as two launches at every batch size (models without the fused kernel)
-                        {"MH_ZV": "0", "MH_ZVF": "0", "MH_ZVB": "0"}):  # ... never: the one-job tree-split kernel at every size
-                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB", "MH_ZVF"):
+                        {"MH_ZV": "0", "MH_ZVF": "0", "MH_ZVB": "0"},  # ... never: the one-job tree-split kernel at every size
+                        {"MH_RNEA_AHEAD": "2"},  # inverse dynamics in the loop that requests the next group's rows ahead, at every batch size
+                        {"MH_RNEA_AHEAD": "0"}):  # ... never (default: from three groups of 64 configurations per CU)
+                for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB", "MH_ZVF", "MH_RNEA_AHEAD"):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 hm = HipModel(d)
@@ -460,7 +462,7 @@ def test_every_specialised_variant(torch_cuda, B):
                 close(t2.cpu().numpy()[idx], t_ref)
                 close(a2.cpu().numpy()[idx], a_ref)
         finally:
-            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB", "MH_ZVF"):
+            for k in ("MH_DISABLE_SPEC", "MH_SPEC_IO", "MH_SPEC_ST", "MH_SPEC_SPLIT", "MH_ZV", "MH_ZV_SAME_L2", "MH_ZVB", "MH_ZVF", "MH_RNEA_AHEAD"):
                 os.environ.pop(k, None)
         assert any(v.startswith("generic") for v in seen) and any(v.startswith("topo:") for v in seen), seen
 
@@ -1790,6 +1792,14 @@ def test_config4_at_full_size_on_one_gpu(torch_cuda):
             for k in env:
                 os.environ.pop(k, None)
         assert (other - qdd).abs().max().item() <= 1e-10, env
+    # the inverse dynamics of that round trip ran in the loop that requests rows ahead (more than two groups per CU): the same walk as the
+    # tree-split kernel's own loop, so bit for bit
+    os.environ["MH_RNEA_AHEAD"] = "0"
+    try:
+        plain = HipModel(d).rnea(tq, tqd, qdd, g)
+    finally:
+        os.environ.pop("MH_RNEA_AHEAD", None)
+    assert torch.equal(plain, back)
 
 
 def test_reference_signatures_on_one_configuration(torch_cuda):
