@@ -567,8 +567,8 @@ int mh_spec_launch_centroidal_parts(int flags, const void *args, int grid, int p
 int mh_spec_launch_centroidal(int flags, const void *args, int grid, void *stream) { return mh_spec_launch_centroidal_parts(flags, args, grid, 1, stream); }
 // tree-split CRBA: identity maps, AoS, packed image + limb exchange in LDS
 static long crba_split_lds(int lanes_per_group)
-{ // lane-major image (odd pitch) of lanes_per_group rows + limb exchange [slot][64] + entry -> slot table
-   return ((long)(mh::HMap<TP>::T.n_slots | 1) * lanes_per_group + (long)SPL::n_limbs() * 10 * 64) * (long)sizeof(double)
+{ // lane-major image (odd pitch) of lanes_per_group rows + limb exchange records of as many lanes (odd pitch) + entry -> slot table
+   return ((long)(mh::HMap<TP>::T.n_slots | 1) + (long)((SPL::n_limbs() * 10) | 1)) * lanes_per_group * (long)sizeof(double)
           + (long)((mh::HMap<TP>::NV * mh::HMap<TP>::NV * 2 + 7) & ~7);
 }
 long mh_spec_crba_split_lds_bytes(void) { return crba_split_lds(64); }

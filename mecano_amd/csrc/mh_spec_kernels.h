@@ -1384,19 +1384,19 @@ MH_DEV void h_put(const CX &cx, T v)
 template <class TP, int LIMB, class CX, typename T>
 MH_DEV void xc_put_ri(const CX &cx, const RI<T> &r)
 {
-   constexpr int S0 = LIMB * 10; // cx.lx = exchange area + lane
-   cx.lx[(S0 + 0) * 64] = r.m, cx.lx[(S0 + 1) * 64] = r.h.x, cx.lx[(S0 + 2) * 64] = r.h.y, cx.lx[(S0 + 3) * 64] = r.h.z;
-   cx.lx[(S0 + 4) * 64] = r.I.xx, cx.lx[(S0 + 5) * 64] = r.I.xy, cx.lx[(S0 + 6) * 64] = r.I.xz, cx.lx[(S0 + 7) * 64] = r.I.yy;
-   cx.lx[(S0 + 8) * 64] = r.I.yz, cx.lx[(S0 + 9) * 64] = r.I.zz;
+   constexpr int S0 = LIMB * 10; // cx.lx = this lane's records in the exchange area (lane-major, odd pitch: Split-independent of the group's width)
+   cx.lx[S0 + 0] = r.m, cx.lx[S0 + 1] = r.h.x, cx.lx[S0 + 2] = r.h.y, cx.lx[S0 + 3] = r.h.z;
+   cx.lx[S0 + 4] = r.I.xx, cx.lx[S0 + 5] = r.I.xy, cx.lx[S0 + 6] = r.I.xz, cx.lx[S0 + 7] = r.I.yy;
+   cx.lx[S0 + 8] = r.I.yz, cx.lx[S0 + 9] = r.I.zz;
 }
 template <class TP, int LIMB, class CX, typename T>
 MH_DEV RI<T> xc_get_ri(const CX &cx)
 {
    constexpr int S0 = LIMB * 10;
    RI<T> r;
-   r.m = cx.lx[(S0 + 0) * 64];
-   r.h = V3<T>{cx.lx[(S0 + 1) * 64], cx.lx[(S0 + 2) * 64], cx.lx[(S0 + 3) * 64]};
-   r.I = S3<T>{cx.lx[(S0 + 4) * 64], cx.lx[(S0 + 5) * 64], cx.lx[(S0 + 6) * 64], cx.lx[(S0 + 7) * 64], cx.lx[(S0 + 8) * 64], cx.lx[(S0 + 9) * 64]};
+   r.m = cx.lx[S0 + 0];
+   r.h = V3<T>{cx.lx[S0 + 1], cx.lx[S0 + 2], cx.lx[S0 + 3]};
+   r.I = S3<T>{cx.lx[S0 + 4], cx.lx[S0 + 5], cx.lx[S0 + 6], cx.lx[S0 + 7], cx.lx[S0 + 8], cx.lx[S0 + 9]};
    return r;
 }
 // MODE 1 (tree-split kernel, trunk pass): a child that is the root of a limb is not walked, its composite inertia comes from the
@@ -1528,21 +1528,53 @@ MH_DEV void crba_trunk_path(const CX &cx, CrbaPath<T, D> &path)
       }
    }
 }
-template <class TP, int K, typename T, class CX>
-MH_DEV void split_crba_limbs(const CX &cx)
+// limbs K2 >= K of wave W that hang off the same trunk body as limb K: one set of trunk joint transforms serves them all
+template <class TP, int W, int K, int K2, typename T, class CX, int D>
+MH_DEV void crba_limbs_same_parent(const CX &cx, const CrbaPath<T, D> &path)
+{
+   using S = Split<TP>;
+   if constexpr (K2 < S::n_limbs())
+   {
+      if constexpr (S::owner_plain(K2) == W && TP::parent[S::limb_root(K2)] == TP::parent[S::limb_root(K)])
+         xc_put_ri<TP, K2, CX, T>(cx, CrbaSub<TP, S::limb_root(K2), T, CX, D, 2, 0>::run(cx, path));
+      crba_limbs_same_parent<TP, W, K, K2 + 1, T, CX, D>(cx, path);
+   }
+}
+template <class TP, int W, int K>
+constexpr bool crba_first_with_parent()
+{
+   using S = Split<TP>;
+   for (int k = 0; k < K; k++)
+      if (S::owner_plain(k) == W && TP::parent[S::limb_root(k)] == TP::parent[S::limb_root(K)])
+         return false;
+   return true;
+}
+template <class TP, int W, int K, typename T, class CX>
+MH_DEV void crba_limbs_of_wave(const CX &cx)
 {
    using S = Split<TP>;
    if constexpr (K < S::n_limbs())
    {
-      if (cx.wave == S::owner_plain(K))
+      if constexpr (S::owner_plain(K) == W && crba_first_with_parent<TP, W, K>())
       {
          constexpr int R = S::limb_root(K), D = Tree<TP>::depth(R);
          CrbaPath<T, D> path;
          if constexpr (D > 0)
             crba_trunk_path<TP, TP::parent[R], T, CX, D>(cx, path);
-         xc_put_ri<TP, K, CX, T>(cx, CrbaSub<TP, R, T, CX, D, 2, 0>::run(cx, path));
+         crba_limbs_same_parent<TP, W, K, K, T, CX, D>(cx, path);
       }
-      split_crba_limbs<TP, K + 1, T, CX>(cx);
+      crba_limbs_of_wave<TP, W, K + 1, T, CX>(cx);
+   }
+}
+template <class TP, int W, typename T, class CX>
+MH_DEV void split_crba_limbs(const CX &cx)
+{
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+         crba_limbs_of_wave<TP, W, 0, T, CX>(cx);
+      else
+         split_crba_limbs<TP, W + 1, T, CX>(cx);
    }
 }
 
@@ -2398,6 +2430,131 @@ __global__ void __launch_bounds__(64) spec_crba_packed_kernel(Args<T> A)
    }
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on gfx950 waits for
+// EVERY outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0)): stores streamed out just before it would be waited for,
+// acknowledgement by acknowledgement.  Safe where no wave of the workgroup reads global memory another wave of it wrote.
+MH_DEV void lds_barrier()
+{
+   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// Coalesced write-out of the tree-split CRBA: the rows of H that belong to the trunk's dofs (TRUNK) or to the limbs' dofs, for the `rows`
+// configurations of a workgroup, from the packed lane-major LDS image (row pitch nsp), zeros included, by threads t of nt.  A run of
+// consecutive rows of one kind is contiguous in the AoS result; element g of a run's slice is entry e0 + g % ne of configuration g / ne.
+template <class TP>
+struct HRows
+{
+   using TR = Tree<TP>;
+   static constexpr int NV = TR::total_dofs();
+   static constexpr bool trunk_row(int r)
+   {
+      for (int j = 0; j < TP::N; j++)
+         if (r >= TR::dof_ofs(j) && r < TR::dof_ofs(j) + TR::ndof(j))
+            return Split<TP>::is_trunk(j);
+      return true;
+   }
+   static constexpr int n_runs(bool trunk)
+   {
+      int n = 0;
+      for (int r = 0; r < NV; r++)
+         if (trunk_row(r) == trunk && (r == 0 || trunk_row(r - 1) != trunk))
+            n++;
+      return n;
+   }
+   static constexpr int run_start(bool trunk, int k)
+   {
+      int n = 0;
+      for (int r = 0; r < NV; r++)
+         if (trunk_row(r) == trunk && (r == 0 || trunk_row(r - 1) != trunk))
+            if (n++ == k)
+               return r;
+      return NV;
+   }
+   static constexpr int run_len(bool trunk, int k)
+   {
+      int r = run_start(trunk, k), n = 0;
+      while (r + n < NV && trunk_row(r + n) == trunk)
+         n++;
+      return n;
+   }
+};
+// (Measured, profiles/r04_crba_writeout_exp.txt: the same loop with constant data and no LDS access at all takes 88 % of the time -- a CU
+// issues these stores at 10-13 bytes per clock whatever feeds them, 256 CUs together at the 6 TB/s the memory takes; plain instead of
+// nontemporal stores: no faster at 4 096, 6 % slower at 262 144.)
+template <typename T, int E0, int NEK, int NE>
+MH_DEV void crba_write_run(T *H, lds_ptr<T> img, const short __attribute__((address_space(3))) *tab, int nsp, int rows, int t, int nt)
+{
+   if constexpr (NEK % 2 == 0 && E0 % 2 == 0 && NE % 2 == 0 && sizeof(T) == 8)
+   { // two entries = 16 bytes per lane and store (a pair never straddles two matrices): half the instructions of the loop and twice the
+     // bytes each store instruction keeps in flight -- the write-out is bound by the latter
+      if ((((unsigned long long)H) & 15) == 0)
+      {
+         typedef double __attribute__((ext_vector_type(2))) d2;
+         constexpr int NP = NEK / 2, UN2 = 4;
+         const int pairs = rows * NP;
+         for (int gp = t; gp < pairs; gp += UN2 * nt)
+         {
+            int s0[UN2], s1[UN2], cc[UN2], pp[UN2];
+#pragma unroll
+            for (int u = 0; u < UN2; u++)
+            {
+               const int g = gp + u * nt;
+               const bool in = g < pairs;
+               const int c = in ? g / NP : 0, p2 = in ? g - c * NP : 0;
+               s0[u] = in ? (int)tab[E0 + 2 * p2] : -1;
+               s1[u] = in ? (int)tab[E0 + 2 * p2 + 1] : -1;
+               cc[u] = c, pp[u] = p2;
+            }
+            d2 v[UN2];
+#pragma unroll
+            for (int u = 0; u < UN2; u++)
+            {
+               v[u].x = s0[u] >= 0 ? img[cc[u] * nsp + s0[u]] : 0.0;
+               v[u].y = s1[u] >= 0 ? img[cc[u] * nsp + s1[u]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN2; u++)
+               if (gp + u * nt < pairs)
+                  __builtin_nontemporal_store(v[u], (d2 *)(H + (long)cc[u] * NE + E0) + pp[u]); // streamed once, never read back by this kernel
+         }
+         return;
+      }
+   }
+   constexpr int UN = 8;
+   const int total = rows * NEK;
+   for (int g0 = t; g0 < total; g0 += UN * nt)
+   { // UN independent look-ups, reads and stores in flight per thread
+      int sl[UN], cc[UN], ee[UN];
+#pragma unroll
+      for (int u = 0; u < UN; u++)
+      {
+         const int g = g0 + u * nt;
+         const bool in = g < total;
+         const int c = in ? g / NEK : 0, e = in ? g - c * NEK : 0;
+         sl[u] = in ? (int)tab[E0 + e] : -1;
+         cc[u] = c, ee[u] = e;
+      }
+      T v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; u++)
+         v[u] = sl[u] >= 0 ? img[cc[u] * nsp + sl[u]] : T(0);
+#pragma unroll
+      for (int u = 0; u < UN; u++)
+         if (g0 + u * nt < total)
+            __builtin_nontemporal_store(v[u], H + (long)cc[u] * NE + E0 + ee[u]);
+   }
+}
+template <class TP, typename T, bool TRUNK, int K = 0>
+MH_DEV void crba_write_rows(T *H, lds_ptr<T> img, const short __attribute__((address_space(3))) *tab, int nsp, int rows, int t, int nt)
+{
+   using HR = HRows<TP>;
+   if constexpr (K < HR::n_runs(TRUNK))
+   {
+      constexpr int NV = HR::NV, R0 = HR::run_start(TRUNK, K), RN = HR::run_len(TRUNK, K);
+      crba_write_run<T, R0 * NV, RN * NV, NV * NV>(H, img, tab, nsp, rows, t, nt);
+      crba_write_rows<TP, T, TRUNK, K + 1>(H, img, tab, nsp, rows, t, nt);
+   }
+}
+
 // Tree-split CRBA (identity index maps, AoS): four waves share 64 configurations.  Each limb's owner walks the limb with the joint
 // transforms of its trunk ancestors in hand, which completes every column of H that belongs to a limb body and leaves the limb's
 // composite inertia in the exchange area; after one barrier wave 0 finishes the trunk bodies' columns; after a second barrier the
@@ -2415,10 +2572,11 @@ MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const 
    const int lane = threadIdx.x & 63;
    const lds_ptr<T> img = (lds_ptr<T>)lds_raw;
    // entry -> slot table of the write-out, staged once (the lookups sit in a dependent chain: LDS latency, not global)
-   // LDS: image of lpg rows | limb exchange [slot][64] | table -- a thin workgroup asks for a thin image (mh_spec.hip: crba_split_lds),
+   // LDS: image of lpg rows | limb exchange, lpg rows | table -- a thin workgroup asks for thin areas (mh_spec.hip: crba_split_lds),
    // which is what lets two workgroups share a CU
+   constexpr int XP = (Split<TP>::n_limbs() * 10) | 1; // pitch of a lane's exchange records (odd, like the image's)
    const int img_words = __builtin_amdgcn_readfirstlane(lpg) * NSP;
-   short __attribute__((address_space(3))) *tab = (short __attribute__((address_space(3))) *)(img + img_words + Split<TP>::n_limbs() * 10 * 64);
+   short __attribute__((address_space(3))) *tab = (short __attribute__((address_space(3))) *)(img + img_words + __builtin_amdgcn_readfirstlane(lpg) * XP);
    for (int e = threadIdx.x; e < NE; e += 256)
       tab[e] = (short)HM::slot_at(e);
    warm_scalar_cache(A.m.consts, A.m.n * MC_STRIDE * (int)sizeof(T));
@@ -2443,93 +2601,37 @@ MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const 
       cx.nv = NV;
       cx.wave = wave;
       cx.xbase = img + lane * NSP;
-      cx.lx = img + img_words + lane;
+      cx.lx = img + img_words + (active ? lane : 0) * XP;
       MH_CSTAMP(1);
       if (active)
          split_crba_limbs<TP, 0, T, CX>(cx);
       MH_CSTAMP(2);
       __syncthreads();
       MH_CSTAMP(3);
-      if (active && wave == 0)
-         crba_roots<TP, T, CX, 2, 1>(cx);
-      MH_CSTAMP(4);
-      __syncthreads();
-      MH_CSTAMP(5);
-      { // coalesced write-out of the group's matrices (contiguous in the AoS result), zeros included: element g of the slice is
-        // entry g % NE of configuration g / NE; consecutive threads write consecutive addresses
-         const long rows = A.B - cfg0 < lpg ? A.B - cfg0 : lpg;
-         const int total = (int)rows * NE;
-         T *H = A.out + cfg0 * NE;
-         if constexpr (NE % 2 == 0 && sizeof(T) == 8)
-         { // two entries = 16 bytes per lane and store (a pair never straddles two matrices): half the instructions of the loop and
-           // twice the bytes each store instruction keeps in flight -- the write-out is bound by the latter
-            if ((((unsigned long long)A.out) & 15) == 0)
-            {
-               typedef double __attribute__((ext_vector_type(2))) d2;
-               constexpr int NP = NE / 2, STEP2 = 256, SC2 = STEP2 / NP, SE2 = STEP2 - SC2 * NP, UN2 = 4;
-               const int pairs = (int)rows * NP;
-               int gp = threadIdx.x, c2 = gp / NP, p2 = gp - c2 * NP;
-               while (gp < pairs)
-               {
-                  int s0[UN2], s1[UN2], cc[UN2];
-#pragma unroll
-                  for (int u = 0; u < UN2; u++)
-                  {
-                     const bool in = gp + u * STEP2 < pairs;
-                     s0[u] = in ? (int)tab[2 * p2] : -1;
-                     s1[u] = in ? (int)tab[2 * p2 + 1] : -1;
-                     cc[u] = c2;
-                     c2 += SC2, p2 += SE2;
-                     if (p2 >= NP)
-                        p2 -= NP, c2++;
-                  }
-                  d2 v[UN2];
-#pragma unroll
-                  for (int u = 0; u < UN2; u++)
-                  {
-                     v[u].x = s0[u] >= 0 ? img[cc[u] * NSP + s0[u]] : 0.0;
-                     v[u].y = s1[u] >= 0 ? img[cc[u] * NSP + s1[u]] : 0.0;
-                  }
-#pragma unroll
-                  for (int u = 0; u < UN2; u++)
-                     if (gp + u * STEP2 < pairs)
-                        __builtin_nontemporal_store(v[u], (d2 *)H + gp + u * STEP2);
-                  gp += UN2 * STEP2;
-               }
-               MH_CSTAMP(6);
-               __syncthreads();
-               MH_CSTAMP(7);
-               continue;
-            }
-         }
-         int g = threadIdx.x, c = g / NE, e = g - c * NE;
-         constexpr int STEP = 256, SC = STEP / NE, SE = STEP - SC * NE;
-         constexpr int UN = 8;
-         while (g < total)
-         { // UN independent look-ups, reads and stores in flight per thread
-            int sl[UN], cc[UN];
-#pragma unroll
-            for (int u = 0; u < UN; u++)
-            {
-               sl[u] = g + u * STEP < total ? (int)tab[e] : -1;
-               cc[u] = c;
-               c += SC, e += SE;
-               if (e >= NE)
-                  e -= NE, c++;
-            }
-            T v[UN];
-#pragma unroll
-            for (int u = 0; u < UN; u++)
-               v[u] = sl[u] >= 0 ? img[cc[u] * NSP + sl[u]] : T(0);
-#pragma unroll
-            for (int u = 0; u < UN; u++)
-               if (g + u * STEP < total)
-                  __builtin_nontemporal_store(v[u], H + g + u * STEP); // streamed once, never read back by this kernel
-            g += UN * STEP;
-         }
+      // Every row of H that belongs to a limb dof is complete now (the limbs' owners wrote their columns up to the root; by symmetry the
+      // rows).  Thin workgroups (small batches: one slice per workgroup, the write-out at the end of everything): waves 1-3 stream those
+      // rows out while wave 0 finishes the trunk bodies' columns, whose entries all lie in rows of trunk dofs; the barrier behind does not
+      // wait for the stores (at B = 4096, 16 configurations per workgroup: limbs 6.9 us | trunk 2.6 | write-out 4.4 before,
+      // profiles/r04_crba_stamps.txt).  Full groups of 64 keep the one write-out by all four waves: splitting it cost more than the
+      // trunk pass it hides (262 144 configurations: 442 -> 525 us).
+      const int rows = (int)(A.B - cfg0 < lpg ? A.B - cfg0 : lpg);
+      const bool early = __builtin_amdgcn_readfirstlane(lpg) < 64;
+      if (wave == 0)
+      {
+         if (active)
+            crba_roots<TP, T, CX, 2, 1>(cx);
       }
+      else if (early)
+         crba_write_rows<TP, T, false>(A.out + cfg0 * NE, img, tab, NSP, rows, (int)threadIdx.x - 64, 192);
+      MH_CSTAMP(4);
+      lds_barrier();
+      MH_CSTAMP(5);
+      if (early) // what is left: the rows of the trunk's dofs
+         crba_write_rows<TP, T, true>(A.out + cfg0 * NE, img, tab, NSP, rows, threadIdx.x, 256);
+      else
+         crba_write_run<T, 0, NE, NE>(A.out + cfg0 * NE, img, tab, NSP, rows, threadIdx.x, 256);
       MH_CSTAMP(6);
-      __syncthreads(); // the image is free for the next slice
+      lds_barrier(); // the image is free for the next slice (the stores took their values from it into registers: nothing waits for their acknowledgements)
       MH_CSTAMP(7);
    }
 }
