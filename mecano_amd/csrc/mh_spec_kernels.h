@@ -2614,6 +2614,9 @@ MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const 
       // wait for the stores (at B = 4096, 16 configurations per workgroup: limbs 6.9 us | trunk 2.6 | write-out 4.4 before,
       // profiles/r04_crba_stamps.txt).  Full groups of 64 keep the one write-out by all four waves: splitting it cost more than the
       // trunk pass it hides (262 144 configurations: 442 -> 525 us).
+      // (Each wave streaming its OWN limbs' rows as soon as it is through with them, counted in through an LDS word instead of the barrier,
+      // was measured too: 17.3 against 16.9 us -- one wave alone stores at 2.5-3.5 bytes per clock, a quarter of what the CU's four waves
+      // reach together: profiles/r04_crba_own_rows_experiment.txt.)
       const int rows = (int)(A.B - cfg0 < lpg ? A.B - cfg0 : lpg);
       const bool early = __builtin_amdgcn_readfirstlane(lpg) < 64;
       if (wave == 0)
