@@ -1285,12 +1285,10 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
             {
                // thin workgroups (16 / 32 of the 64 lanes) while that is what it takes to give every CU a workgroup: the write-out is
                // bound by the stores one CU can have in flight
-               int lpg = 64;
+               // (the width that gives every CU exactly one: 16 at 4 096, 24 at 6 000 -- any width up to 64 runs)
+               int lpg = (int)std::max<long>(16, std::min<long>(64, (B + model->cu_count - 1) / model->cu_count));
                if (const char *e = getenv("MH_CRBA_LPG"))
                   lpg = std::max(1, std::min(64, atoi(e)));
-               else
-                  while (lpg > 16 && (B + lpg - 1) / lpg < (long)model->cu_count)
-                     lpg /= 2;
                const long ng = (B + lpg - 1) / lpg;
                const int rc = model->spec.launch_crba_split(&A, (int)std::min<long>(ng, (long)model->cu_count * 2), lpg, (void *)stream);
                if (rc == 0)
@@ -3013,7 +3011,17 @@ mh_status mh_rnea_crba_f64(mh_model_t model, int64_t B, const double *q, const d
       int lpg = 64;
       while (lpg > 16 && (B + lpg / 2 - 1) / (lpg / 2) + groups <= resident(lpg / 2))
          lpg /= 2;
-      if (const char *e = getenv("MH_RNEA_CRBA_LPG")) // experiments: 16 / 32 / 64
+      // ... and where the CUs the RNEA groups leave can take one CRBA workgroup each, the width that does exactly that: a workgroup that
+      // shares its CU's SIMDs is the launch's last (humanoid, 4 096: 22 configurations in 187 workgroups beside the 64 RNEA groups 17.4 us,
+      // 16 in 256: 18.0, 20 in 205: 19.0, 24: 18.7 -- profiles/r04_rnea_crba_lpg.txt)
+      if (groups < (long)model->cu_count)
+      {
+         const long free_cus = (long)model->cu_count - groups;
+         const long fit = (B + free_cus - 1) / free_cus;
+         if (fit >= 16 && fit <= 64 && fit > lpg)
+            lpg = (int)fit;
+      }
+      if (const char *e = getenv("MH_RNEA_CRBA_LPG")) // experiments: 16 ... 64
          lpg = std::max(16, std::min(64, atoi(e)));
       const long ng = std::min<long>((B + lpg - 1) / lpg, (long)model->cu_count * 2);
       const int rc = model->spec.launch_rnea_crba(&A, (int)groups, (int)ng, lpg, (void *)s);
