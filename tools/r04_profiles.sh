@@ -13,6 +13,7 @@ if has bench; then
   timeout -k 10 400 python bench.py --config 4 > $out/r04_bench_config4.json 2> $out/r04_bench_config4.err || exit 1
   timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $out/r04_bench_line_driver_flags.json 2> $out/r04_bench_line.err || exit 1
   timeout -k 10 400 python bench.py > $out/r04_bench_line.json 2>> $out/r04_bench_line.err || exit 1
+  timeout -k 10 400 python bench.py --config 3 > $out/r04_bench_config3.json 2>> $out/r04_bench_line.err || exit 1
 fi
 if has stamps; then
   MH_SPEC_DIR=$root/exp_probe MH_ZVF=2 MH_ZV=0 timeout -k 10 120 python tools/exp_zvf_probe.py 262144 2>&1 | grep -v "self-check\|amdgpu.ids" > $out/r04_zvf_phase_stamps.txt || exit 1
@@ -29,6 +30,8 @@ if has trace; then
   cp $(find $out/r04_c4_trace -name '*kernel_stats.csv' | head -1) $out/r04_bench_config4_kernel_stats.csv
   ( cd /tmp && export TMPDIR=/tmp MH_BENCH_NO_PMC=1 && timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/r04_hl_trace -o hl --output-format csv -- python3 $root/bench.py --no-cpu-baseline > /dev/null 2>&1 ) || exit 1
   cp $(find $out/r04_hl_trace -name '*kernel_stats.csv' | head -1) $out/r04_final_bench_b4096_kernel_stats.csv
+  ( cd /tmp && export TMPDIR=/tmp MH_BENCH_NO_PMC=1 && timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/r04_c3_trace -o c3 --output-format csv -- python3 $root/bench.py --config 3 --no-cpu-baseline > /dev/null 2>&1 ) || exit 1
+  cp $(find $out/r04_c3_trace -name '*kernel_stats.csv' | head -1) $out/r04_bench_config3_kernel_stats.csv
   ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/r04_c2_trace -o c2 --output-format csv -- python3 $root/tools/exp_c2_floor.py 1024 > /dev/null 2>&1 ) || exit 1
   cp $(find $out/r04_c2_trace -name '*kernel_stats.csv' | head -1) $out/r04_c2_arm7_b1024_kernel_stats.csv
 fi
