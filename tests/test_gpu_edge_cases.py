@@ -244,3 +244,61 @@ def test_zero_length_batches_on_every_entry_point(torch_cuda):
     assert hm.aba(e(hm.nq), e(hm.nv), e(hm.nv), G).shape == (0, hm.nv)
     assert hm.crba(e(hm.nq)).shape == (0, hm.nv, hm.nv)
     assert lib.mh_reserve(h, 0) == _lib.MH_OK and lib.mh_model_check(h, None, None) == _lib.MH_OK
+
+
+def test_inverse_dynamics_loop_that_requests_rows_ahead(torch_cuda):
+    """The persistent inverse-dynamics loop of device-filling batches (spec_zvb_bias_kernel<.., BIAS = false>; default beyond two groups of
+    64 configurations per CU, forced here by MH_RNEA_AHEAD=2 on a ragged batch of a few groups): external wrenches, the Coriolis /
+    acceleration switches (InverseDynamicsCalculator.java:291-306) and index maps that are dense but not the identity -- against the
+    oracle, and bit for bit against the tree-split kernel's own loop (MH_RNEA_AHEAD=0), whose walk it shares."""
+    import os
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from mecano_amd.multibody import ModelDesc
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(90210)
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    d = sys_.toModelDesc()
+    # the same robot with the joints' rows dealt out in reverse listing order (a custom JointMatrixIndexProvider: dense, not the identity)
+    nd = [6 if t == 2 else (0 if t == 3 else 1) for t in d.joint_type]
+    ncfg = [7 if t == 2 else (0 if t == 3 else 1) for t in d.joint_type]
+    ofs_v, ofs_q = np.concatenate([[0], np.cumsum(nd)]), np.concatenate([[0], np.cumsum(ncfg)])  # where joint j's entries sit by default
+    dof_idx, cfg_idx, nv, nq = np.zeros(d.nv, dtype=np.int32), np.zeros(d.nq, dtype=np.int32), 0, 0
+    for j in reversed(range(d.n_joints)):
+        dof_idx[ofs_v[j]:ofs_v[j + 1]] = nv + np.arange(nd[j])
+        cfg_idx[ofs_q[j]:ofs_q[j + 1]] = nq + np.arange(ncfg[j])
+        nv, nq = nv + nd[j], nq + ncfg[j]
+    assert np.array_equal(d.dof_indices, np.arange(d.nv)) and np.array_equal(d.cfg_indices, np.arange(d.nq))
+    d2 = ModelDesc(d.n_joints, d.nq, d.nv, d.parent, d.joint_type, d.axis, d.X_before, d.X_com, d.inertia_J, d.inertia_mass, d.inertia_com, dof_idx, cfg_idx)
+    B = 3 * 64 + 17
+    q, qd, qdd, _ = rt.nextState(rng, sys_, B)
+    fext = rng.uniform(-2, 2, (B, d.n_joints, 6))
+    # the permuted model's matrices: column cfg_idx[c] of q2 is column c of q
+    q2, qd2, qdd2 = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(qdd)
+    q2[:, cfg_idx], qd2[:, dof_idx], qdd2[:, dof_idx] = q, qd, qdd
+    results = {}
+    try:
+        for mode in ("2", "0"):
+            os.environ["MH_RNEA_AHEAD"] = mode
+            out = []
+            for desc, (a, b, c) in ((d, (q, qd, qdd)), (d2, (q2, qd2, qdd2))):
+                hm = HipModel(desc)
+                assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant
+                ta, tb, tc, tf = dev(torch, a), dev(torch, b), dev(torch, c), dev(torch, fext)
+                out.append(hm.rnea(ta, tb, tc, G))
+                out.append(hm.rnea(ta, tb, tc, G, tf))
+                for cc, ca in ((False, True), (True, False), (False, False)):
+                    out.append(hm.rnea(ta, tb, tc, G, tf, consider_coriolis=cc, consider_accelerations=ca))
+            results[mode] = out
+    finally:
+        os.environ.pop("MH_RNEA_AHEAD", None)
+    for x, y in zip(results["2"], results["0"]):
+        assert torch.equal(x, y)
+    k = 0
+    for desc, (a, b, c) in ((d, (q, qd, qdd)), (d2, (q2, qd2, qdd2))):
+        om = OracleModel(desc)
+        close(results["2"][k].cpu().numpy(), om.rnea(a, b, c, G), 1e-10, label="rows ahead"); k += 1
+        close(results["2"][k].cpu().numpy(), om.rnea(a, b, c, G, fext), 1e-10, label="rows ahead, wrenches"); k += 1
+        for cc, ca in ((False, True), (True, False), (False, False)):
+            close(results["2"][k].cpu().numpy(), om.rnea(a, b, c, G, fext, cc, ca), 1e-10, label=f"rows ahead, switches {cc} {ca}"); k += 1
