@@ -54,9 +54,11 @@
  * (environment, default 2000) for its producer; the accelerations of those 64 configurations are then written as NaN, never as numbers.
  *
  * Last bits: mh_aba_f64 / mh_rnea_aba_f64 choose the formulation of forward dynamics by batch size (bias split while every job gets a CU
- * of its own, one-job tree split up to one group of 64 configurations per CU, two launches beyond; MH_ZV / MH_ZVB in the environment force
- * either).  The formulations agree to about 1e-13 relative, not bit for bit: the same configuration evaluated inside batches of different
- * sizes -- e.g. in shards of different sizes on different ranks -- may differ in its last bits.  MH_ZV=0 MH_ZVB=0 pins the one-job form.
+ * of its own, one-job tree split up to one group of 64 configurations per CU, beyond that bias and inertia job fused in one workgroup --
+ * or two launches where the code object has no fused kernel; MH_ZV / MH_ZVF / MH_ZVB in the environment force each off or on).  The
+ * formulations agree to about 1e-13 relative, not bit for bit: the same configuration evaluated inside batches of different sizes -- e.g.
+ * in shards of different sizes on different ranks -- may differ in its last bits.  MH_ZV=0 MH_ZVF=0 MH_ZVB=0 pins the one-job form.
+ * (Inverse dynamics and the mass matrix have one formulation per code object: their results do not depend on the batch size.)
  *
  * No function throws or aborts; every entry point returns an mh_status and
  * mh_last_error() gives a thread-local message.  The library never falls back
