@@ -441,7 +441,7 @@ mh_status check_all_error_words()
 mh_status zv_prepare(mh_model *m, int64_t B, hipStream_t stream)
 {
    const size_t groups = (size_t)((B + 63) / 64);
-   mh_status st = ensure_bytes(m->zv_tau, (size_t)B * m->nv * sizeof(double));
+   mh_status st = ensure_bytes(m->zv_tau, groups * 64 * m->nv * sizeof(double)); // (whole groups: the two-stage hand-off keeps a matrix [nv][64] per group)
    if (st != MH_OK)
       return st;
    if (m->zv_flags.bytes < groups * mh::ZV_SYNC_STRIDE * sizeof(int))

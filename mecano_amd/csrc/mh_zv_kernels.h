@@ -136,14 +136,12 @@ MH_DEV void zv_lds_barrier()
 {
    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// the barriers of the bias fold: the fused kernel (CSMODE 3) has the next group's rows in flight across them
+// the barriers of the bias fold: loads are in flight across them (the fused kernel's next rows, the small-batch kernel's trunk columns), and
+// what the waves exchange there goes through LDS
 template <class CX>
 MH_DEV void zv_fold_barrier()
 {
-   if constexpr (CX::csmode == 3)
-      zv_lds_barrier();
-   else
-      __syncthreads();
+   zv_lds_barrier();
 }
 constexpr int ZV_XW = 21; // limb -> trunk exchange record: the articulated inertia (A 6, L 6, C 9); the bias fold reuses its first 6 slots
 
@@ -821,10 +819,14 @@ MH_DEV void zv_subtrunks_fold_of(const CX &cx)
 // Plain split: limbs | barrier | whole trunk on every wave | pruned outward sweep.  Every wave passes the same number of barriers.
 struct ZvNoHook
 {
-   MH_DEV void operator()() const {}
+   MH_DEV void after_early() const {}
+   MH_DEV void after_late() const {}
+   MH_DEV void before_out() const {}
 };
-// HOOK: called by every wave between its fold and its outward sweep (the fused kernel requests the next group's rows there: the root's
-// factor and the fold's temporaries are dead, the request has the outward sweep and the copy-out to land)
+// HOOK: called by every wave behind its early limbs' fold (plain split: behind its limbs' fold), behind its late limbs' fold (plain split:
+// behind the barrier in front of the trunk) and between its fold and its outward sweep.  The two-stage hand-off of the small-batch kernel
+// asks for the trunk's bias efforts at the first and stores them at the second; the fused kernel requests the next group's rows at the
+// third (the root's factor and the fold's temporaries are dead, the request has the outward sweep and the copy-out to land).
 template <class TP, int W, typename T, class CX, class HOOK = ZvNoHook>
 MH_DEV void zv_fold_out(const CX &cx, const HOOK &hook = HOOK())
 {
@@ -839,9 +841,11 @@ MH_DEV void zv_fold_out(const CX &cx, const HOOK &hook = HOOK())
             const long k = (long)cx.own; // (the group, for the stamps: zv_aba_group leaves it there in probe builds)
 #endif
             zv_limbs_fold_sel<TP, W, 0, 0, T, CX>(cx);
+            hook.after_early();
             ZV_STAMP(1, 7);
             zv_fold_barrier<CX>();
             zv_limbs_fold_sel<TP, W, 0, 1, T, CX>(cx);
+            hook.after_late();
             zv_subtrunks_fold_of<TP, W, 0, T, CX>(cx);
             ZV_STAMP(1, 8);
             zv_fold_barrier<CX>();
@@ -851,7 +855,9 @@ MH_DEV void zv_fold_out(const CX &cx, const HOOK &hook = HOOK())
          else
          {
             zv_limbs_fold_sel<TP, W, 0, -1, T, CX>(cx);
+            hook.after_early();
             zv_fold_barrier<CX>();
+            hook.after_late();
             zv_roots_fold<TP, T, CX>(cx);
          }
          // CSMODE 2 writes the accelerations IN PLACE over the bias rows (no LDS left for rows of their own at two workgroups per CU): no
@@ -859,7 +865,7 @@ MH_DEV void zv_fold_out(const CX &cx, const HOOK &hook = HOOK())
          // lie over the fold's exchange records)
          if constexpr (CX::csmode >= 2)
             zv_fold_barrier<CX>();
-         hook();
+         hook.before_out();
          asm volatile("" ::: "memory");
          zv_roots_out_wave<TP, W, T, CX>(cx);
       }
@@ -951,6 +957,178 @@ MH_DEV void zv_fetch_rows(lds_ptr<T> dst, const T *src, int rows)
    for (int u = 0; u < U; u++)
       if (t + NT * u < 64 * N)
          dst[t + NT * u] = r[u];
+}
+
+// ---- The hand-off in two stages (identity index maps; MH_ZV_TWO_STAGE=0 builds the one-stage form below for every model).
+// Phase stamps of the one-stage form (profiles/r04_zv_phase_stamps_b4096.txt): the inertia job is through with the root body at 9.2 us and
+// holds the bias efforts at 11.5 -- the trunk pass of the bias job (done 9.15), the copy of all rows (9.6), the acknowledgements (9.9), the
+// flag (10.0 -> seen 10.6), the fetch (11.5).  But the LIMBS' bias efforts exist at 8.3 (the barrier in front of the trunk pass), and the
+// limbs' folds are the first 1.5 us of what the inertia job does with the rows; the trunk's entries are needed behind them.  So:
+//   * the hand-off matrix of a group is column-major, [nv][64]: a wave publishes a column with one 512-byte store instruction, so
+//     different waves publish different columns at different times without writing any line in pieces;
+//   * waves 1-3 of the bias job publish the limb dofs' columns while wave 0 folds the trunk; each waits for its stores' acknowledgements
+//     and counts itself in (LDS); the last of the three stores flag A.  Wave 0 publishes the trunk dofs' columns behind its pass, waits,
+//     stores flag B;
+//   * every wave of the inertia job polls flag A itself, loads the columns of ITS limbs' dofs into its lanes' LDS rows and folds its
+//     limbs; it polls flag B and requests the trunk's columns behind its early limbs' fold and stores them to its rows behind its late
+//     limbs' fold, in front of the first use (sub-trunk / root fold).
+// Each of the two hand-offs is the form of MI355X_MICROARCH.md's table, first row: every byte stored sc1 and loaded sc1 (8 bytes per
+// lane), every storing wave drains its stores (s_waitcnt vmcnt(0)) before it is counted, ONE lane signals for all the stores the flag
+// covers (the last arrival at the LDS counter: condition (3) of that guide), the flag is an sc1 store polled by sc1 loads, and a wave
+// loads only after ITS OWN poll has matched.
+#ifndef MH_ZV_TWO_STAGE
+#define MH_ZV_TWO_STAGE 1
+#endif
+template <class TP>
+struct ZvCols
+{
+   static constexpr int NV = Tree<TP>::total_dofs();
+   static constexpr int body_of(int d)
+   {
+      for (int j = 0; j < TP::N; j++)
+         if (d >= Tree<TP>::dof_ofs(j) && d < Tree<TP>::dof_ofs(j) + Tree<TP>::ndof(j))
+            return j;
+      return 0;
+   }
+   static constexpr bool trunk(int d) { return Split<TP>::is_trunk(body_of(d)); }
+   // the wave of the inertia job that folds the limb this dof belongs to (-1: a trunk dof)
+   static constexpr int aba_owner(int d) { return trunk(d) ? -1 : Split<TP>::owner(Split<TP>::limb_index_of_body(body_of(d))); }
+   static constexpr int limb_number(int d)
+   { // how many limb columns come before column d
+      int n = 0;
+      for (int c = 0; c < d; c++)
+         n += trunk(c) ? 0 : 1;
+      return n;
+   }
+};
+// the columns of wave W's limbs (OWNER = W) or of the trunk (OWNER = -1), global -> registers (sc1 loads) -> the lane's LDS row
+template <class TP, typename T, int OWNER>
+struct ZvColRegs
+{
+   static constexpr int count()
+   {
+      int n = 0;
+      for (int d = 0; d < ZvCols<TP>::NV; d++)
+         n += ZvCols<TP>::aba_owner(d) == OWNER ? 1 : 0;
+      return n;
+   }
+   T r[count() > 0 ? count() : 1];
+   template <int D = 0, int K = 0>
+   MH_DEV void issue(const T *src, int lane)
+   {
+      if constexpr (D < ZvCols<TP>::NV)
+      {
+         if constexpr (ZvCols<TP>::aba_owner(D) == OWNER)
+         {
+            r[K] = __hip_atomic_load(src + D * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            issue<D + 1, K + 1>(src, lane);
+         }
+         else
+            issue<D + 1, K>(src, lane);
+      }
+   }
+   template <int D = 0, int K = 0>
+   MH_DEV void commit(lds_ptr<T> row) const
+   {
+      if constexpr (D < ZvCols<TP>::NV)
+      {
+         if constexpr (ZvCols<TP>::aba_owner(D) == OWNER)
+         {
+            row[D] = r[K];
+            commit<D + 1, K + 1>(row);
+         }
+         else
+            commit<D + 1, K>(row);
+      }
+   }
+};
+// columns of this group's hand-off matrix from the lane's LDS row, write-through.  TRUNK: the trunk dofs' columns; else the limb dofs'
+// columns number % 3 == share.
+template <class TP, typename T, bool TRUNK, int D = 0>
+MH_DEV void zv_publish_cols(T *dst, lds_ptr<T> row, int lane, int share)
+{
+   if constexpr (D < ZvCols<TP>::NV)
+   {
+      if constexpr (ZvCols<TP>::trunk(D) == TRUNK)
+      {
+         if (TRUNK || ZvCols<TP>::limb_number(D) % 3 == share)
+            __hip_atomic_store(dst + D * 64 + lane, row[D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      zv_publish_cols<TP, T, TRUNK, D + 1>(dst, row, lane, share);
+   }
+}
+// bias job of group k, two-stage hand-off: taup = this launch's hand-off matrices [groups][nv][64]
+template <class TP, typename T>
+MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, const ZvSync &sy)
+{
+   using S = Split<TP>;
+   using CX = Ctx<T, true, true, SplitStore<TP>, false, 1>;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const int nq = A.m.nq, nv = A.m.nv;
+   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * 6 * 64, lq = lst + S::RNEA_TRUNK_SLOTS * 64, lqd = lq + 64 * nq, lx = lqd + 64 * nv;
+   ZV_STAMP(0, 14);
+   const long cfg0 = k * 64;
+   const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+   const bool active = lane < rows;
+   __shared__ int zv_limb_waves; // waves 1-3 that have published their columns and seen them acknowledged
+   if (threadIdx.x == 0)
+      zv_limb_waves = 0;
+   ZV_STAMP(0, 0);
+   wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
+   __syncthreads();
+   ZV_STAMP(0, 1);
+   CX cx;
+   fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+   cx.coriolis = 1, cx.accel = 0;
+   cx.lq = lq + lane * nq, cx.lqd = lqd + lane * nv, cx.lx = lx + lane * nv, cx.lo = cx.lx;
+   cx.wave = wave;
+   cx.xbase = lxc + lane;
+   cx.st.lbase = lst + lane;
+   cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+   if (active)
+      split_rnea_limbs<TP, 0, T, CX>(cx);
+   ZV_STAMP(0, 2);
+   __syncthreads(); // the limbs' entries of every row are final; the limbs' wrenches are parked for the trunk pass
+   ZV_STAMP(0, 3);
+   T *const dst = taup + k * 64 * nv;
+   int *const flags = sy.flags + k * ZV_SYNC_STRIDE;
+   // (Storing tau - h of a joint to its column the moment it is formed -- no publishing pass at all -- was measured: the stores slow the
+   // limbs' walks by 0.45 us, flag A comes 0.3 us earlier, flag B 0.4 later, the step takes as long: profiles/r04_zv_two_stage.txt.)
+   if (wave == 0)
+   {
+      if (active)
+         rnea_trunk_roots<TP, T, CX>(cx);
+      ZV_STAMP(0, 4);
+      zv_publish_cols<TP, T, true>(dst, lx + lane * nv, lane, 0);
+      ZV_STAMP(0, 5);
+#ifdef MH_ZV_TEST_FLAG_BEFORE_DRAIN // tests/test_handoff_isa.py compiles this ONCE, to ISA text only, to prove that its checks catch a flag
+                                    // that can overtake its columns; it is never linked into anything
+      if (lane == 0)
+         __hip_atomic_store(flags, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the columns have been acknowledged by memory ...
+      ZV_STAMP(0, 6);
+#ifndef MH_ZV_TEST_FLAG_BEFORE_DRAIN
+      if (lane == 0) // ... so flag B, stored by the wave that stored them, is never seen ahead of them
+         __hip_atomic_store(flags, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      ZV_STAMP(0, 7);
+   }
+   else
+   {
+      ZV_STAMP(0, 4);
+      zv_publish_cols<TP, T, false>(dst, lx + lane * nv, lane, wave - 1);
+      ZV_STAMP(0, 5);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's columns have been acknowledged ...
+      ZV_STAMP(0, 6);
+      int before = 0;
+      if (lane == 0) // ... and the wave that learns it is the last of the three to say so stores flag A for all of them
+         before = __hip_atomic_fetch_add(&zv_limb_waves, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0 && before == 2)
+         __hip_atomic_store(flags + 1, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ZV_STAMP(0, 7);
+   }
 }
 
 // bias job of group k: taup rows = tau - RNEA(q, qd, 0); A.in3 = tau
@@ -1137,6 +1315,140 @@ MH_DEV void zv_aba_group(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup
    ZV_STAMP(1, 11);
 }
 
+// polls one word of the group's flag line until it holds this launch's epoch (see zv_wait): true when seen, false after the wall-clock limit
+MH_DEV bool zv_wait_word(const ZvSync &sy, const int *f)
+{
+   if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sy.epoch)
+      return true;
+   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+   for (;;)
+   {
+      __builtin_amdgcn_s_sleep(1);
+      if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sy.epoch)
+         return true;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)sy.wait_ticks)
+      {
+         if ((threadIdx.x & 63) == 0)
+            __hip_atomic_store(sy.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+         return false;
+      }
+   }
+}
+// inertia job of group k, two-stage hand-off (see zv_bias_group2)
+template <class TP, typename T>
+MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup, const ZvSync &sy)
+{
+   using S = Split<TP>;
+   using CX = Ctx<T, true, true, ZvStore<TP>, false, 0>;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int lane = threadIdx.x & 63;
+   const int nq = A.m.nq, nv = A.m.nv;
+   // LDS map: as zv_aba_group
+   const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * ZV_XW * 64, lq = lst + S::ZV_TRUNK_SLOTS * 64, lx = lq + 64 * nq, lres = lx + 64 * nv;
+   ZV_STAMP(1, 14);
+   const long cfg0 = k * 64;
+   const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
+   const bool active = lane < rows;
+   __shared__ int zv_gave_up;
+   if (threadIdx.x == 0)
+      zv_gave_up = 0;
+   ZV_STAMP(1, 0);
+   zv_stage_rows<T, Tree<TP>::total_cfgs(), 256>(lq, A.q + cfg0 * nq, rows);
+   __syncthreads();
+   ZV_STAMP(1, 1);
+   CX cx;
+   fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
+   cx.lq = lq + lane * nq, cx.lqd = lq, cx.lx = lx + lane * nv, cx.lo = lres + lane * nv;
+   cx.wave = wave;
+   cx.xbase = lxc + lane;
+   cx.st.lbase = lst + lane;
+   cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+#ifdef MH_ZV_PROBE
+   cx.own = (unsigned long long)k;
+#endif
+   if (active) // (lane 0 of every wave is active, so each wave reaches the barrier a staged trunk carries in here)
+      zv_limbs_in<TP, 0, T, CX>(cx);
+   ZV_STAMP(1, 2);
+   __syncthreads(); // every limb's (and sub-trunk's) articulated inertia is in the exchange area
+   ZV_STAMP(1, 3);
+   if (active)
+      zv_roots_in<TP, T, CX, (S::staged() ? 2 : 1)>(cx);
+   ZV_STAMP(1, 4);
+   // ---- stage one of the hand-off: the bias efforts of this wave's limbs, straight to its lanes' rows (nobody else reads those entries)
+   const T *const src = taup + k * 64 * nv;
+   const int *const flags = sy.flags + k * ZV_SYNC_STRIDE;
+   const lds_ptr<T> row = lx + lane * nv;
+   bool seen = zv_wait_word(sy, flags + 1);
+   ZV_STAMP(1, 5);
+   if (wave == 0)
+   {
+      ZvColRegs<TP, T, 0> c;
+      c.issue(src, lane), c.commit(row);
+   }
+   else if (wave == 1)
+   {
+      ZvColRegs<TP, T, 1> c;
+      c.issue(src, lane), c.commit(row);
+   }
+   else if (wave == 2)
+   {
+      ZvColRegs<TP, T, 2> c;
+      c.issue(src, lane), c.commit(row);
+   }
+   else
+   {
+      ZvColRegs<TP, T, 3> c;
+      c.issue(src, lane), c.commit(row);
+   }
+   // a first look at flag B, in flight during the early limbs' fold (a poll is a round trip to memory: 0.45 us on the stamps)
+   const int b_first = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   zv_lds_barrier(); // nobody reads the exchange area's inertias any more (the fold's records go over them)
+   ZV_STAMP(1, 6);
+   asm volatile("" ::: "memory");
+   // ---- stage two rides in the fold: the trunk's bias efforts, requested behind the early limbs' fold, stored behind the late limbs'
+   struct TrunkTau : ZvNoHook
+   {
+      mutable ZvColRegs<TP, T, -1> c;
+      const ZvSync &sy;
+      const int *flags;
+      const T *src;
+      lds_ptr<T> row;
+      int lane, b_first;
+      bool &seen;
+      MH_DEV void after_early() const
+      {
+         if (b_first != sy.epoch)
+            seen = zv_wait_word(sy, flags) && seen;
+         c.issue(src, lane);
+      }
+      MH_DEV void after_late() const { c.commit(row); } // (every wave stores the trunk's entries of its own lanes' rows: the same values four times)
+   };
+   const TrunkTau trunk{{}, {}, sy, flags, src, row, lane, b_first, seen};
+   if (active) // (lane 0 of every wave is active: each wave reaches the barriers the fold carries in here)
+      zv_fold_out<TP, 0, T, CX>(cx, trunk);
+   ZV_STAMP(1, 10);
+   if (!seen && lane == 0)
+      zv_gave_up = 1;
+   __syncthreads();
+   // The flags go back to zero once their columns have been consumed: a captured launch is replayed with the SAME epoch (hipGraph), and a flag
+   // left standing from the previous replay would let this job read the previous replay's columns.  (Stream order puts the reset before the
+   // next launch's bias job; every wave's polls and loads lie in front of the barrier above.)
+   if (threadIdx.x == 0)
+   {
+      __hip_atomic_store(const_cast<int *>(flags), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(const_cast<int *>(flags) + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+   if (zv_gave_up)
+   { // (the whole workgroup takes this branch) columns that never came: NaN instead of accelerations formed from whatever the scratch
+     // matrix holds; the error word is set, the host reports MH_ERR_HIP at its next synchronisation point (mh_api.hip)
+      for (int i = threadIdx.x; i < rows * nv; i += 256) // (as a bit pattern: the build's -ffinite-math-only knows no NaN values)
+         reinterpret_cast<unsigned long long *>(A.out)[cfg0 * nv + i] = 0x7ff8000000000000ull;
+      return;
+   }
+   wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
+   ZV_STAMP(1, 11);
+}
+
 // One launch, jobs * ceil(B / 64) workgroups (padded to blocks of eight): blocks of eight consecutive workgroup ids share a role, so
 // the bias job, the inertia job (and the inverse dynamics job) of the same 64 configurations have ids that differ by a multiple of
 // eight -- the dispatcher deals ids round-robin to the eight XCDs, which puts them behind the same L2 -- and the producer's id is lower.
@@ -1157,13 +1469,19 @@ __global__ void __launch_bounds__(256) MH_ZV_KERNEL_ATTR spec_zv_kernel(Args<T> 
    {
       Args<T> A2 = A;
       A2.in3 = A.in3b;
-      zv_bias_group<TP, T, IDENT>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
+      if constexpr (IDENT && MH_ZV_TWO_STAGE && sizeof(T) == 8)
+         zv_bias_group2<TP, T>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
+      else
+         zv_bias_group<TP, T, IDENT>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
    }
    else if (role == 1)
    {
       Args<T> A2 = A;
       A2.out = A.outb;
-      zv_aba_group<TP, T, IDENT>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
+      if constexpr (IDENT && MH_ZV_TWO_STAGE && sizeof(T) == 8)
+         zv_aba_group2<TP, T>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
+      else
+         zv_aba_group<TP, T, IDENT>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
    }
    else
    {
@@ -1472,10 +1790,18 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
    ZV_STAMP(2, 8);
    // ---- bias fold and outward sweep
    asm volatile("" ::: "memory");
-   auto ahead = [&]() {
-      if constexpr (MH_ZVF_AHEAD == 2)
-         rows_ahead.request(A, next); // behind the fold: in flight during the outward sweep and the copy-out
+   struct Ahead : ZvNoHook
+   {
+      ZvfRows<T, ZvfPlan<TP>::NQ, ZvfPlan<TP>::NV> &rows;
+      const Args<T> &A;
+      long next;
+      MH_DEV void before_out() const
+      {
+         if constexpr (MH_ZVF_AHEAD == 2)
+            rows.request(A, next); // behind the fold: in flight during the outward sweep and the copy-out
+      }
    };
+   const Ahead ahead{{}, rows_ahead, A, next};
    if (active) // (lane 0 of every wave is active: each wave reaches the barriers the fold carries in here)
       zv_fold_out<TP, 0, T, CX>(cx, ahead); // (a ragged group is the last one: what it would request is never committed)
    ZV_STAMP(2, 10);

@@ -3,7 +3,9 @@ that hipcc lowers to sc1 accesses, an inline `s_waitcnt vmcnt(0)`, workgroup bar
 update that re-scopes one access or moves the flag store would break it silently.  So every registered code object is
 disassembled and its spec_zv_kernel instruction streams are checked against the protocol (tools/isa_handoff.py); and one deliberately
 broken build (the flag stored BEFORE the rows are drained) proves that the check sees such a break.  No GPU needed: hipcc cross-compiles and
-llvm-objdump reads the code objects the build left in the tree."""
+llvm-objdump reads the code objects the build left in the tree.  Round 4: with identity index maps the hand-off runs in two stages (the limbs'
+columns under one flag, the trunk's under another; three waves counted in through LDS in front of the first) -- the checker recognises
+which form a stream is and holds it to that form's rules; the broken build breaks the two-stage form (flag B in front of wave 0's drain)."""
 import os
 import subprocess
 import sys
@@ -63,4 +65,4 @@ def test_the_check_catches_a_flag_stored_before_the_rows_are_drained(tmp_path):
         assert found, tag
         verdicts[tag] = [b for instrs in found.values() for b in isa_handoff.check_handoff(instrs)]
     assert verdicts["as shipped"] == []
-    assert any("flag can overtake its rows" in b for b in verdicts["flag before drain"]), verdicts["flag before drain"]
+    assert any("flag can overtake its" in b for b in verdicts["flag before drain"]), verdicts["flag before drain"]

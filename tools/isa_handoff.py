@@ -12,6 +12,9 @@ registered code object and checks the instruction stream itself:
              last poll from the first row load; every row load behind it is `global_load_dwordx2 ... sc1`;
   give-up    the wall-clock limit's error word is stored at system scope (sc0 sc1).
 
+Code objects with identity index maps run the hand-off in two stages (limb columns under flag A, trunk columns under flag B: see
+check_two_stage); the stream tells which form it is.
+
 usage: python tools/isa_handoff.py <libmecano_hip_topo_*.so | file.s> ...
 """
 from __future__ import annotations
@@ -58,8 +61,75 @@ def scope(operands: str) -> str:
     return " ".join(b for b in ("sc0", "sc1") if re.search(r"\b" + b + r"\b", operands))
 
 
+def is_two_stage(instrs) -> bool:
+    """The two-stage form counts its publishing waves in through an LDS atomic right in front of a flag store."""
+    for i, (op, a) in enumerate(instrs):
+        if op == "global_store_dword" and scope(a) == "sc1" and any(o.startswith("ds_add_rtn") for o, _ in instrs[max(0, i - 40):i]):
+            return True
+    return False
+
+
+def check_two_stage(instrs) -> list:
+    """The two-stage hand-off (zv_bias_group2 / zv_aba_group2): flag A covers the limb columns of waves 1-3 (each drains its stores, counts
+    itself in through LDS, the last arrival stores the flag), flag B the trunk columns of wave 0 (drains, stores the flag itself); every
+    consumer wave polls for itself and loads only behind its own poll."""
+    bad = []
+    n = len(instrs)
+    idx = lambda pred: [i for i, (op, a) in enumerate(instrs) if pred(op, a)]
+    drains = idx(lambda op, a: op == "s_waitcnt" and re.search(r"vmcnt\(0\)", a))
+    small_stores = idx(lambda op, a: op == "global_store_dword")
+    flag_stores = [i for i in small_stores if scope(instrs[i][1]) == "sc1"]
+    row_stores = idx(lambda op, a: op == "global_store_dwordx2" and scope(a) != "")
+    row_loads = idx(lambda op, a: op == "global_load_dwordx2" and scope(a) == "sc1")
+    polls = idx(lambda op, a: op == "global_load_dword" and scope(a) == "sc1")
+    # ---- producer
+    if not row_stores:
+        bad.append("producer: no scoped column store (global_store_dwordx2 sc1) found")
+    for i in row_stores:
+        if scope(instrs[i][1]) != "sc1":
+            bad.append(f"producer: column store #{i} is {scope(instrs[i][1])}, not write-through (sc1)")
+        nd = next((d for d in drains if d > i), None)
+        if nd is None:
+            bad.append(f"producer: column store #{i} is not followed by `s_waitcnt vmcnt(0)`")
+            continue
+        early = [f for f in small_stores if i < f < nd]
+        if early:
+            bad.append(f"producer: flag-sized store #{early[0]} sits between column store #{i} and its wave's drain #{nd}: the flag can overtake its columns")
+        nf = next((f for f in flag_stores if f > nd), None)
+        if nf is None or nf - nd > 120:
+            bad.append(f"producer: no sc1 flag store within 120 instructions behind the drain #{nd} of column store #{i}")
+    counted = [f for f in flag_stores if any(o.startswith("ds_add_rtn") for o, _ in instrs[max(0, f - 40):f])]
+    if not counted:
+        bad.append("producer: no flag store behind an LDS arrival counter (the limb columns are published by three waves)")
+    for f in counted:
+        add = max(i for i in range(max(0, f - 40), f) if instrs[i][0].startswith("ds_add_rtn"))
+        if not [d for d in drains if row_stores and max((r for r in row_stores if r < add), default=-1) < d < add]:
+            bad.append(f"producer: the arrival count #{add} in front of flag store #{f} is not behind its wave's `s_waitcnt vmcnt(0)`")
+    # ---- consumer
+    if len(polls) < 4:
+        bad.append(f"consumer: expected a first look and a polling loop on each of the two flags (global_load_dword sc1), found {len(polls)}")
+    if not [i for i, (op, a) in enumerate(instrs) if op == "s_sleep" and polls and polls[0] < i < polls[-1] + 40]:
+        bad.append("consumer: the polling loops have no s_sleep")
+    if not row_loads:
+        bad.append("consumer: no sc1 column load (global_load_dwordx2 sc1) found")
+    elif polls:
+        if row_loads[0] < polls[0]:
+            bad.append(f"consumer: column load #{row_loads[0]} comes before the first poll #{polls[0]}")
+        # (the jobs' code lies one behind the other in the stream and shares one exit: the consumer's loads are those between its first
+        # poll and its last sc1 column load -- a plain load among them would be a column read that may be served from this CU's L1)
+        plain = [i for i, (op, a) in enumerate(instrs) if polls[0] < i < row_loads[-1] and op.startswith("global_load_dwordx") and scope(a) != "sc1"]
+        if plain:
+            bad.append(f"consumer: load #{plain[0]} between the first poll and the last column load is not sc1 (it may be served from this CU's L1)")
+    # ---- give-up
+    if not [f for f in small_stores if scope(instrs[f][1]) == "sc0 sc1"]:
+        bad.append("give-up: the error word is not stored at system scope (sc0 sc1)")
+    return bad
+
+
 def check_handoff(instrs) -> list:
     """Violations of the hand-off protocol in one spec_zv_kernel instruction stream (empty list: the stream is as the protocol needs it)."""
+    if is_two_stage(instrs):
+        return check_two_stage(instrs)
     bad = []
     n = len(instrs)
     idx = lambda pred: [i for i, (op, a) in enumerate(instrs) if pred(op, a)]
