@@ -843,6 +843,8 @@ MH_DEV void zv_fold_out(const CX &cx, const HOOK &hook = HOOK())
             zv_limbs_fold_sel<TP, W, 0, 0, T, CX>(cx);
             hook.after_early();
             ZV_STAMP(1, 7);
+            // (An arrival count instead of this barrier -- only the wave that folds a sub-trunk waiting for the early limbs, the legs' waves
+            // going straight on -- was measured: the legs finish 0.3 us earlier, but arm -> torso -> pelvis is the fold's chain: no change.)
             zv_fold_barrier<CX>();
             zv_limbs_fold_sel<TP, W, 0, 1, T, CX>(cx);
             hook.after_late();
@@ -1042,21 +1044,56 @@ struct ZvColRegs
       }
    }
 };
-// columns of this group's hand-off matrix from the lane's LDS row, write-through.  TRUNK: the trunk dofs' columns; else the limb dofs'
-// columns number % 3 == share.
-template <class TP, typename T, bool TRUNK, int D = 0>
-MH_DEV void zv_publish_cols(T *dst, lds_ptr<T> row, int lane, int share)
+// columns of this group's hand-off matrix from the lane's LDS row, write-through.  SHARE = -1: the trunk dofs' columns; 0..2: the limb dofs'
+// columns number % 3 == SHARE.  All LDS reads first, then all stores (read and stored one by one -- the columns picked by a run-time
+// share -- the seven columns of a wave took 0.5 us: a chain of LDS round trips).
+template <class TP, typename T, int SHARE>
+struct ZvPublish
 {
-   if constexpr (D < ZvCols<TP>::NV)
+   static constexpr bool mine(int d) { return SHARE < 0 ? ZvCols<TP>::trunk(d) : (!ZvCols<TP>::trunk(d) && ZvCols<TP>::limb_number(d) % 3 == SHARE); }
+   static constexpr int count()
    {
-      if constexpr (ZvCols<TP>::trunk(D) == TRUNK)
-      {
-         if (TRUNK || ZvCols<TP>::limb_number(D) % 3 == share)
-            __hip_atomic_store(dst + D * 64 + lane, row[D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      zv_publish_cols<TP, T, TRUNK, D + 1>(dst, row, lane, share);
+      int n = 0;
+      for (int d = 0; d < ZvCols<TP>::NV; d++)
+         n += mine(d) ? 1 : 0;
+      return n;
    }
-}
+   T r[count() > 0 ? count() : 1];
+   template <int D = 0, int K = 0>
+   MH_DEV void read(lds_ptr<T> row)
+   {
+      if constexpr (D < ZvCols<TP>::NV)
+      {
+         if constexpr (mine(D))
+         {
+            r[K] = row[D];
+            read<D + 1, K + 1>(row);
+         }
+         else
+            read<D + 1, K>(row);
+      }
+   }
+   template <int D = 0, int K = 0>
+   MH_DEV void store(T *dst, int lane) const
+   {
+      if constexpr (D < ZvCols<TP>::NV)
+      {
+         if constexpr (mine(D))
+         {
+            __hip_atomic_store(dst + D * 64 + lane, r[K], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            store<D + 1, K + 1>(dst, lane);
+         }
+         else
+            store<D + 1, K>(dst, lane);
+      }
+   }
+   static MH_DEV void run(T *dst, lds_ptr<T> row, int lane)
+   {
+      ZvPublish p;
+      p.read(row);
+      p.store(dst, lane);
+   }
+};
 // bias job of group k, two-stage hand-off: taup = this launch's hand-off matrices [groups][nv][64]
 template <class TP, typename T>
 MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, const ZvSync &sy)
@@ -1100,7 +1137,7 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
       if (active)
          rnea_trunk_roots<TP, T, CX>(cx);
       ZV_STAMP(0, 4);
-      zv_publish_cols<TP, T, true>(dst, lx + lane * nv, lane, 0);
+      ZvPublish<TP, T, -1>::run(dst, lx + lane * nv, lane);
       ZV_STAMP(0, 5);
 #ifdef MH_ZV_TEST_FLAG_BEFORE_DRAIN // tests/test_handoff_isa.py compiles this ONCE, to ISA text only, to prove that its checks catch a flag
                                     // that can overtake its columns; it is never linked into anything
@@ -1118,7 +1155,12 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    else
    {
       ZV_STAMP(0, 4);
-      zv_publish_cols<TP, T, false>(dst, lx + lane * nv, lane, wave - 1);
+      if (wave == 1)
+         ZvPublish<TP, T, 0>::run(dst, lx + lane * nv, lane);
+      else if (wave == 2)
+         ZvPublish<TP, T, 1>::run(dst, lx + lane * nv, lane);
+      else
+         ZvPublish<TP, T, 2>::run(dst, lx + lane * nv, lane);
       ZV_STAMP(0, 5);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's columns have been acknowledged ...
       ZV_STAMP(0, 6);
