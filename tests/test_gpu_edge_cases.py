@@ -302,3 +302,46 @@ def test_inverse_dynamics_loop_that_requests_rows_ahead(torch_cuda):
         close(results["2"][k].cpu().numpy(), om.rnea(a, b, c, G, fext), 1e-10, label="rows ahead, wrenches"); k += 1
         for cc, ca in ((False, True), (True, False), (False, False)):
             close(results["2"][k].cpu().numpy(), om.rnea(a, b, c, G, fext, cc, ca), 1e-10, label=f"rows ahead, switches {cc} {ca}"); k += 1
+
+
+def test_a_consumer_that_gives_up_writes_nan_and_reports_at_the_next_synchronisation(torch_cuda, tmp_path):
+    """The one failure of an asynchronous call (include/mecano_hip.h, "Asynchronous failures"): a bias-split forward dynamics
+    launch whose inertia job waits longer than MH_ZV_WAIT_MS for its bias job.  It cannot be provoked on a healthy device, so ONE code
+    object is built here with -DMH_ZV_TEST_NO_FLAG (a bias job that never stores its flags; minimal kernel set, into a scratch directory,
+    loaded through MH_SPEC_DIR with the create-time self-check off) and the contract is checked on it: the call returns MH_OK, every row
+    of the output is NaN -- never numbers formed from stale scratch --, mh_model_check reports MH_ERR_HIP once, the error word is then
+    clear again, and a call that does not take the bias split (MH_ZV=0 view of the same model) is unaffected."""
+    import os
+    import subprocess
+    torch = torch_cuda
+    from mecano_amd import _lib, build as mbuild, random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    d = sys_.toModelDesc()
+    key, parents, kinds = mbuild.topology_of(d)
+    out = tmp_path / os.path.basename(mbuild.spec_path(key))
+    subprocess.check_call([mbuild.hipcc()] + mbuild.SPEC_FLAGS + [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
+                          "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-DMH_SPEC_MINIMAL", "-DMH_ZV_TEST_NO_FLAG", "-o", str(out),
+                          mbuild.SPEC_SOURCE], stderr=subprocess.DEVNULL)
+    B = 200  # four groups of 64 configurations, the last one ragged
+    q, qd, _, tau = rt.nextState(np.random.default_rng(5), sys_, B)
+    keys = ("MH_SPEC_DIR", "MH_SPEC_SELFCHECK", "MH_ZV_WAIT_MS", "MH_ZV")
+    try:
+        os.environ.update({"MH_SPEC_DIR": str(tmp_path), "MH_SPEC_SELFCHECK": "0", "MH_ZV_WAIT_MS": "3"})
+        hm = HipModel(d)
+        assert hm.kernel_variant.startswith("topo:"), hm.kernel_variant
+        a = hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), G)  # returns MH_OK: the failure happens on the device, later
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(a).all()), "rows of a group whose bias efforts never came must be NaN"
+        with pytest.raises(_lib.MecanoHipError) as e:
+            hm.check()
+        assert "gave up waiting" in str(e.value)
+        hm.check()  # reported once: the word is clear again
+        os.environ["MH_ZV"] = "0"  # the same code object without the bias split: the tree-split kernels need no hand-off
+        hm2 = HipModel(d)
+        close(hm2.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), G).cpu().numpy(), OracleModel(d).aba(q, qd, tau, G), 1e-10, label="tree split")
+        hm2.check()
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
