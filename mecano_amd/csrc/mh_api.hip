@@ -221,7 +221,7 @@ struct mh_model
    int use_zvf = 1;       // MH_ZVF=0: never the fused one-launch form; 1: where the two-launch form would be taken (default); 2: whenever the call qualifies
    int zv_epoch = 0;
    int *zv_error_host = nullptr, *zv_error_dev = nullptr;
-   int zv_same_l2 = 0;    // MH_ZV_SAME_L2=1 (experiment, off by default): bias rows and flag of a group whose two jobs prove to sit behind the same L2
+   int zv_same_l2 = 0;    // MH_ZV_SAME_L2=1 (experiment, off by default; one-stage hand-off only: the two-stage form of identity index maps is write-through): bias rows and flag of a group whose two jobs prove to sit behind the same L2
                           // stay in that L2 (workgroup-scope stores) -- cache behaviour the memory model does not promise, for no measured gain
    unsigned zv_wait_ticks = 200000000u; // MH_ZV_WAIT_MS: how long an inertia job waits for its bias rows (100 MHz ticks; default 2 s)
    int use_zv = 1;        // MH_ZV=0: never; 1: while every job's workgroup gets a CU of its own (default); 2: whenever the call qualifies
