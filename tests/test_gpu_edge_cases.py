@@ -345,3 +345,19 @@ def test_a_consumer_that_gives_up_writes_nan_and_reports_at_the_next_synchronisa
     finally:
         for k in keys:
             os.environ.pop(k, None)
+
+
+def test_bias_split_on_every_registered_shape_and_under_graph_replay():
+    """tools/check_zv.py all: the bias-split forward dynamics (two-stage hand-off where the index maps are the identity) forced at every batch
+    size (MH_ZV=2) on the five registered tree shapes -- staged trunks, a plain split, a chain without one -- at B = 1 ... 12 000 with
+    ragged last groups, three launches each, against the oracle; and five replays of a captured mh_rnea_aba_f64 launch (the same epoch every
+    time: the consumer must have put both flags back to zero), bit for bit.  A subprocess: the tool pins MH_ZV before the library loads."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MH_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_zv.py"), "all"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = [l for l in r.stdout.splitlines() if l.startswith("worst scaled error")]
+    assert last and float(last[-1].split()[-1]) < 1e-9, r.stdout[-500:]
