@@ -111,11 +111,26 @@ def build_spec(desc, force: bool = False, verbose: bool = False) -> str:
     out = spec_path(key)
     if not force and not _stale(out, [SPEC_SOURCE] + SPEC_HEADERS):
         return out
-    cmd = [hipcc()] + SPEC_FLAGS + [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
-                               "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-o", out, SPEC_SOURCE]
-    if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    defs = [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
+            "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds)]
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if verbose else []
+    # two translation units (mh_spec.hip, MH_SPEC_PART = 1 | 2), compiled side by side and linked into one code object: hipcc generates the
+    # device code of a unit kernel by kernel on one core, and the humanoid's single unit took five minutes
+    from concurrent.futures import ThreadPoolExecutor
+    compile_flags = [f for f in SPEC_FLAGS if f != "-shared"]
+    objs = [out[:-3] + f".part{part}.o" for part in (1, 2)]
+
+    def one(part):
+        subprocess.check_call([hipcc()] + compile_flags + defs + extra + [f"-DMH_SPEC_PART={part}", "-c", "-o", objs[part - 1], SPEC_SOURCE])
+
+    try:
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            list(pool.map(one, (1, 2)))
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
     return out
 
 

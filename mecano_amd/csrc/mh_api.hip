@@ -216,6 +216,7 @@ struct mh_model
    Workspace zv_tau, zv_flags;
    Workspace zvb_cs;      // two-launch forward dynamics: (cos, sin) of the revolute joints, [2 n_rev][B rounded up to 64]
    int use_rnea_ahead = 1; // MH_RNEA_AHEAD (see rnea_ahead_ok)
+   int use_zv_step = 1;    // MH_ZV_STEP=0: simulation steps never ride in the bias-split / fused forward dynamics (the one-job tree-split kernel integrates instead)
    int use_zvb = 1;       // MH_ZVB=0: never; 1: batches of two or more groups of 64 configurations per CU (default); 2: whenever the call qualifies; MH_ZVB_WHICH = 1 | 2: one of the two launches only (timing)
    int zvb_which = 3;
    int use_zvf = 1;       // MH_ZVF=0: never the fused one-launch form; 1: where the two-launch form would be taken (default); 2: whenever the call qualifies
@@ -1116,26 +1117,43 @@ mh_status launch(Algo algo, mh_model_t model, int64_t B, const T *q, const T *qd
    }
    if constexpr (sizeof(T) == 8)
    {
-      if (algo == ALGO_ABA && !q_next && zv_ok(model, B, soa, 2))
+      // (a simulation step rides in the inertia job where the index maps are the identity: the two-stage form of the hand-off integrates the
+      // rows it holds and writes the new state too -- 17.5 against 20.1 us per step at B = 4096, profiles/r04_step_rates.txt)
+      if (algo == ALGO_ABA && (!q_next || (model->ident_maps && model->use_zv_step)) && zv_ok(model, B, soa, 2))
       { // forward dynamics as two jobs side by side: bias efforts | articulated inertias, then the bias fold (mh_zv_kernels.h)
          if (const mh_status se = zv_check_error(model); se != MH_OK)
             return se;
          A.in3b = in3, A.outb = out;
+         if (q_next)
+            A.dt = (T)step_dt, A.q_next = q_next, A.qd_next = qd_next;
          int rc = 0;
          if (const mh_status sz = zv_launch(model, A, 2, stream, &rc); sz != MH_OK)
             return sz;
          if (rc == 0)
+         {
+            if (q_next && stepped)
+               *stepped = true;
             return MH_OK;
+         }
          A.in3b = nullptr, A.outb = nullptr; // not in this code object: the plans below
+         A.dt = T(0), A.q_next = nullptr, A.qd_next = nullptr;
       }
-      if (algo == ALGO_ABA && !q_next && zvf_ok(model, B, soa))
+      if (algo == ALGO_ABA && (!q_next || model->use_zv_step) && zvf_ok(model, B, soa))
       { // device-filling batches: bias efforts, articulated inertias, fold and outward sweep of a group of 64 configurations by ONE workgroup
+        // (a simulation step rides along: 32.3 against 42.4 us per step at 32 768, 226.5 against 286.7 at 262 144 -- profiles/r04_step_rates.txt)
          const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
+         if (q_next)
+            A.dt = (T)step_dt, A.q_next = q_next, A.qd_next = qd_next;
          const int rc = model->spec.launch_zvf(SPEC_IO_LDS | SPEC_IDENT, &A, (int)groups, (void *)stream);
          if (rc == 0)
+         {
+            if (q_next && stepped)
+               *stepped = true;
             return MH_OK;
+         }
          if (rc != (int)hipErrorNotSupported)
             return fail(MH_ERR_HIP, "fused forward dynamics failed to launch: %s", hipGetErrorString((hipError_t)rc));
+         A.dt = T(0), A.q_next = nullptr, A.qd_next = nullptr;
       }
       if (algo == ALGO_ABA && !q_next && zvb_ok(model, B, soa))
       { // ... or as two launches: bias rows and (cos, sin) pairs by one, articulated inertias + fold + outward sweep by the next
@@ -2209,6 +2227,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_zvf = atoi(e);
    if (const char *e = getenv("MH_RNEA_AHEAD"))
       m->use_rnea_ahead = atoi(e);
+   if (const char *e = getenv("MH_ZV_STEP"))
+      m->use_zv_step = atoi(e) ? 1 : 0;
    if (const char *e = getenv("MH_ZVB_WHICH"))
       m->zvb_which = std::max(1, std::min(3, atoi(e)));
    if (const char *e = getenv("MH_ABA_LDS_FACTOR"))

@@ -2399,7 +2399,7 @@ constexpr unsigned long long spec_abi_stamp()
    const unsigned long long parts[] = {sizeof(Args<double>), sizeof(CentArgs<double>), (unsigned long long)MC_STRIDE, (unsigned long long)MI_STRIDE,
                                        (unsigned long long)MH_FRAME_CONVENTION, (unsigned long long)offsetof(Args<double>, joint_wrench),
                                        (unsigned long long)offsetof(Args<double>, q_next), (unsigned long long)ZV_SYNC_STRIDE,
-                                       3ull /* revision of the mh_spec_* entry points' signatures: 2 = mh_spec_launch_zv(..., same_l2, stream); 3 = mh_spec_launch_zvb */};
+                                       4ull /* revision of the mh_spec_* entry points' signatures: 2 = mh_spec_launch_zv(..., same_l2, stream); 3 = mh_spec_launch_zvb */};
    for (unsigned long long v : parts)
       h = (h ^ v) * 1099511628211ull;
    return h;

@@ -13,6 +13,11 @@
 #include <cstdlib>
 #include <type_traits>
 
+// MH_SPEC_PART = 1 | 2: this file compiled as one of two translation units that are linked into one code object (mecano_amd/build.py: the
+// device code of a unit is generated kernel by kernel on one core, and the humanoid's took five minutes); undefined / 0: everything.
+#ifndef MH_SPEC_PART
+#define MH_SPEC_PART 0
+#endif
 #ifndef MH_TOPO_N
 #error "MH_TOPO_N / MH_TOPO_PARENTS / MH_TOPO_TYPES must be defined"
 #endif
@@ -158,7 +163,7 @@ hipError_t go_fused(const mh::Args<double> &A, int waves, hipStream_t stream)
 }
 
 using SPL = mh::Split<TP>;
-long split_lds_bytes(int algo, int flags, int nq, int nv)
+static long split_lds_bytes(int algo, int flags, int nq, int nv)
 {
    if (algo == 2)
       return std::max(split_lds_bytes(0, flags, nq, nv), split_lds_bytes(1, flags, nq, nv));
@@ -219,6 +224,7 @@ hipError_t go_split_algo(int algo, const mh::Args<double> &A, int groups, hipStr
 
 extern "C" {
 // tree-split kernels (4 waves per 64 configurations): available when the tree has a trunk with at least two limbs
+#if MH_SPEC_PART != 2 // ---- part 1 of a two-part build: everything but the bias-split / fused / rows-ahead launchers
 int mh_spec_split_usable(void) { return SPL::usable() ? 1 : 0; }
 long mh_spec_split_lds_bytes(int algo, int flags, int nq, int nv) { return split_lds_bytes(algo, flags, nq, nv); }
 // algo: 0 = RNEA, 1 = ABA, 2 = fused RNEA+ABA (2 * groups workgroups); groups = ceil(B / 64) or fewer (grid-stride).
@@ -260,6 +266,8 @@ int mh_spec_launch_split(int algo, int flags, const void *args, int groups, void
    return (int)go_split_algo<false, false>(algo, A, groups, s, occ3);
 #endif
 }
+#endif
+#if MH_SPEC_PART != 1 // ---- part 2: the kernels of mh_zv_kernels.h
 // ---- bias-split forward dynamics (mh_zv_kernels.h): AoS matrices with dense index maps, rows staged in LDS
 long mh_spec_zv_lds_bytes(int nq, int nv)
 {
@@ -288,6 +296,17 @@ int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, 
       const long groups = (A.B + 63) / 64, padded = (groups + 7) / 8 * 8;
       const mh::ZvSync sy{sync_flags, error, epoch, jobs, same_l2 ? 1 : 0, wait_ticks};
       hipStream_t s = (hipStream_t)stream;
+      if (A.q_next && (!(flags & F_IDENT) || jobs != 2 || !MH_ZV_TWO_STAGE))
+         return (int)hipErrorNotSupported; // a simulation step rides in the two-stage form only (identity index maps, forward dynamics alone)
+      if ((flags & F_IDENT) && A.q_next)
+      {
+         static LdsAttr attr_step;
+         auto kern = &mh::spec_zv_kernel<TP, double, true, true>;
+         if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr_step); e != hipSuccess)
+            return (int)e;
+         hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A, (double *)taup, sy);
+         return (int)hipGetLastError();
+      }
       if (flags & F_IDENT)
       {
          static LdsAttr attr;
@@ -430,12 +449,24 @@ int mh_spec_launch_zvf(int flags, const void *args, int groups, void *stream)
       const mh::Args<double> &A = *(const mh::Args<double> *)args;
       if (!(flags & F_IO_LDS) || !(flags & F_IDENT) || !mh_spec_zvf_usable() || groups < 1 || A.m.nq != TR::total_cfgs() || A.m.nv != TR::total_dofs())
          return (int)hipErrorNotSupported;
+      if (A.q_next)
+      { // a simulation step: the kernel that integrates the rows it holds and writes the new state too
+         if constexpr (mh::ZvfPlan<TP>::step_usable())
+         {
+            static LdsAttr attr_step;
+            return (int)launch_lds(&mh::spec_zvf_kernel<TP, double, true, true>, A, groups, (size_t)mh_spec_zvf_lds_bytes(), attr_step, (hipStream_t)stream);
+         }
+         else
+            return (int)hipErrorNotSupported;
+      }
       static LdsAttr attr;
       return (int)launch_lds(&mh::spec_zvf_kernel<TP, double, true>, A, groups, (size_t)mh_spec_zvf_lds_bytes(), attr, (hipStream_t)stream);
    }
    else
       return (int)hipErrorNotSupported;
 }
+#endif
+#if MH_SPEC_PART != 2
 // the tree-split plan of this topology, for tests and documentation: out[0] = usable, [1] = staged trunk, [2] = limbs, [3] = sub-trunks,
 // [4] = root trunk body, then per limb (root body, bodies, ABA owner wave, RNEA / CRBA owner wave, late) and per wave the body after
 // whose children its cut barrier sits (-1: explicit barrier).  Returns the number of ints written (<= cap).
@@ -633,4 +664,5 @@ int mh_spec_launch(int algo, int flags, const void *args, int grid, void *stream
    return (int)hipErrorNotSupported;
 #endif
 }
+#endif
 }

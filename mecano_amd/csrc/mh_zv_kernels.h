@@ -961,6 +961,32 @@ MH_DEV void zv_fetch_rows(lds_ptr<T> dst, const T *src, int rows)
          dst[t + NT * u] = r[u];
 }
 
+// The rows of the NEXT group a workgroup will work on, requested while the current one is being finished and held in registers until the
+// LDS rows are free (both launches loop over groups with two workgroups per CU: a wave that sits waiting for its rows is a quarter of what
+// the SIMD has to run).  Stamps at B = 262 144 (profiles/r04_zvb_phase_stamps.txt): staging q, qd, tau took 3.2 of the bias launch's 11.3 us
+// per group, the (cos, sin) pairs and the bias rows ~2 of the inertia launch's 11.4.
+template <typename T, int N, int NT>
+struct RowRegs
+{
+   static constexpr int U = (64 * N + NT - 1) / NT;
+   T r[U];
+   // t: this thread's number among the NT that take part (threadIdx.x when all 256 do; threadIdx.x - 64 when waves 1-3 load for the group)
+   MH_DEV void issue(const T *src, int rows, int t = threadIdx.x)
+   { // rows >= 1.  Entries past the last row are clamped onto it, not selected away: a select on the loaded value makes the load a
+     // synchronous one (the wave waits for it right here -- 1.4 us per group on the stamps), and nobody reads those LDS entries anyway
+      const int last = rows * N - 1;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+         r[u] = src[t + NT * u < last ? t + NT * u : last];
+   }
+   MH_DEV void commit(lds_ptr<T> dst, int t = threadIdx.x) const
+   {
+#pragma unroll
+      for (int u = 0; u < U; u++)
+         if (t + NT * u < 64 * N)
+            dst[t + NT * u] = r[u];
+   }
+};
 // ---- The hand-off in two stages (identity index maps; MH_ZV_TWO_STAGE=0 builds the one-stage form below for every model).
 // Phase stamps of the one-stage form (profiles/r04_zv_phase_stamps_b4096.txt): the inertia job is through with the root body at 9.2 us and
 // holds the bias efforts at 11.5 -- the trunk pass of the bias job (done 9.15), the copy of all rows (9.6), the acknowledgements (9.9), the
@@ -1380,7 +1406,7 @@ MH_DEV bool zv_wait_word(const ZvSync &sy, const int *f)
    }
 }
 // inertia job of group k, two-stage hand-off (see zv_bias_group2)
-template <class TP, typename T>
+template <class TP, typename T, bool STEP>
 MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *taup, const ZvSync &sy)
 {
    using S = Split<TP>;
@@ -1419,6 +1445,12 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
    if (active)
       zv_roots_in<TP, T, CX, (S::staged() ? 2 : 1)>(cx);
    ZV_STAMP(1, 4);
+   // simulation step: the velocities of the group, requested by ALL threads (each its share of the rows, whether its lane holds a
+   // configuration or not), in front of the first poll (tools/isa_handoff.py: every load behind it is a hand-off load) and in flight
+   // until the outward sweep is through
+   RowRegs<T, STEP ? Tree<TP>::total_dofs() : 1, 256> rqd;
+   if constexpr (STEP)
+      rqd.issue(A.qd + cfg0 * nv, rows);
    // ---- stage one of the hand-off: the bias efforts of this wave's limbs, straight to its lanes' rows (nobody else reads those entries)
    const T *const src = taup + k * 64 * nv;
    const int *const flags = sy.flags + k * ZV_SYNC_STRIDE;
@@ -1488,7 +1520,26 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
      // matrix holds; the error word is set, the host reports MH_ERR_HIP at its next synchronisation point (mh_api.hip)
       for (int i = threadIdx.x; i < rows * nv; i += 256) // (as a bit pattern: the build's -ffinite-math-only knows no NaN values)
          reinterpret_cast<unsigned long long *>(A.out)[cfg0 * nv + i] = 0x7ff8000000000000ull;
+      if constexpr (STEP)
+      { // a simulation step: the new state of those configurations is NaN too
+         for (int i = threadIdx.x; i < rows * nq; i += 256)
+            reinterpret_cast<unsigned long long *>(A.q_next)[cfg0 * nq + i] = 0x7ff8000000000000ull;
+         for (int i = threadIdx.x; i < rows * nv; i += 256)
+            reinterpret_cast<unsigned long long *>(A.qd_next)[cfg0 * nv + i] = 0x7ff8000000000000ull;
+      }
       return;
+   }
+   if constexpr (STEP)
+   { // fused simulation step (a kernel of its own, spec_zv_kernel<.., STEP = true>: the plain call's code stays as it is): q (lq) and the fresh accelerations (lres) of the 64 configurations sit in LDS, the velocities arrive in the
+     // rows the bias efforts no longer need (lx) -- integrated in place (MultiBodySystemStateIntegrator.java:365-441, 503-575, 710-733)
+     // and streamed out with the accelerations
+      rqd.commit(lx);
+      __syncthreads();
+      if (active)
+         integrate_rows<TP, 0, T>(wave, lq + lane * nq, lx + lane * nv, lres + lane * nv, A.dt, T(0.5) * A.dt * A.dt);
+      __syncthreads();
+      wave_copy_out<T, 256>(A.q_next + cfg0 * nq, lq, rows * nq);
+      wave_copy_out<T, 256>(A.qd_next + cfg0 * nv, lx, rows * nv);
    }
    wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
    ZV_STAMP(1, 11);
@@ -1500,7 +1551,7 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
 #ifndef MH_ZV_KERNEL_ATTR
 #define MH_ZV_KERNEL_ATTR
 #endif
-template <class TP, typename T, bool IDENT>
+template <class TP, typename T, bool IDENT, bool STEP = false>
 __global__ void __launch_bounds__(256) MH_ZV_KERNEL_ATTR spec_zv_kernel(Args<T> A, T *taup, ZvSync sy)
 {
    extern __shared__ double lds_raw[];
@@ -1524,7 +1575,7 @@ __global__ void __launch_bounds__(256) MH_ZV_KERNEL_ATTR spec_zv_kernel(Args<T> 
       Args<T> A2 = A;
       A2.out = A.outb;
       if constexpr (IDENT && MH_ZV_TWO_STAGE && sizeof(T) == 8)
-         zv_aba_group2<TP, T>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
+         zv_aba_group2<TP, T, STEP>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
       else
          zv_aba_group<TP, T, IDENT>(A2, k, (lds_ptr<T>)lds_raw, taup, sy);
    }
@@ -1557,32 +1608,6 @@ struct ZvbPlan
    static constexpr int bias_lds_slots(int nq, int nv) { return S::n_limbs() * 6 + S::RNEA_TRUNK_SLOTS + nq + 2 * nv; }
 };
 
-// The rows of the NEXT group a workgroup will work on, requested while the current one is being finished and held in registers until the
-// LDS rows are free (both launches loop over groups with two workgroups per CU: a wave that sits waiting for its rows is a quarter of what
-// the SIMD has to run).  Stamps at B = 262 144 (profiles/r04_zvb_phase_stamps.txt): staging q, qd, tau took 3.2 of the bias launch's 11.3 us
-// per group, the (cos, sin) pairs and the bias rows ~2 of the inertia launch's 11.4.
-template <typename T, int N, int NT>
-struct RowRegs
-{
-   static constexpr int U = (64 * N + NT - 1) / NT;
-   T r[U];
-   // t: this thread's number among the NT that take part (threadIdx.x when all 256 do; threadIdx.x - 64 when waves 1-3 load for the group)
-   MH_DEV void issue(const T *src, int rows, int t = threadIdx.x)
-   { // rows >= 1.  Entries past the last row are clamped onto it, not selected away: a select on the loaded value makes the load a
-     // synchronous one (the wave waits for it right here -- 1.4 us per group on the stamps), and nobody reads those LDS entries anyway
-      const int last = rows * N - 1;
-#pragma unroll
-      for (int u = 0; u < U; u++)
-         r[u] = src[t + NT * u < last ? t + NT * u : last];
-   }
-   MH_DEV void commit(lds_ptr<T> dst, int t = threadIdx.x) const
-   {
-#pragma unroll
-      for (int u = 0; u < U; u++)
-         if (t + NT * u < 64 * N)
-            dst[t + NT * u] = r[u];
-   }
-};
 
 // first launch: rows tau - RNEA(q, qd, 0) (A.in3 = tau) to taup [B][nv], (cos, sin) of the revolute joints to cs [2 n_rev][cs_stride].
 // BIAS = false: the plain inverse dynamics of device-filling batches (A.in3 = qdd, rows RNEA(q, qd, qdd) to taup = A.out, cs unused) --
@@ -1757,6 +1782,9 @@ struct ZvfPlan
    // the trunk slots are written while the inverse dynamics' exchange area and parking area are still being read: they must fit under
    // the rows of q and qd, which are dead by then
    static constexpr bool usable() { return S::usable() && joints_ok() && ST::TRUNK_SLOTS <= NQ + NV && lds_slots() * 64 * 8 * 2 <= 160 * 1024; }
+   // a simulation step re-stages the rows of q and qd behind the outward sweep, over the (dead) trunk slots and fold records: they must end
+   // in front of the result rows
+   static constexpr bool step_usable() { return usable() && NQ + NV <= ST::TRUNK_SLOTS + S::n_limbs() * 12; }
 };
 template <typename T, int NQ, int NV>
 struct ZvfRows
@@ -1771,7 +1799,7 @@ struct ZvfRows
    }
 };
 // one group of 64 configurations; `next`: the group whose rows are requested on the way (the same group again on the last turn)
-template <class TP, typename T, bool IDENT>
+template <class TP, typename T, bool IDENT, bool STEP = false>
 MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRows<T, ZvfPlan<TP>::NQ, ZvfPlan<TP>::NV> &rows_ahead)
 {
    using S = Split<TP>;
@@ -1850,6 +1878,23 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
    if (active) // (lane 0 of every wave is active: each wave reaches the barriers the fold carries in here)
       zv_fold_out<TP, 0, T, CX>(cx, ahead); // (a ragged group is the last one: what it would request is never committed)
    ZV_STAMP(2, 10);
+   if constexpr (STEP)
+   { // fused simulation step (spec_zvf_kernel<.., STEP = true>): the rows of q and qd were given up to the trunk's slots long ago -- they are
+     // requested again (nothing else is alive in the registers here), land over the dead trunk slots and fold records in front of the result
+     // rows (ZvfPlan::step_usable), and the new state is integrated in place and streamed out beside the accelerations
+     // (MultiBodySystemStateIntegrator.java:365-441, 503-575, 710-733)
+      RowRegs<T, ZvfPlan<TP>::NQ, 256> rq;
+      RowRegs<T, ZvfPlan<TP>::NV, 256> rd;
+      rq.issue(A.q + cfg0 * nq, rows), rd.issue(A.qd + cfg0 * nv, rows);
+      zv_lds_barrier(); // every wave is through with its outward sweep: the trunk's slots are dead
+      rq.commit(lq), rd.commit(lqd);
+      zv_lds_barrier();
+      if (active)
+         integrate_rows<TP, 0, T>(wave, lq + lane * nq, lqd + lane * nv, lres + lane * nv, A.dt, T(0.5) * A.dt * A.dt);
+      zv_lds_barrier();
+      wave_copy_out<T, 256>(A.q_next + cfg0 * nq, lq, rows * nq);
+      wave_copy_out<T, 256>(A.qd_next + cfg0 * nv, lqd, rows * nv);
+   }
    if constexpr (MH_ZVF_AHEAD == 3)
       rows_ahead.request(A, next); // behind the outward sweep (nothing else is alive any more): in flight during the copy-out
    zv_lds_barrier();
@@ -1858,7 +1903,7 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
    zv_lds_barrier(); // the rows are committed over the result rows by the next turn
    ZV_STAMP(2, 12);
 }
-template <class TP, typename T, bool IDENT>
+template <class TP, typename T, bool IDENT, bool STEP = false>
 __global__ void __launch_bounds__(256, 2) spec_zvf_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -1867,6 +1912,6 @@ __global__ void __launch_bounds__(256, 2) spec_zvf_kernel(Args<T> A)
    if constexpr (MH_ZVF_AHEAD)
       rows_ahead.request(A, blockIdx.x);
    for (long k = blockIdx.x; k < ngroups; k += gridDim.x)
-      zvf_group<TP, T, IDENT>(A, k, k + gridDim.x < ngroups ? k + gridDim.x : k, (lds_ptr<T>)lds_raw, rows_ahead);
+      zvf_group<TP, T, IDENT, STEP>(A, k, k + gridDim.x < ngroups ? k + gridDim.x : k, (lds_ptr<T>)lds_raw, rows_ahead);
 }
 } // namespace mh

@@ -31,11 +31,19 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def disassemble(so_path: str) -> str:
     """Device code (gfx950) of a HIP shared object as llvm-objdump text."""
     with tempfile.TemporaryDirectory() as tmp:
-        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        fat = os.path.join(tmp, "fat.bin")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path, os.path.join(tmp, "copy.so")])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-        return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
+        # a code object linked from several translation units carries one offload bundle per unit, one behind the other
+        blob, magic, text = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__", ""
+        starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+        for n, a in enumerate(starts):
+            part, co = os.path.join(tmp, f"bundle{n}.bin"), os.path.join(tmp, f"dev{n}.co")
+            with open(part, "wb") as f:
+                f.write(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            text += subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
+        return text
 
 
 def kernels(text: str) -> dict:
