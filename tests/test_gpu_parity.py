@@ -749,8 +749,9 @@ def test_body_accelerations_and_twists(torch_cuda, family):
 
 @pytest.mark.parametrize("B", [1, 64, 100, 4096, 20000])
 def test_simulation_step_equals_aba_then_integrate(torch_cuda, B):
-    """mh_aba_integrate_f64 (one launch on the humanoid: the tree-split ABA kernel integrates the rows it holds in LDS; two launches for
-    models without a specialised code object) against oracle ABA + oracle integrator, out of place and in place, several steps."""
+    """mh_aba_integrate_f64 (one launch on the humanoid: the inertia job of the bias-split kernel at small batches, the fused kernel at
+    device-filling ones -- B = 20 000 --, the one-job tree-split kernel with MH_ZV_STEP=0: each integrates the rows it holds in LDS; two
+    launches for models without a specialised code object) against oracle ABA + oracle integrator, out of place and in place, several steps."""
     torch = torch_cuda
     from mecano_amd import random_tools as rt
     from mecano_amd.engine import HipModel
@@ -775,6 +776,17 @@ def test_simulation_step_equals_aba_then_integrate(torch_cuda, B):
             rq, rv, _ = om.integrate(dt, rq, rv, a)
             hm.step(dt, tq, tv, tt, g, inplace=True)
         close(tq.cpu().numpy(), rq, 1e-11), close(tv.cpu().numpy(), rv, 1e-10)
+    os.environ["MH_ZV_STEP"] = "0"  # the one-job tree-split kernel's own fused step (what every batch size took before round 4)
+    try:
+        sys_ = rt.nextHumanoid(np.random.default_rng(6))
+        d = sys_.toModelDesc()
+        q, qd, _, tau = rt.nextState(rng, sys_, B)
+        a = OracleModel(d).aba(q, qd, tau, g)
+        r_q, r_v, _ = OracleModel(d).integrate(dt, q, qd, a)
+        nq, nv, qdd = HipModel(d).step(dt, dev(torch, q), dev(torch, qd), dev(torch, tau), g)
+        close(qdd.cpu().numpy(), a), close(nq.cpu().numpy(), r_q, 1e-12), close(nv.cpu().numpy(), r_v, 1e-11)
+    finally:
+        os.environ.pop("MH_ZV_STEP", None)
     os.environ["MH_SPEC_SPLIT"] = "0"  # forced two-launch path on the humanoid: same answer
     try:
         sys_ = rt.nextHumanoid(np.random.default_rng(5))
