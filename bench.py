@@ -43,7 +43,7 @@ CLOCK_HZ, N_SIMDS = 2.4e9, 1024  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs
 REGIONS = 5
 
 
-def cpu_baseline(desc, q, qd, qdd, tau, gravity, jobs, target_s=10.0):
+def cpu_baseline(desc, q, qd, qdd, tau, gravity, jobs, target_s=20.0):
     """Oracle (CPU port) on the host cores: steps' worth of evaluations per second on a bounded sample of the same batch.  One thread per
     core, each walking its own passes (the C calls release the GIL; the oracle keeps its scratch thread-local); the single-thread rate is
     measured first and quoted in `sample`.  `jobs`: which oracle calls make one evaluation ("rnea", "aba", "crba")."""
