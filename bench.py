@@ -77,7 +77,7 @@ def cpu_baseline(desc, q, qd, qdd, tau, gravity, jobs, target_s=20.0):
         pass
     # bounded: about target_s seconds of wall clock; every thread walks `per` configurations of the batch `reps` times
     per = min(len(q), 4096)
-    reps = int(max(1, min(1024 // cores + 1, target_s * single / per)))
+    reps = int(max(1, min(2048 // cores + 1, target_s * single / per)))
     done = [0] * cores
 
     def work(t):
