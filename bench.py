@@ -12,7 +12,7 @@ model is broadcast once over RCCL before timing and the outputs are all-gathered
   --config 5   configs[4]: random 128-body tree, RNEA + ABA, fp32, 1 048 576 sharded       (strong scaling)
   (no flag)    the metric: humanoid RNEA + ABA, fp64, 4096 per GPU                       (weak scaling)
 
-Timing: --ramp-ms (100) milliseconds of untimed steps for the device's clocks, W warm-up steps, then R >= 5 timed REGIONS of exactly K steps each, every region bracketed by barrier + synchronize on both
+Timing: --ramp-ms (100) milliseconds of untimed steps for the device's clocks, W warm-up steps, then R (25; at least 5 for the long-running configurations) timed REGIONS of exactly K steps each, every region bracketed by barrier + synchronize on both
 sides; `value` and `ms_per_step` come from the MEDIAN region (max over ranks per region), all regions are listed in `region_ms`.  Each is
 followed by a region of the same K steps with HIP events recorded on the launch stream (`event_region_ms`): the roofline's kernel
 durations come from those, `value` from the regions that carry nothing but the steps.  After
@@ -40,7 +40,7 @@ MODEL_SEED, STATE_SEED = 43, 2342
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MEASURED_COPY_GBS = 6290.0   # device copy kernel measured on this pool (profiles/r01_integrate_rates.txt)
 CLOCK_HZ, N_SIMDS = 2.4e9, 1024  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs
-REGIONS = 5
+REGIONS = 25  # 25 regions of the driver's 20 steps are 8 ms of the headline: the median of 25 rests on more than 1.6 ms of GPU time
 
 
 def cpu_baseline(desc, q, qd, qdd, tau, gravity, jobs, target_s=20.0):
@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=(0, 3, 4, 5), help="BASELINE.json configuration (1-based); default 0 = the metric")
     ap.add_argument("--batch", type=int, default=0, help="configurations per step: per GPU for the weak-scaling workloads, in total for --config 4 / 5")
     ap.add_argument("--ramp-ms", type=float, default=100.0, help="untimed steps for this long before the W warm-up steps (device clocks; 0: none)")
-    ap.add_argument("--regions", type=int, default=REGIONS, help="timed regions of --steps steps each; the median is reported (>= 1)")
+    ap.add_argument("--regions", type=int, default=0, help=f"timed regions of --steps steps each; the median is reported.  0 (default): {REGIONS}, fewer (>= 5) when 2 x regions x steps would take longer than ~12 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate", action="store_true", help="two calls per step (mh_rnea_f64, then mh_aba_f64 / mh_crba_f64) instead of mh_rnea_aba_f64 / mh_rnea_crba_f64")
     args = ap.parse_args()
@@ -265,11 +265,33 @@ def main():
     from mecano_amd.engine import HipModel, HipTimer
     from mecano_amd.multibody import MultiBodySystem
 
+    # ---- N > 1 validates itself: one rank per GPU means as many visible devices as ranks, every rank on a device of
+    # its own, and a communicator that counts --gpus ranks -- or the run exits non-zero instead of printing a line that measured one GPU
+    # N times.  The one exception is explicit: MECANO_DIST_BACKEND=gloo (tests that rehearse the N > 1 path with ranks SHARING the box's GPU).
+    shared_gpu_rehearsal = env_world > 1 and os.environ.get("MECANO_DIST_BACKEND") == "gloo"
+    if env_world > 1 and not shared_gpu_rehearsal and torch.cuda.device_count() < env_world:  # (device_count() does not initialise the GPU)
+        raise SystemExit(f"bench.py --gpus {env_world}: only {torch.cuda.device_count()} HIP device(s) visible; one rank per GPU needs {env_world} "
+                         "(ranks folded onto one device would measure that device N times).  MECANO_DIST_BACKEND=gloo rehearses the path with shared devices.")
     rank, world, local_rank = mdist.init_from_env()
     assert world == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if shared_gpu_rehearsal else local_rank)
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    pci = ":".join(f"{int(getattr(props, k)):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(props, k)) or None
+    device_id = {"rank": rank, "host": os.uname().nodename, "device_index": torch.cuda.current_device(), "pci": pci,
+                 "uuid": str(getattr(props, "uuid", "")) or None, "name": props.name}
+    devices = [device_id]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, device_id)
+        ones = torch.ones(1, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)  # what the communicator counts, not what the launcher was asked for
+        if int(ones.item()) != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the communicator counts {int(ones.item())} rank(s), world size {dist.get_world_size()}")
+        where = [(d["host"], d["pci"] or d["uuid"] or d["device_index"]) for d in devices]
+        if len(set(where)) != world and not shared_gpu_rehearsal:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: ranks share a device: {where}")
     if not os.path.exists(build.LIB):
         build.build_lib()
 
@@ -338,14 +360,23 @@ def main():
         while time.perf_counter() < t_end:
             step()
         torch.cuda.synchronize()
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    step_s_estimate = (time.perf_counter() - t_w) / max(1, args.warmup)
     # ---- timed regions: exactly K steps each between barrier + synchronize pairs.  They come in two kinds, interleaved: CLOCK regions carry
     # nothing but the K steps (`value`, `ms_per_step`, `region_ms`); EVENT regions additionally carry the HIP events on the launch stream
     # the roofline's kernel durations come from (`kernels_ms`, `event_region_ms`).  The events are instrumentation with a cost of their
     # own inside a region -- an event pair around 20 steps of the headline: 7-8 us of 340 (profiles/r04_region_overhead.txt) -- so the
     # figure the metric is quoted on is taken where they are absent, and the host clock of the event regions is printed beside it.
-    K, R = args.steps, max(1, args.regions)
+    K, R = args.steps, args.regions
+    if R <= 0:  # every rank must loop the same number of times: rank 0 decides
+        R = max(5, min(REGIONS, int(12.0 / max(1e-9, 2 * K * step_s_estimate))))
+        if world > 1:
+            r_t = torch.tensor([R], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(r_t, src=0)
+            R = int(r_t.item())
     region_s, event_region_s, kernel_ms = [], [], {j: [] for j in ((fused_key,) if fused else jobs)}
 
     def region(with_events):
@@ -407,13 +438,15 @@ def main():
         gather_ms = (time.perf_counter() - t1) * 1e3
         assert full.shape[0] == B_total
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, {"rank": rank, "batch": B, "kernels_ms": kernels_ms})
+        dist.all_gather_object(per_rank, {"rank": rank, "batch": B, "kernels_ms": kernels_ms, "device": device_id})
 
     rccl_ranks = None
     if world > 1:  # what the communicator saw, not what the launcher was asked for
         ones = torch.ones(1, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ones)
         rccl_ranks = {"world_size": dist.get_world_size(), "ranks_counted": int(ones.item())}
+        if rccl_ranks["ranks_counted"] != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: {rccl_ranks}")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -505,6 +538,9 @@ def main():
                    "parallelism": f"dp{world} (batch sharded, no data-path collective)", "kernel_variant": model.kernel_variant,
                    "model_seed": MODEL_SEED if cfg != 5 else 128, "state_seed": STATE_SEED},
         "ramp_ms": args.ramp_ms, "regions": R, "region_ms": [s * 1e3 for s in region_s], "reported_region": "median",
+        "region_ms_min": min(region_s) * 1e3, "region_ms_max": max(region_s) * 1e3,
+        "devices_distinct": (len({(d["host"], d["pci"] or d["uuid"] or d["device_index"]) for d in devices}) == world),
+        "shared_gpu_rehearsal": bool(shared_gpu_rehearsal),
         "event_region_ms": [s * 1e3 for s in event_region_s],  # the same K steps with the HIP events of `kernels_ms` / `roofline` recorded around them
         "roofline": roofline,
         "kernels_ms": kernels_ms,

@@ -75,7 +75,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 4
+#define MH_ABI_VERSION 5
 
 /* ---- status codes (the Java shim maps them back to Mecano's exception types) ---- */
 typedef enum mh_status
@@ -164,6 +164,19 @@ int32_t mh_abi_version(void);
 /* what a topology-specialised code object (libmecano_hip_topo_<key>.so) must report from its mh_spec_abi() to be accepted by this
  * library build: a hash over the argument structs, record strides and the canonical-frame convention the two share */
 uint64_t mh_spec_abi_stamp(void);
+/*
+ * Build provenance (MH_ABI_VERSION 5).  Every binary carries a hash of what it was compiled from -- FNV-1a 64 over the source files, their
+ * headers and the code-generation flags -- as the string "MH_BUILD_ID=<hash>;..." in its file and through these calls:
+ *   mh_build_hash()              this library's own sources and flags
+ *   mh_spec_sources_hash()       the kernel sources + flags a code object libmecano_hip_topo_<key>.so must have been compiled from to be
+ *                                accepted by mh_model_create (it exports the same name; a different hash is refused like a wrong ABI stamp,
+ *                                mh_model_kernel_variant says so)
+ *   mh_spec_sources_hash_of(dir) the hash of the kernel sources found in `dir` (csrc/), "h" + 16 hex digits + NUL into out[18]: what
+ *                                mh_build_code_object checks before it compiles, what mecano_amd/build.py compares instead of file times
+ */
+const char *mh_build_hash(void);
+const char *mh_spec_sources_hash(void);
+mh_status mh_spec_sources_hash_of(const char *csrc_dir, char out[18]);
 const char *mh_last_error(void);           /* thread-local, never NULL */
 mh_status mh_device_count(int32_t *count); /* 0 devices is MH_OK with *count = 0 */
 mh_status mh_set_device(int32_t device);   /* device used by subsequent calls of this thread */
@@ -179,6 +192,25 @@ int32_t mh_model_n_joints(mh_model_t model);
  * libmecano_hip_topo_<key>.so was found, matches this library build (ABI stamp) and passed the create-time self-check against the
  * run-time-topology kernels; "generic" otherwise, followed by the reason in parentheses when a code object was found but refused */
 const char *mh_model_kernel_variant(mh_model_t model);
+/*
+ * Where this engine consciously departs from the reference (MH_ABI_VERSION 5).  mh_model_create inspects the description and sets:
+ *   MH_WARN_NEAR_COORDINATE_AXIS  a revolute axis lies within 1e-7 of +X, +Y or +Z without being that axis.  Mecano then rotates the joint
+ *                                 about the EXACT coordinate axis (roll / pitch / yaw closed forms, tools/MecanoFactories.java:51,237-248)
+ *                                 while the joint's unit twist keeps the axis as given (multiBodySystem/OneDoFJoint.java:170); the engine
+ *                                 uses the given axis for both.  Bound: results differ from Mecano's by <= ~4e-7 relative (instead of 1e-10).
+ *                                 Remedy: snap the axis onto the coordinate axis in the description (then both agree to 1e-10).
+ *   MH_WARN_TINY_COMPOSITE_MASS   a body's mass plus a child subtree's is under 1e-7: Mecano's SpatialInertia.add skips the
+ *                                 renormalisation of the centre of mass (spatial/interfaces/FixedFrameSpatialInertiaBasics.java:174-175);
+ *                                 the engine's composite (m, m c, I) stays consistent.  Concerns mh_crba_* / Coriolis / centroidal outputs
+ *                                 only (RNEA and ABA never add inertias); bound: <= 1e-6 absolute on H for masses of that size.
+ * 0 = the model is in neither class and every output is held to 1e-10 against the reference's arithmetic.  mh_model_warning_text gives
+ * the joints concerned ("" when no bit is set; owned by the model); mh_model_create also leaves that text in mh_last_error() while
+ * returning MH_OK.
+ */
+#define MH_WARN_NEAR_COORDINATE_AXIS 1u
+#define MH_WARN_TINY_COMPOSITE_MASS 2u
+uint32_t mh_model_warnings(mh_model_t model);
+const char *mh_model_warning_text(mh_model_t model);
 
 /*
  * Host-only: validates the description and returns the key of its topology (tree shape + joint kinds, in the engine's
@@ -204,10 +236,13 @@ mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, c
 /*
  * ---- contexts (see "Threading" at the top) ----
  * A context owns everything a compute call writes besides its outputs; the model handle it was made from stays read-only.  Make one per
- * host thread or stream, pass it in opts->context; destroy it before its model.  mh_context_reserve is mh_reserve for a context.
+ * host thread or stream, pass it in opts->context.  mh_context_reserve is mh_reserve for a context.
  * While contexts of a model exist mh_model_set_joint_source_modes is refused (the contexts hold copies of the joint records' host side).
- * A context must be destroyed BEFORE its model (it shares the model's device records); mh_stream_synchronize reports a pending
- * asynchronous failure of ANY context and clears it -- use mh_model_check where the failing context matters.
+ * The model is reference-counted by its contexts (they share its device records): mh_model_destroy on a model with live contexts gives
+ * up the caller's reference only -- calls through the surviving contexts (with the same handle value) stay valid, no new context can be
+ * made -- and the last mh_context_destroy releases the device records.  mh_context_create may run while other threads compute through
+ * the model or its contexts.  mh_stream_synchronize reports a pending asynchronous failure of ANY context and clears it -- use
+ * mh_model_check where the failing context matters.
  */
 mh_status mh_context_create(mh_model_t model, mh_context_t *ctx_out);
 void mh_context_destroy(mh_context_t ctx);

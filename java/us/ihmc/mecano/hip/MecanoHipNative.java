@@ -15,7 +15,7 @@ import static java.lang.foreign.ValueLayout.JAVA_INT;
 import static java.lang.foreign.ValueLayout.JAVA_LONG;
 
 /**
- * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h, ABI version 4.  NOT compiled in this repository's image (no JVM
+ * Panama (java.lang.foreign, JDK 22+) binding of include/mecano_hip.h, ABI version 5.  NOT compiled in this repository's image (no JVM
  * there); it is the reference-side stub a Mecano maintainer adds.  One downcall handle per C entry point the shim classes use; every
  * entry point returns an mh_status int which {@link #check(int)} maps back to the exception types Mecano itself throws.
  * <p>
@@ -37,7 +37,7 @@ public final class MecanoHipNative
    }
 
    /** the ABI version this binding was written against (include/mecano_hip.h: MH_ABI_VERSION); checked when the class loads */
-   static final int ABI = 4;
+   static final int ABI = 5;
 
    /**
     * struct mh_options { int32 consider_coriolis, consider_accelerations, layout, use_root_acceleration; void *stream; double
@@ -53,6 +53,10 @@ public final class MecanoHipNative
    static final MethodHandle MODEL_CREATE = handle("mh_model_create", status(ADDRESS, ADDRESS));
    static final MethodHandle MODEL_DESTROY = handle("mh_model_destroy", FunctionDescriptor.ofVoid(ADDRESS));
    static final MethodHandle MODEL_KERNEL_VARIANT = handle("mh_model_kernel_variant", FunctionDescriptor.of(ADDRESS, ADDRESS));
+   /** MH_WARN_* bits: model classes in which the engine consciously departs from Mecano (include/mecano_hip.h). */
+   static final MethodHandle MODEL_WARNINGS = handle("mh_model_warnings", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+   static final MethodHandle MODEL_WARNING_TEXT = handle("mh_model_warning_text", FunctionDescriptor.of(ADDRESS, ADDRESS));
+   static final int WARN_NEAR_COORDINATE_AXIS = 1, WARN_TINY_COMPOSITE_MASS = 2;
    /** (desc, out_dir|NULL, path_out, path_cap): runs hipcc on the kernel sources next to the library; minutes; once per robot. */
    static final MethodHandle BUILD_CODE_OBJECT = handle("mh_build_code_object", status(ADDRESS, ADDRESS, ADDRESS, JAVA_LONG));
    static final MethodHandle RESERVE = handle("mh_reserve", status(ADDRESS, JAVA_LONG));

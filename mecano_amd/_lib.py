@@ -17,9 +17,9 @@ LAYOUT_AOS, LAYOUT_SOA = 0, 1
 
 # every symbol include/mecano_hip.h declares (tests/test_abi.py checks the library exports each one)
 ABI_SYMBOLS = [
-    "mh_abi_version", "mh_spec_abi_stamp", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
+    "mh_abi_version", "mh_spec_abi_stamp", "mh_build_hash", "mh_spec_sources_hash", "mh_spec_sources_hash_of", "mh_last_error", "mh_device_count", "mh_set_device", "mh_options_default", "mh_model_create", "mh_model_destroy",
     "mh_context_create", "mh_context_destroy", "mh_context_reserve", "mh_model_check",
-    "mh_topology_key", "mh_build_code_object", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64", "mh_rnea_crba_f64", "mh_regressor_f64", "mh_regressor_f32",
+    "mh_topology_key", "mh_build_code_object", "mh_model_nq", "mh_model_nv", "mh_model_n_joints", "mh_model_kernel_variant", "mh_model_warnings", "mh_model_warning_text", "mh_reserve", "mh_rnea_f64", "mh_aba_f64", "mh_crba_f64", "mh_rnea_aba_f64", "mh_rnea_crba_f64", "mh_regressor_f64", "mh_regressor_f32",
     "mh_model_set_joint_source_modes", "mh_model_n_acceleration_sources", "mh_aba_locked_f64", "mh_rnea_bodies_f64", "mh_aba_bodies_f64", "mh_rnea_joint_wrenches_f64", "mh_aba_joint_wrenches_f64", "mh_relative_acceleration_f64", "mh_crba_coriolis_f64", "mh_crba_coriolis_f32", "mh_centroidal_f64", "mh_centroidal_f32", "mh_integrate_f64", "mh_aba_integrate_f64", "mh_integrate_f32", "mh_rnea_f32", "mh_aba_f32", "mh_crba_f32", "mh_rnea_aba_f32", "mh_rnea_bodies_f32", "mh_aba_bodies_f32", "mh_aba_locked_f32", "mh_rnea_f64_host", "mh_aba_f64_host", "mh_crba_f64_host", "mh_rnea_f32_host", "mh_aba_f32_host", "mh_crba_f32_host", "mh_rnea_aba_f64_host", "mh_host_alloc", "mh_host_free", "mh_host_register", "mh_host_unregister", "mh_device_alloc", "mh_device_free", "mh_copy_to_device", "mh_copy_to_host", "mh_stream_synchronize", "mh_crba_coriolis_f64_host", "mh_centroidal_f64_host", "mh_timer_create",
     "mh_timer_destroy", "mh_timer_start", "mh_timer_stop", "mh_timer_elapsed_ms",
     "mh_shard_range", "mh_comm_unique_id", "mh_comm_create", "mh_comm_destroy", "mh_comm_size", "mh_comm_broadcast", "mh_comm_broadcast_host",
@@ -96,6 +96,9 @@ def _load_locked():
     P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.mh_abi_version.restype = I32
     lib.mh_spec_abi_stamp.restype = ctypes.c_uint64
+    lib.mh_build_hash.restype = ctypes.c_char_p
+    lib.mh_spec_sources_hash.restype = ctypes.c_char_p
+    lib.mh_spec_sources_hash_of.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     lib.mh_last_error.restype = ctypes.c_char_p
     lib.mh_device_count.argtypes = [ctypes.POINTER(I32)]
     lib.mh_set_device.argtypes = [I32]
@@ -109,6 +112,10 @@ def _load_locked():
         getattr(lib, f).restype = I32
     lib.mh_model_kernel_variant.argtypes = [P]
     lib.mh_model_kernel_variant.restype = ctypes.c_char_p
+    lib.mh_model_warnings.argtypes = [P]
+    lib.mh_model_warnings.restype = ctypes.c_uint32
+    lib.mh_model_warning_text.argtypes = [P]
+    lib.mh_model_warning_text.restype = ctypes.c_char_p
     lib.mh_topology_key.argtypes = [ctypes.POINTER(MhModelDesc), ctypes.c_char_p, P, P]
     lib.mh_build_code_object.argtypes = [ctypes.POINTER(MhModelDesc), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     lib.mh_reserve.argtypes = [P, I64]

@@ -10,6 +10,7 @@
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 import shutil
 import subprocess
@@ -25,17 +26,22 @@ HEADERS = [os.path.join(CSRC, "mh_kernels.h"), os.path.join(CSRC, "mh_device.h")
 LIB_HEADERS = HEADERS + [os.path.join(CSRC, "mh_dfs_kernels.h"), os.path.join(CSRC, "mh_split_kernels.h")]  # the library's own kernels
 SPEC_SOURCE = os.path.join(CSRC, "mh_spec.hip")
 SPEC_HEADERS = HEADERS + [os.path.join(CSRC, "mh_spec_kernels.h"), os.path.join(CSRC, "mh_zv_kernels.h")]
+# what a code object is hashed over, in this order (mh_api.hip: kSpecHashFiles / kSpecCodegenFlags hold the same lists: the library's
+# own builder, mh_build_code_object, computes the same number; tests/test_build_provenance.py compares the two implementations)
+SPEC_HASH_FILES = [os.path.join(CSRC, n) for n in ("mh_spec.hip", "mh_spec_kernels.h", "mh_zv_kernels.h", "mh_kernels.h", "mh_device.h")]
 # -fno-signed-zeros -ffinite-math-only: lets the compiler drop the multiplications by the structural zeros of the canonical
 # joint frames (S = e_z); no reassociation is enabled, products and sums keep their written order.
 # -fno-slp-vectorize: hipcc 7.2 packs adjacent fp32 operations into v_pk_* instructions; in crba_kernel<float> that came with a wrong
 # component select for the first row of a multi-DoF joint's diagonal block (tools/diag_f32_crba2.py, DESIGN.md open issues), and packed
 # fp32 VALU is no faster on gfx950 anyway.  fp64 code is unaffected (there are no packed fp64 instructions).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize"]
+CODEGEN_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-signed-zeros", "-ffinite-math-only", "-fno-slp-vectorize"]
+FLAGS = CODEGEN_FLAGS + ["-fPIC", "-shared"]
 # the code objects only.  -disable-machine-licm: the kernels that loop over groups of 64 configurations (persistent workgroups at device-
 # filling batches) are a few thousand instructions of straight-line code per turn; the machine-level loop-invariant code motion lifts the
 # literal constants of that body (sincos coefficients, 1.0, ...) out of the loop into ~24 VGPRs that then live across every phase.  Without
 # it: fused forward dynamics 256 registers + 32 bytes of scratch -> 240 and none, tree-split RNEA 220 -> 190, tree-split CRBA 125 -> 98.
-SPEC_FLAGS = FLAGS + ["-mllvm", "-disable-machine-licm"]
+SPEC_CODEGEN_FLAGS = CODEGEN_FLAGS + ["-mllvm", "-disable-machine-licm"]
+SPEC_FLAGS = SPEC_CODEGEN_FLAGS + ["-fPIC", "-shared"]
 
 
 # deepest root-to-leaf path (in joints) a topology-specialised code object is built for: the humanoid is 9 deep; a 30-joint chain needs
@@ -50,24 +56,90 @@ def hipcc() -> str:
     return exe
 
 
-def _stale(target, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(p) > t for p in deps)
+# ---- build provenance: binaries are tied to their sources by CONTENT, not by file times (a reverted experiment plus a
+#      `touch` shipped a stale kernel with every test green against its own self-check).  FNV-1a 64 over, per file, name 0 contents 0,
+#      then the code-generation flags; every binary carries the number in the string "MH_BUILD_ID=...;" (found here by reading the file,
+#      no dlopen) and the library refuses a code object whose number is not the one it was built beside (mh_api.hip: try_load_spec).
+def _fnv1a(data: bytes, h: int = 0xCBF29CE484222325) -> int:
+    for byte in data:
+        h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _hash_files(paths, flags, h: int = 0xCBF29CE484222325) -> int:
+    stamp = tuple((p, os.stat(p).st_mtime_ns, os.stat(p).st_size) for p in paths)  # memo key only: the hash is over contents
+    return _hash_files_memo(stamp, tuple(flags), h)
+
+
+@functools.lru_cache(maxsize=64)
+def _hash_files_memo(stamp, flags, h):
+    for p, _, _ in stamp:
+        h = _fnv1a(os.path.basename(p).encode() + b"\0", h)
+        with open(p, "rb") as f:
+            h = _fnv1a(f.read(), h)
+        h = _fnv1a(b"\0", h)
+    return _fnv1a(" ".join(flags).encode(), h)
+
+
+def spec_sources_hash(csrc: str = CSRC) -> str:
+    """What a code object must carry to be loaded: kernel sources + code-generation flags (the topology is in its name and its tables)."""
+    return "h%016x" % _hash_files([os.path.join(csrc, os.path.basename(p)) for p in SPEC_HASH_FILES], SPEC_CODEGEN_FLAGS)
+
+
+def lib_hash() -> str:
+    """The library's own sources, headers and flags, and the code-object hash it is going to expect."""
+    return "h%016x" % _fnv1a(spec_sources_hash().encode(), _hash_files(SOURCES + LIB_HEADERS, CODEGEN_FLAGS))
+
+
+def extra_hash(extra=()) -> str:
+    return "h%016x" % _fnv1a(" ".join(extra).encode()) if extra else "none"
+
+
+def build_id_of(path: str):
+    """The "MH_BUILD_ID=...;" string a binary carries (None: it has none)."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            m = re.search(rb"MH_BUILD_ID=([ -~]*?;)(?=[^ -~]|$)", f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
+def lib_build_id() -> str:
+    return f"{lib_hash()};spec={spec_sources_hash()};"
+
+
+def spec_build_id(parents, kinds, extra=()) -> str:
+    return (f"{spec_sources_hash()};N={len(parents)};P={','.join(str(int(x)) for x in parents)};T={','.join(str(int(x)) for x in kinds)};"
+            f"X={extra_hash(extra)};")
+
+
+def spec_defines(parents, kinds, extra=()):
+    """The -D flags of a code object: the tree, the hash of its sources (checked by the library at load) and of any extra flags."""
+    return [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
+            "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-DMH_SPEC_SOURCES_HASH=" + spec_sources_hash(),
+            "-DMH_BUILD_EXTRA=" + extra_hash(extra)] + list(extra)
 
 
 def needs_build() -> bool:
-    return _stale(LIB, SOURCES + LIB_HEADERS)
+    return build_id_of(LIB) != lib_build_id()
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-o", LIB] + SOURCES + ["-ldl"]
+    tmp = f"{LIB}.tmp{os.getpid()}"
+    cmd = [hipcc()] + FLAGS + [f"-DMH_BUILD_HASH={lib_hash()}", f"-DMH_SPEC_SOURCES_HASH={spec_sources_hash()}",
+                               "-I" + os.path.join(ROOT, "include"), "-o", tmp] + SOURCES + ["-ldl"]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)  # atomic: a concurrent load never sees a half-written library
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
@@ -109,16 +181,17 @@ def build_spec(desc, force: bool = False, verbose: bool = False) -> str:
                          f"registers, which stops paying (512 registers plus hundreds of spills, minutes of compile time) beyond "
                          f"{MAX_SPEC_DEPTH}; such models run on the run-time-topology kernels")
     out = spec_path(key)
-    if not force and not _stale(out, [SPEC_SOURCE] + SPEC_HEADERS):
+    if not force and build_id_of(out) == spec_build_id(parents, kinds):
         return out
-    defs = [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
-            "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds)]
+    defs = spec_defines(parents, kinds)
     extra = ["-Rpass-analysis=kernel-resource-usage"] if verbose else []
     # two translation units (mh_spec.hip, MH_SPEC_PART = 1 | 2), compiled side by side and linked into one code object: hipcc generates the
-    # device code of a unit kernel by kernel on one core, and the humanoid's single unit took five minutes
+    # device code of a unit kernel by kernel on one core, and the humanoid's single unit took five minutes.  Objects and the linked file
+    # carry this process' id until the finished object is moved into place (two ranks or two test workers may build the same tree at once).
     from concurrent.futures import ThreadPoolExecutor
     compile_flags = [f for f in SPEC_FLAGS if f != "-shared"]
-    objs = [out[:-3] + f".part{part}.o" for part in (1, 2)]
+    objs = [f"{out[:-3]}.part{part}.{os.getpid()}.o" for part in (1, 2)]
+    tmp = f"{out}.tmp{os.getpid()}"
 
     def one(part):
         subprocess.check_call([hipcc()] + compile_flags + defs + extra + [f"-DMH_SPEC_PART={part}", "-c", "-o", objs[part - 1], SPEC_SOURCE])
@@ -126,12 +199,26 @@ def build_spec(desc, force: bool = False, verbose: bool = False) -> str:
     try:
         with ThreadPoolExecutor(max_workers=2) as pool:
             list(pool.map(one, (1, 2)))
-        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+        os.replace(tmp, out)
     finally:
-        for o in objs:
+        for o in objs + [tmp]:
             if os.path.exists(o):
                 os.remove(o)
     return out
+
+
+def verify(paths=None):
+    """Every shipped binary must carry the build id of the CURRENT sources: [(path, found, expected)] of those that do not."""
+    bad = []
+    if build_id_of(LIB) != lib_build_id():
+        bad.append((LIB, build_id_of(LIB), lib_build_id()))
+    for name, desc in registered_models().items():
+        key, parents, kinds = topology_of(desc)
+        want = spec_build_id(parents, kinds)
+        if build_id_of(spec_path(key)) != want:
+            bad.append((spec_path(key), build_id_of(spec_path(key)), want))
+    return bad
 
 
 def registered_models():

@@ -100,6 +100,47 @@ inline bool nan_bits(const double &x)
    asm volatile("" : "+r"(u)); // the optimiser must not trace the word back to a floating-point value
    return nan_word(u);
 }
+// ---- build provenance (mecano_amd/build.py computes the same numbers): FNV-1a 64 over, per file, name 0 contents 0, then the
+//      code-generation flags.  The library carries the hash of its own sources (MH_BUILD_HASH) and the hash it expects of a code
+//      object's sources (MH_SPEC_SOURCES_HASH); a code object carries the latter and is refused when it differs (try_load_spec).
+#define MH_STR2_(...) #__VA_ARGS__
+#define MH_STR_(...) MH_STR2_(__VA_ARGS__)
+#ifndef MH_BUILD_HASH
+#define MH_BUILD_HASH unhashed
+#endif
+#ifndef MH_SPEC_SOURCES_HASH
+#define MH_SPEC_SOURCES_HASH unhashed
+#endif
+__attribute__((used)) const char kBuildId[] = "MH_BUILD_ID=" MH_STR_(MH_BUILD_HASH) ";spec=" MH_STR_(MH_SPEC_SOURCES_HASH) ";";
+const char *const kSpecHashFiles[] = {"mh_spec.hip", "mh_spec_kernels.h", "mh_zv_kernels.h", "mh_kernels.h", "mh_device.h"};
+const char kSpecCodegenFlags[] = "--offload-arch=gfx950 -O3 -std=c++17 -fno-signed-zeros -ffinite-math-only -fno-slp-vectorize -mllvm -disable-machine-licm";
+uint64_t fnv1a(uint64_t h, const void *data, size_t n)
+{
+   const unsigned char *p = (const unsigned char *)data;
+   for (size_t k = 0; k < n; k++)
+      h = (h ^ p[k]) * 0x100000001b3ull;
+   return h;
+}
+bool hash_spec_sources(const std::string &csrc_dir, char out[18])
+{
+   uint64_t h = 0xcbf29ce484222325ull;
+   for (const char *name : kSpecHashFiles)
+   {
+      FILE *f = fopen((csrc_dir + "/" + name).c_str(), "rb");
+      if (!f)
+         return false;
+      h = fnv1a(h, name, strlen(name) + 1);
+      char buf[1 << 16];
+      size_t got;
+      while ((got = fread(buf, 1, sizeof buf, f)) > 0)
+         h = fnv1a(h, buf, got);
+      fclose(f);
+      h = fnv1a(h, "", 1);
+   }
+   h = fnv1a(h, kSpecCodegenFlags, sizeof kSpecCodegenFlags - 1);
+   snprintf(out, 18, "h%016llx", (unsigned long long)h);
+   return true;
+}
 int joint_ndof(int t) { return mh::dof_count(t); }
 int joint_ncfg(int t) { return mh::cfg_count(t); }
 
@@ -107,6 +148,20 @@ struct Workspace
 {
    void *ptr = nullptr;
    size_t bytes = 0;
+};
+// A member of mh_model that a compute call may be WRITING while another thread copies the model into a new context
+// (mh_context_create): the copy never reads it -- it starts empty, which is what a context wants anyway.
+template <class T>
+struct FreshOnCopy : T
+{
+   FreshOnCopy() = default;
+   FreshOnCopy(const FreshOnCopy &) : T() {}
+   FreshOnCopy &operator=(const FreshOnCopy &) { return *this; }
+   FreshOnCopy &operator=(const T &v)
+   {
+      T::operator=(v);
+      return *this;
+   }
 };
 } // namespace
 
@@ -134,6 +189,7 @@ struct SpecLib
    int (*launch_coriolis_parts)(int flags, const void *args, int grid, int parts, void *stream) = nullptr;
    int (*launch_centroidal_parts)(int flags, const void *args, int grid, int parts, void *stream) = nullptr;
    unsigned long long (*abi)(void) = nullptr;
+   const char *(*sources_hash)(void) = nullptr;
    // bias-split forward dynamics (mh_zv_kernels.h)
    int (*zv_usable)(void) = nullptr;
    long (*zv_lds_bytes)(int nq, int nv) = nullptr;
@@ -171,7 +227,7 @@ struct mh_model
    std::vector<int> prog; // event program of the depth-first kernels
    int rnea_stack = 0, aba_stack = 0, aba_hand = 0; // per-lane slots: depth stacks, ABA hand-over
    int use_dfs = 1;       // MH_DFS=0: the sweep kernels of mh_kernels.h serve plain RNEA / ABA calls too (A/B measurements)
-   std::map<const void *, size_t> lds_attr; // dynamic-LDS limit already raised per kernel (the model lives on one device, one host thread at a time)
+   FreshOnCopy<std::map<const void *, size_t>> lds_attr; // dynamic-LDS limit already raised per kernel (the model lives on one device, one host thread at a time)
    double nonleaf_fraction = 1.0; // share of bodies with children: those are the ones that touch the depth stack
    // depth-first kernels: frame homes for a given LDS budget (slots per wave), one copy of the body records per (algorithm, budget) on
    // the device; built on first use (dfs_plan), dropped when the records change (joint source modes)
@@ -180,7 +236,7 @@ struct mh_model
       int algo, budget, lds_slots, glb_slots, glb_frames;
       int *d_meta;
    };
-   std::deque<DfsPlan> dfs_plans; // references stay valid across push_back; kept by the model itself (a context uses its model's: dfs_plan)
+   FreshOnCopy<std::deque<DfsPlan>> dfs_plans; // references stay valid across push_back; kept by the model itself (a context uses its model's: dfs_plan)
    struct PlainMutex : std::mutex
    { // a context starts as a copy of its model (context_clone): the copy gets a mutex of its own
       PlainMutex() = default;
@@ -191,6 +247,7 @@ struct mh_model
    // owns everything compute calls write -- workspace, scratch matrices, staging buffers, streams, hand-off flags, the error word
    mh_model *parent = nullptr;
    int n_contexts = 0; // live contexts of this model (guarded by g_context_mutex)
+   bool destroy_pending = false; // mh_model_destroy was called while contexts were alive: the last mh_context_destroy releases the model
    int use_win = 1;       // MH_DFS_WIN=0: AoS rows are read per lane instead of through LDS windows (A/B measurements)
    int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
    int dfs_budget = -1;   // MH_DFS_BUDGET: cap of the stack's LDS budget in slots per wave (measurements)
@@ -245,9 +302,11 @@ struct mh_model
    // scratch of the composite entry points: efforts of the Newton-Euler sweep behind mh_aba_joint_wrenches_f64, pair lists of
    // mh_relative_acceleration_f64
    Workspace aux, pairs;
-   std::vector<int> pairs_host;
+   FreshOnCopy<std::vector<int>> pairs_host;
    int use_transpose = -1; // MH_GENERIC_TRANSPOSE = 0 | 1 overrides the size heuristic
    std::string variant = "generic";
+   uint32_t warnings = 0;    // MH_WARN_* bits set by mh_model_create (mh_model_warnings)
+   std::string warning_text; // ... and what they mean for this model
    int use_split = -1;      // MH_SPEC_SPLIT = 0 | 1: never / whenever possible use the tree-split kernels (default: small batches)
    int use_fused = 1;       // MH_DISABLE_FUSED=1: mh_rnea_aba_f64 always issues two launches
    int fused_factor = 4;    // one launch for RNEA + ABA while 2 * ceil(B / 64) workgroups <= cu_count * factor (MH_FUSED_FACTOR)
@@ -1632,6 +1691,18 @@ void try_load_spec(mh_model *m, const Plan &P)
       dlclose(h);
       return;
    }
+   // ... and from the same KERNEL sources and code-generation flags as the ones this library was built beside: a code object left over
+   // from an experiment or an older tree computes something, passes its own self-check against nothing but itself, and is not HEAD's
+   s.sources_hash = (decltype(s.sources_hash))dlsym(h, "mh_spec_sources_hash");
+   if (!s.sources_hash || strcmp(s.sources_hash(), MH_STR_(MH_SPEC_SOURCES_HASH)) != 0)
+   {
+      char note[320];
+      snprintf(note, sizeof note, "generic (code object %s refused: built from other kernel sources or flags, source hash %s, this library expects %s)",
+               path.c_str(), s.sources_hash ? s.sources_hash() : "(none)", MH_STR_(MH_SPEC_SOURCES_HASH));
+      m->variant = note;
+      dlclose(h);
+      return;
+   }
    bool ok = f_n && f_p && f_t && s.launch && s.lds_bytes && s.aba_slots && s.supports && f_n() == m->n;
    for (int e = 0; ok && e < m->n; e++)
       ok = f_p()[e] == P.eparent[e] && f_t()[e] == P.etype[e];
@@ -1876,6 +1947,16 @@ extern "C" {
 
 int32_t mh_abi_version(void) { return MH_ABI_VERSION; }
 uint64_t mh_spec_abi_stamp(void) { return mh::spec_abi_stamp(); }
+const char *mh_build_hash(void) { return MH_STR_(MH_BUILD_HASH); }
+const char *mh_spec_sources_hash(void) { return MH_STR_(MH_SPEC_SOURCES_HASH); }
+mh_status mh_spec_sources_hash_of(const char *csrc_dir, char out[18])
+{
+   if (!csrc_dir || !out)
+      return fail(MH_ERR_INVALID_ARGUMENT, "csrc_dir / out is NULL");
+   if (!hash_spec_sources(csrc_dir, out))
+      return fail(MH_ERR_INVALID_ARGUMENT, "%s does not hold the kernel sources (mh_spec.hip and its headers)", csrc_dir);
+   return MH_OK;
+}
 const char *mh_last_error(void) { return g_err; }
 // the library's other translation units (mh_comm.hip) report through the same thread-local message
 mh_status mh_internal_fail(mh_status code, const char *message) { return fail(code, "%s", message); }
@@ -1973,6 +2054,62 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    mh_model *m = new mh_model();
    m->n = n, m->nq = d->nq, m->nv = d->nv;
    m->engine_of = engine_of;
+   // ---- the two places where this engine consciously departs from the reference: told to the caller, not hidden
+   {
+      char buf[512];
+      // (1) tools/MecanoFactories.java:51, 237-248: a revolute axis that geometricallyEquals X, Y or Z within 1e-7 WITHOUT being that axis
+      // gets a joint rotation about the exact coordinate axis while the unit twist keeps the axis as given; the engine uses the given axis for both
+      for (int i = 0; i < n; i++)
+      {
+         if (d->joint_type[i] != MH_JOINT_REVOLUTE)
+            continue;
+         const double *a = d->axis + 3 * i;
+         for (int k = 0; k < 3; k++)
+         {
+            const double dx = a[0] - (k == 0), dy = a[1] - (k == 1), dz = a[2] - (k == 2);
+            const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (dist <= 1.0e-7 && dist > 0.0)
+            {
+               if (!(m->warnings & MH_WARN_NEAR_COORDINATE_AXIS))
+               {
+                  snprintf(buf, sizeof buf,
+                           "joint %d: axis (%.17g, %.17g, %.17g) is within 1e-7 of the %c axis but not on it: Mecano rotates such a joint about the exact "
+                           "coordinate axis and keeps the given axis in its unit twist (MecanoFactories.java:237-248); this engine uses the given axis for "
+                           "both, results differ from Mecano's by up to ~4e-7 relative. ",
+                           i, a[0], a[1], a[2], "XYZ"[k]);
+                  m->warning_text += buf;
+               }
+               m->warnings |= MH_WARN_NEAR_COORDINATE_AXIS;
+               break;
+            }
+         }
+      }
+      // (2) spatial/interfaces/FixedFrameSpatialInertiaBasics.java:167-176: SpatialInertia.add skips the renormalisation of the centre of
+      // mass when the summed mass is under 1e-7; the mass matrix of a body whose composite with a child's subtree stays under it differs
+      std::vector<double> sub(n, 0.0);
+      for (int e = n - 1; e >= 0; e--)
+      {
+         const int i = order[e];
+         sub[i] += d->inertia_mass[i];
+         if (d->parent[i] >= 0)
+            sub[d->parent[i]] += sub[i];
+      }
+      for (int i = 0; i < n; i++)
+         for (int ch : children[i])
+            if (std::fabs(d->inertia_mass[i] + sub[ch]) < 1.0e-7)
+            {
+               if (!(m->warnings & MH_WARN_TINY_COMPOSITE_MASS))
+               {
+                  snprintf(buf, sizeof buf,
+                           "joint %d: the body's mass plus the subtree of joint %d is %.3g < 1e-7: Mecano's SpatialInertia.add leaves such a composite's "
+                           "centre of mass un-normalised (FixedFrameSpatialInertiaBasics.java:174-175); this engine's mass matrix stays consistent "
+                           "with its inverse dynamics and differs from Mecano's by less than the masses involved (<= 1e-6). ",
+                           i, ch, d->inertia_mass[i] + sub[ch]);
+                  m->warning_text += buf;
+               }
+               m->warnings |= MH_WARN_TINY_COMPOSITE_MASS;
+            }
+   }
    m->meta.assign((size_t)n * mh::MI_STRIDE, 0);
    m->consts.assign((size_t)n * mh::MC_STRIDE, 0.0);
    // index maps re-concatenated in ENGINE order: the offset of a joint in them is then a function of the topology alone
@@ -2306,6 +2443,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       selfcheck = atoi(e);
    if (m->spec.handle && m->use_spec && selfcheck)
       self_check_spec(m);
+   if (m->warnings)
+      (void)fail(MH_OK, "warning: %s", m->warning_text.c_str()); // (text for mh_last_error; the status stays MH_OK)
    *model_out = m;
    return MH_OK;
 }
@@ -2365,18 +2504,9 @@ static void reset_scratch(mh_model *m)
    m->pairs_host.clear();
    m->lds_attr.clear();
 }
-void mh_model_destroy(mh_model_t m)
+// the device records, the code object and the host-side description: released once, by whoever holds the last reference
+static void release_model(mh_model *m)
 {
-   if (!m)
-      return;
-   if (m->parent)
-      return; // (the inner handle of a context cannot reach a caller; should one ever be passed here, its model owns the device records)
-   {
-      std::lock_guard<std::mutex> lock(g_context_mutex);
-      if (m->n_contexts > 0)
-         (void)fail(MH_ERR_INVALID_ARGUMENT, "mh_model_destroy: %d context(s) of this model are still alive; destroy them first (they share its device records)",
-                    m->n_contexts); // (void function: the message is left for mh_last_error; the model is destroyed all the same)
-   }
    dfs_plans_drop(m);
    split_rt_free(m);
    (void)hipFree(m->d_meta);
@@ -2390,6 +2520,26 @@ void mh_model_destroy(mh_model_t m)
       dlclose(m->spec.handle);
    delete m;
 }
+// The model is reference-counted by its contexts: they share its device records, so a model destroyed while contexts are alive only
+// gives up the caller's reference (its handle must not be used again); the last mh_context_destroy releases everything.
+void mh_model_destroy(mh_model_t m)
+{
+   if (!m)
+      return;
+   if (m->parent)
+      return; // (the inner handle of a context cannot reach a caller; should one ever be passed here, its model owns the device records)
+   {
+      std::lock_guard<std::mutex> lock(g_context_mutex);
+      if (m->destroy_pending)
+         return; // destroyed twice
+      if (m->n_contexts > 0)
+      {
+         m->destroy_pending = true;
+         return;
+      }
+   }
+   release_model(m);
+}
 // ---- contexts: the model handle is read-only and may be shared by any number of host threads and streams, each calling through a
 //      context of its own ("Threading"; the reference keeps this state inside the calculator object, which is why
 //      it needs one calculator per thread: InverseDynamicsCalculator.java:706-707)
@@ -2402,6 +2552,11 @@ mh_status mh_context_create(mh_model_t model, mh_context_t *ctx_out)
    mh_model *c = nullptr;
    {
       std::lock_guard<std::mutex> lock(g_context_mutex);
+      if (root->destroy_pending)
+         return fail(MH_ERR_INVALID_ARGUMENT, "mh_context_create: the model has been destroyed (it lives on only for its remaining contexts)");
+      // The copy reads the immutable description only: what the default context's calls (or another context's first depth-first call, under
+      // dfs_mutex) may be inserting into at this moment -- dfs_plans, lds_attr, pairs_host -- is FreshOnCopy and starts empty here; the
+      // plain scratch words (Workspace, streams, events) are overwritten by reset_scratch below whatever was read.
       c = new (std::nothrow) mh_model(*root);
       if (!c)
          return fail(MH_ERR_OUT_OF_MEMORY, "out of host memory");
@@ -2409,7 +2564,7 @@ mh_status mh_context_create(mh_model_t model, mh_context_t *ctx_out)
    }
    c->parent = root;
    c->n_contexts = 0;
-   c->dfs_plans.clear(); // (dfs_plan looks them up in the model)
+   c->destroy_pending = false;
    reset_scratch(c);
    mh_context *ctx = new (std::nothrow) mh_context{c};
    if (!ctx)
@@ -2427,13 +2582,17 @@ void mh_context_destroy(mh_context_t ctx)
    if (!ctx)
       return;
    mh_model *c = ctx->m;
+   mh_model *root = c->parent;
    free_scratch(c);
+   bool last = false;
    {
       std::lock_guard<std::mutex> lock(g_context_mutex);
-      c->parent->n_contexts--;
+      last = --root->n_contexts == 0 && root->destroy_pending;
    }
    delete c;
    delete ctx;
+   if (last)
+      release_model(root); // mh_model_destroy came first: this was the last reference
 }
 mh_status mh_context_reserve(mh_context_t ctx, int64_t max_batch)
 {
@@ -2473,6 +2632,8 @@ int32_t mh_model_nq(mh_model_t m) { return m ? m->nq : -1; }
 int32_t mh_model_nv(mh_model_t m) { return m ? m->nv : -1; }
 int32_t mh_model_n_joints(mh_model_t m) { return m ? m->n : -1; }
 const char *mh_model_kernel_variant(mh_model_t m) { return m ? m->variant.c_str() : ""; }
+uint32_t mh_model_warnings(mh_model_t m) { return m ? m->warnings : 0u; }
+const char *mh_model_warning_text(mh_model_t m) { return m ? m->warning_text.c_str() : ""; }
 
 // Builds the topology-specialised code object of a model with hipcc (what mecano_amd/build.py does), for hosts without Python.
 mh_status mh_build_code_object(const mh_model_desc *desc, const char *out_dir, char *path_out, size_t path_cap)
@@ -2508,6 +2669,12 @@ static mh_status build_code_object(const mh_model_desc *desc, const char *out_di
       fclose(f);
    else
       return fail(MH_ERR_INVALID_ARGUMENT, "%s not found: the kernel sources must sit next to the library (csrc/)", src.c_str());
+   char src_hash[18];
+   if (!hash_spec_sources(dir + "/csrc", src_hash))
+      return fail(MH_ERR_INVALID_ARGUMENT, "%s/csrc does not hold all the kernel sources", dir.c_str());
+   if (strcmp(src_hash, MH_STR_(MH_SPEC_SOURCES_HASH)) != 0)
+      return fail(MH_ERR_INVALID_ARGUMENT, "the kernel sources in %s/csrc (hash %s) are not the ones this library was built beside (%s): the code object would be refused at load; rebuild the library",
+                  dir.c_str(), src_hash, MH_STR_(MH_SPEC_SOURCES_HASH));
    // The compiler is clang++ itself, not the hipcc wrapper: hipcc assembles a command line of its own and hands it to a shell, so a
    // directory name with shell syntax in it would be interpreted there (seen in tests/test_abi.py).  MH_HIPCC overrides the choice.
    const char *hipcc = getenv("MH_HIPCC");
@@ -2549,6 +2716,16 @@ static mh_status build_code_object(const mh_model_desc *desc, const char *out_di
    }
    if (fast)
       argv_s.push_back("-DMH_SPEC_MINIMAL");
+   argv_s.push_back(std::string("-DMH_SPEC_SOURCES_HASH=") + src_hash);
+   {
+      // what else shaped this object (the fast form, a caller's extra flags): part of the build id its file carries
+      uint64_t xh = fnv1a(0xcbf29ce484222325ull, fast ? "-DMH_SPEC_MINIMAL" : "", fast ? 17 : 0);
+      if (const char *extra = getenv("MH_HIPCC_FLAGS"))
+         xh = fnv1a(xh, extra, strlen(extra));
+      char xs[48];
+      snprintf(xs, sizeof xs, "-DMH_BUILD_EXTRA=h%016llx", (unsigned long long)xh);
+      argv_s.push_back(xs);
+   }
    if (const char *extra = getenv("MH_HIPCC_FLAGS"))
    {
       std::string word;
@@ -2769,7 +2946,17 @@ mh_status mh_aba_joint_wrenches_f64(mh_model_t model, int64_t B, const double *q
 {
    if (B > 0 && !joint_wrench_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "joint_wrench_out is NULL");
-   mh_status st = launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
+   // the scratch below belongs to the CONTEXT of the call: resolve it before anything mutable is touched (launch() does so for itself only)
+   mh_options o;
+   if (opts)
+      o = *opts;
+   else
+      mh_options_default(&o);
+   opts = &o;
+   mh_status st = check_common(model, B, opts);
+   if (st != MH_OK)
+      return st;
+   st = launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out);
    if (st != MH_OK || B == 0)
       return st;
    // ForwardDynamicsCalculator.getJointWrench (ForwardDynamicsCalculator.java:1330-1363) is a Newton-Euler sweep over the accelerations

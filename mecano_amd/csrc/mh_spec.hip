@@ -487,6 +487,21 @@ int mh_spec_split_plan(int *out, int cap)
 }
 // everything this object shares with libmecano_hip.so beyond its own entry points (argument structs, record strides, frame convention)
 unsigned long long mh_spec_abi(void) { return mh::spec_abi_stamp(); }
+// build provenance: the hash of the kernel sources and code-generation flags this object was compiled from (mecano_amd/build.py and
+// mh_build_code_object compute it and pass it in; libmecano_hip.so refuses an object whose hash is not the one it was built beside),
+// and, as a string any tool can find in the file without loading it, the whole build id: sources, tree, extra flags
+#define MH_SPEC_STR2_(...) #__VA_ARGS__
+#define MH_SPEC_STR_(...) MH_SPEC_STR2_(__VA_ARGS__)
+#ifndef MH_SPEC_SOURCES_HASH
+#define MH_SPEC_SOURCES_HASH unhashed
+#endif
+#ifndef MH_BUILD_EXTRA
+#define MH_BUILD_EXTRA none
+#endif
+__attribute__((used)) const char mh_spec_build_id_string[] = "MH_BUILD_ID=" MH_SPEC_STR_(MH_SPEC_SOURCES_HASH) ";N=" MH_SPEC_STR_(MH_TOPO_N) ";P=" MH_SPEC_STR_(
+   MH_TOPO_PARENTS) ";T=" MH_SPEC_STR_(MH_TOPO_TYPES) ";X=" MH_SPEC_STR_(MH_BUILD_EXTRA) ";";
+const char *mh_spec_sources_hash(void) { return MH_SPEC_STR_(MH_SPEC_SOURCES_HASH); }
+const char *mh_spec_build_id(void) { return mh_spec_build_id_string; }
 // 1: built with -DMH_SPEC_MINIMAL (mh_build_code_object's fast form, tools/isa.py): only the tree-split RNEA / ABA / pair kernels
 int mh_spec_minimal(void)
 {

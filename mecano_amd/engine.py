@@ -78,6 +78,15 @@ class HipModel:
     def kernel_variant(self) -> str:
         return _lib.load().mh_model_kernel_variant(self._h).decode()
 
+    @property
+    def warnings(self) -> int:
+        """MH_WARN_* bits (include/mecano_hip.h): the two model classes in which the engine consciously departs from Mecano."""
+        return int(_lib.load().mh_model_warnings(self._h))
+
+    @property
+    def warning_text(self) -> str:
+        return _lib.load().mh_model_warning_text(self._h).decode()
+
     def reserve(self, max_batch: int):
         if self._ctx:
             _lib.check(_lib.load().mh_context_reserve(self._ctx, int(max_batch)))

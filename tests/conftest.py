@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def hip_lib():
-    """Builds (if hipcc is here and sources are newer) and loads the C-ABI library."""
+    """Builds (if hipcc is here and the library does not carry the build id of the current sources) and loads the C-ABI library."""
     from mecano_amd import build, _lib
     try:
         build.build_lib()

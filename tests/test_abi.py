@@ -27,7 +27,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(hip_lib):
     for name in declared_symbols():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.mh_abi_version() == 4
+    assert hip_lib.mh_abi_version() == 5
 
 
 def _desc_struct(desc, keep):

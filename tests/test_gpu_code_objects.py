@@ -19,6 +19,7 @@ FAKE = r"""
 static const int parents[] = {PARENTS};
 static const int types[] = {TYPES};
 unsigned long long mh_spec_abi(void) { return STAMP; }
+const char *mh_spec_sources_hash(void) { return "SRCHASH"; }
 int mh_spec_n(void) { return sizeof(parents) / sizeof(int); }
 const int *mh_spec_parents(void) { return parents; }
 const int *mh_spec_types(void) { return types; }
@@ -48,12 +49,12 @@ def _arm(n=5):
     return MultiBodySystem.toMultiBodySystemInput(rt.nextJointChain(rng, n, ("revolute", "prismatic"))[0].getPredecessor())
 
 
-def _fake_object(tmp_path, desc, stamp):
+def _fake_object(tmp_path, desc, stamp, sources_hash=None):
     from mecano_amd import build as b
     key, parents, kinds = b.topology_of(desc)
     src = tmp_path / "fake.c"
     src.write_text(FAKE.replace("PARENTS", ",".join(str(int(x)) for x in parents)).replace("TYPES", ",".join(str(int(x)) for x in kinds))
-                   .replace("STAMP", f"{int(stamp)}ull"))
+                   .replace("STAMP", f"{int(stamp)}ull").replace("SRCHASH", sources_hash or b.spec_sources_hash()))
     out = tmp_path / f"libmecano_hip_topo_{key}.so"
     subprocess.check_call([shutil.which("gcc") or "cc", "-shared", "-fPIC", "-o", str(out), str(src)])
     return key
@@ -73,6 +74,40 @@ def test_foreign_code_object_is_refused_by_its_abi_stamp(torch_cuda, hip_lib, tm
     assert v.startswith("generic (code object") and "ABI stamp" in v and key in v, v
     q, qd, qdd, _ = rt.nextState(np.random.default_rng(1), sys_, 70)
     close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd)).cpu().numpy(), OracleModel(d).rnea(q, qd, qdd))
+
+
+def test_code_object_from_other_sources_is_refused_by_its_source_hash(torch_cuda, hip_lib, tmp_path, monkeypatch):
+    """Build provenance: a code object carries the hash of the kernel sources and flags it was compiled from and the
+    library refuses one whose hash is not the one it was built beside -- like a wrong ABI stamp, visibly, and the run-time-topology kernels
+    serve the model.  Shown on a stand-in object with the right stamp and tree, and on a COPY of a shipped object whose hash string was
+    patched in place (same machine code, wrong provenance)."""
+    torch = torch_cuda
+    from mecano_amd import build as b, random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    sys_ = _arm()
+    d = sys_.toModelDesc()
+    key = _fake_object(tmp_path, d, hip_lib.mh_spec_abi_stamp(), sources_hash="h0123456789abcdef")
+    monkeypatch.setenv("MH_SPEC_DIR", str(tmp_path))
+    hm = HipModel(d)
+    v = hm.kernel_variant
+    assert v.startswith("generic (code object") and "other kernel sources" in v and "h0123456789abcdef" in v and b.spec_sources_hash() in v, v
+    q, qd, qdd, _ = rt.nextState(np.random.default_rng(1), sys_, 70)
+    close(hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd)).cpu().numpy(), OracleModel(d).rnea(q, qd, qdd))
+    # a shipped object, byte for byte, except for the hash it claims
+    arm = b.registered_models()["arm7"]
+    path = b.spec_path(b.topology_of(arm)[0])
+    good = b.spec_sources_hash().encode()
+    blob = open(path, "rb").read()
+    assert blob.count(good) >= 2  # the build-id string and what mh_spec_sources_hash() returns
+    sub = tmp_path / "patched"
+    sub.mkdir()
+    (sub / os.path.basename(path)).write_bytes(blob.replace(good, b"h" + b"0" * 16))
+    monkeypatch.setenv("MH_SPEC_DIR", str(sub))
+    v = HipModel(arm).kernel_variant
+    assert v.startswith("generic (code object") and "other kernel sources" in v, v
+    monkeypatch.delenv("MH_SPEC_DIR")
+    assert HipModel(arm).kernel_variant.startswith("topo:")
 
 
 def test_wrong_results_are_caught_by_the_create_time_self_check(torch_cuda, hip_lib, tmp_path, monkeypatch):

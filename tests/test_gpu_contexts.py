@@ -125,3 +125,70 @@ def test_context_misuse_is_refused(torch_cuda):
     view.close()
     assert lib.mh_model_set_joint_source_modes(a._h, modes) == 0
     assert lib.mh_model_check(a._h, None, None) == 0
+
+
+def test_a_model_destroyed_before_its_contexts_lives_on_for_them(torch_cuda):
+    """The model is reference-counted by its contexts (include/mecano_hip.h, contexts): mh_model_destroy with live contexts gives up the
+    caller's reference only, calls through the surviving contexts stay valid, no new context can be made, the last mh_context_destroy
+    releases the device records (this used to free the records under the contexts)."""
+    torch = torch_cuda
+    from mecano_amd import _lib, random_tools as rt
+    from mecano_amd.engine import HipModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    hm = HipModel(sys_.toModelDesc())
+    q, qd, qdd, tau = (dev(torch, x) for x in rt.nextState(np.random.default_rng(5), sys_, 4096))
+    g = (0.0, 0.0, -9.81)
+    want_tau, want_qdd = hm.rnea(q, qd, qdd, g).clone(), hm.aba(q, qd, tau, g).clone()
+    torch.cuda.synchronize()
+    v1, v2 = hm.context(), hm.context()
+    handle = hm._h
+    hm.close()                          # mh_model_destroy while two contexts are alive
+    assert torch.equal(v1.rnea(q, qd, qdd, g), want_tau) and torch.equal(v2.aba(q, qd, tau, g), want_qdd)
+    w, qdd2 = v2.aba_joint_wrenches(q, qd, tau, g) if hasattr(v2, "aba_joint_wrenches") else (None, None)
+    torch.cuda.synchronize()
+    ctx = ctypes.c_void_p()
+    assert _lib.load().mh_context_create(handle, ctypes.byref(ctx)) == 1  # MH_ERR_INVALID_ARGUMENT: the model has been destroyed
+    v1.close()
+    assert torch.equal(v2.rnea(q, qd, qdd, g), want_tau)
+    torch.cuda.synchronize()
+    v2.close()                          # the last reference: releases the model
+
+
+def test_joint_wrenches_of_forward_dynamics_use_the_context_of_the_call(torch_cuda):
+    """mh_aba_joint_wrenches_f64 keeps the efforts of its Newton-Euler sweep in scratch: two threads with a context each on one handle
+    (the scratch used to be the model's whatever opts->context said)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    hm = HipModel(sys_.toModelDesc())
+    if not hasattr(hm, "aba_joint_wrenches"):
+        pytest.skip("no Python mirror of mh_aba_joint_wrenches_f64")
+    g = (0.0, 0.0, -9.81)
+    data = {B: tuple(dev(torch, x) for x in rt.nextState(np.random.default_rng(B), sys_, B)) for B in (1000, 9000)}
+    want = {B: [t.clone() for t in hm.aba_joint_wrenches(q, qd, tau, g)] for B, (q, qd, qdd, tau) in data.items()}
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(view, stream):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    for B, (q, qd, qdd, tau) in data.items():  # alternating sizes: the scratch is re-allocated in every call but the first
+                        got = view.aba_joint_wrenches(q, qd, tau, g)
+                        stream.synchronize()
+                        for a, b in zip(got, want[B]):
+                            if not torch.equal(a, b):
+                                errors.append(B)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    views = [hm.context(), hm.context()]
+    threads = [threading.Thread(target=worker, args=(v, torch.cuda.Stream())) for v in views]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for v in views:
+        v.close()
+    assert not errors, errors[:4]

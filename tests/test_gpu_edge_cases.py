@@ -159,6 +159,14 @@ def test_revolute_axes_at_and_around_the_coordinate_axes(torch_cuda):
     from mecano_amd.engine import HipModel
     from oracle.cpu_oracle import OracleModel
     hm, om = HipModel(desc), OracleModel(desc)
+    # the boundary says so (include/mecano_hip.h, MH_WARN_NEAR_COORDINATE_AXIS): bit, text naming a joint, text left in mh_last_error
+    from mecano_amd import _lib
+    assert hm.warnings == 1 and "within 1e-7" in hm.warning_text and "joint" in hm.warning_text, (hm.warnings, hm.warning_text)
+    for label, axes in (("exact", exact), ("outside", outside)):
+        assert HipModel(_chain_with_axes(np.random.default_rng(8), axes).toModelDesc()).warnings == 0, label
+    assert HipModel(rt.nextHumanoid(np.random.default_rng(43)).toModelDesc()).warnings == 0
+    HipModel(desc)
+    assert _lib.load().mh_last_error().decode().startswith("warning: joint")
     t_dev, t_ref = hm.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), G).cpu().numpy(), om.rnea(q, qd, qdd, G)
     gap = np.abs(t_dev - t_ref).max() / max(1.0, np.abs(t_ref).max())
     assert gap <= 4.0e-7, gap          # the axis error (<= 1e-7) times a handful of transforms
@@ -187,11 +195,13 @@ def test_bodies_with_tiny_mass(torch_cuda):
     tau[:, 5] *= 1e-7  # (efforts on a 5e-8 kg leaf: keep its acceleration finite-sized)
     _against_oracle(torch, sys_.toModelDesc(), q, qd, qdd, tau, "light bodies, ordinary composites", 1e-10, crba=False)
     hm, om = HipModel(sys_.toModelDesc()), OracleModel(sys_.toModelDesc())
+    assert hm.warnings == 0, hm.warning_text  # no composite under the threshold: nothing to warn about
     close(hm.crba(dev(torch, q)).cpu().numpy(), om.crba(q), 1e-10, label="light leaf crba")
     # two light bodies at the end: the composite of the last two is 1e-7 exactly at the threshold's wrong side
     sys2 = _chain_with_axes(rng, axes, tiny_mass_bodies=(4, 5))
     desc2 = sys2.toModelDesc()
     hm2, om2 = HipModel(desc2), OracleModel(desc2)
+    assert hm2.warnings == 2 and "1e-7" in hm2.warning_text, (hm2.warnings, hm2.warning_text)  # MH_WARN_TINY_COMPOSITE_MASS
     q, qd, qdd, tau = rt.nextState(rng, sys2, 64)
     close(hm2.rnea(dev(torch, q), dev(torch, qd), dev(torch, qdd), G).cpu().numpy(), om2.rnea(q, qd, qdd, G), 1e-10, label="two light bodies rnea")
     H = hm2.crba(dev(torch, q)).cpu().numpy()
@@ -321,9 +331,8 @@ def test_a_consumer_that_gives_up_writes_nan_and_reports_at_the_next_synchronisa
     d = sys_.toModelDesc()
     key, parents, kinds = mbuild.topology_of(d)
     out = tmp_path / os.path.basename(mbuild.spec_path(key))
-    subprocess.check_call([mbuild.hipcc()] + mbuild.SPEC_FLAGS + [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
-                          "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-DMH_SPEC_MINIMAL", "-DMH_ZV_TEST_NO_FLAG", "-o", str(out),
-                          mbuild.SPEC_SOURCE], stderr=subprocess.DEVNULL)
+    subprocess.check_call([mbuild.hipcc()] + mbuild.SPEC_FLAGS + mbuild.spec_defines(parents, kinds, ("-DMH_SPEC_MINIMAL", "-DMH_ZV_TEST_NO_FLAG"))
+                          + ["-o", str(out), mbuild.SPEC_SOURCE], stderr=subprocess.DEVNULL)
     B = 200  # four groups of 64 configurations, the last one ragged
     q, qd, _, tau = rt.nextState(np.random.default_rng(5), sys_, B)
     keys = ("MH_SPEC_DIR", "MH_SPEC_SELFCHECK", "MH_ZV_WAIT_MS", "MH_ZV")

@@ -1574,6 +1574,27 @@ def test_bench_launches_its_own_ranks(torch_cuda):
     assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
     assert line["check"]["ok"] is True
     assert len(line["per_rank"]) == 2
+    # every rank says where it ran; here both share the box's GPU, which the line admits (and which only the explicit gloo override allows)
+    assert all(r["device"]["device_index"] == 0 and r["device"]["name"] for r in line["per_rank"])
+    assert line["devices_distinct"] is False and line["shared_gpu_rehearsal"] is True
+    assert line["region_ms_min"] <= line["region_ms_max"]
+
+
+def test_bench_refuses_more_ranks_than_devices_under_rccl(torch_cuda):
+    """without the explicit gloo override `bench.py --gpus N` is one rank per GPU over RCCL -- on a box with fewer than
+    N devices every rank exits non-zero BEFORE it touches a GPU or a communicator (folding ranks onto one device would print a line that
+    measured one GPU N times), the parent relays the failure, and no JSON line appears."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MECANO_DIST_BACKEND")}
+    env.update(MH_BENCH_NO_PMC="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--regions", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "HIP device(s) visible" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")], (p.stdout, p.stderr[-1500:])
 
 
 def test_config4_strong_scaling_path_on_five_ranks_with_a_ragged_total(torch_cuda):
@@ -1600,6 +1621,7 @@ def test_config4_strong_scaling_path_on_five_ranks_with_a_ragged_total(torch_cud
     assert sorted(r["batch"] for r in line["per_rank"]) == [52429, 52430, 52430, 52430, 52430] and [r["rank"] for r in line["per_rank"]] == list(range(5))
     assert all(r["kernels_ms"]["aba"] > 0 for r in line["per_rank"]) and line["gather_ms"] > 0
     assert line["check"]["ok"] is True and line["config"]["kernel_variant"].startswith("topo:")
+    assert len({r["device"]["pci"] or r["device"]["uuid"] for r in line["per_rank"]}) == 1 and line["shared_gpu_rehearsal"] is True
 
 
 @pytest.mark.parametrize("case", ["humanoid", "arm", "torso", "mixed_tree", "floating_onedof_tree", "planar_spherical"])

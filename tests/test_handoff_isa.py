@@ -53,8 +53,7 @@ def test_the_check_catches_a_flag_stored_before_the_rows_are_drained(tmp_path):
     only (the smallest staged topology, the minimal kernel set), never linked.  The same source without the macro must pass."""
     desc = _registered()["torso13"]
     key, parents, kinds = mbuild.topology_of(desc)
-    defs = [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents),
-            "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds), "-DMH_SPEC_MINIMAL"]
+    defs = mbuild.spec_defines(parents, kinds, ("-DMH_SPEC_MINIMAL",))
     flags = [f for f in mbuild.SPEC_FLAGS if f not in ("-shared", "-fPIC")]
     verdicts = {}
     for tag, extra in (("as shipped", []), ("flag before drain", ["-DMH_ZV_TEST_FLAG_BEFORE_DRAIN"])):

@@ -30,7 +30,7 @@ def c_kind(decl):
     if "*" in decl or "[" in decl or re.match(r"(const\s+)?mh_\w+_t\b", decl):  # opaque handles (mh_model_t, mh_timer_t) are pointers
         return "ADDRESS"
     base = decl.split()[0] if decl.split()[0] != "const" else decl.split()[1]
-    return {"int64_t": "JAVA_LONG", "size_t": "JAVA_LONG", "uint64_t": "JAVA_LONG", "int32_t": "JAVA_INT", "int": "JAVA_INT",
+    return {"int64_t": "JAVA_LONG", "size_t": "JAVA_LONG", "uint64_t": "JAVA_LONG", "int32_t": "JAVA_INT", "uint32_t": "JAVA_INT", "int": "JAVA_INT",
             "mh_status": "JAVA_INT", "mh_layout": "JAVA_INT", "mh_joint_type": "JAVA_INT", "double": "JAVA_DOUBLE", "float": "JAVA_FLOAT"}[base]
 
 

@@ -7,14 +7,14 @@ from mecano_amd import build as b
 name = os.environ.get("ISA_MODEL", "humanoid30")  # ISA_MODEL=arm7 ISA_FULL=1: the chain's whole-tree kernels (not in a minimal build)
 desc = b.registered_models()[name]
 key, parents, kinds = b.topology_of(desc)
-defs = [f"-DMH_TOPO_N={len(parents)}", "-DMH_TOPO_PARENTS=" + ",".join(str(int(x)) for x in parents), "-DMH_TOPO_TYPES=" + ",".join(str(int(x)) for x in kinds)]
-if not os.environ.get("ISA_FULL"):
-    defs.append("-DMH_SPEC_MINIMAL")
 extra = [a for a in sys.argv[1:] if a != "--so"]
+if not os.environ.get("ISA_FULL"):
+    extra.insert(0, "-DMH_SPEC_MINIMAL")
+defs, extra = b.spec_defines(parents, kinds, extra), []  # (tree, source hash the library checks at load, the extra flags and their hash)
 t = time.time()
 if "--so" in sys.argv:
-    out_dir = os.environ.get("EXP_DIR", "exp_build")
-    os.makedirs(out_dir, exist_ok=True)  # never clobbers the shipped code object: run with MH_SPEC_DIR=exp_build
+    out_dir = os.environ.get("EXP_DIR", "build/exp")  # git-ignored, travels to the GPU box (gpurun_out/ does not)
+    os.makedirs(out_dir, exist_ok=True)  # never clobbers the shipped code object: run with MH_SPEC_DIR=build/exp
     cmd = [b.hipcc()] + b.SPEC_FLAGS + defs + extra + ["-o", os.path.join(out_dir, os.path.basename(b.spec_path(key))), b.SPEC_SOURCE]
 else:
     os.makedirs("gpurun_out/isa", exist_ok=True)
