@@ -206,6 +206,27 @@ MH_DEV M3<T> quat_to_R(T x, T y, T z, T s)
    return R;
 }
 
+// ---- 1 / d by v_rcp_f64 and two Newton steps: the reciprocal the compiler's own fp64 division starts from, without its scaling and fix-up
+//      of denormal / overflowing quotients -- twelve dependent instructions on the critical path of every body step of the bias-split
+//      forward dynamics against five here; error about one ulp.  For joint-space inertias (D = S^T IA S, sums of rigid inertias: far from
+//      either end of the exponent range) and the pivots of the floating base's LDL^T (mh_zv_kernels.h: ZvIn, spd6_factor).
+#ifndef MH_FAST_RCP
+#define MH_FAST_RCP 1 // 0: IEEE division (A/B measurements)
+#endif
+MH_DEV double rcp_fast(double d)
+{
+#if MH_FAST_RCP
+   double r = __builtin_amdgcn_rcp(d);
+   double e = fma(-d, r, 1.0);
+   r = fma(r, e, r);
+   e = fma(-d, r, 1.0);
+   return fma(r, e, r);
+#else
+   return 1.0 / d;
+#endif
+}
+MH_DEV float rcp_fast(float d) { return 1.0f / d; }
+
 // ---- R S R^T for symmetric S
 template <typename T>
 MH_DEV S3<T> conj(const M3<T> &R, const S3<T> &S)
@@ -488,14 +509,24 @@ __device__ __attribute__((noinline)) SinCos sincos_slow(double x)
    sincos(x, &r.s, &r.c);
    return r;
 }
+// The fast path alone: straight-line code, valid for |x| < 2^19 (sincos_in_fast_range).  Several of these in one basic block interleave
+// -- six joints of a limb formed together cost little more than one --, which the branch to the slow path inside sincos_t prevents: a
+// caller that forms many pairs calls this for all of them, ORs the range tests, and repeats the lot with sincos_t behind ONE branch.
+MH_DEV bool sincos_in_fast_range(double x) { return fabs(x) < 524288.0; }
+MH_DEV bool sincos_in_fast_range(float) { return true; }
+MH_DEV void sincos_fast(double x, double &s, double &c);
 MH_DEV void sincos_t(double x, double &s, double &c)
 {
-   if (__builtin_expect(!(fabs(x) < 524288.0), 0))
+   if (__builtin_expect(!sincos_in_fast_range(x), 0))
    {
       const SinCos r = sincos_slow(x);
       s = r.s, c = r.c;
       return;
    }
+   sincos_fast(x, s, c);
+}
+MH_DEV void sincos_fast(double x, double &s, double &c)
+{
    const double k = rint(x * 6.36619772367581382433e-01);
    double r = fma(-k, 1.57079632679489655800e+00, x);
    r = fma(-k, 6.12323399573676603587e-17, r);
@@ -519,5 +550,6 @@ MH_DEV void sincos_t(double x, double &s, double &c)
    c = ((n + 1) & 2) ? -c1 : c1;
 }
 MH_DEV void sincos_t(float x, float &s, float &c) { sincosf(x, &s, &c); }
+MH_DEV void sincos_fast(float x, float &s, float &c) { sincosf(x, &s, &c); }
 
 } // namespace mh

@@ -850,7 +850,7 @@ MH_DEV LDL6<T> spd6_factor(const ABI<T> &I)
 #pragma unroll
    for (int k = 0; k < 6; k++)
    {
-      const T dinv = T(1) / M[k][k];
+      const T dinv = rcp_fast(M[k][k]);
       F.f[15 + k] = dinv;
 #pragma unroll
       for (int j = k + 1; j < 6; j++)

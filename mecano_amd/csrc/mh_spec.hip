@@ -279,6 +279,7 @@ long mh_spec_zv_lds_bytes(int nq, int nv)
 int mh_spec_zv_usable(void) { return SPL::usable() ? 1 : 0; }
 #ifdef MH_ZV_PROBE
 int mh_spec_zv_probe_read(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mh::zv_probe), bytes); }
+int mh_spec_zv_probe_body_read(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mh::zv_probe_body), bytes); }
 #endif
 // jobs = 2: qdd = ABA(q, qd, tau) with args->in3b = tau, args->outb = qdd.  jobs = 3: additionally args->out = RNEA(q, qd, args->in3).
 // taup: scratch [B][nv]; sync_flags: ceil(B / 64) * ZV_SYNC_STRIDE ints that never held `epoch` before; same_l2: rows may stay in a shared L2; error: one int

@@ -564,6 +564,32 @@ struct SplitStore
    static constexpr int kind(int j) { return Split<TP>::is_trunk(j) ? ST_LDS_KIND : ST_REG_KIND; }
    static constexpr int index(int j) { return Split<TP>::is_trunk(j) ? Split<TP>::trunk_slot(j) : Split<TP>::reg_slot(j); }
 };
+// Tree-split inverse dynamics with the pairs (cos, sin) of every revolute joint a wave evaluates formed BEFORE its walks, by the
+// straight-line fast path of the sincos (rnea_pre_pass below): slots 2 j and 2 j + 1 of the wave's registers.  A context with this store
+// policy (Ctx::rnea_pre) makes RneaSub / trunk_va take the pairs from there instead of evaluating sincos_t -- a basic block of its own
+// with a 45-instruction dependent chain -- inside every body step.  The pre-pass sits at the head of the wave's OWN `if` chain
+// (split_rnea_limbs), so the scheduler interleaves its tail with the first bodies' constant loads.  Measured and not kept
+// (profiles/r05_headline_steps.txt): the pairs in LDS and the pre-pass as a phase of its own between the arrival of the rows of q and
+// that of the velocities and efforts -- the rows of q are there 0.37 us ahead of the rest, and a pre-pass that overlaps nothing else takes
+// 1.2 us (eight or nine chains of ~48 instructions) against ~0.6 us of added walk time here.
+template <class TP>
+struct RneaPreStore
+{
+   static constexpr int REG_SLOTS = 2 * TP::N;
+   static constexpr bool rnea_pre = true;
+   static constexpr int kind(int) { return ST_REG_KIND; }
+   static constexpr int index(int j) { return 2 * j; }
+};
+template <class SP, class = void>
+struct policy_rnea_pre
+{
+   static constexpr bool value = false;
+};
+template <class SP>
+struct policy_rnea_pre<SP, std::enable_if_t<SP::rnea_pre>>
+{
+   static constexpr bool value = true;
+};
 template <typename T, class SP>
 struct LaneStore
 {
@@ -609,6 +635,7 @@ struct Ctx
 {
    using SPolicy = SP;
    static constexpr int csmode = CSMODE;
+   static constexpr bool rnea_pre = policy_rnea_pre<SP>::value; // (cos, sin) of the wave's revolute joints already in st (RneaPreStore)
    static constexpr int fold_xw = CSMODE >= 2 ? 12 : 21; // width of a limb's record in the bias fold (ZV_XW while the inertias' records are reused)
    T *cs;          // CSMODE 1, 2: this configuration's column of the (cos, sin) scratch
    long cs_stride;
@@ -844,13 +871,20 @@ struct RneaSub
       constexpr int TYPE = TP::type[J];
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
       const CRef<T, false> c{cx.C + J * MC_STRIDE};
-      const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
+      constexpr bool PRE = CX::rnea_pre && TYPE == JT_REVOLUTE;
+      JQ<T> jq;
+      if constexpr (!PRE)
+         jq = spec_joint_read<TYPE, CO, CX, T>(cx);
       const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
       const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
       const XF<T> Xb = load_xb_j<TP, J, T>(c);
       const RI<T> I = load_inertia<T>(c);
       MH_BODY_FENCE(); // everything the body reads is requested before its arithmetic starts (see JQ)
-      const JX<T> jx = spec_joint_from<TYPE, T>(jq);
+      JX<T> jx;
+      if constexpr (PRE)
+         jx.c = cx.st.template get<J, 0>(), jx.s = cx.st.template get<J, 1>(), jx.d = T(0);
+      else
+         jx = spec_joint_from<TYPE, T>(jq);
       if constexpr (CX::csmode == 1 && TYPE == JT_REVOLUTE)
       {
          constexpr int R = Tree<TP>::rev_index(J);
@@ -921,12 +955,19 @@ MH_DEV void trunk_va(const CX &cx, SV<T> &v, SV<T> &a)
       trunk_va<TP, TP::parent[J], T, CX, FK, OWN>(cx, vp, ap);
    MH_BODY_FENCE();
    const CRef<T, false> c{cx.C + J * MC_STRIDE};
-   const JQ<T> jq = spec_joint_read<TYPE, CO, CX, T>(cx);
+   constexpr bool PRE = CX::rnea_pre && TYPE == JT_REVOLUTE;
+   JQ<T> jq;
+   if constexpr (!PRE)
+      jq = spec_joint_read<TYPE, CO, CX, T>(cx);
    const SV<T> vJ = spec_vec<TYPE, DO, 0, CX, T>(cx, cx.coriolis != 0);
    const SV<T> aJ = spec_vec<TYPE, DO, 1, CX, T>(cx, cx.accel != 0);
    const XF<T> Xb = load_xb_j<TP, J, T>(c);
    MH_BODY_FENCE();
-   const JX<T> jx = spec_joint_from<TYPE, T>(jq);
+   JX<T> jx;
+   if constexpr (PRE)
+      jx.c = cx.st.template get<J, 0>(), jx.s = cx.st.template get<J, 1>(), jx.d = T(0);
+   else
+      jx = spec_joint_from<TYPE, T>(jq);
    v = motion_down(TYPE, jx, Xb, vp) + vJ;
    a = motion_down(TYPE, jx, Xb, ap) + aJ + crm(v, vJ);
    if (!cx.coriolis)
@@ -2045,6 +2086,61 @@ __global__ void __launch_bounds__(64) spec_fused_kernel(Args<T> A)
 // (trunk + its longest limb); the batch occupies 4x as many SIMDs.  Built for small batches, where latency is everything.
 // The limbs of one owner wave W, in limb order.  PC = trunk body whose velocity (and acceleration) the previous limb of this wave
 // hung from (-2: none yet): limbs sharing a parent -- an arm and the neck on the chest -- walk the trunk down to it once.
+// ---- the pre-pass of a context with RneaPreStore: (cos, sin) of every revolute joint wave W evaluates -- the bodies of its limbs and the
+//      trunk bodies above them -- formed together, in front of the walks.  FAST: the straight-line fast path for all of them (six to
+//      nine independent chains that interleave), `bad` = an angle outside its range; the caller repeats with FAST = false behind ONE branch.
+template <class TP, int OWN>
+struct RneaPreSet
+{
+   using S = Split<TP>;
+   static constexpr bool evaluates(int W, int J)
+   {
+      for (int k = 0; k < S::n_limbs(); k++)
+         if (S::template owner_sel<OWN>(k) == W)
+         {
+            for (int a = S::limb_root(k); a >= 0; a = TP::parent[a])
+               if (a == J)
+                  return true; // the limb's root or a trunk body above it
+            for (int a = J; a >= 0; a = TP::parent[a])
+               if (a == S::limb_root(k))
+                  return true; // a body of the limb
+         }
+      return false;
+   }
+};
+template <class TP, int W, int OWN, bool FAST, int J, typename T, class CX>
+MH_DEV void rnea_pre_bodies(const CX &cx, bool &bad)
+{
+   if constexpr (J < TP::N)
+   {
+      if constexpr (TP::type[J] == JT_REVOLUTE && RneaPreSet<TP, OWN>::evaluates(W, J))
+      {
+         const T x = cx.q(Tree<TP>::cfg_ofs(J));
+         T s, c;
+         if constexpr (FAST)
+         {
+            sincos_fast(x, s, c);
+            bad = bad || !sincos_in_fast_range(x);
+         }
+         else
+            sincos_t(x, s, c);
+         cx.st.template put<J, 0>(c);
+         cx.st.template put<J, 1>(s);
+      }
+      rnea_pre_bodies<TP, W, OWN, FAST, J + 1, T, CX>(cx, bad);
+   }
+}
+template <class TP, int W, int OWN, typename T, class CX>
+MH_DEV void rnea_pre_pass(const CX &cx)
+{
+   if constexpr (CX::rnea_pre)
+   {
+      bool bad = false;
+      rnea_pre_bodies<TP, W, OWN, true, 0, T, CX>(cx, bad);
+      if (__builtin_expect(bad, 0)) // an angle of 2^19 rad or more among them: once more, every pair through the full sincos
+         rnea_pre_bodies<TP, W, OWN, false, 0, T, CX>(cx, bad);
+   }
+}
 template <class TP, int W, int K, int PC, typename T, class CX, int OWN = 0>
 MH_DEV void split_rnea_limbs_of(const CX &cx, SV<T> &vp, SV<T> &ap)
 {
@@ -2098,6 +2194,7 @@ MH_DEV void split_rnea_limbs(const CX &cx)
    {
       if (cx.wave == W)
       {
+         rnea_pre_pass<TP, W, OWN, T, CX>(cx);
          const V3<T> Z{T(0), T(0), T(0)};
          SV<T> vp{Z, Z}, ap{Z, Z};
          split_rnea_limbs_of<TP, W, 0, -2, T, CX, OWN>(cx, vp, ap);

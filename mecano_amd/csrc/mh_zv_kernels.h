@@ -126,8 +126,25 @@ __device__ unsigned long long zv_probe[4096 * 3 * 4 * 16];
       if ((threadIdx.x & 63) == 0 && k < 4096)                                                                                             \
          zv_probe[((k * 3 + (job)) * 4 + (threadIdx.x >> 6)) * 16 + (ph)] = t_;                                                            \
    } while (0)
+// ... and inside the inward walk of the inertia job: per group, body and point of the body step (0 children done, 1 constants in and
+// inertia summed, 2 division and downdate done, 3 handed up), stamped by the wave that walks the body (the root body: wave 0)
+// (-DMH_ZV_PROBE_BODY on top of -DMH_ZV_PROBE: these stamps' stores are waited for at every __syncthreads() and stretch the phases around
+// the barriers; read the per-body durations from such a build, the phase times from a build without them)
+__device__ unsigned long long zv_probe_body[4096 * 32 * 4];
+#ifdef MH_ZV_PROBE_BODY
+#define ZV_STAMP_BODY(body, ph)                                                                                                            \
+   do                                                                                                                                      \
+   {                                                                                                                                       \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                                      \
+      if ((threadIdx.x & 63) == 0 && cx.own < 4096 && ((body) != 0 || cx.wave == 0))                                                      \
+         zv_probe_body[(cx.own * 32 + (body)) * 4 + (ph)] = t_;                                                                            \
+   } while (0)
+#else
+#define ZV_STAMP_BODY(body, ph)
+#endif
 #else
 #define ZV_STAMP(job, ph)
+#define ZV_STAMP_BODY(body, ph)
 #endif
 // A workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on gfx950 waits for
 // EVERY outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0)): loads requested ahead of time would be waited for at the
@@ -224,64 +241,135 @@ MH_DEV JX<T> zv_revolute_joint(const CX &cx)
    else
       return spec_joint<JT_REVOLUTE, Tree<TP>::cfg_ofs(J), CX, T>(cx);
 }
-template <class TP, int J, typename T, class CX>
+// FAST: every pair by the straight-line fast path of the sincos (mh_device.h: sincos_fast), `bad` collects the angles outside its range;
+// the caller repeats the walk with FAST = false behind one branch when any is (zv_pre).  Round 5: with the range test INSIDE every
+// evaluation (sincos_t) each pair was a basic block of its own and the six of a leg ran one after the other -- 1.5 us on the per-body
+// stamps (profiles/r05_zv_body_stamps_before.txt) against 0.55 for six interleaved chains.
+template <class TP, int J, typename T, class CX, bool FAST = false>
 struct ZvPre
 {
    template <int K>
-   static MH_DEV void children(const CX &cx)
+   static MH_DEV void children(const CX &cx, bool &bad)
    {
       if constexpr (K < Tree<TP>::n_children(J))
       {
-         ZvPre<TP, Tree<TP>::child(J, K), T, CX>::run(cx);
-         children<K + 1>(cx);
+         ZvPre<TP, Tree<TP>::child(J, K), T, CX, FAST>::run(cx, bad);
+         children<K + 1>(cx, bad);
       }
    }
-   static MH_DEV void run(const CX &cx)
+   static MH_DEV void run(const CX &cx, bool &bad)
    {
-      children<0>(cx);
+      children<0>(cx, bad);
       if constexpr (TP::type[J] == JT_REVOLUTE)
       {
-         const JX<T> jx = zv_revolute_joint<TP, J, CX, T>(cx);
-         cx.st.template put<J, 7>(jx.c);
-         cx.st.template put<J, 8>(jx.s);
+         if constexpr (FAST && CX::csmode != 2)
+         {
+            const T x = cx.q(Tree<TP>::cfg_ofs(J));
+            T s, c;
+            sincos_fast(x, s, c);
+            bad = bad || !sincos_in_fast_range(x);
+            cx.st.template put<J, 7>(c);
+            cx.st.template put<J, 8>(s);
+         }
+         else
+         {
+            const JX<T> jx = zv_revolute_joint<TP, J, CX, T>(cx);
+            cx.st.template put<J, 7>(jx.c);
+            cx.st.template put<J, 8>(jx.s);
+         }
       }
    }
 };
-// The same for the revolute TRUNK bodies of the sub-trunk rooted at J (two-launch form, CSMODE 2: the pairs come from memory, so the wave
-// that will fold the sub-trunk requests them before it starts on its limbs and finds them in the trunk's LDS slots when it gets there)
+#ifndef MH_ZV_PRE_FAST
+#define MH_ZV_PRE_FAST 1 // 0: every pair through sincos_t, as before round 5 (A/B measurements)
+#endif
 template <class TP, int J, typename T, class CX>
+MH_DEV void zv_pre(const CX &cx)
+{
+   bool bad = !MH_ZV_PRE_FAST;
+   ZvPre<TP, J, T, CX, MH_ZV_PRE_FAST != 0>::run(cx, bad);
+   if (__builtin_expect(bad, 0)) // an angle of 2^19 rad or more somewhere in this limb: once more, every pair through the full sincos
+      ZvPre<TP, J, T, CX, false>::run(cx, bad);
+}
+// The same for the revolute TRUNK bodies of the sub-trunk rooted at J (the wave that will fold the sub-trunk forms them -- or, CSMODE 2,
+// requests them from memory -- before it starts on its limbs and finds them in the trunk's LDS slots when it gets there)
+template <class TP, int J, typename T, class CX, bool FAST = false>
 struct ZvPreTrunk
 {
    template <int K>
-   static MH_DEV void children(const CX &cx)
+   static MH_DEV void children(const CX &cx, bool &bad)
    {
       if constexpr (K < Tree<TP>::n_children(J))
       {
          if constexpr (Split<TP>::is_trunk(Tree<TP>::child(J, K)))
-            ZvPreTrunk<TP, Tree<TP>::child(J, K), T, CX>::run(cx);
-         children<K + 1>(cx);
+            ZvPreTrunk<TP, Tree<TP>::child(J, K), T, CX, FAST>::run(cx, bad);
+         children<K + 1>(cx, bad);
       }
    }
-   static MH_DEV void run(const CX &cx)
+   static MH_DEV void run(const CX &cx, bool &bad)
    {
-      children<0>(cx);
+      children<0>(cx, bad);
       if constexpr (TP::type[J] == JT_REVOLUTE)
       {
-         const JX<T> jx = zv_revolute_joint<TP, J, CX, T>(cx);
-         cx.st.template put<J, 7>(jx.c);
-         cx.st.template put<J, 8>(jx.s);
+         if constexpr (FAST && CX::csmode != 2)
+         {
+            const T x = cx.q(Tree<TP>::cfg_ofs(J));
+            T s, c;
+            sincos_fast(x, s, c);
+            bad = bad || !sincos_in_fast_range(x);
+            cx.st.template put<J, 7>(c);
+            cx.st.template put<J, 8>(s);
+         }
+         else
+         {
+            const JX<T> jx = zv_revolute_joint<TP, J, CX, T>(cx);
+            cx.st.template put<J, 7>(jx.c);
+            cx.st.template put<J, 8>(jx.s);
+         }
       }
    }
 };
-template <class TP, int W, int I, typename T, class CX>
-MH_DEV void zv_pre_subtrunks_of(const CX &cx)
+template <class TP, int W, int I, typename T, class CX, bool FAST = false>
+MH_DEV void zv_pre_subtrunks_of(const CX &cx, bool &bad)
 {
    using S = Split<TP>;
    if constexpr (I < S::n_sub())
    {
       if constexpr (S::sub_owner(S::sub_top(I)) == W)
-         ZvPreTrunk<TP, S::sub_top(I), T, CX>::run(cx);
-      zv_pre_subtrunks_of<TP, W, I + 1, T, CX>(cx);
+         ZvPreTrunk<TP, S::sub_top(I), T, CX, FAST>::run(cx, bad);
+      zv_pre_subtrunks_of<TP, W, I + 1, T, CX, FAST>(cx, bad);
+   }
+}
+// every pair wave W needs for its inward walks -- its limbs, early and late, and the sub-trunks it folds -- formed in ONE straight-line
+// block in front of them (round 5: seven to nine independent sincos chains interleave; the pairs of the sub-trunk's bodies used to be
+// evaluated inside their body steps, 0.2 us each on the wave with the longest path)
+#ifndef MH_ZV_PRE_WAVE
+#define MH_ZV_PRE_WAVE 1 // 0: one pre-pass per limb, the sub-trunk's pairs inside its body steps, as before (A/B measurements)
+#endif
+template <class TP, int W, int K, typename T, class CX, bool FAST>
+MH_DEV void zv_pre_limbs_of(const CX &cx, bool &bad)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if constexpr (S::owner(K) == W)
+         ZvPre<TP, S::limb_root(K), T, CX, FAST>::run(cx, bad);
+      zv_pre_limbs_of<TP, W, K + 1, T, CX, FAST>(cx, bad);
+   }
+}
+template <class TP, int W, typename T, class CX>
+MH_DEV void zv_pre_wave(const CX &cx)
+{
+   using S = Split<TP>;
+   bool bad = false;
+   zv_pre_limbs_of<TP, W, 0, T, CX, true>(cx, bad);
+   if constexpr (S::staged())
+      zv_pre_subtrunks_of<TP, W, 0, T, CX, true>(cx, bad);
+   if (__builtin_expect(bad, 0)) // an angle of 2^19 rad or more among them: once more, every pair through the full sincos
+   {
+      zv_pre_limbs_of<TP, W, 0, T, CX, false>(cx, bad);
+      if constexpr (S::staged())
+         zv_pre_subtrunks_of<TP, W, 0, T, CX, false>(cx, bad);
    }
 }
 template <class TP, int J, typename T, class CX, int MODE = 0>
@@ -320,11 +408,12 @@ struct ZvIn
       if constexpr (MODE == 3 && Split<TP>::is_cut(J))
          __syncthreads(); // barrier 1 of the staged trunk: the early limbs of every wave are in the exchange area
       MH_BODY_FENCE();
+      ZV_STAMP_BODY(J, 0);
       const T *cp = cx.C + J * MC_STRIDE;
       asm volatile("" : "+s"(cp)); // the constants are read where they are used, never kept across a subtree
       const CRef<T, false> c{cp};
       // (cos, sin) already in the body's slots: limbs (ZvPre ran, zv_limbs_in_of); CSMODE 2: the bodies of a staged sub-trunk too (ZvPreTrunk); CSMODE 3: every body (left there by the inverse dynamics of the same workgroup)
-      constexpr bool PRE = TYPE == JT_REVOLUTE && ((!Split<TP>::is_trunk(J) && (MODE == 0 || MODE == 3)) || (CX::csmode == 2 && Split<TP>::staged() && Split<TP>::is_trunk(J) && MODE == 1) || (CX::csmode == 3 && Split<TP>::is_trunk(J)));
+      constexpr bool PRE = TYPE == JT_REVOLUTE && ((!Split<TP>::is_trunk(J) && (MODE == 0 || MODE == 3)) || ((CX::csmode == 2 || (CX::csmode == 0 && MH_ZV_PRE_WAVE)) && Split<TP>::staged() && Split<TP>::is_trunk(J) && MODE == 1) || (CX::csmode == 3 && Split<TP>::is_trunk(J)));
       JQ<T> jq;
       JX<T> jx;
       if constexpr (TYPE == JT_REVOLUTE && CX::csmode == 2 && !PRE)
@@ -337,6 +426,7 @@ struct ZvIn
       if constexpr (!LEAF)
          add(IA, up);
       MH_BODY_FENCE();
+      ZV_STAMP_BODY(J, 1);
       // the pose is requested only now, when the ten inertia constants have been consumed: requested together they hold 44 SGPRs next to
       // the kernel's arguments, more than the file has, and every use became a v_readlane from a spill lane (15 % of the instructions of
       // this chain); the sincos and the rank-1 downdate in front of its first use cover the latency
@@ -354,7 +444,7 @@ struct ZvIn
             ua = V3<T>{IA.A.xz, IA.A.yz, IA.A.zz}, ul = V3<T>{IA.C.zx, IA.C.zy, IA.C.zz}, D = IA.A.zz;
          else
             ua = V3<T>{IA.C.xz, IA.C.yz, IA.C.zz}, ul = V3<T>{IA.L.xz, IA.L.yz, IA.L.zz}, D = IA.L.zz;
-         const T dinv = T(1) / D;
+         const T dinv = rcp_fast(D); // (:1183 has 1.0 / D: a correctly rounded quotient; this one is within an ulp of it)
          const V3<T> sa = dinv * ua, sl = dinv * ul;
          cx.st.template put<J, 0>(sa.x), cx.st.template put<J, 1>(sa.y), cx.st.template put<J, 2>(sa.z);
          cx.st.template put<J, 3>(sl.x), cx.st.template put<J, 4>(sl.y), cx.st.template put<J, 5>(sl.z);
@@ -370,6 +460,10 @@ struct ZvIn
                rank1_down_revolute(IA, ua, ul, dinv);
             else
                rank1_down(IA, ua, ul, dinv);
+#ifdef MH_ZV_PROBE_BODY
+            MH_BODY_FENCE();
+            ZV_STAMP_BODY(J, 2);
+#endif
             abi_up(TYPE, jx, Xb, IA);
             out = IA;
          }
@@ -382,6 +476,7 @@ struct ZvIn
          out = IA;
       }
       MH_BODY_FENCE();
+      ZV_STAMP_BODY(J, 3);
       return out;
    }
 };
@@ -589,8 +684,8 @@ MH_DEV void zv_limbs_in_of(const CX &cx)
    {
       if constexpr (S::owner(K) == W && (LATE < 0 || (S::is_late(K) ? 1 : 0) == LATE))
       {
-         if constexpr (CX::csmode != 3) // (CSMODE 3: the inverse dynamics of this workgroup left the pairs in the slots)
-            ZvPre<TP, S::limb_root(K), T, CX>::run(cx);
+         if constexpr (CX::csmode != 3 && !(CX::csmode == 0 && MH_ZV_PRE_WAVE)) // (CSMODE 3: the inverse dynamics of this workgroup left the pairs in the slots; CSMODE 0: zv_pre_wave)
+            zv_pre<TP, S::limb_root(K), T, CX>(cx);
          x_put_ia<K, CX, T>(cx, ZvIn<TP, S::limb_root(K), T, CX, (LATE >= 0 && S::cut_limb(W) == K ? 3 : 0)>::run(cx));
       }
       zv_limbs_in_of<TP, W, K + 1, LATE, T, CX>(cx);
@@ -640,10 +735,15 @@ MH_DEV void zv_limbs_in(const CX &cx)
       {
          if constexpr (CX::csmode == 3)
             zvf_park_late_tau<TP, W, 0, T, CX>(cx);
+         if constexpr (CX::csmode == 0 && MH_ZV_PRE_WAVE)
+            zv_pre_wave<TP, W, T, CX>(cx);
          if constexpr (S::staged())
          {
             if constexpr (CX::csmode == 2)
-               zv_pre_subtrunks_of<TP, W, 0, T, CX>(cx);
+            {
+               bool unused = false;
+               zv_pre_subtrunks_of<TP, W, 0, T, CX>(cx, unused);
+            }
             zv_limbs_in_of<TP, W, 0, 0, T, CX>(cx);
             if constexpr (S::cut_limb(W) < 0)
                __syncthreads();
@@ -1121,11 +1221,14 @@ struct ZvPublish
    }
 };
 // bias job of group k, two-stage hand-off: taup = this launch's hand-off matrices [groups][nv][64]
+#ifndef MH_RNEA_PRE
+#define MH_RNEA_PRE 1 // 0: sincos_t inside every body step of the bias job, as before round 5 (A/B measurements)
+#endif
 template <class TP, typename T>
 MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, const ZvSync &sy)
 {
    using S = Split<TP>;
-   using CX = Ctx<T, true, true, SplitStore<TP>, false, 1>;
+   using CX = Ctx<T, true, true, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, SplitStore<TP>>, false, 1>;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
    const int nq = A.m.nq, nv = A.m.nv;
@@ -1140,7 +1243,6 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    ZV_STAMP(0, 0);
    wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
    __syncthreads();
-   ZV_STAMP(0, 1);
    CX cx;
    fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
    cx.coriolis = 1, cx.accel = 0;
@@ -1149,6 +1251,7 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    cx.xbase = lxc + lane;
    cx.st.lbase = lst + lane;
    cx.st.gbase = nullptr, cx.st.stride = 0, cx.st.lane = 0;
+   ZV_STAMP(0, 1);
    if (active)
       split_rnea_limbs<TP, 0, T, CX>(cx);
    ZV_STAMP(0, 2);

@@ -1,5 +1,5 @@
 """Phase stamps (100 MHz real-time counter, 10 ns ticks) of the bias-split forward dynamics; needs the code object built with -DMH_ZV_PROBE:
-python tools/isa.py --so -DMH_ZV_PROBE ; MH_SPEC_DIR=exp_build python tools/exp_zv_probe.py [B] [jobs: aba|pair]"""
+python tools/isa.py --so -DMH_ZV_PROBE ; MH_SPEC_DIR=build/exp python tools/exp_zv_probe.py [B] [jobs: aba|pair]"""
 import ctypes, os, sys, glob
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
@@ -31,7 +31,7 @@ buf = read()
 G = min((B + 63) // 64, 4096)
 st = buf.reshape(4096, 3, 4, 16)[:G].astype(np.int64)
 t0 = st[:, :, :, 15].min()  # first instruction of the launch
-names = {0: ["entry", "staged", "limbs", "barrier", "trunk", "copied", "fenced", "flag"],
+names = {0: ["entry", "staged", "limbs", "barrier", "trunk", "copied", "fenced", "flag", "q_staged", "pairs"],
          1: ["entry", "staged(q)", "limbs_in", "barrier2", "root", "flag_seen", "tau_staged", "early_fold", "late_fold+sub", "root_fold", "out", "copied"]}
 print("B", B, what, "variant", hm.kernel_variant, "(times in us relative to the first entry; median over groups)")
 for job in (0, 1):
@@ -48,3 +48,14 @@ print("kernel entry (first instruction) relative to t0: bias %.2f..%.2f, inertia
 if what == "pair":
     print("inverse dynamics job: kernel entry %.2f..%.2f us, end %.2f..%.2f us (median %.2f)" % ((st[:, 2, :, 15].min() - t0) / 100, (st[:, 2, :, 15].max() - t0) / 100, (st[:, 2, :, 1].min() - t0) / 100, (st[:, 2, :, 1].max() - t0) / 100, np.median(st[:, 2, :, 1] - t0) / 100))
 print("span: %.2f us" % ((st[:, :2, :, :12].max() - t0) / 100))
+# ---- per-body stamps of the inertia job's inward walk (ZV_STAMP_BODY): 0 children done, 1 constants in + inertia summed, 2 division and
+#      downdate done, 3 handed up; us relative to the first entry, median over the groups
+if hasattr(so, "mh_spec_zv_probe_body_read"):
+    bb = np.zeros(4096 * 32 * 4, dtype=np.uint64)
+    assert so.mh_spec_zv_probe_body_read(bb.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(bb.nbytes)) == 0
+    bb = bb.reshape(4096, 32, 4)[:G].astype(np.int64)
+    print("inertia job, inward walk, per body (us after the first entry): children_done  summed  downdated  handed_up | step = handed_up - children_done")
+    for j in range(hm.n_joints):
+        m = np.median(bb[:, j, :] - t0, axis=0) / 100
+        if (bb[:, j, 3] > 0).all():
+            print(f"  body {j:2d}: {m[0]:6.2f} {m[1]:6.2f} {m[2]:6.2f} {m[3]:6.2f} | {m[3] - m[0]:5.2f}   (sum {m[1]-m[0]:.2f}, divide+downdate {m[2]-m[1]:.2f}, congruence+translate {m[3]-m[2]:.2f})")
