@@ -194,6 +194,7 @@ struct SpecLib
    int (*zv_usable)(void) = nullptr;
    long (*zv_lds_bytes)(int nq, int nv) = nullptr;
    int (*launch_zv)(int flags, const void *args, void *taup, int *sync_flags, int *error, int epoch, int jobs, int same_l2, unsigned wait_ticks, void *stream) = nullptr;
+   int (*zv_self_signal)(void) = nullptr; // 1: identity-map launches expect taup to hold the sentinel wherever no column has been published
    // forward dynamics of device-filling batches as two launches (mh_zv_kernels.h, spec_zvb_*)
    int (*zvb_usable)(void) = nullptr;
    int (*zvb_cs_rows)(void) = nullptr;
@@ -271,6 +272,8 @@ struct mh_model
    // bias-split forward dynamics (mh_zv_kernels.h): tau - h(q, qd) rows, one flag per 64 configurations (a launch stores its epoch there),
    // an error word in mapped host memory that a timed-out wait sets (read at the next call of the model)
    Workspace zv_tau, zv_flags;
+   Workspace zv_cols;     // two-stage hand-off with self-signalling limb columns (identity index maps): [groups][nv][64], holds the sentinel
+                          // between launches (mh_zv_kernels.h: ZV_SENTINEL) -- written by nothing but those launches
    Workspace zvb_cs;      // two-launch forward dynamics: (cos, sin) of the revolute joints, [2 n_rev][B rounded up to 64]
    int use_rnea_ahead = 1; // MH_RNEA_AHEAD (see rnea_ahead_ok)
    int use_zv_step = 1;    // MH_ZV_STEP=0: simulation steps never ride in the bias-split / fused forward dynamics (the one-job tree-split kernel integrates instead)
@@ -498,12 +501,20 @@ mh_status check_all_error_words()
    return MH_OK;
 }
 // scratch of the bias-split launches for batches up to B: the bias rows, the flags (zeroed on `stream`), the mapped error word
+bool zv_self_signalling(const mh_model *m) { return m->ident_maps && m->spec.zv_self_signal && m->spec.zv_self_signal() != 0; }
 mh_status zv_prepare(mh_model *m, int64_t B, hipStream_t stream)
 {
    const size_t groups = (size_t)((B + 63) / 64);
    mh_status st = ensure_bytes(m->zv_tau, groups * 64 * m->nv * sizeof(double)); // (whole groups: the two-stage hand-off keeps a matrix [nv][64] per group)
    if (st != MH_OK)
       return st;
+   if (zv_self_signalling(m) && m->zv_cols.bytes < groups * 64 * m->nv * sizeof(double))
+   { // the matrix whose limb columns signal themselves: sentinels wherever nothing has been published (filled ON THE LAUNCH STREAM, like the flags)
+      st = ensure_bytes(m->zv_cols, std::max<size_t>(groups, 128) * 64 * m->nv * sizeof(double));
+      if (st != MH_OK)
+         return st;
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)m->zv_cols.ptr, 0x7ff4a5a5, m->zv_cols.bytes / 4, stream));
+   }
    if (m->zv_flags.bytes < groups * mh::ZV_SYNC_STRIDE * sizeof(int))
    {
       st = ensure_bytes(m->zv_flags, std::max<size_t>(groups, 1024) * mh::ZV_SYNC_STRIDE * sizeof(int));
@@ -516,8 +527,8 @@ mh_status zv_prepare(mh_model *m, int64_t B, hipStream_t stream)
    }
    if (!m->zv_error_host)
    {
-      HIP_TRY(hipHostMalloc((void **)&m->zv_error_host, sizeof(int), hipHostMallocMapped));
-      *m->zv_error_host = 0;
+      HIP_TRY(hipHostMalloc((void **)&m->zv_error_host, 2 * sizeof(int), hipHostMallocMapped)); // [0] the error word, [1] the poison word's host copy
+      m->zv_error_host[0] = m->zv_error_host[1] = 0;
       HIP_TRY(hipHostGetDevicePointer((void **)&m->zv_error_dev, m->zv_error_host, 0));
       std::lock_guard<std::mutex> lock(g_error_words_mutex);
       g_error_words.push_back(m->zv_error_host);
@@ -537,9 +548,20 @@ mh_status zv_launch(mh_model *m, mh::Args<double> &A, int jobs, hipStream_t stre
       HIP_TRY(hipMemsetAsync(m->zv_flags.ptr, 0, m->zv_flags.bytes, stream));
       m->zv_epoch = 0;
    }
+   const bool self_signal = zv_self_signalling(m);
+   if (self_signal && *(volatile int *)(m->zv_error_host + 1) != 0)
+   { // A consumer of this context gave up (mh_zv_kernels.h: zv_take_cols): its producer may have published AFTERWARDS, into a matrix nobody
+     // reset -- every launch since has written NaN rows.  Wait for whatever is still running, sentinels everywhere, poison word cleared.
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)m->zv_cols.ptr, 0x7ff4a5a5, m->zv_cols.bytes / 4, stream));
+      HIP_TRY(hipMemsetAsync(m->zv_flags.ptr, 0, m->zv_flags.bytes, stream));
+      m->zv_epoch = 0;
+      *(volatile int *)(m->zv_error_host + 1) = 0;
+   }
    const int epoch = ++m->zv_epoch;
    int flags = SPEC_IO_LDS | (m->ident_maps ? SPEC_IDENT : 0);
-   *rc = m->spec.launch_zv(flags, &A, m->zv_tau.ptr, (int *)m->zv_flags.ptr, m->zv_error_dev, epoch, jobs, m->zv_same_l2, m->zv_wait_ticks, (void *)stream);
+   *rc = m->spec.launch_zv(flags, &A, self_signal ? m->zv_cols.ptr : m->zv_tau.ptr, (int *)m->zv_flags.ptr, m->zv_error_dev, epoch, jobs, m->zv_same_l2,
+                           m->zv_wait_ticks, (void *)stream);
    if (*rc != 0 && *rc != (int)hipErrorNotSupported)
       return fail(MH_ERR_HIP, "bias-split kernel launch failed: %s", hipGetErrorString((hipError_t)*rc));
    return MH_OK;
@@ -1667,6 +1689,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.zv_usable = (decltype(s.zv_usable))dlsym(h, "mh_spec_zv_usable");
    s.zv_lds_bytes = (decltype(s.zv_lds_bytes))dlsym(h, "mh_spec_zv_lds_bytes");
    s.launch_zv = (decltype(s.launch_zv))dlsym(h, "mh_spec_launch_zv");
+   s.zv_self_signal = (decltype(s.zv_self_signal))dlsym(h, "mh_spec_zv_self_signal");
    s.zvb_usable = (decltype(s.zvb_usable))dlsym(h, "mh_spec_zvb_usable");
    s.zvb_cs_rows = (decltype(s.zvb_cs_rows))dlsym(h, "mh_spec_zvb_cs_rows");
    s.zvb_lds_bytes = (decltype(s.zvb_lds_bytes))dlsym(h, "mh_spec_zvb_lds_bytes");
@@ -2456,6 +2479,7 @@ static void free_scratch(mh_model *m)
    (void)hipFree(m->ws_pair.ptr);
    (void)hipFree(m->tr_pair.ptr);
    (void)hipFree(m->zv_tau.ptr);
+   (void)hipFree(m->zv_cols.ptr);
    (void)hipFree(m->zvb_cs.ptr);
    (void)hipFree(m->zv_flags.ptr);
    if (m->zv_error_host)
@@ -2495,7 +2519,7 @@ static void free_scratch(mh_model *m)
 // a fresh set of the above for a copy of a handle
 static void reset_scratch(mh_model *m)
 {
-   m->ws = m->stage = m->ws_pair = m->zv_tau = m->zv_flags = m->zvb_cs = m->tr = m->tr_pair = m->aux = m->pairs = Workspace{};
+   m->ws = m->stage = m->ws_pair = m->zv_tau = m->zv_cols = m->zv_flags = m->zvb_cs = m->tr = m->tr_pair = m->aux = m->pairs = Workspace{};
    m->hs_in = m->hs_run = m->hs_out = nullptr;
    for (int k = 0; k < 3; k++)
       m->ev_in[k] = m->ev_run[k] = m->ev_out[k] = nullptr;

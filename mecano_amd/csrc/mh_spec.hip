@@ -277,6 +277,9 @@ long mh_spec_zv_lds_bytes(int nq, int nv)
    return std::max(inertia, split_lds_bytes(0, F_IO_LDS, nq, nv));
 }
 int mh_spec_zv_usable(void) { return SPL::usable() ? 1 : 0; }
+// 1: launches with identity index maps (the two-stage hand-off) expect `taup` to hold the sentinel wherever no column has been published
+// (mh_zv_kernels.h, "Stage one without a flag"); the library keeps a matrix of its own for them and refills it after a give-up
+int mh_spec_zv_self_signal(void) { return MH_ZV_TWO_STAGE && MH_ZV_SELF_SIGNAL ? 1 : 0; }
 #ifdef MH_ZV_PROBE
 int mh_spec_zv_probe_read(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mh::zv_probe), bytes); }
 int mh_spec_zv_probe_body_read(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mh::zv_probe_body), bytes); }
@@ -305,7 +308,7 @@ int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, 
          auto kern = &mh::spec_zv_kernel<TP, double, true, true>;
          if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr_step); e != hipSuccess)
             return (int)e;
-         hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A, (double *)taup, sy);
+         hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A.q, A.qd, A.in3b, A.B, jobs, A, (double *)taup, sy);
          return (int)hipGetLastError();
       }
       if (flags & F_IDENT)
@@ -314,7 +317,7 @@ int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, 
          auto kern = &mh::spec_zv_kernel<TP, double, true>;
          if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr); e != hipSuccess)
             return (int)e;
-         hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A, (double *)taup, sy);
+         hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A.q, A.qd, A.in3b, A.B, jobs, A, (double *)taup, sy);
          return (int)hipGetLastError();
       }
 #ifdef MH_SPEC_MINIMAL
@@ -324,7 +327,7 @@ int mh_spec_launch_zv(int flags, const void *args, void *taup, int *sync_flags, 
       auto kern = &mh::spec_zv_kernel<TP, double, false>;
       if (const hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(kern), lds, attr2); e != hipSuccess)
          return (int)e;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A, (double *)taup, sy);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(padded * jobs)), dim3(256), lds, s, A.q, A.qd, A.in3b, A.B, jobs, A, (double *)taup, sy);
       return (int)hipGetLastError();
 #endif
    }

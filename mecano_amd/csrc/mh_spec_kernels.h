@@ -572,6 +572,12 @@ struct SplitStore
 // (profiles/r05_headline_steps.txt): the pairs in LDS and the pre-pass as a phase of its own between the arrival of the rows of q and
 // that of the velocities and efforts -- the rows of q are there 0.37 us ahead of the rest, and a pre-pass that overlaps nothing else takes
 // 1.2 us (eight or nine chains of ~48 instructions) against ~0.6 us of added walk time here.
+#ifndef MH_RNEA_PRE
+#define MH_RNEA_PRE 1 // 0: sincos_t inside every body step of the tree-split inverse dynamics, as before round 5 (A/B measurements)
+#endif
+#ifndef MH_ZVF_PRE
+#define MH_ZVF_PRE 1 // the same switch for the fused forward dynamics of device-filling batches (its limb joints' pairs: slots 7, 8 of its own store)
+#endif
 template <class TP>
 struct RneaPreStore
 {
@@ -871,7 +877,11 @@ struct RneaSub
       constexpr int TYPE = TP::type[J];
       constexpr int DO = Tree<TP>::dof_ofs(J), CO = Tree<TP>::cfg_ofs(J);
       const CRef<T, false> c{cx.C + J * MC_STRIDE};
-      constexpr bool PRE = CX::rnea_pre && TYPE == JT_REVOLUTE;
+      // (cos, sin) formed in front of the walk: RneaPreStore (slots 0, 1), or -- fused forward dynamics, the bodies of a limb -- the slots the
+      // inertia walk of the same wave reads them from (7, 8; rnea_pre_pass)
+      constexpr bool PRE3 = CX::csmode == 3 && MH_ZVF_PRE && TYPE == JT_REVOLUTE && Split<TP>::usable() && !Split<TP>::is_trunk(J);
+      constexpr bool PRE = (CX::rnea_pre && TYPE == JT_REVOLUTE) || PRE3;
+      constexpr int PS = PRE3 ? 7 : 0;
       JQ<T> jq;
       if constexpr (!PRE)
          jq = spec_joint_read<TYPE, CO, CX, T>(cx);
@@ -882,7 +892,7 @@ struct RneaSub
       MH_BODY_FENCE(); // everything the body reads is requested before its arithmetic starts (see JQ)
       JX<T> jx;
       if constexpr (PRE)
-         jx.c = cx.st.template get<J, 0>(), jx.s = cx.st.template get<J, 1>(), jx.d = T(0);
+         jx.c = cx.st.template get<J, PS>(), jx.s = cx.st.template get<J, PS + 1>(), jx.d = T(0);
       else
          jx = spec_joint_from<TYPE, T>(jq);
       if constexpr (CX::csmode == 1 && TYPE == JT_REVOLUTE)
@@ -890,7 +900,7 @@ struct RneaSub
          constexpr int R = Tree<TP>::rev_index(J);
          cx.cs[(2 * R) * cx.cs_stride] = jx.c, cx.cs[(2 * R + 1) * cx.cs_stride] = jx.s;
       }
-      if constexpr (CX::csmode == 3 && TYPE == JT_REVOLUTE)
+      if constexpr (CX::csmode == 3 && TYPE == JT_REVOLUTE && !PRE3)
       { // fused kernel: the pair stays in this wave's registers, in the slots the inertia walk of the same limb reads it from
          cx.st.template put<J, 7>(jx.c);
          cx.st.template put<J, 8>(jx.s);
@@ -2113,7 +2123,9 @@ MH_DEV void rnea_pre_bodies(const CX &cx, bool &bad)
 {
    if constexpr (J < TP::N)
    {
-      if constexpr (TP::type[J] == JT_REVOLUTE && RneaPreSet<TP, OWN>::evaluates(W, J))
+      // (the fused forward dynamics: the limbs' bodies only -- its trunk slots lie over the rows of q while the inverse dynamics runs)
+      constexpr int PS = CX::rnea_pre ? 0 : 7;
+      if constexpr (TP::type[J] == JT_REVOLUTE && RneaPreSet<TP, OWN>::evaluates(W, J) && (CX::rnea_pre || !Split<TP>::is_trunk(J)))
       {
          const T x = cx.q(Tree<TP>::cfg_ofs(J));
          T s, c;
@@ -2124,8 +2136,8 @@ MH_DEV void rnea_pre_bodies(const CX &cx, bool &bad)
          }
          else
             sincos_t(x, s, c);
-         cx.st.template put<J, 0>(c);
-         cx.st.template put<J, 1>(s);
+         cx.st.template put<J, PS>(c);
+         cx.st.template put<J, PS + 1>(s);
       }
       rnea_pre_bodies<TP, W, OWN, FAST, J + 1, T, CX>(cx, bad);
    }
@@ -2133,7 +2145,7 @@ MH_DEV void rnea_pre_bodies(const CX &cx, bool &bad)
 template <class TP, int W, int OWN, typename T, class CX>
 MH_DEV void rnea_pre_pass(const CX &cx)
 {
-   if constexpr (CX::rnea_pre)
+   if constexpr (CX::rnea_pre || (CX::csmode == 3 && MH_ZVF_PRE))
    {
       bool bad = false;
       rnea_pre_bodies<TP, W, OWN, true, 0, T, CX>(cx, bad);
@@ -2319,7 +2331,7 @@ template <class TP, typename T, int ALGO, bool IDENT, bool IO_LDS, bool BODIES =
 MH_DEV void split_group(const Args<T> &A, long group, long ngroups, lds_ptr<T> lds)
 {
    using S = Split<TP>;
-   using CX = Ctx<T, IO_LDS, IDENT, SplitStore<TP>, BODIES>;
+   using CX = Ctx<T, IO_LDS, IDENT, std::conditional_t<ALGO == 0 && MH_RNEA_PRE != 0, RneaPreStore<TP>, SplitStore<TP>>, BODIES>;
    constexpr int XW = ALGO == 0 ? 6 : 27;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;

@@ -1169,7 +1169,96 @@ struct ZvColRegs
             commit<D + 1, K>(row);
       }
    }
+   // the sentinel back into the columns this wave has consumed (self-signalling stage one, below)
+   template <int D = 0>
+   MH_DEV void reset(T *dst, int lane) const
+   {
+      if constexpr (D < ZvCols<TP>::NV && sizeof(T) == 8)
+      {
+         if constexpr (ZvCols<TP>::aba_owner(D) == OWNER)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst) + D * 64 + lane, 0x7ff4a5a57ff4a5a5ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         reset<D + 1>(dst, lane);
+      }
+   }
 };
+// ---- Stage one without a flag (round 5): the limb columns SIGNAL THEMSELVES.
+// Stamps of the flag form (profiles/r05_zv_phase_stamps_prepass_rcp.txt): limb barrier of the bias job 7.00 us, columns stored 7.35, stores
+// acknowledged 7.75, flag A stored 7.90, seen by the inertia job 8.30, columns fetched 8.95 -- two round trips on the producer's side (drain,
+// flag) and two on the consumer's (poll, fetch) for 15 KB.  Each element of a column is ONE aligned 8-byte store and one 8-byte load: a
+// reader sees either what was there before or the value, never a mixture.  So the hand-off matrix holds a SENTINEL between launches -- a
+// signalling-NaN bit pattern, which no arithmetic instruction can produce (tau - h comes out of a v_add_f64: a NaN result is quieted) --,
+// the producer just stores its columns (sc1, no drain, no count, no flag) and every consumer wave polls THE COLUMNS of its own limbs (sc1
+// loads) until no lane that holds a configuration reads the sentinel any more: one round trip behind the store's arrival.  The wave then
+// writes the sentinel back (sc1; ordered behind its own loads of the same addresses; the next launch on the stream starts behind this
+// kernel's end).  The bit patterns are compared as integers (the build's -ffinite-math-only knows no NaN values).
+// What the epoch in the flag used to give for free -- a producer that publishes AFTER its consumer gave up cannot be taken for the next
+// launch's -- is kept by a poison word: a consumer that runs into the wall-clock limit sets it (device word flags[ZV_POISON_WORD] of the
+// context, and error[1] in mapped host memory beside the error word), every later consumer of the context gives up at once (NaN rows,
+// MH_ERR_HIP at the next synchronisation point) until the host has seen error[1], waited for the device, refilled the matrix with
+// sentinels and cleared both (mh_api.hip: zv_launch).  Stage two (the trunk's columns under flag B) has a microsecond of slack and stays
+// as it was.
+#ifndef MH_ZV_SELF_SIGNAL
+#define MH_ZV_SELF_SIGNAL 1 // 0: stage one under flag A, as in round 4 (A/B measurements)
+#endif
+constexpr unsigned long long ZV_SENTINEL = 0x7ff4a5a57ff4a5a5ull; // (both halves equal: the host fills with a 32-bit pattern)
+constexpr int ZV_POISON_WORD = 3;                                  // index into the context's flag words (group 0's line)
+template <typename T>
+MH_DEV bool zv_is_sentinel(T v)
+{
+   if constexpr (sizeof(T) == 8)
+      return __builtin_bit_cast(unsigned long long, v) == ZV_SENTINEL;
+   else
+      return false;
+}
+template <class TP, typename T, int OWNER>
+MH_DEV bool zv_cols_pending(const ZvColRegs<TP, T, OWNER> &c)
+{
+   bool p = false;
+#pragma unroll
+   for (int i = 0; i < ZvColRegs<TP, T, OWNER>::count(); i++)
+      p = p || zv_is_sentinel(c.r[i]);
+   return p;
+}
+// the limb columns of wave OWNER into its lanes' LDS rows, polled until they are all there; false: gave up (wall-clock limit, or the
+// context is poisoned)
+template <class TP, typename T, int OWNER>
+MH_DEV bool zv_take_cols(const ZvSync &sy, const T *src, T *reset, lds_ptr<T> row, int lane, bool active, int poison)
+{
+   ZvColRegs<TP, T, OWNER> c;
+   bool ok = poison == 0;
+   if (ok)
+   {
+      c.issue(src, lane);
+      if (__builtin_amdgcn_ballot_w64(active && zv_cols_pending(c)) != 0)
+      {
+         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+         for (;;)
+         {
+            __builtin_amdgcn_s_sleep(1);
+            c.issue(src, lane);
+            if (__builtin_amdgcn_ballot_w64(active && zv_cols_pending(c)) == 0)
+               break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)sy.wait_ticks)
+            {
+               ok = false;
+               break;
+            }
+         }
+      }
+   }
+   if (ok)
+   {
+      c.commit(row);
+      c.reset(reset, lane);
+   }
+   else if ((threadIdx.x & 63) == 0)
+   { // (whatever arrives in this matrix from now on may be a late producer's: nothing of it is trusted until the host has refilled it)
+      __hip_atomic_store(sy.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(sy.error + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(sy.flags + ZV_POISON_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   }
+   return ok;
+}
 // columns of this group's hand-off matrix from the lane's LDS row, write-through.  SHARE = -1: the trunk dofs' columns; 0..2: the limb dofs'
 // columns number % 3 == SHARE.  All LDS reads first, then all stores (read and stored one by one -- the columns picked by a run-time
 // share -- the seven columns of a wave took 0.5 us: a chain of LDS round trips).
@@ -1221,9 +1310,6 @@ struct ZvPublish
    }
 };
 // bias job of group k, two-stage hand-off: taup = this launch's hand-off matrices [groups][nv][64]
-#ifndef MH_RNEA_PRE
-#define MH_RNEA_PRE 1 // 0: sincos_t inside every body step of the bias job, as before round 5 (A/B measurements)
-#endif
 template <class TP, typename T>
 MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, const ZvSync &sy)
 {
@@ -1231,7 +1317,7 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    using CX = Ctx<T, true, true, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, SplitStore<TP>>, false, 1>;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
-   const int nq = A.m.nq, nv = A.m.nv;
+   constexpr int nq = Tree<TP>::total_cfgs(), nv = Tree<TP>::total_dofs(); // (dense index maps: the model's nq, nv -- known without the kernel-argument segment)
    const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * 6 * 64, lq = lst + S::RNEA_TRUNK_SLOTS * 64, lqd = lq + 64 * nq, lx = lqd + 64 * nv;
    ZV_STAMP(0, 14);
    const long cfg0 = k * 64;
@@ -1284,13 +1370,16 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    else
    {
       ZV_STAMP(0, 4);
+#if !(MH_ZV_SELF_SIGNAL && defined(MH_ZV_TEST_NO_FLAG)) // (the test build of a producer that never signals: here, one that never publishes)
       if (wave == 1)
          ZvPublish<TP, T, 0>::run(dst, lx + lane * nv, lane);
       else if (wave == 2)
          ZvPublish<TP, T, 1>::run(dst, lx + lane * nv, lane);
       else
          ZvPublish<TP, T, 2>::run(dst, lx + lane * nv, lane);
+#endif
       ZV_STAMP(0, 5);
+#if !MH_ZV_SELF_SIGNAL
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's columns have been acknowledged ...
       ZV_STAMP(0, 6);
       int before = 0;
@@ -1301,6 +1390,7 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
       if (lane == 0 && before == 2)
          __hip_atomic_store(flags + 1, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+#endif // (self-signalling: the columns are their own flag -- nothing to wait for, nothing to count)
       ZV_STAMP(0, 7);
    }
 }
@@ -1310,7 +1400,7 @@ template <class TP, typename T, bool IDENT>
 MH_DEV void zv_bias_group(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, const ZvSync &sy)
 {
    using S = Split<TP>;
-   using CX = Ctx<T, true, IDENT, SplitStore<TP>, false, 1>;
+   using CX = Ctx<T, true, IDENT, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, SplitStore<TP>>, false, 1>;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
    const int nq = A.m.nq, nv = A.m.nv;
@@ -1516,7 +1606,7 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
    using CX = Ctx<T, true, true, ZvStore<TP>, false, 0>;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
-   const int nq = A.m.nq, nv = A.m.nv;
+   constexpr int nq = Tree<TP>::total_cfgs(), nv = Tree<TP>::total_dofs(); // (dense index maps: the model's nq, nv -- known without the kernel-argument segment)
    // LDS map: as zv_aba_group
    const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * ZV_XW * 64, lq = lst + S::ZV_TRUNK_SLOTS * 64, lx = lq + 64 * nq, lres = lx + 64 * nv;
    ZV_STAMP(1, 14);
@@ -1527,6 +1617,10 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
    if (threadIdx.x == 0)
       zv_gave_up = 0;
    ZV_STAMP(1, 0);
+#if MH_ZV_SELF_SIGNAL
+   // the context's poison word (see zv_take_cols), requested with the rows and long there when it is looked at
+   const int poison = __hip_atomic_load(sy.flags + ZV_POISON_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
    zv_stage_rows<T, Tree<TP>::total_cfgs(), 256>(lq, A.q + cfg0 * nq, rows);
    __syncthreads();
    ZV_STAMP(1, 1);
@@ -1558,6 +1652,21 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
    const T *const src = taup + k * 64 * nv;
    const int *const flags = sy.flags + k * ZV_SYNC_STRIDE;
    const lds_ptr<T> row = lx + lane * nv;
+#if MH_ZV_SELF_SIGNAL
+   bool seen;
+   {
+      T *const back = const_cast<T *>(src);
+      if (wave == 0)
+         seen = zv_take_cols<TP, T, 0>(sy, src, back, row, lane, active, poison);
+      else if (wave == 1)
+         seen = zv_take_cols<TP, T, 1>(sy, src, back, row, lane, active, poison);
+      else if (wave == 2)
+         seen = zv_take_cols<TP, T, 2>(sy, src, back, row, lane, active, poison);
+      else
+         seen = zv_take_cols<TP, T, 3>(sy, src, back, row, lane, active, poison);
+   }
+   ZV_STAMP(1, 5);
+#else
    bool seen = zv_wait_word(sy, flags + 1);
    ZV_STAMP(1, 5);
    if (wave == 0)
@@ -1580,6 +1689,7 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
       ZvColRegs<TP, T, 3> c;
       c.issue(src, lane), c.commit(row);
    }
+#endif
    // a first look at flag B, in flight during the early limbs' fold (a poll is a round trip to memory: 0.45 us on the stamps)
    const int b_first = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    zv_lds_barrier(); // nobody reads the exchange area's inertias any more (the fold's records go over them)
@@ -1654,11 +1764,21 @@ MH_DEV void zv_aba_group2(const Args<T> &A, long k, lds_ptr<T> lds, const T *tau
 #ifndef MH_ZV_KERNEL_ATTR
 #define MH_ZV_KERNEL_ATTR
 #endif
+// The first five arguments repeat what the jobs need to REQUEST THEIR ROWS -- the three state matrices of the critical jobs, the batch size,
+// the number of jobs (which job is this workgroup?) -- as plain leading arguments: the code objects are compiled with
+// -amdgpu-kernarg-preload-count (mecano_amd/build.py), so the dispatcher hands those ten dwords over in SGPRs and the staging loads are issued
+// without waiting for the kernel-argument segment (0.65 us from the first instruction to the end of the prologue on the stamps: one cold
+// read of device memory that every wave of every launch used to sit out before it could ask for anything).
 template <class TP, typename T, bool IDENT, bool STEP = false>
-__global__ void __launch_bounds__(256) MH_ZV_KERNEL_ATTR spec_zv_kernel(Args<T> A, T *taup, ZvSync sy)
+__global__ void __launch_bounds__(256) MH_ZV_KERNEL_ATTR spec_zv_kernel(const T *q0, const T *qd0, const T *tau0, long B0, int jobs0, Args<T> A_full, T *taup,
+                                                                        ZvSync sy_full)
 {
    extern __shared__ double lds_raw[];
    const int blk = (int)blockIdx.x;
+   Args<T> A = A_full;
+   A.q = q0, A.qd = qd0, A.in3b = tau0, A.B = B0;
+   ZvSync sy = sy_full;
+   sy.jobs = jobs0;
    // bias and inertia job alternate in blocks of eight; the inverse dynamics job of the pair call (five microseconds of slack) takes the ids
    // behind all of them, so that the two jobs on the critical path are dispatched first (15.55 -> 15.35 us per step)
    const int padded = (int)gridDim.x / sy.jobs;
@@ -1724,7 +1844,7 @@ __global__ void __launch_bounds__(256, 2) spec_zvb_bias_kernel(Args<T> A, T *tau
 {
    extern __shared__ double lds_raw[];
    using S = Split<TP>;
-   using CX = Ctx<T, true, IDENT, SplitStore<TP>, false, BIAS ? 1 : 0, BIAS ? 1 : 0>;
+   using CX = Ctx<T, true, IDENT, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, SplitStore<TP>>, false, BIAS ? 1 : 0, BIAS ? 1 : 0>;
    constexpr int NQ = Tree<TP>::total_cfgs(), NV = Tree<TP>::total_dofs();
    const lds_ptr<T> lds = (lds_ptr<T>)lds_raw;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

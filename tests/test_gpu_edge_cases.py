@@ -349,6 +349,16 @@ def test_a_consumer_that_gives_up_writes_nan_and_reports_at_the_next_synchronisa
             hm.check()
         assert "gave up waiting" in str(e.value)
         hm.check()  # reported once: the word is clear again
+        # Round 5 (the limb columns signal themselves, mh_zv_kernels.h "Stage one without a flag"): a give-up poisons the context -- a
+        # producer that publishes late must not be taken for the next launch's -- until the library has seen it, waited for the device and
+        # refilled the hand-off matrix with sentinels, which it does at the context's next bias-split launch.  This producer never
+        # publishes, so that launch gives up as well: NaN rows again, reported once again.
+        a = hm.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), G)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(a).all())
+        with pytest.raises(_lib.MecanoHipError):
+            hm.check()
+        hm.check()
         os.environ["MH_ZV"] = "0"  # the same code object without the bias split: the tree-split kernels need no hand-off
         hm2 = HipModel(d)
         close(hm2.aba(dev(torch, q), dev(torch, qd), dev(torch, tau), G).cpu().numpy(), OracleModel(d).aba(q, qd, tau, G), 1e-10, label="tree split")

@@ -13,7 +13,8 @@ registered code object and checks the instruction stream itself:
   give-up    the wall-clock limit's error word is stored at system scope (sc0 sc1).
 
 Code objects with identity index maps run the hand-off in two stages (limb columns under flag A, trunk columns under flag B: see
-check_two_stage); the stream tells which form it is.
+check_two_stage); the stream tells which form it is.  Round 5: stage one needs no flag -- the limb columns signal themselves (the matrix
+holds a signalling-NaN sentinel between launches, the consumer polls the columns): see check_self_signal.
 
 usage: python tools/isa_handoff.py <libmecano_hip_topo_*.so | file.s> ...
 """
@@ -134,8 +135,90 @@ def check_two_stage(instrs) -> list:
     return bad
 
 
+SENTINEL_HALF = "0x7ff4a5a5"  # mh_zv_kernels.h: ZV_SENTINEL, both 32-bit halves
+
+
+def is_self_signal(instrs) -> bool:
+    """The self-signalling form compares what it loads with the sentinel: its 32-bit half appears as a literal."""
+    return any(SENTINEL_HALF in a for _, a in instrs)
+
+
+def check_self_signal(instrs) -> list:
+    """Two-stage hand-off whose FIRST stage has no flag (mh_zv_kernels.h, "Stage one without a flag"):
+      producer   every published column store is write-through (global_store_dwordx2 sc1).  A run of column stores that is followed by its
+                 wave's drain (`s_waitcnt vmcnt(0)` within 40 instructions) is the trunk's (stage two, flag B): no flag-sized store between the
+                 run and the drain, an sc1 flag store within 120 instructions behind it; there is at least one such run.  The other runs are
+                 the limbs' self-signalling columns (and, in the consumer, the sentinels written back): no rule beyond sc1 -- each element is
+                 one aligned 8-byte store, valid by itself;
+      consumer   the limb columns are POLLED: per wave a loop with s_sleep, sc1 column loads and a comparison with the sentinel, under a
+                 wall-clock limit (s_memrealtime); flag B is polled with global_load_dword sc1 (a first look and a loop); every 8-byte
+                 load from the first polled column to the last column load is sc1;
+      give-up    error word and the poison word's host copy at system scope (sc0 sc1), the device poison word right behind them (sc1)."""
+    bad = []
+    idx = lambda pred: [i for i, (op, a) in enumerate(instrs) if pred(op, a)]
+    drains = idx(lambda op, a: op == "s_waitcnt" and re.search(r"vmcnt\(0\)", a))
+    small_stores = idx(lambda op, a: op == "global_store_dword")
+    flag_stores = [i for i in small_stores if scope(instrs[i][1]) == "sc1"]
+    col_stores = idx(lambda op, a: op == "global_store_dwordx2" and scope(a) != "")
+    col_loads = idx(lambda op, a: op == "global_load_dwordx2" and scope(a) == "sc1")
+    polls = idx(lambda op, a: op == "global_load_dword" and scope(a) == "sc1")
+    sleeps = idx(lambda op, a: op == "s_sleep")
+    sentinels = idx(lambda op, a: SENTINEL_HALF in a)
+    # ---- producer
+    if not col_stores:
+        bad.append("producer: no scoped column store (global_store_dwordx2 sc1) found")
+    for i in col_stores:
+        if scope(instrs[i][1]) != "sc1":
+            bad.append(f"producer: column store #{i} is {scope(instrs[i][1])}, not write-through (sc1)")
+    runs = []  # [first, last] of consecutive column stores
+    for i in col_stores:
+        if runs and i - runs[-1][1] <= 3:
+            runs[-1][1] = i
+        else:
+            runs.append([i, i])
+    flagged = 0
+    for first, last in runs:
+        nd = next((d for d in drains if last < d <= last + 40), None)
+        nf = next((f for f in flag_stores if f > last), None)
+        if nd is None:
+            if nf is not None and nf - last <= 40:
+                bad.append(f"producer: flag-sized sc1 store #{nf} right behind the column stores #{first}..#{last} without a drain: the flag can overtake its columns")
+            continue
+        early = [f for f in small_stores if last < f < nd]
+        if early:
+            bad.append(f"producer: flag-sized store #{early[0]} sits between column store #{last} and its wave's drain #{nd}: the flag can overtake its columns")
+            continue
+        nf = next((f for f in flag_stores if f > nd), None)
+        if nf is not None and nf - nd <= 120:
+            flagged += 1
+    if not flagged:
+        bad.append("producer: no run of column stores that is drained and then flagged (stage two: the trunk's columns under flag B)")
+    # ---- consumer
+    loops = [s for s in sleeps if [l for l in col_loads if s < l <= s + 30] and [c for c in sentinels if s < c <= s + 60]
+             and [i for i, (op, a) in enumerate(instrs) if s < i <= s + 90 and op == "s_memrealtime"]]
+    if len(loops) < 4:
+        bad.append(f"consumer: expected a polling loop (s_sleep, sc1 column loads, comparison with the sentinel, wall-clock limit) for each of the four waves, found {len(loops)}")
+    if len(polls) < 3:
+        bad.append(f"consumer: expected the poison word's load and a first look + polling loop on flag B (global_load_dword sc1), found {len(polls)}")
+    if not col_loads:
+        bad.append("consumer: no sc1 column load (global_load_dwordx2 sc1) found")
+    else:
+        plain = [i for i, (op, a) in enumerate(instrs) if col_loads[0] < i < col_loads[-1] and op.startswith("global_load_dwordx") and scope(a) != "sc1"]
+        if plain:
+            bad.append(f"consumer: load #{plain[0]} between the first and the last column load is not sc1 (it may be served from this CU's L1)")
+    # ---- give-up
+    system = [f for f in small_stores if scope(instrs[f][1]) == "sc0 sc1"]
+    if not system:
+        bad.append("give-up: the error word is not stored at system scope (sc0 sc1)")
+    elif not [f for f in flag_stores if any(0 < f - s <= 4 for s in system)]:
+        bad.append("give-up: no device poison word (global_store_dword sc1) stored right behind the error word")
+    return bad
+
+
 def check_handoff(instrs) -> list:
     """Violations of the hand-off protocol in one spec_zv_kernel instruction stream (empty list: the stream is as the protocol needs it)."""
+    if is_self_signal(instrs):
+        return check_self_signal(instrs)
     if is_two_stage(instrs):
         return check_two_stage(instrs)
     bad = []
