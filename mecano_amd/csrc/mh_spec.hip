@@ -274,7 +274,8 @@ long mh_spec_zv_lds_bytes(int nq, int nv)
    if constexpr (!SPL::usable())
       return 0;
    const long inertia = (long)(SPL::n_limbs() * mh::ZV_XW + SPL::ZV_TRUNK_SLOTS + nq + 2 * nv) * 64 * (long)sizeof(double);
-   return std::max(inertia, split_lds_bytes(0, F_IO_LDS, nq, nv));
+   // (the bias job: the tree-split inverse dynamics' map + the efforts' rows of their own, mh_zv_kernels.h: MH_ZV_TAU_LATE)
+   return std::max(inertia, split_lds_bytes(0, F_IO_LDS, nq, nv) + (long)mh::zv_bias_extra_rows<TP>() * 64 * (long)sizeof(double));
 }
 int mh_spec_zv_usable(void) { return SPL::usable() ? 1 : 0; }
 // 1: launches with identity index maps (the two-stage hand-off) expect `taup` to hold the sentinel wherever no column has been published

@@ -1288,6 +1288,21 @@ struct ZvPublish
             read<D + 1, K>(row);
       }
    }
+   // the rows hold h, the efforts arrived on their own (MH_ZV_TAU_LATE): tau - h is formed here
+   template <int D = 0, int K = 0>
+   MH_DEV void read_minus(lds_ptr<T> tau_row, lds_ptr<T> row)
+   {
+      if constexpr (D < ZvCols<TP>::NV)
+      {
+         if constexpr (mine(D))
+         {
+            r[K] = tau_row[D] - row[D];
+            read_minus<D + 1, K + 1>(tau_row, row);
+         }
+         else
+            read_minus<D + 1, K>(tau_row, row);
+      }
+   }
    template <int D = 0, int K = 0>
    MH_DEV void store(T *dst, int lane) const
    {
@@ -1308,17 +1323,37 @@ struct ZvPublish
       p.read(row);
       p.store(dst, lane);
    }
+   static MH_DEV void run_minus(T *dst, lds_ptr<T> tau_row, lds_ptr<T> row, int lane)
+   {
+      ZvPublish p;
+      p.read_minus(tau_row, row);
+      p.store(dst, lane);
+   }
 };
+// The bias job's efforts are needed LAST (tau - h, when the columns are published) and are a third of what it stages: with MH_ZV_TAU_LATE
+// they are requested with the other rows but stored to LDS rows of their own only in front of the limb barrier, the walks start as soon as
+// q and qd are there (46 KB at the ~11 bytes per clock a CU takes in: 1.25 us; 31 KB: ~0.95), write h, and the publishing waves subtract.
+// Measured (profiles/r05_ab_tau_late.txt): 14.15-14.26 us per step either way on one box -- the walks do not start sooner by what the
+// staging saves.  Off.
+#ifndef MH_ZV_TAU_LATE
+#define MH_ZV_TAU_LATE 0 // 1: the efforts stored late, tau - h formed by the publishing waves (experiment)
+#endif
+template <class TP>
+constexpr int zv_bias_extra_rows()
+{
+   return MH_ZV_TAU_LATE && MH_ZV_TWO_STAGE ? Tree<TP>::total_dofs() : 0;
+}
 // bias job of group k, two-stage hand-off: taup = this launch's hand-off matrices [groups][nv][64]
 template <class TP, typename T>
 MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, const ZvSync &sy)
 {
    using S = Split<TP>;
-   using CX = Ctx<T, true, true, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, SplitStore<TP>>, false, 1>;
+   using CX = Ctx<T, true, true, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, SplitStore<TP>>, false, MH_ZV_TAU_LATE ? 0 : 1>;
    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int lane = threadIdx.x & 63;
    constexpr int nq = Tree<TP>::total_cfgs(), nv = Tree<TP>::total_dofs(); // (dense index maps: the model's nq, nv -- known without the kernel-argument segment)
    const lds_ptr<T> lxc = lds, lst = lxc + S::n_limbs() * 6 * 64, lq = lst + S::RNEA_TRUNK_SLOTS * 64, lqd = lq + 64 * nq, lx = lqd + 64 * nv;
+   const lds_ptr<T> lt = lx + 64 * nv; // MH_ZV_TAU_LATE: the efforts' rows
    ZV_STAMP(0, 14);
    const long cfg0 = k * 64;
    const int rows = (int)(A.B - cfg0 < 64 ? A.B - cfg0 : 64);
@@ -1327,8 +1362,20 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    if (threadIdx.x == 0)
       zv_limb_waves = 0;
    ZV_STAMP(0, 0);
-   wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
-   __syncthreads();
+   RowRegs<T, MH_ZV_TAU_LATE ? Tree<TP>::total_dofs() : 1, 256> rtau;
+   if constexpr (MH_ZV_TAU_LATE)
+   {
+      RowRegs<T, Tree<TP>::total_cfgs(), 256> rq;
+      RowRegs<T, Tree<TP>::total_dofs(), 256> rd;
+      rq.issue(A.q + cfg0 * nq, rows), rd.issue(A.qd + cfg0 * nv, rows), rtau.issue(A.in3 + cfg0 * nv, rows);
+      rq.commit(lq), rd.commit(lqd);
+      zv_lds_barrier(); // (LDS only: the efforts stay in flight)
+   }
+   else
+   {
+      wave_stage_in<T, Tree<TP>::total_cfgs(), Tree<TP>::total_dofs(), 256>(lq, lqd, lx, A.q + cfg0 * nq, A.qd + cfg0 * nv, A.in3 + cfg0 * nv, rows);
+      __syncthreads();
+   }
    CX cx;
    fill_ctx<T>(cx, A, active ? cfg0 + lane : cfg0);
    cx.coriolis = 1, cx.accel = 0;
@@ -1341,6 +1388,8 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    if (active)
       split_rnea_limbs<TP, 0, T, CX>(cx);
    ZV_STAMP(0, 2);
+   if constexpr (MH_ZV_TAU_LATE)
+      rtau.commit(lt);
    __syncthreads(); // the limbs' entries of every row are final; the limbs' wrenches are parked for the trunk pass
    ZV_STAMP(0, 3);
    T *const dst = taup + k * 64 * nv;
@@ -1352,7 +1401,10 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
       if (active)
          rnea_trunk_roots<TP, T, CX>(cx);
       ZV_STAMP(0, 4);
-      ZvPublish<TP, T, -1>::run(dst, lx + lane * nv, lane);
+      if constexpr (MH_ZV_TAU_LATE)
+         ZvPublish<TP, T, -1>::run_minus(dst, lt + lane * nv, lx + lane * nv, lane);
+      else
+         ZvPublish<TP, T, -1>::run(dst, lx + lane * nv, lane);
       ZV_STAMP(0, 5);
 #ifdef MH_ZV_TEST_FLAG_BEFORE_DRAIN // tests/test_handoff_isa.py compiles this ONCE, to ISA text only, to prove that its checks catch a flag
                                     // that can overtake its columns; it is never linked into anything
@@ -1371,7 +1423,16 @@ MH_DEV void zv_bias_group2(const Args<T> &A, long k, lds_ptr<T> lds, T *taup, co
    {
       ZV_STAMP(0, 4);
 #if !(MH_ZV_SELF_SIGNAL && defined(MH_ZV_TEST_NO_FLAG)) // (the test build of a producer that never signals: here, one that never publishes)
-      if (wave == 1)
+      if constexpr (MH_ZV_TAU_LATE)
+      {
+         if (wave == 1)
+            ZvPublish<TP, T, 0>::run_minus(dst, lt + lane * nv, lx + lane * nv, lane);
+         else if (wave == 2)
+            ZvPublish<TP, T, 1>::run_minus(dst, lt + lane * nv, lx + lane * nv, lane);
+         else
+            ZvPublish<TP, T, 2>::run_minus(dst, lt + lane * nv, lx + lane * nv, lane);
+      }
+      else if (wave == 1)
          ZvPublish<TP, T, 0>::run(dst, lx + lane * nv, lane);
       else if (wave == 2)
          ZvPublish<TP, T, 1>::run(dst, lx + lane * nv, lane);

@@ -49,6 +49,8 @@ while time.time() - t0 < budget:
         worst = max(worst, err)
         assert err <= 1e-9, (name, B, err)
     n += 1
+    if n % 25 == 0:
+        print(f"... {n} models, {time.time() - t0:.0f} s, worst so far {worst:.2e} / {worst_pair:.2e}", flush=True)
 os.environ.pop("MH_ZV", None)
 print(f"{n} models x 6 batches x 2 modes x 3 launches in {time.time() - t0:.0f} s: worst scaled error against the oracle {worst:.2e}, "
       f"worst bias-split vs tree-split over all rows {worst_pair:.2e}")
