@@ -227,6 +227,8 @@ struct mh_model
    int *d_meta = nullptr, *d_dof = nullptr, *d_cfg = nullptr, *d_prog = nullptr;
    std::vector<int> prog; // event program of the depth-first kernels
    int rnea_stack = 0, aba_stack = 0, aba_hand = 0; // per-lane slots: depth stacks, ABA hand-over
+   int pair_stack = 0;    // ... of the fused RNEA + ABA walk (aba_dfs_kernel<.., PAIR>)
+   int use_dfs_pair = 1;  // MH_DFS_PAIR=0: mh_rnea_aba_f32 on big batches issues the two depth-first kernels one after the other, as before round 5
    int use_dfs = 1;       // MH_DFS=0: the sweep kernels of mh_kernels.h serve plain RNEA / ABA calls too (A/B measurements)
    FreshOnCopy<std::map<const void *, size_t>> lds_attr; // dynamic-LDS limit already raised per kernel (the model lives on one device, one host thread at a time)
    double nonleaf_fraction = 1.0; // share of bodies with children: those are the ones that touch the depth stack
@@ -647,8 +649,9 @@ const mh_model::DfsPlan *dfs_plan(mh_model *m, int algo, int budget)
    std::vector<int> meta = m->meta, frame(n), below(n, 0), lofs(n, 0), gofs(n, 0);
    std::vector<char> home(n, 0);
    auto MI = [&](int e, int k) -> int & { return meta[(size_t)e * mh::MI_STRIDE + k]; };
-   for (int e = 0; e < n; e++)
-      frame[e] = algo == 0 ? mh::rnea_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH)) : mh::aba_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH));
+   for (int e = 0; e < n; e++) // algo 2: the fused RNEA + ABA walk (the forward dynamics' frame + the inverse dynamics' wrench and acceleration)
+      frame[e] = algo == 0 ? mh::rnea_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH))
+                           : (algo == 1 ? mh::aba_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH)) : mh::pair_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH)));
    for (int e = n - 1; e >= 0; e--)
    { // engine order is depth-first: children come after their parent
       int need = below[e];
@@ -685,6 +688,11 @@ const mh_model::DfsPlan *dfs_plan(mh_model *m, int algo, int budget)
          MI(e, mh::MI_DFS_A) = code(e);
          if (pe >= 0)
             MI(e, mh::MI_PFR_A) = code(pe), MI(e, mh::MI_PV_A) = code(pe) + 12 + pj, MI(e, mh::MI_PACC_A) = code(pe) + 18 + pj;
+         if (algo == 2 && pe >= 0)
+         { // the inverse dynamics' slots of the parent's frame: behind the forward dynamics' part
+            const int pa = mh::aba_frame_slots(MI(pe, mh::MI_TYPE), MI(pe, mh::MI_NCH));
+            MI(e, mh::MI_PFR_R) = code(pe) + pa, MI(e, mh::MI_PVA_R) = code(pe) + pa + 6;
+         }
       }
    }
    plan.glb_slots = std::max(plan.glb_slots, 6);
@@ -1024,7 +1032,7 @@ struct DfsChoice
    long per_cu, budget, hand, b_win, slot_bytes;
    bool hand_lds;
 };
-DfsChoice dfs_choose(const mh_model *model, Algo algo, size_t elem, int64_t B, bool win)
+DfsChoice dfs_choose(const mh_model *model, Algo algo, size_t elem, int64_t B, bool win, bool pair = false)
 {
    DfsChoice c{};
    const long waves = (B + 63) / 64;
@@ -1033,7 +1041,7 @@ DfsChoice dfs_choose(const mh_model *model, Algo algo, size_t elem, int64_t B, b
    const long cus = model->cu_count;
    const long reg_cap = (algo == ALGO_ABA && elem == 8) ? 4 : model->waves_per_cu; // resident waves per CU the registers allow
    c.per_cu = std::max<long>(1, std::min<long>(std::min<long>(model->waves_per_cu, reg_cap), (waves + cus - 1) / cus));
-   const long full_stack = algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack;
+   const long full_stack = pair ? model->pair_stack : (algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack);
    c.hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
    if (model->dfs_place >= 0)
    { // forced placements: give the stack what it needs and let the occupancy follow
@@ -1056,16 +1064,17 @@ bool dfs_windows(const mh_model *model, Algo algo, size_t elem, bool aos)
 { // AoS matrices with identity index maps and rows that span many cache lines: RNEA reads them through LDS windows (mh_dfs_kernels.h)
    return algo == ALGO_RNEA && aos && model->ident_maps && model->use_win && (long)model->nv * (long)elem >= 512;
 }
+// pair: the fused RNEA + ABA walk (aba_dfs_kernel<.., PAIR>; algo = ALGO_ABA, A.in3 = qdd, A.out = tau, A.in3b = tau in, A.outb = qdd out)
 template <typename T>
-mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipStream_t stream)
+mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipStream_t stream, bool pair = false)
 {
    const long waves = (B + 63) / 64;
-   const bool win = dfs_windows(model, algo, sizeof(T), A.q_es == 1 && A.v_es == 1);
-   const DfsChoice ch = dfs_choose(model, algo, sizeof(T), B, win);
+   const bool win = !pair && dfs_windows(model, algo, sizeof(T), A.q_es == 1 && A.v_es == 1);
+   const DfsChoice ch = dfs_choose(model, algo, sizeof(T), B, win, pair);
    const long b_win = ch.b_win, slot_bytes = ch.slot_bytes, hand = ch.hand, budget = ch.budget, cus = model->cu_count;
    long per_cu = ch.per_cu;
    const bool hand_lds = ch.hand_lds;
-   const mh_model::DfsPlan *plan = dfs_plan(model, algo == ALGO_RNEA ? 0 : 1, (int)budget);
+   const mh_model::DfsPlan *plan = dfs_plan(model, pair ? 2 : (algo == ALGO_RNEA ? 0 : 1), (int)budget);
    if (!plan)
       return fail(MH_ERR_HIP, "depth-first kernels: the body records of the frame plan could not be uploaded");
    const long lds = (plan->lds_slots + (hand_lds ? hand : 0)) * slot_bytes + b_win;
@@ -1092,6 +1101,19 @@ mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipS
          kern = mode == 0 ? (const void *)&mh::rnea_dfs_kernel<T, true, 0> : (mode == 1 ? (const void *)&mh::rnea_dfs_kernel<T, true, 1> : (const void *)&mh::rnea_dfs_kernel<T, true, 2>);
       else
          kern = mode == 0 ? (const void *)&mh::rnea_dfs_kernel<T, false, 0> : (mode == 1 ? (const void *)&mh::rnea_dfs_kernel<T, false, 1> : (const void *)&mh::rnea_dfs_kernel<T, false, 2>);
+   }
+   else if (pair)
+   {
+      if constexpr (sizeof(T) == 4)
+      {
+         if (hand_lds)
+            kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, false, 0, true> : (const void *)&mh::aba_dfs_kernel<T, true, false, 2, true>;
+         else
+            kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, false, false, 0, true>
+                             : (mode == 1 ? (const void *)&mh::aba_dfs_kernel<T, false, false, 1, true> : (const void *)&mh::aba_dfs_kernel<T, false, false, 2, true>);
+      }
+      else
+         return fail(MH_ERR_INVALID_ARGUMENT, "the fused depth-first pair walk is built in fp32 only");
    }
    else if (hand_lds)
       kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, false, 0> : (const void *)&mh::aba_dfs_kernel<T, true, false, 2>;
@@ -2259,7 +2281,7 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
 
    // ---- depth-first kernels: children counts, stack-frame / hand-over offsets, event program (mh_dfs_kernels.h)
    {
-      std::vector<int> nch(n, 0), ofs_r(n, 0), ofs_a(n, 0);
+      std::vector<int> nch(n, 0), ofs_r(n, 0), ofs_a(n, 0), ofs_p(n, 0);
       for (int e = 0; e < n; e++)
          if (P.eparent[e] >= 0)
             nch[P.eparent[e]]++;
@@ -2271,6 +2293,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
          ofs_a[e] = pe < 0 ? 0 : ofs_a[pe] + mh::aba_frame_slots(P.etype[pe], nch[pe]);
          m->rnea_stack = std::max(m->rnea_stack, ofs_r[e] + mh::rnea_frame_slots(t, nch[e]));
          m->aba_stack = std::max(m->aba_stack, ofs_a[e] + mh::aba_frame_slots(t, nch[e]));
+         ofs_p[e] = pe < 0 ? 0 : ofs_p[pe] + mh::pair_frame_slots(P.etype[pe], nch[pe]);
+         m->pair_stack = std::max(m->pair_stack, ofs_p[e] + mh::pair_frame_slots(t, nch[e]));
          int *mi = &m->meta[(size_t)e * mh::MI_STRIDE];
          mi[mh::MI_NCH] = nch[e], mi[mh::MI_DFS_R] = ofs_r[e], mi[mh::MI_DFS_A] = ofs_a[e], mi[mh::MI_HAND] = hand;
          hand += mh::aba_hand_slots(t, nch[e]);
@@ -2410,6 +2434,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->force_st = atoi(e);
    if (const char *e = getenv("MH_DFS"))
       m->use_dfs = atoi(e) != 0;
+   if (const char *e = getenv("MH_DFS_PAIR"))
+      m->use_dfs_pair = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_TRANSPOSE"))
       m->dfs_transpose = atoi(e) != 0;
    // fp64 forward dynamics at device-filling batches: the sweep kernel accumulates the children of a branching body through the workspace
@@ -3313,9 +3339,38 @@ mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const flo
       opts = *opts_in;
    else
       mh_options_default(&opts);
-   const bool shared = model && B >= 8192 && q && qd && qdd && tau && tau_out && qdd_out && !f_ext && opts.layout == MH_LAYOUT_AOS
-                       && model->use_dfs && model->n_locked == 0 && model->use_transpose < 0 && model->dfs_transpose < 0
-                       && model->nq + model->nv >= 64 && opts.consider_coriolis && opts.consider_accelerations;
+   const bool big = model && B >= 8192 && q && qd && qdd && tau && tau_out && qdd_out && !f_ext && model->use_dfs && model->n_locked == 0
+                    && model->use_transpose < 0 && model->dfs_transpose < 0 && model->nq + model->nv >= 64 && opts.consider_coriolis
+                    && opts.consider_accelerations;
+   const bool shared = big && opts.layout == MH_LAYOUT_AOS;
+   // ONE walk for both (round 5; mh_dfs_kernels.h: aba_dfs_kernel<.., PAIR>) unless a run-time tree split or a code object serves the model
+   // (small / specialised models hardly get here: 8192 configurations of >= 64 state entries); MH_DFS_PAIR=0 keeps the two launches
+   const bool fused = big && model->use_dfs_pair && !(model->spec.handle && model->use_spec)
+                      && !(model->split_rt.usable && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2));
+   auto fused_walk = [&](mh_model *mdl, const float *sq, const float *sqd, const float *sqdd, const float *stau, float *o1, float *o2) -> mh_status {
+      mh::Args<float> A{};
+      A.m = dev_model<float>(mdl);
+      A.B = B;
+      A.q = sq, A.qd = sqd, A.in3 = sqdd, A.out = o1, A.in3b = stau, A.outb = o2;
+      A.fext = nullptr, A.body_acc = nullptr, A.body_twist = nullptr, A.joint_wrench = nullptr;
+      A.dt = 0.0f, A.q_next = nullptr, A.qd_next = nullptr;
+      A.q_bs = 1, A.q_es = B, A.v_bs = 1, A.v_es = B, A.f_bs = 1, A.f_es = B;
+      set_root_acceleration(A, opts, gravity);
+      A.coriolis = 1, A.accel = 1;
+      const mh_status r = launch_dfs<float>(ALGO_ABA, mdl, B, A, (hipStream_t)opts.stream, true);
+      if (r == MH_OK)
+         HIP_TRY(hipGetLastError());
+      return r;
+   };
+   if (fused && opts.layout == MH_LAYOUT_SOA)
+   { // SoA matrices: the walk reads and writes the caller's buffers
+      mh_status st = check_common(model, B, &opts);
+      if (st != MH_OK)
+         return st;
+      if (!gravity && !opts.use_root_acceleration)
+         return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+      return fused_walk(model, q, qd, qdd, tau, tau_out, qdd_out);
+   }
    if (!shared)
    {
       const mh_status r = mh_rnea_f32(model, B, q, qd, qdd, gravity, f_ext, &opts, tau_out);
@@ -3324,6 +3379,8 @@ mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const flo
    mh_status st = check_common(model, B, &opts);
    if (st != MH_OK)
       return st;
+   if (!gravity && !opts.use_root_acceleration)
+      return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
    const size_t nq = model->nq, nv = model->nv, Bz = (size_t)B;
    st = ensure_bytes(model->tr_pair, Bz * (nq + 5 * nv) * sizeof(float));
    if (st != MH_OK)
@@ -3338,9 +3395,14 @@ mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const flo
    HIP_TRY(hipGetLastError());
    mh_options so = opts;
    so.layout = MH_LAYOUT_SOA;
-   st = launch<float>(ALGO_RNEA, model, B, t_q, t_qd, t_qdd, gravity, nullptr, &so, t_o1);
-   if (st == MH_OK)
-      st = launch<float>(ALGO_ABA, model, B, t_q, t_qd, t_tau, gravity, nullptr, &so, t_o2);
+   if (fused)
+      st = fused_walk(model, t_q, t_qd, t_qdd, t_tau, t_o1, t_o2);
+   else
+   {
+      st = launch<float>(ALGO_RNEA, model, B, t_q, t_qd, t_qdd, gravity, nullptr, &so, t_o1);
+      if (st == MH_OK)
+         st = launch<float>(ALGO_ABA, model, B, t_q, t_qd, t_tau, gravity, nullptr, &so, t_o2);
+   }
    if (st != MH_OK)
       return st;
    mh::transpose_rows<float>(t_o1, tau_out, (long)B, (long)nv, false, stream);

@@ -52,6 +52,12 @@ __host__ __device__ constexpr int aba_frame_slots(int type, int n_children)
 { // [p 6][c 6][jx][v 6, articulated-inertia accumulator 21 + bias accumulator 6 when several children contribute]
    return n_children == 0 ? 0 : 12 + jx_slots(type) + (n_children >= 2 ? 33 : 0);
 }
+// frame of the fused RNEA + ABA walk (aba_dfs_kernel<.., PAIR>): the forward dynamics' frame, then the inverse dynamics' wrench [f 6] and,
+// when later children re-read it, its acceleration [a 6] (jx and v are the forward dynamics' own)
+__host__ __device__ constexpr int pair_frame_slots(int type, int n_children)
+{
+   return n_children == 0 ? 0 : aba_frame_slots(type, n_children) + 6 + (n_children >= 2 ? 6 : 0);
+}
 __host__ __device__ constexpr int aba_hand_slots(int type, int n_children)
 { // inward -> outward hand-over; + the bias acceleration c (or the body acceleration of a 6-DoF joint) when children need this body's a
    const int own = type == JT_REVOLUTE ? 10 : (type == JT_PRISMATIC ? 8 : (type == JT_SIXDOF ? 6 : (type == JT_FIXED ? 0 : 27)));
@@ -488,7 +494,13 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
 // outward hand-over lives in LDS behind the stack, else at the start of the wave's global block (the global part of the stack follows).
 // WIN: the inward sweep reads q and qd of AoS matrices through LDS windows (window_refill); tau (consumed in post-order), the outward
 // sweep's re-reads of q and the accelerations written are per-lane accesses.
-template <typename T, bool HND_LDS, bool WIN, int MODE>
+// PAIR (round 5; mh_rnea_aba_f32 on big batches): the SAME walk also carries the inverse dynamics of (q, qd, A.in3 = qdd) -> A.out = tau,
+// while the forward dynamics reads A.in3b = tau and writes A.outb = qdd.  Pass one of the forward dynamics already forms what the inverse
+// dynamics' outward sweep needs -- joint transform, velocity v, bias acceleration c = v x vJ, bias wrench p = v x* I v - f_ext
+// (ForwardDynamicsCalculator.java:1085-1127 against InverseDynamicsCalculator.java:873-917) -- so the inverse dynamics costs one more
+// motion transform (its acceleration), one product I a and, inwards, one force transform per body, and q / qd are read once.  Frames:
+// pair_frame_slots; MI_PFR_R / MI_PVA_R hold the parent's wrench / acceleration slots of the inverse dynamics (dfs_plan, algo 2).
+template <typename T, bool HND_LDS, bool WIN, int MODE, bool PAIR = false>
 __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -509,9 +521,11 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
          const long cfg = active ? cfg0 + tid : A.B - 1;
          const T *qrow = A.q + cfg * A.q_bs;
          const T *qdrow = A.qd + cfg * A.v_bs;
-         const T *taurow = A.in3 + cfg * A.v_bs;
+         const T *taurow = (PAIR ? A.in3b : A.in3) + cfg * A.v_bs;
          const T *frow = A.fext ? A.fext + cfg * A.f_bs : nullptr;
-         T *orow = A.out + cfg * A.v_bs;
+         T *orow = (PAIR ? A.outb : A.out) + cfg * A.v_bs;
+         const T *qddrow = A.in3 + cfg * A.v_bs; // PAIR: the inverse dynamics' accelerations ...
+         T *trow = A.out + cfg * A.v_bs;         // ... and efforts
          RowWindow<T> Wq, Wv;
          if constexpr (WIN)
             Wq.init(wq, A.q, m.nq, cfg0, A.B), Wv.init(wv, A.qd, m.nv, cfg0, A.B);
@@ -529,6 +543,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
          };
          // ---- inward part: passes one and two (ForwardDynamicsCalculator.java:1085-1254) fused into one depth-first walk
          SV<T> v_reg{Z, Z}, p_reg{Z, Z}, c_reg{Z, Z}, pcarry{Z, Z};
+         SV<T> ar_reg{Z, Z}, fr_reg{Z, Z}, rcarry{Z, Z}; // PAIR: acceleration and wrench of the inverse dynamics, its hand-up
          JX<T> jx_reg;
          jx_reg.c = T(1), jx_reg.s = T(0), jx_reg.d = T(0);
          ABI<T> Icarry = abi_from_rigid(RI<T>{T(0), Z, S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)}});
@@ -543,7 +558,11 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             if (ev1 & EV_POP)
                nxt.x = taurow[m1[MI_ROW_V] * A.v_es];
             else
+            {
                nxt.q = getq(m1[MI_ROW_Q]), nxt.v = getv(m1[MI_ROW_V]);
+               if constexpr (PAIR)
+                  nxt.x = qddrow[m1[MI_ROW_V] * A.v_es];
+            }
          };
          prefetch(0);
          for (int e = 0; e < m.n_events; e++)
@@ -559,7 +578,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
             const XF<T> Xb = load_xb<T>(c);
             const In<T> in = nxt;
             JX<T> jxm;
-            SV<T> vJm{Z, Z};
+            SV<T> vJm{Z, Z}, aJm{Z, Z};
             if (!(ev & EV_POP) && !one_dof(type) && type != JT_FIXED)
             { // a multi-DoF joint reads its entries now, before the next event's prefetch may move the windows on
                T mq[7], mv[6];
@@ -572,7 +591,16 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   mv[k] = k < nd ? getv(WIN ? mi[MI_DOF] + k : dof_map[mi[MI_DOF] + k]) : T(0);
                jxm = joint_of_vals<T>(type, mq);
                vJm = joint_vec_vals<T>(type, mv, true);
+               if constexpr (PAIR)
+               {
+                  T mx[6];
+#pragma unroll
+                  for (int k = 0; k < 6; k++)
+                     mx[k] = k < nd ? qddrow[dof_map[mi[MI_DOF] + k] * A.v_es] : T(0);
+                  aJm = joint_vec_vals<T>(type, mx, true);
+               }
             }
+            const int xr = fr + aba_frame_slots(type, nch); // PAIR: the inverse dynamics' part of the frame
             prefetch(e + 1);
             if (!(ev & EV_POP))
             { // ---- VISIT (:1085-1127): velocity, bias wrench p, bias acceleration c
@@ -608,6 +636,31 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   if (nch >= 2)
                      st_store6<T>(S, fr + 12 + jxs, v);
                }
+               if constexpr (PAIR)
+               { // InverseDynamicsCalculator.java:873-917 with this walk's jx, v, c and p: a = X a_parent + aJ + c, f = I a + p
+                  SV<T> apr, aJ{Z, Z};
+                  if (parent < 0)
+                     apr = root_acceleration(A); // :343-348
+                  else if (ev & EV_PARENT_REGS)
+                     apr = ar_reg;
+                  else
+                     apr = st_load6<T>(S, mi[MI_PVA_R]);
+                  if (type == JT_REVOLUTE)
+                     aJ.a.z = in.x;
+                  else if (type == JT_PRISMATIC)
+                     aJ.l.z = in.x;
+                  else if (type != JT_FIXED)
+                     aJ = aJm;
+                  const SV<T> ar = motion_down(type, jx, Xb, apr) + aJ + cj;
+                  const SV<T> fr_ = mul(I, ar) + p;
+                  if (nch >= 1)
+                  {
+                     st_store6<T>(S, xr, fr_);
+                     if (nch >= 2)
+                        st_store6<T>(S, xr + 6, ar);
+                  }
+                  ar_reg = ar, fr_reg = fr_;
+               }
                v_reg = v, p_reg = p, c_reg = cj, jx_reg = jx;
             }
             else
@@ -626,6 +679,20 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   {
                      add(IA, st_load_abi<T>(S, fr + 18 + jxs));
                      pA = pA + st_load6<T>(S, fr + 39 + jxs);
+                  }
+               }
+               if constexpr (PAIR)
+               { // the inverse dynamics' half of the POP (:930-966): joint effort, wrench handed to the parent
+                  const SV<T> f = (ev & EV_LEAF) ? fr_reg : st_load6<T>(S, xr) + rcarry;
+                  if (active)
+                     write_joint_rows<T>(type, dof_map + mi[MI_DOF], trow, A.v_es, f);
+                  if (parent >= 0)
+                  {
+                     const SV<T> fp = force_up(type, jx, Xb, f);
+                     if (ev & EV_LAST_CHILD)
+                        rcarry = fp;
+                     else
+                        st_add6<T>(S, mi[MI_PFR_R], fp);
                   }
                }
                ABI<T> Ia = IA;

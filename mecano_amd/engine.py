@@ -366,9 +366,10 @@ class HipModel:
                                             vn.data_ptr()))
         return qn, vn, qdd
 
-    def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, out=None):
-        """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call (fp64, AoS).  Device tensors: mh_rnea_aba_f64; numpy arrays:
-        the pipelined host-pointer entry point mh_rnea_aba_f64_host (``out`` = (tau_out, qdd_out) arrays to write into, e.g. pinned ones)."""
+    def rnea_aba(self, q, qd, qdd, tau, gravity=(0.0, 0.0, -9.81), f_ext=None, out=None, layout=_lib.LAYOUT_AOS):
+        """tau_out = RNEA(q, qd, qdd) and qdd_out = ABA(q, qd, tau) in one call.  Device tensors: mh_rnea_aba_f64 / mh_rnea_aba_f32 (``layout``:
+        AoS [B, n] or SoA [n, B]); numpy arrays (fp64, AoS): the pipelined host-pointer entry point mh_rnea_aba_f64_host (``out`` = (tau_out,
+        qdd_out) arrays to write into, e.g. pinned ones)."""
         lib = _lib.load()
         if not self._is_torch(q):
             q, qd, qdd, tau = (_np(x, np.float64) for x in (q, qd, qdd, tau))
@@ -387,11 +388,11 @@ class HipModel:
         for t in (q, qd, qdd, tau) + ((f_ext,) if f_ext is not None else ()):
             if not t.is_cuda or t.dtype not in (torch.float64, torch.float32) or t.dtype != q.dtype or not t.is_contiguous():
                 raise ValueError("rnea_aba needs contiguous float64 (or float32) tensors of one dtype on the HIP device")
-        B = self._batch(q, self.nq, _lib.LAYOUT_AOS)
-        if any(self._batch(x, self.nv, _lib.LAYOUT_AOS) != B for x in (qd, qdd, tau)):
+        B = self._batch(q, self.nq, layout)
+        if any(self._batch(x, self.nv, layout) != B for x in (qd, qdd, tau)):
             raise _lib.MecanoHipError(2, "batch sizes of the state matrices differ")
         g, ra = self._root(gravity)
-        opts = self._options(_lib.LAYOUT_AOS, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
+        opts = self._options(layout, True, True, torch.cuda.current_stream(q.device).cuda_stream, root_acceleration=ra)
         tau_out, qdd_out = torch.empty_like(qd), torch.empty_like(qd)
         fn = lib.mh_rnea_aba_f64 if q.dtype == torch.float64 else lib.mh_rnea_aba_f32
         _lib.check(fn(self._h, B, q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), tau.data_ptr(), g,

@@ -1791,6 +1791,24 @@ def test_config5_at_its_full_per_gpu_shard(torch_cuda, layout_name):
     rt_err = (back - ttau).abs().max().item()
     record_parity(rt_err, 2 * f32_aba_backward_tol(n) * scale, f"fp32 round trip RNEA(ABA(tau)) {layout_name} 131072")
     assert rt_err <= 2 * f32_aba_backward_tol(n) * scale, (rt_err, scale)
+    # Round 5: mh_rnea_aba_f32 on such batches is ONE depth-first walk that carries the inverse dynamics along with the forward dynamics
+    # (mh_dfs_kernels.h: aba_dfs_kernel<.., PAIR>; AoS callers through shared transposed copies, SoA callers in place).  The same formulas
+    # as the two single calls, in another kernel (the compiler contracts multiply-adds differently): efforts within a few fp32 roundings
+    # of the single call's on every row, accelerations by the round trip on every row; MH_DFS_PAIR=0 (two launches, shared copies) likewise
+    u32 = 2.0 ** -24
+    for env in (None, "0"):
+        if env is not None:
+            os.environ["MH_DFS_PAIR"] = env
+        try:
+            t2, a2 = HipModel(d).rnea_aba(put(tq), put(tqd), put(tqdd), put(ttau), g, layout=layout)
+        finally:
+            os.environ.pop("MH_DFS_PAIR", None)
+        dt = (rows(t2) - t32).abs().max().item()
+        assert dt <= 64 * u32 * max(1.0, t32.abs().max().item()), (env, dt)
+        back2 = rows(hm.rnea(put(tq), put(tqd), put(rows(a2).contiguous()), g, layout=layout))
+        rt2 = (back2 - ttau).abs().max().item()
+        record_parity(rt2, 2 * f32_aba_backward_tol(n) * scale, f"fp32 pair call, round trip {layout_name} 131072 MH_DFS_PAIR={env}")
+        assert rt2 <= 2 * f32_aba_backward_tol(n) * scale, (env, rt2, scale)
 
 
 def test_config4_at_full_size_on_one_gpu(torch_cuda):
