@@ -49,7 +49,7 @@ __host__ __device__ constexpr int rnea_frame_slots(int type, int n_children)
    return n_children == 0 ? 0 : 6 + jx_slots(type) + (n_children >= 2 ? 12 : 0);
 }
 __host__ __device__ constexpr int aba_frame_slots(int type, int n_children)
-{ // [p 6][c 6][jx][v 6, articulated-inertia accumulator 21 + bias accumulator 6 when several children contribute]
+{ // [p 6][w 6: written when several children follow][jx][v 6, articulated-inertia accumulator 21 + bias accumulator 6 when several children contribute]
    return n_children == 0 ? 0 : 12 + jx_slots(type) + (n_children >= 2 ? 33 : 0);
 }
 // frame of the fused RNEA + ABA walk (aba_dfs_kernel<.., PAIR>): the forward dynamics' frame, then the inverse dynamics' wrench [f 6] and,
@@ -59,9 +59,10 @@ __host__ __device__ constexpr int pair_frame_slots(int type, int n_children)
    return n_children == 0 ? 0 : aba_frame_slots(type, n_children) + 6 + (n_children >= 2 ? 6 : 0);
 }
 __host__ __device__ constexpr int aba_hand_slots(int type, int n_children)
-{ // inward -> outward hand-over; + the bias acceleration c (or the body acceleration of a 6-DoF joint) when children need this body's a
-   const int own = type == JT_REVOLUTE ? 10 : (type == JT_PRISMATIC ? 8 : (type == JT_SIXDOF ? 6 : (type == JT_FIXED ? 0 : 27)));
-   return own + ((n_children > 0 && type != JT_FIXED) ? 6 : 0);
+{ // inward -> outward hand-over: U (6), 1 / D, u (+ cos, sin) of a 1-DoF joint; the body's a~ of a floating one; 3 U, D^-1 (6), u (3) of a
+  // 3-DoF one.  (Until round 5 bodies with children also handed their bias acceleration c over: it is absorbed into the bias wrenches now.)
+   (void)n_children;
+   return type == JT_REVOLUTE ? 10 : (type == JT_PRISMATIC ? 8 : (type == JT_SIXDOF ? 6 : (type == JT_FIXED ? 0 : 27)));
 }
 
 // ---- the per-lane depth stack: slot codes carry the frame's home
@@ -542,7 +543,14 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                return qdrow[row * A.v_es];
          };
          // ---- inward part: passes one and two (ForwardDynamicsCalculator.java:1085-1254) fused into one depth-first walk
-         SV<T> v_reg{Z, Z}, p_reg{Z, Z}, c_reg{Z, Z}, pcarry{Z, Z};
+         // Round 5: the velocity-product accelerations are ABSORBED INTO THE BIAS WRENCHES.  With w_j = X w_parent + c_j (the acceleration
+         // every body would have with all joint accelerations and the root's at zero) and a_j = a~_j + w_j, the recursion in a~ has no bias
+         // acceleration at all: a~_j = X a~_parent + S qdd_j, f_j = IA_j a~_j + (pA_j + IA_j w_j).  So pass one adds I_j w_j to the body's bias
+         // wrench (one motion transform and one product I w) and passes two and three run with c = 0 (:1224-1235, :1263-1305): no Ia c,
+         // no U.c, and -- what pays -- c is no longer handed from the inward to the outward sweep (6 of the 16 hand-over slots of every
+         // 1-DoF body with children, 6 of 12 of a floating one) nor kept in the stack frames.  w rides where c used to (slot fr + 6, for
+         // later children of a body that has several).  Same qdd; the efforts of the PAIR walk use the untouched c and p.
+         SV<T> v_reg{Z, Z}, p_reg{Z, Z}, w_reg{Z, Z}, pcarry{Z, Z};
          SV<T> ar_reg{Z, Z}, fr_reg{Z, Z}, rcarry{Z, Z}; // PAIR: acceleration and wrench of the inverse dynamics, its hand-up
          JX<T> jx_reg;
          jx_reg.c = T(1), jx_reg.s = T(0), jx_reg.d = T(0);
@@ -625,16 +633,25 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   jx = jxm, vJ = vJm;
                const SV<T> v = motion_down(type, jx, Xb, vp) + vJ;
                const RI<T> I = load_inertia<T>(c);
-               SV<T> p = crf(v, mul(I, v));
+               SV<T> p0 = crf(v, mul(I, v));
                if (frow)
-                  p = p - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
+                  p0 = p0 - load_fext<T>(c, frow, A.f_es, mi[MI_EXT]);
                const SV<T> cj = crm(v, vJ);
+               SV<T> wp;
+               if (parent < 0)
+                  wp = SV<T>{Z, Z};
+               else if (ev & EV_PARENT_REGS)
+                  wp = w_reg;
+               else
+                  wp = st_load6<T>(S, mi[MI_PFR_A] + 6);
+               const SV<T> w = motion_down(type, jx, Xb, wp) + cj;
+               const SV<T> p = p0 + mul(I, w);
                if (nch >= 1)
                {
-                  st_store6<T>(S, fr, p), st_store6<T>(S, fr + 6, cj);
+                  st_store6<T>(S, fr, p);
                   st_store_jx<T>(S, fr + 12, type, jx);
                   if (nch >= 2)
-                     st_store6<T>(S, fr + 12 + jxs, v);
+                     st_store6<T>(S, fr + 6, w), st_store6<T>(S, fr + 12 + jxs, v);
                }
                if constexpr (PAIR)
                { // InverseDynamicsCalculator.java:873-917 with this walk's jx, v, c and p: a = X a_parent + aJ + c, f = I a + p
@@ -652,7 +669,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   else if (type != JT_FIXED)
                      aJ = aJm;
                   const SV<T> ar = motion_down(type, jx, Xb, apr) + aJ + cj;
-                  const SV<T> fr_ = mul(I, ar) + p;
+                  const SV<T> fr_ = mul(I, ar) + p0;
                   if (nch >= 1)
                   {
                      st_store6<T>(S, xr, fr_);
@@ -661,18 +678,18 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   }
                   ar_reg = ar, fr_reg = fr_;
                }
-               v_reg = v, p_reg = p, c_reg = cj, jx_reg = jx;
+               v_reg = v, p_reg = p, w_reg = w, jx_reg = jx;
             }
             else
             { // ---- POP (:1136-1254): articulated inertia and bias wrench of the finished subtree, joint-space quantities, hand-up
                ABI<T> IA = abi_from_rigid(load_inertia<T>(c));
-               SV<T> pA, cj;
+               SV<T> pA;
                JX<T> jx;
                if (ev & EV_LEAF)
-                  pA = p_reg, cj = c_reg, jx = jx_reg;
+                  pA = p_reg, jx = jx_reg;
                else
                {
-                  pA = st_load6<T>(S, fr) + pcarry, cj = st_load6<T>(S, fr + 6);
+                  pA = st_load6<T>(S, fr) + pcarry;
                   jx = st_load_jx<T>(S, fr + 12, type);
                   add(IA, Icarry);
                   if (nch >= 2)
@@ -710,26 +727,23 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   const T u = in.x - pz;                   // :1200-1215
                   MH_HD(hf + 0) = ua.x, MH_HD(hf + 1) = ua.y, MH_HD(hf + 2) = ua.z, MH_HD(hf + 3) = ul.x, MH_HD(hf + 4) = ul.y, MH_HD(hf + 5) = ul.z;
                   MH_HD(hf + 6) = dinv;
-                  MH_HD(hf + 7) = u - (dot(ua, cj.a) + dot(ul, cj.l)); // u' = u - U.c: the outward sweep then needs U.(X a_parent) only
-                  int hn = hf + 8;
+                  MH_HD(hf + 7) = u; // (pA carries IA w: this is u - U.w, and the outward sweep needs U.(X a~_parent) only)
                   if (type == JT_REVOLUTE)
-                     MH_HD(hf + 8) = jx.c, MH_HD(hf + 9) = jx.s, hn = hf + 10;
-                  if (nch >= 1)
-                     MH_HD(hn + 0) = cj.a.x, MH_HD(hn + 1) = cj.a.y, MH_HD(hn + 2) = cj.a.z, MH_HD(hn + 3) = cj.l.x, MH_HD(hn + 4) = cj.l.y, MH_HD(hn + 5) = cj.l.z;
+                     MH_HD(hf + 8) = jx.c, MH_HD(hf + 9) = jx.s;
                   if (parent >= 0)
                   {
                      const T ud = u * dinv;
                      if (type == JT_REVOLUTE)
                      { // Ia S = 0: exact structural zeros -- and the hand-up in the SAME block, so that every product with them folds
-                        rank1_down_revolute(Ia, ua, ul, dinv);           // :1220-1226
-                        pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul}; // :1229-1234
-                        revolute_up(jx, Xb, Ia, pa);                     // :1156-1166; pa is now expressed in the parent's frame
+                        rank1_down_revolute(Ia, ua, ul, dinv);  // :1220-1226
+                        pa = pA + SV<T>{ud * ua, ud * ul};      // :1229-1234 with c = 0
+                        revolute_up(jx, Xb, Ia, pa);            // :1156-1166; pa is now expressed in the parent's frame
                         handed_up = true;
                      }
                      else
                      {
                         rank1_down(Ia, ua, ul, dinv);
-                        pa = pA + mul(Ia, cj) + SV<T>{ud * ua, ud * ul};
+                        pa = pA + SV<T>{ud * ua, ud * ul};
                      }
                   }
                }
@@ -749,26 +763,19 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                      MH_HD(hf + 6 * k + 3) = Us[k].l.x, MH_HD(hf + 6 * k + 4) = Us[k].l.y, MH_HD(hf + 6 * k + 5) = Us[k].l.z;
                   }
                   MH_HD(hf + 18) = Di.xx, MH_HD(hf + 19) = Di.xy, MH_HD(hf + 20) = Di.xz, MH_HD(hf + 21) = Di.yy, MH_HD(hf + 22) = Di.yz, MH_HD(hf + 23) = Di.zz;
-                  MH_HD(hf + 24) = u3.x - (dot(U0.a, cj.a) + dot(U0.l, cj.l));
-                  MH_HD(hf + 25) = u3.y - (dot(U1.a, cj.a) + dot(U1.l, cj.l));
-                  MH_HD(hf + 26) = u3.z - (dot(U2.a, cj.a) + dot(U2.l, cj.l));
-                  if (nch >= 1)
-                     MH_HD(hf + 27) = cj.a.x, MH_HD(hf + 28) = cj.a.y, MH_HD(hf + 29) = cj.a.z, MH_HD(hf + 30) = cj.l.x, MH_HD(hf + 31) = cj.l.y, MH_HD(hf + 32) = cj.l.z;
+                  MH_HD(hf + 24) = u3.x, MH_HD(hf + 25) = u3.y, MH_HD(hf + 26) = u3.z;
                   if (parent >= 0)
                   {
                      const SV<T> W0 = Di.xx * U0 + Di.xy * U1 + Di.xz * U2, W1 = Di.xy * U0 + Di.yy * U1 + Di.yz * U2, W2 = Di.xz * U0 + Di.yz * U1 + Di.zz * U2;
                      rank1_pair_down(Ia, W0, U0), rank1_pair_down(Ia, W1, U1), rank1_pair_down(Ia, W2, U2);
-                     pa = pA + mul(Ia, cj) + u3.x * W0 + u3.y * W1 + u3.z * W2;
+                     pa = pA + u3.x * W0 + u3.y * W1 + u3.z * W2;
                   }
                }
                else if (type == JT_SIXDOF)
                { // S = 1_6: x = IA^-1 (tau - pA) is the body acceleration; for the parent Ia = 0, pa = tau
                   const SV<T> tau = joint_vec<T>(type, dof_map, mi[MI_DOF], taurow, A.v_es, true);
-                  const SV<T> x = spd6_solve(IA, tau - pA);
-                  const SV<T> xc = x - cj; // qdd = x - (X a_parent + c)
-                  MH_HD(hf + 0) = xc.a.x, MH_HD(hf + 1) = xc.a.y, MH_HD(hf + 2) = xc.a.z, MH_HD(hf + 3) = xc.l.x, MH_HD(hf + 4) = xc.l.y, MH_HD(hf + 5) = xc.l.z;
-                  if (nch >= 1)
-                     MH_HD(hf + 6) = x.a.x, MH_HD(hf + 7) = x.a.y, MH_HD(hf + 8) = x.a.z, MH_HD(hf + 9) = x.l.x, MH_HD(hf + 10) = x.l.y, MH_HD(hf + 11) = x.l.z;
+                  const SV<T> x = spd6_solve(IA, tau - pA); // = a~ of this body: qdd = x - X a~_parent, and the children start from x
+                  MH_HD(hf + 0) = x.a.x, MH_HD(hf + 1) = x.a.y, MH_HD(hf + 2) = x.a.z, MH_HD(hf + 3) = x.l.x, MH_HD(hf + 4) = x.l.y, MH_HD(hf + 5) = x.l.z;
                   if (parent >= 0)
                   {
                      Ia.A = S3<T>{T(0), T(0), T(0), T(0), T(0), T(0)};
@@ -857,8 +864,6 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   orow[di[0] * A.v_es] = qdd;
                if (nch >= 1)
                {
-                  const int hn = hf + (type == JT_REVOLUTE ? 10 : 8);
-                  a = apx + SV<T>{V3<T>{MH_HD(hn + 0), MH_HD(hn + 1), MH_HD(hn + 2)}, V3<T>{MH_HD(hn + 3), MH_HD(hn + 4), MH_HD(hn + 5)}};
                   if (type == JT_REVOLUTE)
                      a.a.z += qdd;
                   else
@@ -881,7 +886,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                if (active)
                   orow[di[0] * A.v_es] = qdd.x, orow[di[1] * A.v_es] = qdd.y, orow[di[2] * A.v_es] = qdd.z;
                if (nch >= 1)
-                  a = apx + SV<T>{V3<T>{MH_HD(hf + 27), MH_HD(hf + 28), MH_HD(hf + 29)}, V3<T>{MH_HD(hf + 30), MH_HD(hf + 31), MH_HD(hf + 32)}} + from_comp3(type, qdd);
+                  a = apx + from_comp3(type, qdd);
             }
             else if (type == JT_SIXDOF)
             {
@@ -893,7 +898,7 @@ __global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
                   orow[di[3] * A.v_es] = qdd.l.x, orow[di[4] * A.v_es] = qdd.l.y, orow[di[5] * A.v_es] = qdd.l.z;
                }
                if (nch >= 1)
-                  a = SV<T>{V3<T>{MH_HD(hf + 6), MH_HD(hf + 7), MH_HD(hf + 8)}, V3<T>{MH_HD(hf + 9), MH_HD(hf + 10), MH_HD(hf + 11)}};
+                  a = xc;
             }
             if (nch >= 2)
                st_store6<T>(S, fr, a); // later children re-read it
