@@ -1052,7 +1052,10 @@ DfsChoice dfs_choose(const mh_model *model, Algo algo, size_t elem, int64_t B, b
    }
    else
    {
-      const long avail = 160 * 1024 / c.per_cu - c.b_win;
+      // (a wave's share of the 160 KB, rounded DOWN to 2 KB: LDS is allocated in blocks, and a share that fills 160 KB / per_cu to the byte
+      // left room for per_cu - 1 workgroups only -- 98 304 configurations of the 128-body tree, six waves per CU wanted, five resident: 0.99 ms
+      // against 0.61 with eight slots less, profiles/r05_c5_rnea_budget.txt)
+      const long avail = (160 * 1024 / c.per_cu) / 2048 * 2048 - c.b_win;
       c.hand_lds = algo == ALGO_ABA && (full_stack + c.hand) * c.slot_bytes <= avail;
       c.budget = std::max<long>(0, std::min<long>(full_stack, (avail - (c.hand_lds ? c.hand * c.slot_bytes : 0)) / c.slot_bytes));
       if (model->dfs_budget >= 0)
