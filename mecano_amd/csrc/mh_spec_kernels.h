@@ -1439,6 +1439,41 @@ MH_DEV RI<T> xc_get_ri(const CX &cx)
    r.I = S3<T>{cx.lx[S0 + 4], cx.lx[S0 + 5], cx.lx[S0 + 6], cx.lx[S0 + 7], cx.lx[S0 + 8], cx.lx[S0 + 9]};
    return r;
 }
+// which revolute joints wave W of a tree-split walk evaluates under the limb owner map OWN (0: inverse dynamics / mass matrix, 1: forward
+// dynamics): the bodies of its limbs and the trunk bodies above them
+template <class TP, int OWN>
+struct RneaPreSet
+{
+   using S = Split<TP>;
+   static constexpr bool evaluates(int W, int J)
+   {
+      for (int k = 0; k < S::n_limbs(); k++)
+         if (S::template owner_sel<OWN>(k) == W)
+         {
+            for (int a = S::limb_root(k); a >= 0; a = TP::parent[a])
+               if (a == J)
+                  return true; // the limb's root or a trunk body above it
+            for (int a = J; a >= 0; a = TP::parent[a])
+               if (a == S::limb_root(k))
+                  return true; // a body of the limb
+         }
+      return false;
+   }
+};
+// joint transform of body J for the mass-matrix walks: a revolute joint's (cos, sin) from the slots of a context with RneaPreStore (formed
+// in front of the walk: crba_pre_pass), else evaluated here
+template <class TP, int J, class CX, typename T>
+MH_DEV JX<T> crba_joint(const CX &cx)
+{
+   if constexpr (CX::rnea_pre && TP::type[J] == JT_REVOLUTE)
+   {
+      JX<T> jx;
+      jx.c = cx.st.template get<J, 0>(), jx.s = cx.st.template get<J, 1>(), jx.d = T(0);
+      return jx;
+   }
+   else
+      return spec_joint<TP::type[J], Tree<TP>::cfg_ofs(J), CX, T>(cx);
+}
 // MODE 1 (tree-split kernel, trunk pass): a child that is the root of a limb is not walked, its composite inertia comes from the
 // exchange area where the limb's owner left it (the limb's own columns of H are complete by then).
 template <class TP, int J, typename T, class CX, int D, int PACK, int MODE = 0>
@@ -1524,7 +1559,7 @@ struct CrbaSub
 #pragma unroll
       for (int d = 0; d < D; d++)
          path.jx[d] = up.jx[d];
-      path.jx[D] = spec_joint<TYPE, CO, CX, T>(cx);
+      path.jx[D] = crba_joint<TP, J, CX, T>(cx);
       RI<T> acc;
       MH_BODY_FENCE();
       if constexpr (!LEAF)
@@ -1557,7 +1592,7 @@ MH_DEV void crba_trunk_path(const CX &cx, CrbaPath<T, D> &path)
 { // J = the ancestor at depth D - 1
    if constexpr (D > 0)
    {
-      path.jx[D - 1] = spec_joint<TP::type[J], Tree<TP>::cfg_ofs(J), CX, T>(cx);
+      path.jx[D - 1] = crba_joint<TP, J, CX, T>(cx);
       if constexpr (D > 1)
       {
          CrbaPath<T, D - 1> up;
@@ -1606,13 +1641,52 @@ MH_DEV void crba_limbs_of_wave(const CX &cx)
       crba_limbs_of_wave<TP, W, K + 1, T, CX>(cx);
    }
 }
+// the pre-pass of the tree-split mass matrix (context with RneaPreStore): WHICH = 0..3 the pairs wave WHICH needs for its limbs (their
+// bodies and the trunk bodies above them, under the inverse dynamics' owner map); WHICH = -1 the trunk's, for the trunk pass
+template <class TP, int WHICH, bool FAST, int J, typename T, class CX>
+MH_DEV void crba_pre_bodies(const CX &cx, bool &bad)
+{
+   if constexpr (J < TP::N)
+   {
+      constexpr bool MINE = WHICH < 0 ? Split<TP>::is_trunk(J) : RneaPreSet<TP, 0>::evaluates(WHICH, J);
+      if constexpr (TP::type[J] == JT_REVOLUTE && MINE)
+      {
+         const T x = cx.q(Tree<TP>::cfg_ofs(J));
+         T s, c;
+         if constexpr (FAST)
+         {
+            sincos_fast(x, s, c);
+            bad = bad || !sincos_in_fast_range(x);
+         }
+         else
+            sincos_t(x, s, c);
+         cx.st.template put<J, 0>(c);
+         cx.st.template put<J, 1>(s);
+      }
+      crba_pre_bodies<TP, WHICH, FAST, J + 1, T, CX>(cx, bad);
+   }
+}
+template <class TP, int WHICH, typename T, class CX>
+MH_DEV void crba_pre_pass(const CX &cx)
+{
+   if constexpr (CX::rnea_pre)
+   {
+      bool bad = false;
+      crba_pre_bodies<TP, WHICH, true, 0, T, CX>(cx, bad);
+      if (__builtin_expect(bad, 0))
+         crba_pre_bodies<TP, WHICH, false, 0, T, CX>(cx, bad);
+   }
+}
 template <class TP, int W, typename T, class CX>
 MH_DEV void split_crba_limbs(const CX &cx)
 {
    if constexpr (W < 4)
    {
       if (cx.wave == W)
+      {
+         crba_pre_pass<TP, W, T, CX>(cx);
          crba_limbs_of_wave<TP, W, 0, T, CX>(cx);
+      }
       else
          split_crba_limbs<TP, W + 1, T, CX>(cx);
    }
@@ -1992,10 +2066,47 @@ MH_DEV void warm_scalar_cache(const void *p, int bytes)
 }
 
 // One wave's share of a batch.  ALGO: 0 = RNEA, 1 = ABA.
+// (cos, sin) of EVERY revolute joint of the tree into the slots of a context with RneaPreStore (whole-tree inverse dynamics): the
+// straight-line fast path for all of them, `sincos_t` for all of them behind one branch when an angle is outside its range
+template <class TP, bool FAST, int J, typename T, class CX>
+MH_DEV void rnea_pre_all_bodies(const CX &cx, bool &bad)
+{
+   if constexpr (J < TP::N)
+   {
+      if constexpr (TP::type[J] == JT_REVOLUTE)
+      {
+         const T x = cx.q(Tree<TP>::cfg_ofs(J));
+         T s, c;
+         if constexpr (FAST)
+         {
+            sincos_fast(x, s, c);
+            bad = bad || !sincos_in_fast_range(x);
+         }
+         else
+            sincos_t(x, s, c);
+         cx.st.template put<J, 0>(c);
+         cx.st.template put<J, 1>(s);
+      }
+      rnea_pre_all_bodies<TP, FAST, J + 1, T, CX>(cx, bad);
+   }
+}
+template <class TP, typename T, class CX>
+MH_DEV void rnea_pre_all(const CX &cx)
+{
+   if constexpr (CX::rnea_pre)
+   {
+      bool bad = false;
+      rnea_pre_all_bodies<TP, true, 0, T, CX>(cx, bad);
+      if (__builtin_expect(bad, 0))
+         rnea_pre_all_bodies<TP, false, 0, T, CX>(cx, bad);
+   }
+}
 template <class TP, typename T, int ALGO, bool IO_LDS, bool IDENT, bool ST_LDS>
 MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
 {
-   using CX = Ctx<T, IO_LDS, IDENT, WholeStore<TP, ST_LDS ? ST_LDS_KIND : ST_GLOBAL_KIND>>;
+   // (the whole-tree inverse dynamics -- chains, which have no tree split -- forms the pairs of ALL its joints in front of the walk, like the
+   // tree-split kernels: RneaPreStore, rnea_pre_all below)
+   using CX = Ctx<T, IO_LDS, IDENT, std::conditional_t<ALGO == 0 && MH_RNEA_PRE != 0, RneaPreStore<TP>, WholeStore<TP, ST_LDS ? ST_LDS_KIND : ST_GLOBAL_KIND>>>;
    const int nq = A.m.nq, nv = A.m.nv;
    // LDS map: [64][nq] q | [64][nv] qd | [64][nv] qdd or tau, overwritten by the result | hand-over slots [slot][64]
    const lds_ptr<T> lq = lds, lqd = lq + (IO_LDS ? 64 * nq : 0), lx = lqd + (IO_LDS ? 64 * nv : 0), lst = lx + (IO_LDS ? 64 * nv : 0);
@@ -2038,7 +2149,10 @@ MH_DEV void spec_wave(const Args<T> &A, long wave, long nwaves, lds_ptr<T> lds)
          cx.st.stride = A.ws_stride, cx.st.lane = wave * 64 + threadIdx.x;
          asm volatile("" : "+v"(cx.st.lane)); // per configuration: keeps the N * 9 slot addresses from being hoisted out of the loop
          if constexpr (ALGO == 0)
+         {
+            rnea_pre_all<TP, T, CX>(cx);
             rnea_roots<TP, T, CX>(cx);
+         }
          else
          {
             aba_roots_in<TP, T, CX>(cx);
@@ -2099,25 +2213,6 @@ __global__ void __launch_bounds__(64) spec_fused_kernel(Args<T> A)
 // ---- the pre-pass of a context with RneaPreStore: (cos, sin) of every revolute joint wave W evaluates -- the bodies of its limbs and the
 //      trunk bodies above them -- formed together, in front of the walks.  FAST: the straight-line fast path for all of them (six to
 //      nine independent chains that interleave), `bad` = an angle outside its range; the caller repeats with FAST = false behind ONE branch.
-template <class TP, int OWN>
-struct RneaPreSet
-{
-   using S = Split<TP>;
-   static constexpr bool evaluates(int W, int J)
-   {
-      for (int k = 0; k < S::n_limbs(); k++)
-         if (S::template owner_sel<OWN>(k) == W)
-         {
-            for (int a = S::limb_root(k); a >= 0; a = TP::parent[a])
-               if (a == J)
-                  return true; // the limb's root or a trunk body above it
-            for (int a = J; a >= 0; a = TP::parent[a])
-               if (a == S::limb_root(k))
-                  return true; // a body of the limb
-         }
-      return false;
-   }
-};
 template <class TP, int W, int OWN, bool FAST, int J, typename T, class CX>
 MH_DEV void rnea_pre_bodies(const CX &cx, bool &bad)
 {
@@ -2482,7 +2577,7 @@ template <class TP, typename T>
 __global__ void __launch_bounds__(64) spec_crba_packed_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
-   using CX = Ctx<T, false, true, WholeStore<TP, ST_GLOBAL_KIND>>;
+   using CX = Ctx<T, false, true, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, WholeStore<TP, ST_GLOBAL_KIND>>>;
    using HM = HMap<TP>;
    constexpr int NV = HM::NV;
    const lds_ptr<T> img = (lds_ptr<T>)lds_raw + threadIdx.x;
@@ -2498,6 +2593,7 @@ __global__ void __launch_bounds__(64) spec_crba_packed_kernel(Args<T> A)
          cx.nv = NV;
          cx.wave = 0;
          cx.xbase = img;
+         rnea_pre_all<TP, T, CX>(cx); // the pairs of every revolute joint in one block (RneaPreStore; crba_joint takes them from there)
          crba_roots<TP, T, CX, true>(cx);
          asm volatile("" ::: "memory");
          T *H = A.out + cfg * A.v_bs;
@@ -2662,7 +2758,7 @@ MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const 
 { // lpg = configurations per workgroup (<= 64).  The write-out of 7.2 KB per configuration is bound by what ONE CU can have in
   // flight, so a small batch is spread over more, thinner workgroups (16 lanes of each wave active) to put every CU's store path to work.
   // block / nblocks: this workgroup's position among the workgroups that do this job (a fused launch gives the rest another job).
-   using CX = Ctx<T, false, true, WholeStore<TP, ST_GLOBAL_KIND>>;
+   using CX = Ctx<T, false, true, std::conditional_t<MH_RNEA_PRE != 0, RneaPreStore<TP>, WholeStore<TP, ST_GLOBAL_KIND>>>;
    using HM = HMap<TP>;
    constexpr int NV = HM::NV, NE = NV * NV;
    constexpr int NSP = HM::T.n_slots | 1; // odd row pitch of the lane-major image: lanes writing one slot spread over all banks
@@ -2720,7 +2816,10 @@ MH_DEV void crba_split_group(const Args<T> &A, int lpg, const long block, const 
       if (wave == 0)
       {
          if (active)
+         {
+            crba_pre_pass<TP, -1, T, CX>(cx); // the trunk's pairs, in one block (the limb phase's were another wave's, or are dead by now)
             crba_roots<TP, T, CX, 2, 1>(cx);
+         }
       }
       else if (early)
          crba_write_rows<TP, T, false>(A.out + cfg0 * NE, img, tab, NSP, rows, (int)threadIdx.x - 64, 192);

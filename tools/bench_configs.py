@@ -90,4 +90,5 @@ def main():
         report(f"C5 tree128 ABA fp32 SoA", B, timeit(lambda: hm.aba(qs, qds, taus, g, layout=_lib.LAYOUT_SOA), stream, iters=5), 4 * (nq + 3 * nv))
 
 
-main()
+if __name__ == "__main__":
+    main()
