@@ -228,6 +228,7 @@ struct mh_model
    std::vector<int> prog; // event program of the depth-first kernels
    int rnea_stack = 0, aba_stack = 0, aba_hand = 0; // per-lane slots: depth stacks, ABA hand-over
    int pair_stack = 0;    // ... of the fused RNEA + ABA walk (aba_dfs_kernel<.., PAIR>)
+   int dfs_aba_occ3 = 1;  // MH_DFS_ABA_OCC3=0: never the three-waves-per-SIMD build of the fp32 depth-first forward dynamics
    int use_dfs_pair = 1;  // MH_DFS_PAIR=0: mh_rnea_aba_f32 on big batches issues the two depth-first kernels one after the other, as before round 5
    int use_dfs = 1;       // MH_DFS=0: the sweep kernels of mh_kernels.h serve plain RNEA / ABA calls too (A/B measurements)
    FreshOnCopy<std::map<const void *, size_t>> lds_attr; // dynamic-LDS limit already raised per kernel (the model lives on one device, one host thread at a time)
@@ -324,6 +325,7 @@ struct mh_model
    int n_locked = 0;        // joints in MH_ACCELERATION_SOURCE mode (mh_model_set_joint_source_modes)
    int lds_consts = 0;      // run-time-topology kernels: per-joint constants staged in LDS (large models: they overflow the scalar cache) or read by scalar loads
    int waves_per_cu = 8;    // resident waves per CU the run-time-topology kernels are launched with (MH_WAVES_PER_CU)
+   bool waves_per_cu_set = false; // MH_WAVES_PER_CU given: the depth-first kernels take it instead of what their registers allow (dfs_reg_cap)
 };
 
 struct mh_context
@@ -1030,7 +1032,7 @@ mh_status launch_split_rt_pair(mh_model *model, int64_t B, mh::Args<double> &A, 
 struct DfsChoice
 {
    long per_cu, budget, hand, b_win, slot_bytes;
-   bool hand_lds;
+   bool hand_lds, occ3;
 };
 DfsChoice dfs_choose(const mh_model *model, Algo algo, size_t elem, int64_t B, bool win, bool pair = false)
 {
@@ -1039,8 +1041,25 @@ DfsChoice dfs_choose(const mh_model *model, Algo algo, size_t elem, int64_t B, b
    c.b_win = win ? 3L * mh::ROW_WIN * mh::ROW_PITCH * (long)elem : 0;
    c.slot_bytes = 64 * (long)elem;
    const long cus = model->cu_count;
-   const long reg_cap = (algo == ALGO_ABA && elem == 8) ? 4 : model->waves_per_cu; // resident waves per CU the registers allow
-   c.per_cu = std::max<long>(1, std::min<long>(std::min<long>(model->waves_per_cu, reg_cap), (waves + cus - 1) / cus));
+   // resident waves per CU the kernel's registers allow (hipcc -Rpass-analysis=kernel-resource-usage, round 5): fp32 inverse dynamics on
+   // SoA / transposed rows 134-136 VGPRs = three waves per SIMD (with the LDS windows of AoS rows 232-234: two); fp32 forward dynamics
+   // 181-184 = two, or 168 in the OCC3 build (48 bytes of scratch) = three, taken beyond eight waves per CU, the fused pair walk 216-219 = two; fp64
+   // 254-256 = one.  The grid used to be sized for eight everywhere: an inverse dynamics that could keep twelve waves per CU resident ran
+   // with eight (1.88 against 1.56 ms at 524 288 configurations of the 128-body tree, profiles/r05_c5_occ.txt), and a fp64 walk planned
+   // its LDS for eight waves of which four were resident.
+   // Twelve resident waves per CU finish a round 1.32 x later than eight (measured: 13 % more throughput for 50 % more waves), and the
+   // waves loop over the groups of 64 configurations: twelve are taken where they save enough ROUNDS to pay for that -- 196 608 (one round
+   // of twelve instead of two of eight) and from 393 216 configurations upwards, not at 262 144 (two rounds either way: 2.05 against 1.9 ms)
+   long reg_cap = elem == 8 ? 4 : 8;
+   const long wpc = (waves + cus - 1) / cus;
+   const bool twelve_pays = ((wpc + 11) / 12) * 132 < ((wpc + 7) / 8) * 100;
+   if (elem == 4 && algo == ALGO_RNEA && !win && twelve_pays)
+      reg_cap = 12;
+   if (elem == 4 && algo == ALGO_ABA && !pair && model->dfs_aba_occ3 && twelve_pays)
+      reg_cap = 12, c.occ3 = true; // the build with a register budget for three waves per SIMD (mh_dfs_kernels.h: OCC3)
+   if (model->waves_per_cu_set)
+      reg_cap = std::min<long>(reg_cap, model->waves_per_cu);
+   c.per_cu = std::max<long>(1, std::min<long>(reg_cap, (waves + cus - 1) / cus));
    const long full_stack = pair ? model->pair_stack : (algo == ALGO_RNEA ? model->rnea_stack : model->aba_stack);
    c.hand = algo == ALGO_RNEA ? 0 : model->aba_hand;
    if (model->dfs_place >= 0)
@@ -1117,6 +1136,17 @@ mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipS
       }
       else
          return fail(MH_ERR_INVALID_ARGUMENT, "the fused depth-first pair walk is built in fp32 only");
+   }
+   else if (ch.occ3 && sizeof(T) == 4)
+   {
+      if constexpr (sizeof(T) == 4)
+      {
+         if (hand_lds)
+            kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, false, 0, false, true> : (const void *)&mh::aba_dfs_kernel<T, true, false, 2, false, true>;
+         else
+            kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, false, false, 0, false, true>
+                             : (mode == 1 ? (const void *)&mh::aba_dfs_kernel<T, false, false, 1, false, true> : (const void *)&mh::aba_dfs_kernel<T, false, false, 2, false, true>);
+      }
    }
    else if (hand_lds)
       kern = mode == 0 ? (const void *)&mh::aba_dfs_kernel<T, true, false, 0> : (const void *)&mh::aba_dfs_kernel<T, true, false, 2>;
@@ -2432,13 +2462,15 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
    if (const char *e = getenv("MH_GENERIC_TRANSPOSE"))
       m->use_transpose = atoi(e) != 0;
    if (const char *e = getenv("MH_WAVES_PER_CU"))
-      m->waves_per_cu = std::max(1, std::min(32, atoi(e)));
+      m->waves_per_cu = std::max(1, std::min(32, atoi(e))), m->waves_per_cu_set = true;
    if (const char *e = getenv("MH_SPEC_ST"))
       m->force_st = atoi(e);
    if (const char *e = getenv("MH_DFS"))
       m->use_dfs = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_PAIR"))
       m->use_dfs_pair = atoi(e) != 0;
+   if (const char *e = getenv("MH_DFS_ABA_OCC3"))
+      m->dfs_aba_occ3 = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_TRANSPOSE"))
       m->dfs_transpose = atoi(e) != 0;
    // fp64 forward dynamics at device-filling batches: the sweep kernel accumulates the children of a branching body through the workspace
@@ -3348,7 +3380,17 @@ mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const flo
    const bool shared = big && opts.layout == MH_LAYOUT_AOS;
    // ONE walk for both (round 5; mh_dfs_kernels.h: aba_dfs_kernel<.., PAIR>) unless a run-time tree split or a code object serves the model
    // (small / specialised models hardly get here: 8192 configurations of >= 64 state entries); MH_DFS_PAIR=0 keeps the two launches
-   const bool fused = big && model->use_dfs_pair && !(model->spec.handle && model->use_spec)
+   // ... and unless the two single walks, which may keep twelve waves per CU resident where the pair walk keeps eight (dfs_choose), need so
+   // many fewer rounds that they win: together they take 1.25 x the pair walk's time at equal occupancy, a round of twelve 1.32 x a round
+   // of eight -- which leaves the batches of nine to twelve waves per CU (196 608 configurations: 1.82 against 2.11 ms)
+   bool rounds_favour_two = false;
+   if (big)
+   {
+      const long wpc = ((B + 63) / 64 + model->cu_count - 1) / model->cu_count, r8 = (wpc + 7) / 8, r12 = (wpc + 11) / 12;
+      const long two = (r12 * 132 < r8 * 100 ? r12 * 132 : r8 * 100) * 125; // (x 1e4)
+      rounds_favour_two = !model->waves_per_cu_set && two < r8 * 10000;
+   }
+   const bool fused = big && model->use_dfs_pair && !rounds_favour_two && !(model->spec.handle && model->use_spec)
                       && !(model->split_rt.usable && (model->use_split_rt == 1 || (B + 63) / 64 <= (long)model->cu_count * 2));
    auto fused_walk = [&](mh_model *mdl, const float *sq, const float *sqd, const float *sqdd, const float *stau, float *o1, float *o2) -> mh_status {
       mh::Args<float> A{};

@@ -501,8 +501,13 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
 // (ForwardDynamicsCalculator.java:1085-1127 against InverseDynamicsCalculator.java:873-917) -- so the inverse dynamics costs one more
 // motion transform (its acceleration), one product I a and, inwards, one force transform per body, and q / qd are read once.  Frames:
 // pair_frame_slots; MI_PFR_R / MI_PVA_R hold the parent's wrench / acceleration slots of the inverse dynamics (dfs_plan, algo 2).
-template <typename T, bool HND_LDS, bool WIN, int MODE, bool PAIR = false>
-__global__ void __launch_bounds__(64) aba_dfs_kernel(Args<T> A)
+// OCC3: a register budget for three waves per SIMD (168 VGPRs; the plain build takes 181-184 and keeps two).  The walk waits on its own
+// workspace more than it computes, so a third wave per SIMD pays where the batch has one to offer: forward dynamics at 524 288
+// configurations 3.86 -> 3.38 ms, at 1 M 7.35 -> 6.48 (profiles/r05_c5_occ.txt), for 48 bytes of scratch per lane -- which cost 2 % where
+// only eight waves per CU exist anyway (131 072), so the host picks the build by batch size (dfs_choose).  The fused pair walk would need
+// 176 bytes of scratch for the same budget: 2 x slower, measured (profiles/r05_c5_occ_pair3.txt), not built.
+template <typename T, bool HND_LDS, bool WIN, int MODE, bool PAIR = false, bool OCC3 = false>
+__global__ void __launch_bounds__(64, OCC3 ? 3 : 1) aba_dfs_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
    const DevModel &m = A.m;
