@@ -254,6 +254,7 @@ struct mh_model
    bool destroy_pending = false; // mh_model_destroy was called while contexts were alive: the last mh_context_destroy releases the model
    int use_win = 1;       // MH_DFS_WIN=0: AoS rows are read per lane instead of through LDS windows (A/B measurements)
    int dfs_place = -1;    // MH_DFS_PLACE = 0 | 1 | 2: force all-LDS / stack in LDS + hand-over global / all global
+   bool dfs_place_greedy = false; // MH_DFS_GREEDY=1: the frames' homes from the leaves upwards as in rounds 2-4 (A/B measurements; dfs_plan)
    int dfs_budget = -1;   // MH_DFS_BUDGET: cap of the stack's LDS budget in slots per wave (measurements)
    int dfs_aba64 = 0;     // fp64 forward dynamics on the depth-first kernel too: bushy trees (below), or MH_DFS_ABA64=0|1
    int n_nonadjacent = 0; // bodies whose parent is not the body before them in engine order (branch points of the tree)
@@ -654,14 +655,74 @@ const mh_model::DfsPlan *dfs_plan(mh_model *m, int algo, int budget)
    for (int e = 0; e < n; e++) // algo 2: the fused RNEA + ABA walk (the forward dynamics' frame + the inverse dynamics' wrench and acceleration)
       frame[e] = algo == 0 ? mh::rnea_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH))
                            : (algo == 1 ? mh::aba_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH)) : mh::pair_frame_slots(MI(e, mh::MI_TYPE), MI(e, mh::MI_NCH)));
-   for (int e = n - 1; e >= 0; e--)
-   { // engine order is depth-first: children come after their parent
-      int need = below[e];
-      if (frame[e] > 0 && below[e] + frame[e] <= budget)
-         home[e] = 1, need += frame[e];
-      const int pe = MI(e, mh::MI_PARENT);
-      if (pe >= 0)
-         below[pe] = std::max(below[pe], need);
+   // (The inverse dynamics at twelve waves per CU -- 48 slots per lane -- keeps the old placement: it waits on its frames more than it
+   // moves them, and the frames next to the leaves are the ones read back right after they were written: 2.92 ms against 3.00 at 1 M
+   // configurations, while at eight waves the knapsack wins 2 %: profiles/r05_c5_frame_placement.txt.)
+   if (m->dfs_place_greedy || (algo == 0 && budget < 64))
+   { // rounds 2-4: from the leaves upwards, whatever the frame is worth
+      for (int e = n - 1; e >= 0; e--)
+      { // engine order is depth-first: children come after their parent
+         int need = below[e];
+         if (frame[e] > 0 && below[e] + frame[e] <= budget)
+            home[e] = 1, need += frame[e];
+         const int pe = MI(e, mh::MI_PARENT);
+         if (pe >= 0)
+            below[pe] = std::max(below[pe], need);
+      }
+   }
+   else
+   { // Round 5: by what a frame in LDS SAVES.  A frame is touched 2 (6 + jx) times under a single child, but under k children it is
+     // written at the visit, re-read by every later child (v, w / a), read and written by the pop of every child that is not the last
+     // (the 27 accumulators of the forward dynamics, the 6 of the inverse dynamics) and read at its own pop: 100 accesses for 47 slots at
+     // k = 2, 500 at k = 8, against 16 for 14 under one child.  The budget binds along every root-to-leaf path, so the best set of homes
+     // is a knapsack on the tree: best[e][b] = the accesses saved in e's subtree with b slots left for it = max(sum of best[c][b] over
+     // the children (e global), worth(e) + sum of best[c][b - frame(e)] (e in LDS)).  128-body tree of configs[4], 80 slots per lane:
+     // 5 314 -> 4 680 global slot accesses per configuration in the fused walk (model), 5 144 -> 4 134 for the forward dynamics at 48.
+      std::vector<int> worth(n, 0);
+      for (int e = 0; e < n; e++)
+      {
+         const int k = MI(e, mh::MI_NCH), jx = mh::jx_slots(MI(e, mh::MI_TYPE));
+         if (k == 0)
+            continue;
+         if (algo == 0)
+            worth[e] = k == 1 ? 2 * (6 + jx) : (6 + jx + 12) + (k - 1) * 12 + 6 + (k - 2) * 12 + (6 + jx);
+         else
+         {
+            const int id = algo == 2 ? 6 : 0; // the inverse dynamics' wrench (and acceleration) beside the forward dynamics' slots
+            const int acc = 27 + id;
+            worth[e] = k == 1 ? 2 * (6 + jx) + 2 * id : (12 + jx + 6 + id) + (k - 1) * (12 + id) + acc + (k - 2) * 2 * acc + (12 + jx + acc);
+         }
+      }
+      const int W = budget + 1;
+      std::vector<long> best((size_t)n * W, 0);
+      std::vector<char> take((size_t)n * W, 0);
+      std::vector<std::vector<int>> kids(n);
+      for (int e = 0; e < n; e++)
+         if (MI(e, mh::MI_PARENT) >= 0)
+            kids[MI(e, mh::MI_PARENT)].push_back(e);
+      for (int e = n - 1; e >= 0; e--) // children come after their parent: their rows are complete
+         for (int b = 0; b <= budget; b++)
+         {
+            long out = 0, in = -1;
+            for (int c : kids[e])
+               out += best[(size_t)c * W + b];
+            if (frame[e] > 0 && frame[e] <= b)
+            {
+               in = worth[e];
+               for (int c : kids[e])
+                  in += best[(size_t)c * W + b - frame[e]];
+            }
+            best[(size_t)e * W + b] = std::max(out, in);
+            take[(size_t)e * W + b] = in > out;
+         }
+      std::vector<int> left(n, budget);
+      for (int e = 0; e < n; e++)
+      {
+         const int pe = MI(e, mh::MI_PARENT);
+         if (pe >= 0)
+            left[e] = left[pe] - (home[pe] ? frame[pe] : 0);
+         home[e] = take[(size_t)e * W + left[e]];
+      }
    }
    mh_model::DfsPlan plan{algo, budget, 0, 0, 0, nullptr};
    for (int e = 0; e < n; e++)
@@ -2484,6 +2545,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->dfs_budget = std::max(0, atoi(e));
    if (const char *e = getenv("MH_DFS_PLACE"))
       m->dfs_place = atoi(e);
+   if (const char *e = getenv("MH_DFS_GREEDY"))
+      m->dfs_place_greedy = atoi(e) != 0;
    if (const char *e = getenv("MH_DFS_WIN"))
       m->use_win = atoi(e) != 0;
    if (getenv("MH_DISABLE_PAIR"))

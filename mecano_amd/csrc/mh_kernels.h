@@ -15,7 +15,9 @@
 #pragma once
 #include "mh_device.h"
 
+#include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <type_traits>
 
 namespace mh
@@ -517,56 +519,127 @@ struct RowBlock
    static constexpr int V = 16 / (int)sizeof(T), R = 128 / (int)sizeof(T), LPC = R / V; // LPC lanes per column segment (8)
    typedef T VT __attribute__((ext_vector_type(V)));
 };
+// Round 5: the workgroups are persistent (cus * workgroups-per-CU of them, block b, b + grid, ...) and a block's accesses are requested
+// while the block before it is still passing through LDS -- one block per workgroup left the read stream idle during every gather /
+// store phase (4.5-4.8 TB/s read + write at 3 workgroups per CU: profiles/r05_c5_pair_traffic_bias_absorbed.txt).  The barriers order LDS traffic only
+// (__syncthreads() would drain the requests just issued).
+MH_DEV void lds_only_barrier()
+{
+   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+constexpr int ROW_BLOCK_MAX_N = 512; // 128 n bytes of LDS <= 64 KB; 16 vectors of 16 bytes per thread and block
+// Non-temporal accesses (tools/proto_transpose.hip, profiles/r05_proto_transpose.txt: 131 072 x 323 floats, rows -> columns 5.2 -> 6.5 TB/s
+// with nt stores, columns -> rows 4.7 -> 6.3; a float4 copy of the same bytes 5.2-5.8 plain, 5.7-6.3 nt)
+template <bool NT, class VT, typename T>
+MH_DEV VT row_block_load(const T *p)
+{
+   if constexpr (NT)
+      return __builtin_nontemporal_load((const VT *)p);
+   else
+      return *(const VT *)p;
+}
+template <bool NT, class VT, typename T>
+MH_DEV void row_block_store(T *p, VT v)
+{
+   if constexpr (NT)
+      __builtin_nontemporal_store(v, (VT *)p);
+   else
+      *(VT *)p = v;
+}
 // src [B][n] (AoS) -> dst [n][B] (SoA)
-template <typename T>
-__global__ void __launch_bounds__(256) rows_to_columns_kernel(const T *__restrict__ src, T *__restrict__ dst, long B, int n)
+template <typename T, bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) rows_to_columns_kernel(const T *__restrict__ src, T *__restrict__ dst, long B, int n, long blocks)
 {
    using RB = RowBlock<T>;
    using VT = typename RB::VT;
-   constexpr int V = RB::V, R = RB::R, LPC = RB::LPC;
+   constexpr int V = RB::V, R = RB::R, LPC = RB::LPC, NU = ROW_BLOCK_MAX_N * R / (256 * V);
    extern __shared__ double lds_raw[];
    T *const blk = (T *)lds_raw;
-   const long r0 = (long)blockIdx.x * R;
-   const int rows = (int)(B - r0 < R ? B - r0 : R), len = rows * n; // rows % V == 0, hence len % V == 0
-   const T *const flat = src + r0 * n;
-   for (int i = threadIdx.x * V; i + V <= len; i += 256 * V)
-      *(VT *)(blk + i) = *(const VT *)(flat + i);
-   __syncthreads();
    const int rb = (threadIdx.x % LPC) * V, jl = threadIdx.x / LPC;
-   if (rb < rows)
-      for (int j = jl; j < n; j += 256 / LPC)
-      {
-         VT w;
+   VT reg[NU];
+   auto request = [&](long b) { // the block as it lies in memory, 16 bytes per lane
+      const long r0 = b * R;
+      const int len = (int)(B - r0 < R ? B - r0 : R) * n; // rows % V == 0, hence len % V == 0
+      const T *const flat = src + r0 * n;
 #pragma unroll
-         for (int k = 0; k < V; k++)
-            w[k] = blk[(rb + k) * n + j];
-         *(VT *)(dst + (long)j * B + r0 + rb) = w;
-      }
+      for (int u = 0; u < NU; u++)
+         if ((threadIdx.x + 256 * u) * V + V <= len)
+            reg[u] = row_block_load<NTL, VT>(flat + (threadIdx.x + 256 * u) * V);
+   };
+   long b = blockIdx.x;
+   if (b < blocks)
+      request(b);
+   for (; b < blocks; b += gridDim.x)
+   {
+      const long r0 = b * R;
+      const int rows = (int)(B - r0 < R ? B - r0 : R), len = rows * n;
+#pragma unroll
+      for (int u = 0; u < NU; u++)
+         if ((threadIdx.x + 256 * u) * V + V <= len)
+            *(VT *)(blk + (threadIdx.x + 256 * u) * V) = reg[u];
+      lds_only_barrier();
+      if (b + gridDim.x < blocks)
+         request(b + gridDim.x);
+      if (rb < rows)
+         for (int j = jl; j < n; j += 256 / LPC)
+         {
+            VT w;
+#pragma unroll
+            for (int k = 0; k < V; k++)
+               w[k] = blk[(rb + k) * n + j];
+            row_block_store<NTS, VT>(dst + (long)j * B + r0 + rb, w);
+         }
+      lds_only_barrier(); // the block is free for the next one
+   }
 }
 // src [n][B] (SoA) -> dst [B][n] (AoS)
-template <typename T>
-__global__ void __launch_bounds__(256) columns_to_rows_kernel(const T *__restrict__ src, T *__restrict__ dst, long B, int n)
+template <typename T, bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) columns_to_rows_kernel(const T *__restrict__ src, T *__restrict__ dst, long B, int n, long blocks)
 {
    using RB = RowBlock<T>;
    using VT = typename RB::VT;
-   constexpr int V = RB::V, R = RB::R, LPC = RB::LPC;
+   constexpr int V = RB::V, R = RB::R, LPC = RB::LPC, NU = ROW_BLOCK_MAX_N / (256 / LPC);
    extern __shared__ double lds_raw[];
    T *const blk = (T *)lds_raw;
-   const long r0 = (long)blockIdx.x * R;
-   const int rows = (int)(B - r0 < R ? B - r0 : R), len = rows * n;
    const int rb = (threadIdx.x % LPC) * V, jl = threadIdx.x / LPC;
-   if (rb < rows)
-      for (int j = jl; j < n; j += 256 / LPC)
+   VT reg[NU];
+   auto request = [&](long b) { // R entries of every column: LPC lanes take a 128-byte line
+      const long r0 = b * R;
+      const int rows = (int)(B - r0 < R ? B - r0 : R);
+      if (rb < rows)
       {
-         const VT w = *(const VT *)(src + (long)j * B + r0 + rb);
 #pragma unroll
-         for (int k = 0; k < V; k++)
-            blk[(rb + k) * n + j] = w[k];
+         for (int u = 0; u < NU; u++)
+            if (jl + (256 / LPC) * u < n)
+               reg[u] = row_block_load<NTL, VT>(src + (long)(jl + (256 / LPC) * u) * B + r0 + rb);
       }
-   __syncthreads();
-   T *const flat = dst + r0 * n;
-   for (int i = threadIdx.x * V; i + V <= len; i += 256 * V)
-      *(VT *)(flat + i) = *(const VT *)(blk + i);
+   };
+   long b = blockIdx.x;
+   if (b < blocks)
+      request(b);
+   for (; b < blocks; b += gridDim.x)
+   {
+      const long r0 = b * R;
+      const int rows = (int)(B - r0 < R ? B - r0 : R), len = rows * n;
+      if (rb < rows)
+      {
+#pragma unroll
+         for (int u = 0; u < NU; u++)
+            if (jl + (256 / LPC) * u < n)
+            {
+#pragma unroll
+               for (int k = 0; k < V; k++)
+                  blk[(rb + k) * n + jl + (256 / LPC) * u] = reg[u][k];
+            }
+      }
+      lds_only_barrier();
+      if (b + gridDim.x < blocks)
+         request(b + gridDim.x);
+      T *const flat = dst + r0 * n;
+      for (int i = threadIdx.x * V; i + V <= len; i += 256 * V)
+         row_block_store<NTS, VT>(flat + i, *(const VT *)(blk + i));
+      lds_only_barrier();
+   }
 }
 // [B][n] -> [n][B] (to_columns) or [n][B] -> [B][n] on `stream`: row blocks for wide matrices, 64 x 64 tiles otherwise
 template <typename T>
@@ -574,13 +647,34 @@ inline void transpose_rows(const T *src, T *dst, long B, long n, bool to_columns
 {
    using RB = RowBlock<T>;
    const size_t lds = (size_t)128 * (size_t)n;
-   if (B % RB::V == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && lds >= 16 * 1024 && lds <= 64 * 1024)
+   if (B % RB::V == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && lds >= 16 * 1024 && n <= ROW_BLOCK_MAX_N)
    {
-      const dim3 grid((unsigned)((B + RB::R - 1) / RB::R));
-      if (to_columns)
-         hipLaunchKernelGGL((rows_to_columns_kernel<T>), grid, dim3(256), lds, stream, src, dst, B, (int)n);
+      static const long cus = [] {
+         int dev = 0, v = 0;
+         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+         return (long)v;
+      }();
+      const long blocks = (B + RB::R - 1) / RB::R, per_cu = std::max<long>(1, (long)(160 * 1024 / lds));
+      const dim3 grid((unsigned)std::min<long>(blocks, cus * per_cu));
+      static const int nt = [] { // MH_TRANSPOSE_NT: bit 0 non-temporal stores, bit 1 non-temporal loads (measurements)
+         const char *e = getenv("MH_TRANSPOSE_NT");
+         return e ? atoi(e) : 3; // (in the pair call of the 128-body tree 3 is ahead of 1 and 0 by about 1 %: profiles/r05_c5_transpose_nt.txt)
+      }();
+      auto go = [&](auto ntl, auto nts) {
+         if (to_columns)
+            hipLaunchKernelGGL((rows_to_columns_kernel<T, decltype(ntl)::value, decltype(nts)::value>), grid, dim3(256), lds, stream, src, dst, B, (int)n, blocks);
+         else
+            hipLaunchKernelGGL((columns_to_rows_kernel<T, decltype(ntl)::value, decltype(nts)::value>), grid, dim3(256), lds, stream, src, dst, B, (int)n, blocks);
+      };
+      if (nt == 3)
+         go(std::true_type{}, std::true_type{});
+      else if (nt == 2)
+         go(std::true_type{}, std::false_type{});
+      else if (nt == 1)
+         go(std::false_type{}, std::true_type{});
       else
-         hipLaunchKernelGGL((columns_to_rows_kernel<T>), grid, dim3(256), lds, stream, src, dst, B, (int)n);
+         go(std::false_type{}, std::false_type{});
       return;
    }
    const dim3 grid((unsigned)(((B + 63) / 64) * ((n + 63) / 64)));
