@@ -491,6 +491,8 @@ def main():
     bytes_of = {"rnea": bytes_rnea, "aba": bytes_aba, "crba": bytes_crba, "rnea_aba": bytes_rnea + bytes_aba, "rnea_crba": bytes_rnea + bytes_crba}
     if fused:  # one launch computing both: 968 + 968 (config 3: 968 + 7448) algorithmic bytes per configuration
         dom, dom_name = fused_key, fused_key.replace("_", "+") + (" fused" if fused_launch else " (two launches)")
+        if cfg == 5:  # mh_rnea_aba_f32 on a big AoS batch: transposed copies in, ONE depth-first walk for both algorithms, results transposed back
+            dom_name = "rnea+aba, the whole call (one fused depth-first walk + six AoS <-> SoA transposes)"
     else:      # dominant kernel = the slowest launch of a step
         dom = max(kernels_ms, key=kernels_ms.get)
         dom_name = dom
