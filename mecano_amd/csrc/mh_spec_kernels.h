@@ -162,6 +162,12 @@ struct Tree
    }
 };
 
+#ifndef MH_ZVF_MAIL
+#define MH_ZVF_MAIL 1 // 0: the fused kernel's inverse dynamics walks every limb on its forward-dynamics owner, as before (A/B measurements)
+#endif
+#ifndef MH_ZVF_MAIL_COUNT_WALKS
+#define MH_ZVF_MAIL_COUNT_WALKS 1 // trunk wrench duties under the mailed owners: by bodies + trunk walks + duties (1) or by the limbs' bodies alone (0)
+#endif
 // Compile-time partition of the tree for the tree-split kernels: 4 waves of a workgroup walk the SAME 64 configurations.
 //   trunk = every body with two or more child subtrees, and all its ancestors  (humanoid: pelvis, spine 1-3)
 //   limbs = the chains hanging off the trunk with at least MIN_LIMB bodies       (legs, arms, neck)
@@ -194,6 +200,10 @@ struct Split
       int trunk_rank[N] = {};
       int f_limb[N] = {};
       int f_limb_aba[N] = {}; // the same under the ABA's limb owners (the fused bias + inertia kernel walks its inverse dynamics with those)
+      // ... and with ONE one-body limb given to another wave for the inverse dynamics only (mailed < 0: none): see mail_one_limb()
+      int owner_f[N] = {};
+      int f_limb_f[N] = {};
+      int mailed = -1;
       int n_trunk = 0;
       // ---- staged trunk (ABA): see make_stages()
       bool staged = false;
@@ -373,6 +383,61 @@ struct Split
             load[owner[f[j]]]++;
       }
    }
+   // Bodies a wave steps through in the limb phase of an inverse dynamics under `owner`: its limbs' bodies + the trunk bodies it walks
+   // down to reach them (once per distinct parent chain).
+   static constexpr void rnea_loads(const Plan &P, const int (&owner)[N], int (&load)[WAVES])
+   {
+      bool passes[WAVES][N] = {};
+      for (int w = 0; w < WAVES; w++)
+         load[w] = 0;
+      for (int k = 0; k < P.n_limbs; k++)
+      {
+         const int w = owner[k];
+         load[w] += P.size_of[k];
+         for (int a = TP::parent[P.root_of[k]]; a >= 0; a = TP::parent[a])
+            if (!passes[w][a])
+               passes[w][a] = true, load[w]++;
+      }
+   }
+   // The fused bias + inertia kernel (mh_zv_kernels.h) walks its inverse dynamics with the forward dynamics' limb owners, so that a limb
+   // joint's (cos, sin) and tau - h stay in the registers of the wave that needs them next.  On the humanoid that puts the head (one body
+   // on the chest) beside a leg: that wave steps through leg + root + the three trunk bodies down to the chest + head = 10 bodies while a
+   // leg alone is 7 and an arm 8, and the other three wait 1.1-1.9 us of a 20 us group for it (profiles/r05_zvf_phase_stamps.txt).  A
+   // ONE-body revolute limb may therefore be walked by another wave in that phase: its three values travel through three LDS slots
+   // (ZvfStore: slot kinds per slot).  Chosen: the move that lowers the largest load most; ties keep the forward dynamics' owner.
+   static constexpr void mail_one_limb(Plan &P)
+   {
+      for (int k = 0; k < P.n_limbs; k++)
+         P.owner_f[k] = P.owner[k];
+      P.mailed = -1;
+      int load[WAVES] = {};
+      rnea_loads(P, P.owner, load);
+      int best = 0;
+      for (int w = 0; w < WAVES; w++)
+         best = load[w] > best ? load[w] : best;
+      int bk = -1, bw = -1;
+      for (int k = 0; k < P.n_limbs; k++)
+      {
+         if (P.size_of[k] != 1 || TP::type[P.root_of[k]] != JT_REVOLUTE)
+            continue;
+         for (int w = 0; w < WAVES; w++)
+         {
+            if (w == P.owner[k])
+               continue;
+            int trial[N] = {};
+            for (int i = 0; i < P.n_limbs; i++)
+               trial[i] = i == k ? w : P.owner[i];
+            rnea_loads(P, trial, load);
+            int worst = 0;
+            for (int v = 0; v < WAVES; v++)
+               worst = load[v] > worst ? load[v] : worst;
+            if (worst < best)
+               best = worst, bk = k, bw = w;
+         }
+      }
+      if (bk >= 0)
+         P.owner_f[bk] = bw, P.mailed = bk;
+   }
    static constexpr Plan make()
    {
       Plan P;
@@ -453,6 +518,8 @@ struct Split
       // ... under the final ABA owners (the fused kernel's inverse dynamics walks with those), by the limbs' bodies alone: there the wave with a
       // leg AND the neck is the last one whatever the others do, and the refined count made the step 2 % slower (27.3 -> 27.8 us at 32 768)
       assign_wrench_duties(P, P.owner, P.f_limb_aba, false);
+      mail_one_limb(P);
+      assign_wrench_duties(P, P.owner_f, P.f_limb_f, MH_ZVF_MAIL_COUNT_WALKS != 0);
       // ABA hand-over placement: trunk bodies in LDS (all waves write the same values), limb bodies in the owner's registers
       int regs[WAVES] = {};
       for (int j = 0; j < N; j++)
@@ -492,10 +559,12 @@ struct Split
    static constexpr int owner_plain(int k) { return P.owner_plain[k]; } // RNEA, CRBA
    static constexpr int f_limb(int j) { return P.f_limb[j]; }
    // OWN = 1: the inverse dynamics walks its limbs with the ABA's owners (fused bias + inertia kernel, mh_zv_kernels.h)
+   // OWN = 2: the same with one one-body limb walked by another wave (mail_one_limb)
    template <int OWN>
-   static constexpr int owner_sel(int k) { return OWN ? P.owner[k] : P.owner_plain[k]; }
+   static constexpr int owner_sel(int k) { return OWN == 2 ? P.owner_f[k] : (OWN ? P.owner[k] : P.owner_plain[k]); }
    template <int OWN>
-   static constexpr int f_limb_sel(int j) { return OWN ? P.f_limb_aba[j] : P.f_limb[j]; }
+   static constexpr int f_limb_sel(int j) { return OWN == 2 ? P.f_limb_f[j] : (OWN ? P.f_limb_aba[j] : P.f_limb[j]); }
+   static constexpr int mailed_limb() { return P.mailed; }
    static constexpr int rnea_trunk_slot(int j) { return 8 * P.trunk_rank[j]; }
    static constexpr int RNEA_TRUNK_SLOTS = 8 * P.n_trunk;
    static constexpr bool staged() { return P.staged; }
@@ -596,6 +665,19 @@ struct policy_rnea_pre<SP, std::enable_if_t<SP::rnea_pre>>
 {
    static constexpr bool value = true;
 };
+// a policy may place the slots of one body in different homes (ZvfStore: the mailed limb): slot_kind(j, k) / slot_index(j, k)
+template <class SP, class = void>
+struct policy_slot_homes
+{
+   static constexpr int kind(int j, int) { return SP::kind(j); }
+   static constexpr int index(int j, int k) { return SP::index(j) + k; }
+};
+template <class SP>
+struct policy_slot_homes<SP, std::enable_if_t<SP::slot_homes>>
+{
+   static constexpr int kind(int j, int k) { return SP::slot_kind(j, k); }
+   static constexpr int index(int j, int k) { return SP::slot_index(j, k); }
+};
 template <typename T, class SP>
 struct LaneStore
 {
@@ -606,7 +688,7 @@ struct LaneStore
    template <int J, int K>
    MH_DEV void put(T v) const
    {
-      constexpr int kind = SP::kind(J), slot = SP::index(J) + K;
+      constexpr int kind = policy_slot_homes<SP>::kind(J, K), slot = policy_slot_homes<SP>::index(J, K);
       if constexpr (kind == ST_LDS_KIND)
          lbase[slot * 64] = v;
       else if constexpr (kind == ST_GLOBAL_KIND)
@@ -617,7 +699,7 @@ struct LaneStore
    template <int J, int K>
    MH_DEV T get() const
    {
-      constexpr int kind = SP::kind(J), slot = SP::index(J) + K;
+      constexpr int kind = policy_slot_homes<SP>::kind(J, K), slot = policy_slot_homes<SP>::index(J, K);
       if constexpr (kind == ST_LDS_KIND)
          return lbase[slot * 64];
       else if constexpr (kind == ST_GLOBAL_KIND)

@@ -57,11 +57,21 @@ struct ZvbStore
 // bias-split slots.  A trunk body in LDS: ndof more slots (of their own: a plain split folds the trunk on every wave at its own pace, so
 // the result may not overwrite the effort it was formed from).  A root body kept in registers: its tau - h in ndof LDS slots behind the
 // trunk's (every wave folds the root, one wave computed the efforts).
+// Round 5: the MAILED limb (Split::mail_one_limb: a one-body revolute limb whose inverse dynamics another wave walks than the one that owns
+// it in the forward dynamics).  Its pair and tau - h -- slots 7, 8, 9 of the body -- live in three LDS slots behind everything either
+// phase keeps there (ZvfPlan::mail_base), written by the walking wave, read by the owner behind the barrier between the phases; its other
+// slots stay registers of the owner.
+template <class TP>
+struct ZvfPlan;
 template <class TP>
 struct ZvfStore
 {
    using S = Split<TP>;
    using TR = Tree<TP>;
+   static constexpr bool slot_homes = true;
+   static constexpr bool mailed(int j) { return ZvfPlan<TP>::use_mail() && !S::is_trunk(j) && S::limb_index_of_body(j) == S::mailed_limb(); }
+   static constexpr int slot_kind(int j, int k) { return mailed(j) && k >= 7 ? ST_LDS_KIND : kind(j); }
+   static constexpr int slot_index(int j, int k) { return mailed(j) && k >= 7 ? ZvfPlan<TP>::mail_base() + (k - 7) : index(j) + k; }
    static constexpr bool root_in_regs(int j) { return S::staged() && j == S::root(); }
    static constexpr int limb_slots(int j) { return TR::zv_slots_of(j, true) + TR::ndof(j); }
    static constexpr int reg_slot(int j)
@@ -2066,7 +2076,10 @@ struct ZvfPlan
    }
    static constexpr int rnea_slots() { return NQ + 2 * NV + S::n_limbs() * 6 + S::RNEA_TRUNK_SLOTS; }
    static constexpr int aba_slots() { return ST::TRUNK_SLOTS + x_slots(); }
-   static constexpr int lds_slots() { return rnea_slots() > aba_slots() ? rnea_slots() : aba_slots(); }
+   // the mailed limb's three slots: behind what either phase keeps in LDS -- if two workgroups per CU still fit
+   static constexpr int mail_base() { return rnea_slots() > aba_slots() ? rnea_slots() : aba_slots(); }
+   static constexpr bool use_mail() { return MH_ZVF_MAIL != 0 && S::staged() && S::mailed_limb() >= 0 && (mail_base() + 3) * 64 * 8 * 2 <= 160 * 1024; }
+   static constexpr int lds_slots() { return mail_base() + (use_mail() ? 3 : 0); }
    // the trunk slots are written while the inverse dynamics' exchange area and parking area are still being read: they must fit under
    // the rows of q and qd, which are dead by then
    static constexpr bool usable() { return S::usable() && joints_ok() && ST::TRUNK_SLOTS <= NQ + NV && lds_slots() * 64 * 8 * 2 <= 160 * 1024; }
@@ -2126,7 +2139,7 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
 #endif
    // ---- inverse dynamics at zero acceleration, limbs by the forward dynamics' owners: pairs and tau - h of the limb joints to registers
    if (active)
-      split_rnea_limbs<TP, 0, T, CX, 1>(cx);
+      split_rnea_limbs<TP, 0, T, CX, (ZvfPlan<TP>::use_mail() ? 2 : 1)>(cx);
    ZV_STAMP(2, 2);
    __syncthreads(); // the limbs' wrenches are in the exchange area; nobody reads the rows of q and qd any more
    ZV_STAMP(2, 3);
