@@ -272,6 +272,45 @@ def test_config5_random_128_body_tree_fp32(torch_cuda):
         assert torch.equal(out[:4096], hm.aba(cq[:4096].contiguous(), cqd[:4096].contiguous(), ctau[:4096].contiguous(), g))  # direct AoS reads
 
 
+def test_depth_first_frame_homes_do_not_change_the_numbers(torch_cuda, monkeypatch):
+    """dfs_plan (mh_api.hip) decides which stack frames of the depth-first walks live in LDS: since round 5 by the accesses a frame saves
+    (a knapsack on the tree), before that from the leaves upwards (MH_DFS_GREEDY=1 keeps the old rule for measurements).  A frame's home
+    changes where a value waits, never the arithmetic: both placements -- and an all-global stack, MH_DFS_PLACE=2 -- give the same bits,
+    at the budgets of eight and of twelve waves per CU (80 and 48 slots per lane in fp32: MH_DFS_BUDGET, the batch here is too small to
+    be given less than the whole stack otherwise), in both precisions."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    rng = np.random.default_rng(128)
+    sys_ = system_of(rt.nextJointTree(rng, 128, ("revolute", "prismatic", "sixdof")))
+    d = sys_.toModelDesc()
+    g = (0.0, 0.0, -9.81)
+    B = 8192 + 36
+    q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+    results = {}
+    for tag, env in (("knapsack, 80 slots", {"MH_DFS_BUDGET": "80"}), ("leaves upwards, 80 slots", {"MH_DFS_BUDGET": "80", "MH_DFS_GREEDY": "1"}),
+                     ("knapsack, 48 slots", {"MH_DFS_BUDGET": "48"}), ("leaves upwards, 48 slots", {"MH_DFS_BUDGET": "48", "MH_DFS_GREEDY": "1"}),
+                     ("everything in LDS that fits", {}), ("global", {"MH_DFS_PLACE": "2"})):
+        for k in ("MH_DFS_GREEDY", "MH_DFS_PLACE", "MH_DFS_BUDGET"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hm = HipModel(d)  # (the switches are read when the model is created)
+        out = []
+        for dt in (torch.float32, torch.float64):
+            tq, tqd, tqdd, ttau = (dev(torch, x, dt) for x in (q, qd, qdd, tau))
+            out += [hm.rnea(tq, tqd, tqdd, g), hm.aba(tq, tqd, ttau, g)]
+            if dt == torch.float32:
+                out += list(hm.rnea_aba(tq, tqd, tqdd, ttau, g))
+        results[tag] = out
+        hm.close()
+    ref = results["knapsack, 80 slots"]
+    assert all(torch.isfinite(x).all().item() for x in ref)
+    for tag, out in results.items():
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b), tag
+
+
 def test_layouts_soa_equals_aos(torch_cuda):
     torch = torch_cuda
     from mecano_amd import _lib
