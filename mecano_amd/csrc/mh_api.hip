@@ -17,6 +17,7 @@ extern char **environ;
 #include <unistd.h>
 
 #include <algorithm>
+#include <functional>
 #include <array>
 #include <cmath>
 #include <cstdarg>
@@ -226,6 +227,8 @@ struct mh_model
    std::vector<double> consts;
    int *d_meta = nullptr, *d_dof = nullptr, *d_cfg = nullptr, *d_prog = nullptr;
    std::vector<int> prog; // event program of the depth-first kernels
+   std::vector<int> prog_seq; // the same walk with the siblings in engine order (the kernels that read AoS rows through LDS windows)
+   int *d_prog_seq = nullptr;
    int rnea_stack = 0, aba_stack = 0, aba_hand = 0; // per-lane slots: depth stacks, ABA hand-over
    int pair_stack = 0;    // ... of the fused RNEA + ABA walk (aba_dfs_kernel<.., PAIR>)
    int dfs_aba_occ3 = 1;  // MH_DFS_ABA_OCC3=0: never the three-waves-per-SIMD build of the fp32 depth-first forward dynamics
@@ -679,18 +682,23 @@ const mh_model::DfsPlan *dfs_plan(mh_model *m, int algo, int budget)
      // the children (e global), worth(e) + sum of best[c][b - frame(e)] (e in LDS)).  128-body tree of configs[4], 80 slots per lane:
      // 5 314 -> 4 680 global slot accesses per configuration in the fused walk (model), 5 144 -> 4 134 for the forward dynamics at 48.
       std::vector<int> worth(n, 0);
+      std::vector<int> with_subtree(n, 0); // children that have children of their own: all but the last of them accumulate in the frame
+      for (int e = 0; e < n; e++)          // (the leaves are walked behind them and add to the carry: mh_model_create, build_program)
+         if (MI(e, mh::MI_PARENT) >= 0 && MI(e, mh::MI_NCH) > 0)
+            with_subtree[MI(e, mh::MI_PARENT)]++;
       for (int e = 0; e < n; e++)
       {
-         const int k = MI(e, mh::MI_NCH), jx = mh::jx_slots(MI(e, mh::MI_TYPE));
+         const int k = MI(e, mh::MI_NCH), jx = mh::jx_slots(MI(e, mh::MI_TYPE)), in_frame = std::max(0, with_subtree[e] - 1);
          if (k == 0)
             continue;
          if (algo == 0)
-            worth[e] = k == 1 ? 2 * (6 + jx) : (6 + jx + 12) + (k - 1) * 12 + 6 + (k - 2) * 12 + (6 + jx);
+            worth[e] = k == 1 ? 2 * (6 + jx) : (6 + jx + 12) + (k - 1) * 12 + 6 + in_frame * 12 + (6 + jx);
          else
          {
             const int id = algo == 2 ? 6 : 0; // the inverse dynamics' wrench (and acceleration) beside the forward dynamics' slots
             const int acc = 27 + id;
-            worth[e] = k == 1 ? 2 * (6 + jx) + 2 * id : (12 + jx + 6 + id) + (k - 1) * (12 + id) + acc + (k - 2) * 2 * acc + (12 + jx + acc);
+            worth[e] = k == 1 ? 2 * (6 + jx) + 2 * id
+                              : (12 + jx + 6 + id) + (k - 1) * (12 + id) + (in_frame > 0 ? acc + (in_frame - 1) * 2 * acc + acc : 0) + (12 + jx);
          }
       }
       const int W = budget + 1;
@@ -1178,6 +1186,8 @@ mh_status launch_dfs(Algo algo, mh_model *model, int64_t B, mh::Args<T> &A, hipS
    // every frame in LDS / every frame global: builds without the per-group branch
    const int mode = plan->glb_frames == 0 ? 0 : (plan->lds_slots == 0 ? 1 : 2);
    const void *kern = nullptr;
+   if (win)
+      A.m.prog = model->d_prog_seq; // (the windows follow the matrices in engine order)
    if (algo == ALGO_RNEA)
    {
       if (win)
@@ -2404,46 +2414,60 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->aba_hand = std::max(hand, 1);
       m->nonleaf_fraction = (double)std::count_if(nch.begin(), nch.end(), [](int c) { return c > 0; }) / (double)n;
       m->rnea_stack = std::max(m->rnea_stack, 1), m->aba_stack = std::max(m->aba_stack, 6);
-      std::vector<int> path;
-      auto pop = [&]() {
-         const int j = path.back();
-         path.pop_back();
-         int ev = (j << mh::EV_BODY_SHIFT) | mh::EV_POP;
-         if (!m->prog.empty() && m->prog.back() == (j << mh::EV_BODY_SHIFT) + (m->prog.back() & mh::EV_PARENT_REGS))
-            ev |= mh::EV_LEAF; // the previous event is VISIT(j)
-         m->prog.push_back(ev);
-      };
-      for (int e = 0; e < n; e++)
-      {
-         while (!path.empty() && path.back() != P.eparent[e])
-            pop();
-         int ev = e << mh::EV_BODY_SHIFT;
-         if (!m->prog.empty() && P.eparent[e] >= 0 && !(m->prog.back() & mh::EV_POP) && (m->prog.back() >> mh::EV_BODY_SHIFT) == P.eparent[e])
-            ev |= mh::EV_PARENT_REGS;
-         m->prog.push_back(ev);
-         path.push_back(e);
-      }
-      while (!path.empty())
-         pop();
-      std::vector<char> contributed(n, 0);
-      for (size_t i = 0; i < m->prog.size(); i++)
-      {
-         int &ev = m->prog[i];
-         if (!(ev & mh::EV_POP))
-            continue;
-         const int j = ev >> mh::EV_BODY_SHIFT, pe = P.eparent[j];
-         if (pe < 0)
-            continue;
-         const bool last = i + 1 < m->prog.size() && (m->prog[i + 1] & mh::EV_POP) && (m->prog[i + 1] >> mh::EV_BODY_SHIFT) == pe;
-         if (last)
-            ev |= mh::EV_LAST_CHILD;
-         else
+      // The walk: depth-first, the children of a body in the order [those with children of their own | the leaves].  A child's contribution
+      // to its parent (wrench; articulated inertia + bias wrench) is either accumulated in the parent's frame (read-modify-write of 6 / 27 /
+      // 33 slots) or handed over in registers, the carry.  The carry survives a LEAF sibling's two events (they never touch it), so the
+      // last child with children of its own sets it and every leaf behind it adds to it: only the other children with subtrees go through
+      // the frame (128-body tree of configs[4]: 26 of 127 child pops, before the leaves were sorted behind: 64).
+      // (The kernels that read AoS rows through LDS windows consume the matrices in engine order and refill synchronously on a jump: they
+      // keep a program in engine order -- prog_seq --, with the same carry rule applied to whatever leaves happen to come last.)
+      auto build_program = [&](bool leaves_last, std::vector<int> &prog) {
+         std::vector<std::vector<int>> kids(n);
+         std::vector<int> roots;
+         for (int e = 0; e < n; e++)
+            (P.eparent[e] >= 0 ? kids[P.eparent[e]] : roots).push_back(e);
+         if (leaves_last)
+            for (int e = 0; e < n; e++)
+               std::stable_partition(kids[e].begin(), kids[e].end(), [&](int c) { return nch[c] > 0; });
+         std::vector<size_t> pop_at(n, 0);
+         std::function<void(int)> walk = [&](int e) {
+            int ev = e << mh::EV_BODY_SHIFT;
+            if (!prog.empty() && P.eparent[e] >= 0 && !(prog.back() & mh::EV_POP) && (prog.back() >> mh::EV_BODY_SHIFT) == P.eparent[e])
+               ev |= mh::EV_PARENT_REGS;
+            prog.push_back(ev);
+            for (int c : kids[e])
+               walk(c);
+            int pv = (e << mh::EV_BODY_SHIFT) | mh::EV_POP;
+            if (prog.back() == (e << mh::EV_BODY_SHIFT) + (prog.back() & mh::EV_PARENT_REGS))
+               pv |= mh::EV_LEAF; // the previous event is VISIT(e)
+            pop_at[e] = prog.size();
+            prog.push_back(pv);
+         };
+         for (int r : roots)
+            walk(r);
+         for (int e = 0; e < n; e++)
          {
-            if (!contributed[pe])
-               ev |= mh::EV_ACC_FIRST;
-            contributed[pe] = 1;
+            const std::vector<int> &k = kids[e];
+            if (k.empty())
+               continue;
+            int first_carried = 0; // the last child with children of its own (only leaves behind it), or the first child
+            for (size_t i = 0; i < k.size(); i++)
+               if (nch[k[i]] > 0)
+                  first_carried = (int)i;
+            for (size_t i = 0; i < k.size(); i++)
+            {
+               int &ev = prog[pop_at[k[i]]];
+               if ((int)i < first_carried)
+                  ev |= i == 0 ? mh::EV_ACC_FIRST : 0;
+               else
+                  ev |= (int)i == first_carried ? mh::EV_LAST_CHILD : mh::EV_CARRY_ADD;
+            }
+            if (first_carried > 0)
+               prog[pop_at[e]] |= mh::EV_ACC_USED;
          }
-      }
+      };
+      build_program(!getenv("MH_DFS_ENGINE_ORDER"), m->prog); // (MH_DFS_ENGINE_ORDER=1: the siblings in engine order everywhere, for measurements)
+      build_program(false, m->prog_seq);
    }
 
    // ---- device side
@@ -2478,6 +2502,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       e = up((void **)&m->d_cfg, m->cfg_map.data(), m->cfg_map.size() * sizeof(int));
    if (e == hipSuccess)
       e = up((void **)&m->d_prog, m->prog.data(), m->prog.size() * sizeof(int));
+   if (e == hipSuccess)
+      e = up((void **)&m->d_prog_seq, m->prog_seq.data(), m->prog_seq.size() * sizeof(int));
    if (e == hipSuccess)
       e = up((void **)&m->d_consts64, m->consts.data(), m->consts.size() * sizeof(double));
    if (e == hipSuccess)
@@ -2661,6 +2687,7 @@ static void release_model(mh_model *m)
    (void)hipFree(m->d_dof);
    (void)hipFree(m->d_cfg);
    (void)hipFree(m->d_prog);
+   (void)hipFree(m->d_prog_seq);
    (void)hipFree(m->d_consts64);
    (void)hipFree(m->d_consts32);
    free_scratch(m);

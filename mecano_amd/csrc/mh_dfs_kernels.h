@@ -38,8 +38,12 @@ enum : int
    EV_POP = 1,          // else VISIT
    EV_PARENT_REGS = 2,  // VISIT: the previous event was VISIT(parent): its state is in registers
    EV_LEAF = 2,         // POP: the previous event was VISIT(this body): its state is in registers
-   EV_LAST_CHILD = 4,   // POP: next event is POP(parent): hand the contribution over in registers
+   EV_LAST_CHILD = 4,   // POP: hand the contribution over in registers (the carry): the parent's last child with children of its own -- or its
+                        // first child when all are leaves; only leaf siblings follow before POP(parent), and a leaf's events leave the carry alone
    EV_ACC_FIRST = 8,    // POP (ABA): first contribution to the parent's accumulator: store, do not add
+   EV_CARRY_ADD = 16,   // POP of a leaf sibling behind the EV_LAST_CHILD one: ADD the contribution to the carry (round 5: of the 64 child pops
+                        // of the 128-body tree of configs[4] that read and wrote 27-33 accumulator slots of their parent's frame, 38 are such leaves)
+   EV_ACC_USED = 32,    // POP of a body with children: some child went through the frame's accumulators (else they are never read)
    EV_BODY_SHIFT = 8
 };
 // stack-frame slots a joint transform takes (revolute: cos, sin; prismatic: q; fixed: nothing)
@@ -468,6 +472,8 @@ __global__ void __launch_bounds__(64) rnea_dfs_kernel(Args<T> A)
                   const SV<T> fp = force_up(type, jx, Xb, f);
                   if (ev & EV_LAST_CHILD)
                      carry = fp;
+                  else if (ev & EV_CARRY_ADD)
+                     carry = carry + fp;
                   else
                      st_add6<T>(S, mi[MI_PFR_R], fp);
                }
@@ -697,7 +703,7 @@ __global__ void __launch_bounds__(64, OCC3 ? 3 : 1) aba_dfs_kernel(Args<T> A)
                   pA = st_load6<T>(S, fr) + pcarry;
                   jx = st_load_jx<T>(S, fr + 12, type);
                   add(IA, Icarry);
-                  if (nch >= 2)
+                  if (ev & EV_ACC_USED)
                   {
                      add(IA, st_load_abi<T>(S, fr + 18 + jxs));
                      pA = pA + st_load6<T>(S, fr + 39 + jxs);
@@ -713,6 +719,8 @@ __global__ void __launch_bounds__(64, OCC3 ? 3 : 1) aba_dfs_kernel(Args<T> A)
                      const SV<T> fp = force_up(type, jx, Xb, f);
                      if (ev & EV_LAST_CHILD)
                         rcarry = fp;
+                     else if (ev & EV_CARRY_ADD)
+                        rcarry = rcarry + fp;
                      else
                         st_add6<T>(S, mi[MI_PFR_R], fp);
                   }
@@ -801,6 +809,8 @@ __global__ void __launch_bounds__(64, OCC3 ? 3 : 1) aba_dfs_kernel(Args<T> A)
                   }
                   if (ev & EV_LAST_CHILD)
                      Icarry = Ia, pcarry = pp;
+                  else if (ev & EV_CARRY_ADD)
+                     add(Icarry, Ia), pcarry = pcarry + pp;
                   else
                   {
                      const int acc = mi[MI_PACC_A];
