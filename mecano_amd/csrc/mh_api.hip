@@ -203,6 +203,7 @@ struct SpecLib
    int (*launch_zvb)(int flags, const void *args, void *taup, void *cs, long cs_stride, int groups, int which, void *stream) = nullptr;
    // ... as one launch, both jobs fused in a workgroup (spec_zvf_kernel)
    int (*zvf_usable)(void) = nullptr;
+   int (*zvf_pair_usable)(void) = nullptr; // 1: launch_zvf serves the pair call too (args->in3b = qdd, args->outb = tau)
    int (*launch_zvf)(int flags, const void *args, int groups, void *stream) = nullptr;
    int (*launch_rnea_ahead)(int flags, const void *args, int groups, void *stream) = nullptr;
 };
@@ -287,6 +288,7 @@ struct mh_model
    int use_zvb = 1;       // MH_ZVB=0: never; 1: batches of two or more groups of 64 configurations per CU (default); 2: whenever the call qualifies; MH_ZVB_WHICH = 1 | 2: one of the two launches only (timing)
    int zvb_which = 3;
    int use_zvf = 1;       // MH_ZVF=0: never the fused one-launch form; 1: where the two-launch form would be taken (default); 2: whenever the call qualifies
+   int use_zvf_pair = 1;  // MH_ZVF_PAIR=0: the pair call of device-filling batches as two launches (A/B measurements)
    int zv_epoch = 0;
    int *zv_error_host = nullptr, *zv_error_dev = nullptr;
    int zv_same_l2 = 0;    // MH_ZV_SAME_L2=1 (experiment, off by default; one-stage hand-off only: the two-stage form of identity index maps is write-through): bias rows and flag of a group whose two jobs prove to sit behind the same L2
@@ -1821,6 +1823,7 @@ void try_load_spec(mh_model *m, const Plan &P)
    s.zvb_lds_bytes = (decltype(s.zvb_lds_bytes))dlsym(h, "mh_spec_zvb_lds_bytes");
    s.launch_zvb = (decltype(s.launch_zvb))dlsym(h, "mh_spec_launch_zvb");
    s.zvf_usable = (decltype(s.zvf_usable))dlsym(h, "mh_spec_zvf_usable");
+   s.zvf_pair_usable = (decltype(s.zvf_pair_usable))dlsym(h, "mh_spec_zvf_pair_usable");
    s.launch_zvf = (decltype(s.launch_zvf))dlsym(h, "mh_spec_launch_zvf");
    s.launch_rnea_ahead = (decltype(s.launch_rnea_ahead))dlsym(h, "mh_spec_launch_rnea_ahead");
    s.rnea_crba_lds_bytes = (decltype(s.rnea_crba_lds_bytes))dlsym(h, "mh_spec_rnea_crba_lds_bytes");
@@ -2529,6 +2532,8 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
       m->use_zvb = atoi(e);
    if (const char *e = getenv("MH_ZVF"))
       m->use_zvf = atoi(e);
+   if (const char *e = getenv("MH_ZVF_PAIR"))
+      m->use_zvf_pair = atoi(e);
    if (const char *e = getenv("MH_RNEA_AHEAD"))
       m->use_rnea_ahead = atoi(e);
    if (const char *e = getenv("MH_ZV_STEP"))
@@ -3309,6 +3314,27 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
       HIP_TRY(hipStreamWaitEvent(s, model->pair_join, 0));
       return rb != MH_OK ? rb : ra;
    };
+   // Device-filling batches: the fused forward-dynamics kernel computes tau too (its inverse-dynamics phase has h, one more walk without
+   // velocities adds M(q) qdd of the caller's accelerations: mh_zv_kernels.h, ZvfDelta) -- one launch instead of the inverse dynamics'
+   // own (humanoid, 262 144 configurations: 254 us for the two).  MH_ZVF_PAIR=0: the two launches.
+   if (model->n_locked == 0 && model->use_spec && model->use_zvf_pair && opts.layout == MH_LAYOUT_AOS && opts.consider_coriolis && opts.consider_accelerations
+       && zvf_ok(model, B, false) && model->spec.zvf_pair_usable && model->spec.zvf_pair_usable())
+   {
+      mh::Args<double> Z{};
+      Z.m = dev_model<double>(model);
+      Z.B = B;
+      Z.q = q, Z.qd = qd, Z.in3 = tau, Z.fext = f_ext, Z.out = qdd_out;
+      Z.in3b = qdd, Z.outb = tau_out;
+      Z.q_bs = model->nq, Z.q_es = 1, Z.v_bs = model->nv, Z.v_es = 1, Z.f_bs = (long)model->n * 6, Z.f_es = 1;
+      set_root_acceleration(Z, opts, gravity);
+      Z.coriolis = 1, Z.accel = 1;
+      const long groups = std::min<long>((B + 63) / 64, (long)model->cu_count * 2);
+      const int rcz = model->spec.launch_zvf(SPEC_IO_LDS | SPEC_IDENT, &Z, (int)groups, opts.stream);
+      if (rcz == 0)
+         return MH_OK;
+      if (rcz != (int)hipErrorNotSupported)
+         return fail(MH_ERR_HIP, "fused forward + inverse dynamics failed to launch: %s", hipGetErrorString((hipError_t)rcz));
+   }
    if (!fusable)
       return two_calls();
    mh::Args<double> A{};

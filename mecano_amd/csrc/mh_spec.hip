@@ -464,11 +464,29 @@ int mh_spec_launch_zvf(int flags, const void *args, int groups, void *stream)
          else
             return (int)hipErrorNotSupported;
       }
+      if (A.in3b && A.outb)
+      { // the pair call: args->in3b = qdd of the caller, args->outb = tau (mh_zv_kernels.h: ZvfDelta)
+         if constexpr (mh::ZvfPlan<TP>::pair_usable())
+         {
+            static LdsAttr attr_pair;
+            return (int)launch_lds(&mh::spec_zvf_kernel<TP, double, true, false, true>, A, groups, (size_t)mh_spec_zvf_lds_bytes(), attr_pair, (hipStream_t)stream);
+         }
+         else
+            return (int)hipErrorNotSupported;
+      }
       static LdsAttr attr;
       return (int)launch_lds(&mh::spec_zvf_kernel<TP, double, true>, A, groups, (size_t)mh_spec_zvf_lds_bytes(), attr, (hipStream_t)stream);
    }
    else
       return (int)hipErrorNotSupported;
+}
+// 1: mh_spec_launch_zvf serves the pair call too (args->in3b, args->outb)
+int mh_spec_zvf_pair_usable(void)
+{
+   if constexpr (SPL::usable())
+      return mh::ZvfPlan<TP>::pair_usable() ? 1 : 0;
+   else
+      return 0;
 }
 #endif
 #if MH_SPEC_PART != 2

@@ -2083,10 +2083,146 @@ struct ZvfPlan
    // the trunk slots are written while the inverse dynamics' exchange area and parking area are still being read: they must fit under
    // the rows of q and qd, which are dead by then
    static constexpr bool usable() { return S::usable() && joints_ok() && ST::TRUNK_SLOTS <= NQ + NV && lds_slots() * 64 * 8 * 2 <= 160 * 1024; }
+   // the pair call's last phase: [qdd rows | tau rows | limb wrenches] behind the trunk's slots, in front of the mailed limb's
+   static constexpr bool pair_usable() { return usable() && ST::TRUNK_SLOTS + 2 * NV + S::n_limbs() * 6 <= mail_base(); }
    // a simulation step re-stages the rows of q and qd behind the outward sweep, over the (dead) trunk slots and fold records: they must end
    // in front of the result rows
    static constexpr bool step_usable() { return usable() && NQ + NV <= ST::TRUNK_SLOTS + S::n_limbs() * 12; }
 };
+// ---- The pair call (mh_rnea_aba_f64) of device-filling batches in the SAME launch (round 5).  Inverse dynamics is linear in the joint
+// accelerations: tau = h(q, qd, a_root, f_ext) + M(q) qdd, and the fused kernel has h -- its first phase leaves tau_in - h of every joint
+// where the bias fold reads it, and they are still there when the group's accelerations have been written.  What is missing is M(q) qdd of
+// the caller's qdd: one more walk WITHOUT velocities -- da = X da_parent + S qdd outwards, df = I da + sum X^T df_child inwards,
+// tau = tau_in - (tau_in - h) + S^T df -- with the pairs (cos, sin) the other phases left in the store's slots: no sincos, no cross
+// products, no staging of q and qd.  It runs behind the outward sweep, when the workgroup's LDS is free but for the trunk's slots:
+// [qdd rows | tau_in rows, overwritten in place by tau | limb wrenches].  The limbs are walked by the waves that hold their pairs (the
+// owners of the first phase), each wave walks da down the trunk to its limbs for itself, wave 0 folds the trunk (MODE 1: limb roots from the
+// exchange area).  Against a launch of its own for the inverse dynamics (q, qd, qdd staged again, every sincos again, its own barriers
+// and tail: 95 us at 262 144 configurations beside the forward dynamics' 166) this phase adds ~25 % to the group.
+template <class TP, int J, typename T, class CX>
+MH_DEV JX<T> zvf_delta_joint(const CX &cx)
+{
+   JX<T> jx;
+   jx.c = T(1), jx.s = T(0), jx.d = T(0);
+   if constexpr (TP::type[J] == JT_REVOLUTE)
+      jx.c = cx.st.template get<J, 7>(), jx.s = cx.st.template get<J, 8>();
+   return jx;
+}
+// da of trunk body J, walked down from the root
+template <class TP, int J, typename T, class CX>
+MH_DEV SV<T> zvf_delta_trunk_a(const CX &cx)
+{
+   constexpr int TYPE = TP::type[J], P = TP::parent[J];
+   const SV<T> aJ = spec_vec<TYPE, Tree<TP>::dof_ofs(J), 1, CX, T>(cx, true);
+   if constexpr (P < 0)
+      return aJ;
+   else
+   {
+      const SV<T> ap = zvf_delta_trunk_a<TP, P, T, CX>(cx);
+      const CRef<T, false> c{cx.C + J * MC_STRIDE};
+      return motion_down(TYPE, zvf_delta_joint<TP, J, T, CX>(cx), load_xb_j<TP, J, T>(c), ap) + aJ;
+   }
+}
+template <class TP, int J, int K, class CX, typename T>
+MH_DEV void zvf_delta_tau1(const CX &cx, T v)
+{ // the row holds tau_in: tau = tau_in - (tau_in - h) + S^T df
+   constexpr int DO = Tree<TP>::dof_ofs(J) + K;
+   cx.lo[cx.di(DO)] = cx.lo[cx.di(DO)] - zvf_tau_get1<TP, J, K, CX, T>(cx) + v;
+}
+template <class TP, int J, typename T, class CX, int MODE = 0>
+struct ZvfDelta
+{
+   template <int K>
+   static MH_DEV void children(const CX &cx, const SV<T> &a, SV<T> &f)
+   {
+      if constexpr (K < Tree<TP>::n_children(J))
+      {
+         constexpr int C = Tree<TP>::child(J, K);
+         if constexpr (MODE == 1 && !Split<TP>::is_trunk(C))
+            f = f + x_get6<Split<TP>::limb_index(C), 6, 0, CX, T>(cx);
+         else
+            f = f + ZvfDelta<TP, C, T, CX, MODE>::run(cx, a);
+         children<K + 1>(cx, a, f);
+      }
+   }
+   static MH_DEV SV<T> run(const CX &cx, const SV<T> &ap)
+   {
+      MH_BODY_FENCE();
+      constexpr int TYPE = TP::type[J];
+      constexpr bool HAS_PARENT = TP::parent[J] >= 0;
+      const T *cp = cx.C + J * MC_STRIDE;
+      asm volatile("" : "+s"(cp));
+      const CRef<T, false> c{cp};
+      const SV<T> aJ = spec_vec<TYPE, Tree<TP>::dof_ofs(J), 1, CX, T>(cx, true);
+      SV<T> a = aJ;
+      if constexpr (HAS_PARENT)
+         a = motion_down(TYPE, zvf_delta_joint<TP, J, T, CX>(cx), load_xb_j<TP, J, T>(c), ap) + aJ;
+      SV<T> f = mul(load_inertia<T>(c), a);
+      MH_BODY_FENCE();
+      children<0>(cx, a, f);
+      MH_BODY_FENCE();
+      if constexpr (TYPE == JT_REVOLUTE)
+         zvf_delta_tau1<TP, J, 0, CX, T>(cx, f.a.z);
+      else if constexpr (TYPE == JT_PRISMATIC)
+         zvf_delta_tau1<TP, J, 0, CX, T>(cx, f.l.z);
+      else if constexpr (TYPE == JT_SIXDOF)
+      {
+         zvf_delta_tau1<TP, J, 0, CX, T>(cx, f.a.x), zvf_delta_tau1<TP, J, 1, CX, T>(cx, f.a.y), zvf_delta_tau1<TP, J, 2, CX, T>(cx, f.a.z);
+         zvf_delta_tau1<TP, J, 3, CX, T>(cx, f.l.x), zvf_delta_tau1<TP, J, 4, CX, T>(cx, f.l.y), zvf_delta_tau1<TP, J, 5, CX, T>(cx, f.l.z);
+      }
+      const V3<T> Z{T(0), T(0), T(0)};
+      SV<T> up{Z, Z};
+      if constexpr (HAS_PARENT)
+      { // (the pose is read again rather than kept across the subtree: see RneaSub)
+         const T *c2p = cx.C + J * MC_STRIDE;
+         asm volatile("" : "+s"(c2p));
+         up = force_up(TYPE, zvf_delta_joint<TP, J, T, CX>(cx), load_xb_j<TP, J, T>(CRef<T, false>{c2p}), f);
+      }
+      MH_BODY_FENCE();
+      return up;
+   }
+};
+// the limbs of wave W -- under the owners of the kernel's first phase: the mailed limb's pair and tau - h are in LDS, so the wave that
+// shares its trunk walk takes it here too --: da walked down the trunk to each, the limb's wrench into the exchange area
+template <class TP, int W, int K, typename T, class CX>
+MH_DEV void zvf_delta_limbs_of(const CX &cx)
+{
+   using S = Split<TP>;
+   if constexpr (K < S::n_limbs())
+   {
+      if constexpr (S::template owner_sel<(ZvfPlan<TP>::use_mail() ? 2 : 1)>(K) == W)
+      {
+         constexpr int R = S::limb_root(K), P = TP::parent[R];
+         const V3<T> Z{T(0), T(0), T(0)};
+         SV<T> ap{Z, Z};
+         if constexpr (P >= 0)
+            ap = zvf_delta_trunk_a<TP, P, T, CX>(cx);
+         x_put6<K, 6, 0, CX, T>(cx, ZvfDelta<TP, R, T, CX, 0>::run(cx, ap));
+      }
+      zvf_delta_limbs_of<TP, W, K + 1, T, CX>(cx);
+   }
+}
+template <class TP, int W, typename T, class CX>
+MH_DEV void zvf_delta_limbs(const CX &cx)
+{
+   if constexpr (W < 4)
+   {
+      if (cx.wave == W)
+         zvf_delta_limbs_of<TP, W, 0, T, CX>(cx);
+      else
+         zvf_delta_limbs<TP, W + 1, T, CX>(cx);
+   }
+}
+template <class TP, typename T, class CX, int K = 0>
+MH_DEV void zvf_delta_roots(const CX &cx)
+{
+   if constexpr (K < Tree<TP>::n_children(-1))
+   {
+      const V3<T> Z{T(0), T(0), T(0)};
+      (void)ZvfDelta<TP, Tree<TP>::child(-1, K), T, CX, 1>::run(cx, SV<T>{Z, Z});
+      zvf_delta_roots<TP, T, CX, K + 1>(cx);
+   }
+}
 template <typename T, int NQ, int NV>
 struct ZvfRows
 { // the three input matrices' rows of the NEXT group (requested during the fold of the current one)
@@ -2100,7 +2236,7 @@ struct ZvfRows
    }
 };
 // one group of 64 configurations; `next`: the group whose rows are requested on the way (the same group again on the last turn)
-template <class TP, typename T, bool IDENT, bool STEP = false>
+template <class TP, typename T, bool IDENT, bool STEP = false, bool PAIR = false>
 MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRows<T, ZvfPlan<TP>::NQ, ZvfPlan<TP>::NV> &rows_ahead)
 {
    using S = Split<TP>;
@@ -2196,15 +2332,37 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
       wave_copy_out<T, 256>(A.q_next + cfg0 * nq, lq, rows * nq);
       wave_copy_out<T, 256>(A.qd_next + cfg0 * nv, lqd, rows * nv);
    }
-   if constexpr (MH_ZVF_AHEAD == 3)
+   if constexpr (MH_ZVF_AHEAD == 3 && !PAIR)
       rows_ahead.request(A, next); // behind the outward sweep (nothing else is alive any more): in flight during the copy-out
+   RowRegs<T, PAIR ? ZvfPlan<TP>::NV : 1, 256> ra, rt; // PAIR: the caller's accelerations and the efforts once more, in flight during the copy-out
+   if constexpr (PAIR)
+      ra.issue(A.in3b + cfg0 * nv, rows), rt.issue(A.in3 + cfg0 * nv, rows);
    zv_lds_barrier();
    wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
    ZV_STAMP(2, 11);
+   if constexpr (PAIR)
+   { // ---- tau = h + M(q) qdd of the caller's accelerations (A.in3b) into A.outb: see ZvfDelta
+      const lds_ptr<T> lqdd = lxc2, ltau = lqdd + 64 * nv, lxd = ltau + 64 * nv;
+      zv_lds_barrier(); // the accelerations have left their rows
+      ra.commit(lqdd), rt.commit(ltau);
+      if constexpr (MH_ZVF_AHEAD == 3)
+         rows_ahead.request(A, next); // (in flight during the whole phase)
+      zv_lds_barrier();
+      cx.lx = lqdd + lane * nv, cx.lo = ltau + lane * nv;
+      cx.xbase = lxd + lane;
+      asm volatile("" ::: "memory");
+      if (active)
+         zvf_delta_limbs<TP, 0, T, CX>(cx);
+      zv_lds_barrier(); // the limbs' wrenches are in the exchange area
+      if (active && wave == 0)
+         zvf_delta_roots<TP, T, CX>(cx);
+      zv_lds_barrier();
+      wave_copy_out<T, 256>(A.outb + cfg0 * nv, ltau, rows * nv);
+   }
    zv_lds_barrier(); // the rows are committed over the result rows by the next turn
    ZV_STAMP(2, 12);
 }
-template <class TP, typename T, bool IDENT, bool STEP = false>
+template <class TP, typename T, bool IDENT, bool STEP = false, bool PAIR = false>
 __global__ void __launch_bounds__(256, 2) spec_zvf_kernel(Args<T> A)
 {
    extern __shared__ double lds_raw[];
@@ -2213,6 +2371,6 @@ __global__ void __launch_bounds__(256, 2) spec_zvf_kernel(Args<T> A)
    if constexpr (MH_ZVF_AHEAD)
       rows_ahead.request(A, blockIdx.x);
    for (long k = blockIdx.x; k < ngroups; k += gridDim.x)
-      zvf_group<TP, T, IDENT, STEP>(A, k, k + gridDim.x < ngroups ? k + gridDim.x : k, (lds_ptr<T>)lds_raw, rows_ahead);
+      zvf_group<TP, T, IDENT, STEP, PAIR>(A, k, k + gridDim.x < ngroups ? k + gridDim.x : k, (lds_ptr<T>)lds_raw, rows_ahead);
 }
 } // namespace mh

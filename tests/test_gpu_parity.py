@@ -1893,6 +1893,44 @@ def test_config4_at_full_size_on_one_gpu(torch_cuda):
     assert torch.equal(plain, back)
 
 
+def test_pair_call_of_device_filling_batches_is_one_launch(torch_cuda, monkeypatch):
+    """mh_rnea_aba_f64 beyond one group of 64 configurations per CU: the fused forward-dynamics kernel also writes
+    tau = h + M(q) qdd -- h from its inverse-dynamics phase (InverseDynamicsCalculator.java:873-959 at zero joint acceleration), M(q) qdd from
+    one more walk without velocities behind the outward sweep (mh_zv_kernels.h: ZvfDelta).  Against the two single calls on every row (the
+    accelerations bit for bit: the same phases; the efforts to rounding: h + M qdd is summed in another order), against the oracle on
+    a sample, with external wrenches and a 6-D root acceleration, a ragged last group, and the two-launch form (MH_ZVF_PAIR=0)."""
+    torch = torch_cuda
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    from oracle.cpu_oracle import OracleModel
+    rng = np.random.default_rng(77)
+    sys_ = rt.nextHumanoid(rng)
+    d = sys_.toModelDesc()
+    om = OracleModel(d)
+    g = (0.3, -0.2, -9.81)
+    hm = HipModel(d)
+    assert hm.kernel_variant.startswith("topo:")
+    for B, wrench in ((20480 + 37, False), (32768, True), (70000, False)):
+        q, qd, qdd, tau = rt.nextState(rng, sys_, B)
+        fext = rng.uniform(-1, 1, (B, d.n_joints, 6)) if wrench else None
+        tq, tqd, tqdd, ttau = (dev(torch, x) for x in (q, qd, qdd, tau))
+        tf = dev(torch, fext) if wrench else None
+        t_pair, a_pair = hm.rnea_aba(tq, tqd, tqdd, ttau, g, tf)
+        t_one, a_one = hm.rnea(tq, tqd, tqdd, g, tf), hm.aba(tq, tqd, ttau, g, tf)
+        assert torch.equal(a_pair, a_one)
+        scale = t_one.abs().max().item()
+        assert (t_pair - t_one).abs().max().item() <= 1e-12 * scale, B
+        idx = np.arange(0, B, 499)
+        close(t_pair.cpu().numpy()[idx], om.rnea(q[idx], qd[idx], qdd[idx], g, fext[idx] if wrench else None), 1e-10, absolute=True, label=f"pair tau {B}")
+        close(a_pair.cpu().numpy()[idx], om.aba(q[idx], qd[idx], tau[idx], g, fext[idx] if wrench else None), 1e-10, absolute=True, label=f"pair qdd {B}")
+    # the two-launch form gives the single calls' bits; both forms leave the inputs alone
+    monkeypatch.setenv("MH_ZVF_PAIR", "0")
+    hm2 = HipModel(d)
+    t2, a2 = hm2.rnea_aba(tq, tqd, tqdd, ttau, g)
+    assert torch.equal(t2, t_one) and torch.equal(a2, a_one)
+    assert torch.equal(tqdd, dev(torch, qdd)) and torch.equal(ttau, dev(torch, tau))
+
+
 def test_reference_signatures_on_one_configuration(torch_cuda):
     """The calculators' OWN signatures (VERDICT r2 missing 2; BASELINE configs[0] is exactly this plumbing): compute() reading q, qd, qdd /
     tau from the joints, compute(matrix), setExternalWrench(body, wrench) / getExternalWrench, getComputedJointTau,
