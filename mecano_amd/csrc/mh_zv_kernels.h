@@ -2098,7 +2098,9 @@ struct ZvfPlan
 // [qdd rows | tau_in rows, overwritten in place by tau | limb wrenches].  The limbs are walked by the waves that hold their pairs (the
 // owners of the first phase), each wave walks da down the trunk to its limbs for itself, wave 0 folds the trunk (MODE 1: limb roots from the
 // exchange area).  Against a launch of its own for the inverse dynamics (q, qd, qdd staged again, every sincos again, its own barriers
-// and tail: 95 us at 262 144 configurations beside the forward dynamics' 166) this phase adds ~25 % to the group.
+// and tail: 95 us at 262 144 configurations beside the forward dynamics' 166) this phase adds 8 us to a group of 17 -- the limbs' walk
+// 3.7-4.6 us, wave 0's fold of the trunk 2.2, copy-out 0.4 (profiles/r05_zvf_phase_stamps_pair.txt); without the scheduling fences between
+// a body's phases the same (profiles/r05_ab_delta_fences.txt).
 template <class TP, int J, typename T, class CX>
 MH_DEV JX<T> zvf_delta_joint(const CX &cx)
 {
@@ -2341,9 +2343,12 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
    wave_copy_out<T, 256>(A.out + cfg0 * nv, lres, rows * nv);
    ZV_STAMP(2, 11);
    if constexpr (PAIR)
-   { // ---- tau = h + M(q) qdd of the caller's accelerations (A.in3b) into A.outb: see ZvfDelta
+   { // ---- tau = h + M(q) qdd of the caller's accelerations (A.in3b) into A.outb: see ZvfDelta.  The two matrices' rows land over the
+     // fold's records (dead since the outward sweep began), in front of the result rows that are being copied out; the limbs' wrenches go
+     // over the result rows, behind the barrier that ends the copy.
       const lds_ptr<T> lqdd = lxc2, ltau = lqdd + 64 * nv, lxd = ltau + 64 * nv;
-      zv_lds_barrier(); // the accelerations have left their rows
+      if constexpr (2 * ZvfPlan<TP>::NV > S::n_limbs() * 12)
+         zv_lds_barrier(); // (the tau rows reach into the result rows: wait for the copy)
       ra.commit(lqdd), rt.commit(ltau);
       if constexpr (MH_ZVF_AHEAD == 3)
          rows_ahead.request(A, next); // (in flight during the whole phase)
@@ -2353,9 +2358,11 @@ MH_DEV void zvf_group(const Args<T> &A, long k, long next, lds_ptr<T> lds, ZvfRo
       asm volatile("" ::: "memory");
       if (active)
          zvf_delta_limbs<TP, 0, T, CX>(cx);
+      ZV_STAMP(2, 13);
       zv_lds_barrier(); // the limbs' wrenches are in the exchange area
       if (active && wave == 0)
          zvf_delta_roots<TP, T, CX>(cx);
+      ZV_STAMP(2, 14);
       zv_lds_barrier();
       wave_copy_out<T, 256>(A.outb + cfg0 * nv, ltau, rows * nv);
    }
