@@ -58,7 +58,9 @@
  * or two launches where the code object has no fused kernel; MH_ZV / MH_ZVF / MH_ZVB in the environment force each off or on).  The
  * formulations agree to about 1e-13 relative, not bit for bit: the same configuration evaluated inside batches of different sizes -- e.g.
  * in shards of different sizes on different ranks -- may differ in its last bits.  MH_ZV=0 MH_ZVF=0 MH_ZVB=0 pins the one-job form.
- * (Inverse dynamics and the mass matrix have one formulation per code object: their results do not depend on the batch size.)
+ * (Inverse dynamics and the mass matrix have one formulation per code object: their results do not depend on the batch size -- with one
+ * exception: beyond one group of 64 configurations per CU mh_rnea_aba_f64 forms its efforts as h + M(q) qdd inside the forward-dynamics
+ * launch, within ~1e-15 relative of mh_rnea_f64's, not bit for bit; MH_ZVF_PAIR=0 in the environment keeps the two launches.)
  *
  * No function throws or aborts; every entry point returns an mh_status and
  * mh_last_error() gives a thread-local message.  The library never falls back
