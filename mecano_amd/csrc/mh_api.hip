@@ -663,19 +663,21 @@ const mh_model::DfsPlan *dfs_plan(mh_model *m, int algo, int budget)
    // (The inverse dynamics at twelve waves per CU -- 48 slots per lane -- keeps the old placement: it waits on its frames more than it
    // moves them, and the frames next to the leaves are the ones read back right after they were written: 2.92 ms against 3.00 at 1 M
    // configurations, while at eight waves the knapsack wins 2 %: profiles/r05_c5_frame_placement.txt.)
-   if (m->dfs_place_greedy || (algo == 0 && budget < 64))
+   bool all_fit = true;
    { // rounds 2-4: from the leaves upwards, whatever the frame is worth
       for (int e = n - 1; e >= 0; e--)
       { // engine order is depth-first: children come after their parent
          int need = below[e];
          if (frame[e] > 0 && below[e] + frame[e] <= budget)
             home[e] = 1, need += frame[e];
+         else if (frame[e] > 0)
+            all_fit = false;
          const int pe = MI(e, mh::MI_PARENT);
          if (pe >= 0)
             below[pe] = std::max(below[pe], need);
       }
    }
-   else
+   if (!(m->dfs_place_greedy || (algo == 0 && budget < 64) || all_fit)) // (every frame in LDS already: nothing to choose)
    { // Round 5: by what a frame in LDS SAVES.  A frame is touched 2 (6 + jx) times under a single child, but under k children it is
      // written at the visit, re-read by every later child (v, w / a), read and written by the pop of every child that is not the last
      // (the 27 accumulators of the forward dynamics, the 6 of the inverse dynamics) and read at its own pop: 100 accesses for 47 slots at
@@ -2433,21 +2435,40 @@ mh_status mh_model_create(const mh_model_desc *d, mh_model_t *model_out)
             for (int e = 0; e < n; e++)
                std::stable_partition(kids[e].begin(), kids[e].end(), [&](int c) { return nch[c] > 0; });
          std::vector<size_t> pop_at(n, 0);
-         std::function<void(int)> walk = [&](int e) {
+         auto visit = [&](int e) {
             int ev = e << mh::EV_BODY_SHIFT;
             if (!prog.empty() && P.eparent[e] >= 0 && !(prog.back() & mh::EV_POP) && (prog.back() >> mh::EV_BODY_SHIFT) == P.eparent[e])
                ev |= mh::EV_PARENT_REGS;
             prog.push_back(ev);
-            for (int c : kids[e])
-               walk(c);
+         };
+         auto pop = [&](int e) {
             int pv = (e << mh::EV_BODY_SHIFT) | mh::EV_POP;
             if (prog.back() == (e << mh::EV_BODY_SHIFT) + (prog.back() & mh::EV_PARENT_REGS))
                pv |= mh::EV_LEAF; // the previous event is VISIT(e)
             pop_at[e] = prog.size();
             prog.push_back(pv);
          };
+         std::vector<std::pair<int, size_t>> path; // (body, next child to walk): an explicit stack -- a chain of 100 000 bodies is a model too
          for (int r : roots)
-            walk(r);
+         {
+            visit(r);
+            path.emplace_back(r, 0);
+            while (!path.empty())
+            {
+               const int e = path.back().first;
+               if (path.back().second < kids[e].size())
+               {
+                  const int c = kids[e][path.back().second++];
+                  visit(c);
+                  path.emplace_back(c, 0);
+               }
+               else
+               {
+                  pop(e);
+                  path.pop_back();
+               }
+            }
+         }
          for (int e = 0; e < n; e++)
          {
             const std::vector<int> &k = kids[e];
