@@ -199,6 +199,52 @@ def live_traffic(B, config=0):
     return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
 
 
+def _pmc_call_sum(counter, B, config, per_call, parts, min_grid=65536):
+    """Bytes counter of a call that is several launches (config 5: one depth-first walk + six transposes): one child pass as in _pmc_pass;
+    the counter summed over every BIG launch (>= min_grid threads: the create-time self-check runs the same kernels on a few hundred
+    configurations) of the kernels in `parts`, divided by the number of big launches of `per_call` (one per call)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    out = tempfile.mkdtemp(prefix="mh_bench_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", MH_BENCH_PMC_INNER="1")
+        subprocess.run([exe, "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                        "--steps", "5", "--warmup", "2", "--regions", "1", "--ramp-ms", "0", "--no-cpu-baseline", "--batch", str(B), "--config", str(config)],
+                       cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200, check=True)
+        total, calls = 0.0, 0
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != counter or int(r["Grid_Size"]) < min_grid:
+                    continue
+                if any(k in r["Kernel_Name"] for k in parts):
+                    total += float(r["Counter_Value"])
+                if per_call in r["Kernel_Name"]:
+                    calls += 1
+        return total / calls if calls >= 5 else None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def live_traffic_of_call(B, config):
+    """roofline.traffic of a configuration whose step is several launches or a launch not picked by grid size (3: the RNEA + CRBA launch; 5: the
+    fused depth-first walk + the six AoS <-> SoA transposes): 2 x FETCH_SIZE + WRITE_SIZE over the call's kernels, per call."""
+    if not _pmc_allowed():
+        return None
+    per_call, parts = {3: ("spec_rnea_crba_split_kernel", ("spec_rnea_crba_split_kernel",)),
+                       5: ("aba_dfs_kernel", ("aba_dfs_kernel", "rnea_dfs_kernel", "rows_to_columns_kernel", "columns_to_rows_kernel", "transpose_kernel"))}[config]
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        got = _pmc_call_sum(counter, B, config, per_call, parts, 65536 if config == 5 else 64 * 256)
+        if got is None:
+            return None
+        kb[counter] = got
+    return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+
+
 def live_issue_counters(B, config=0):
     """SQ counters of the dominant kernel for THIS run (one more child pass, same mechanism): wave-level VALU instructions, wave cycles and
     the cycles waves spent waiting, per launch.  None when unavailable."""
@@ -257,6 +303,9 @@ def main():
     headline = args.gpus == 1 and args.config in (0, 4) and not args.separate
     pmc_batch = args.batch or (262144 if args.config == 4 else BATCH)
     pmc_bytes = live_traffic(pmc_batch, args.config) if headline else None
+    call_bytes = None
+    if args.gpus == 1 and args.config in (3, 5) and not args.separate:
+        call_bytes = live_traffic_of_call(args.batch or (1048576 if args.config == 5 else BATCH), args.config)
     sq = live_issue_counters(pmc_batch, args.config) if headline else None
 
     import torch
@@ -508,6 +557,8 @@ def main():
     one_launch = fused_launch or (cfg == 4 and model.kernel_variant.startswith("topo:") and (B + 63) // 64 > 256)  # the counters were picked for that launch
     if pmc_bytes is not None and one_launch:
         traffic, traffic_source = pmc_bytes, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, child processes of this run), 2 x FETCH + WRITE"
+    elif call_bytes is not None:
+        traffic, traffic_source = call_bytes, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, child processes of this run), 2 x FETCH + WRITE summed over the kernels of one call"
     else:
         traffic, traffic_source = committed_traffic(fused_launch and cfg == 0, B)
     # The bounding roofline is HBM by north_star's reporting rule; what actually limits the launch is read off the counters: a launch
