@@ -11,7 +11,7 @@ from oracle.cpu_oracle import OracleModel
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(2026)
-edges = [1, 2, 63, 64, 65, 127, 128, 129, 511, 512, 513, 4095, 4096, 4097, 5440, 5441, 8191, 8192, 8193, 16384, 20000]
+edges = [1, 2, 63, 64, 65, 127, 128, 129, 511, 512, 513, 4095, 4096, 4097, 5440, 5441, 8191, 8192, 8193, 16384, 16385, 16448, 20000, 23999]
 shapes = {"humanoid": rt.nextHumanoid, "torso": rt.nextFixedBaseTorso, "centaur": rt.nextCentaur, "quadruped": rt.nextQuadruped}
 t0, n, worst, worst_pair = time.time(), 0, 0.0, 0.0
 while time.time() - t0 < budget:
@@ -41,6 +41,11 @@ while time.time() - t0 < budget:
             e1, e2 = float((a - a0).abs().max()) / scale, float((ap - a0p).abs().max()) / scale
             worst_pair = max(worst_pair, e1, e2)
             assert e1 <= 1e-9 and e2 <= 1e-9 and torch.equal(t, t0_), (name, mode, B, e1, e2)
+        # the pair call's efforts against the inverse dynamics' own call (beyond one group per CU they are h + M qdd of the fused kernel)
+        t_one = models["0"].rnea(q, qd, qdd, g, f_ext=fx)
+        e3 = float((t0_ - t_one).abs().max()) / max(1.0, float(t_one.abs().max()))
+        worst_pair = max(worst_pair, e3)
+        assert e3 <= 1e-12, (name, B, e3)
         idx = np.unique(np.concatenate([[0, B - 1], rng.integers(0, B, 4)]))
         ti = torch.as_tensor(idx, device="cuda")
         sf = fx[ti].cpu().numpy() if fx is not None else None
