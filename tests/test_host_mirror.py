@@ -142,6 +142,31 @@ def test_tree_split_plans_of_the_registered_code_objects():
         print(name, "staged" if staged else "plain", limbs, cuts)
 
 
+def test_fused_kernel_capabilities_of_the_registered_code_objects():
+    """What the host asks a code object before it sends device-filling batches to the fused forward-dynamics kernel (host-only exports):
+    mh_spec_zvf_usable (joints below the root revolute / fixed, two workgroups per CU fit) and -- round 5 -- mh_spec_zvf_pair_usable (the same
+    launch writes tau = h + M(q) qdd for mh_rnea_aba_f64).  The humanoid has both; a chain has neither; whoever serves the pair serves the
+    forward dynamics; the LDS of a workgroup never exceeds half a CU's."""
+    import ctypes
+    from mecano_amd import build as b
+    try:
+        b.build_all(jobs=5)
+        paths = {name: b.build_spec(desc) for name, desc in b.registered_models().items()}
+    except Exception as e:  # no hipcc and no prebuilt objects
+        pytest.skip(f"specialised code objects unavailable: {e}")
+    seen = {}
+    for name, path in paths.items():
+        lib = ctypes.CDLL(path)
+        lib.mh_spec_zvf_lds_bytes.restype = ctypes.c_long
+        zvf, pair, lds = lib.mh_spec_zvf_usable(), lib.mh_spec_zvf_pair_usable(), lib.mh_spec_zvf_lds_bytes()
+        seen[name] = (zvf, pair, lds)
+        assert pair <= zvf, (name, zvf, pair)
+        if zvf:
+            assert 0 < lds * 2 <= 160 * 1024, (name, lds)
+    assert seen["humanoid30"][:2] == (1, 1) and seen["arm7"][:2] == (0, 0), seen
+    assert seen["humanoid30"][2] == 160 * 64 * 8  # 157 slots of both phases + the mailed head's three (tests/test_split_plan.py)
+
+
 def test_committed_humanoid_model_is_what_the_generator_produces():
     """mecano_amd/models/humanoid30.json (the benchmark model) against nextHumanoid(default_rng(43)): identical."""
     from mecano_amd import random_tools as rt
