@@ -274,8 +274,11 @@ mh_status mh_aba_f64(mh_model_t model, int64_t B, const double *q, const double 
 mh_status mh_crba_f64(mh_model_t model, int64_t B, const double *q, const mh_options *opts, double *H_out);
 /*
  * RNEA and ABA of the same B configurations in one call: tau_out = RNEA(q, qd, qdd), qdd_out = ABA(q, qd, tau).  The two are
- * independent; batches up to 32768 configurations run them side by side in a single launch (a 4096-configuration batch is 64 waves,
- * a quarter of what fills an MI355X), larger batches as two back-to-back launches.  Same results as mh_rnea_f64 followed by mh_aba_f64.
+ * independent.  With a code object the call is ONE launch at every batch size: up to one group of 64 configurations per CU the two run
+ * side by side on different workgroups (a 4096-configuration batch is 64 waves, a quarter of what fills an MI355X); beyond that the
+ * forward-dynamics kernel also writes tau_out = h + M(q) qdd ("Last bits" above).  Same results as mh_rnea_f64 followed by mh_aba_f64.
+ * Because the two run concurrently, tau_out and qdd_out must not overlap q, qd, qdd, tau or each other (MH_ERR_INVALID_ARGUMENT); for
+ * in-place use call mh_rnea_f64 and mh_aba_f64 one after the other.
  */
 mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
                           const double gravity[3], const double *f_ext, const mh_options *opts, double *tau_out, double *qdd_out);
@@ -444,8 +447,10 @@ mh_status mh_rnea_f32(mh_model_t model, int64_t B, const float *q, const float *
 mh_status mh_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *tau,
                      const double gravity[3], const float *f_ext, const mh_options *opts, float *qdd_out);
 mh_status mh_crba_f32(mh_model_t model, int64_t B, const float *q, const mh_options *opts, float *H_out);
-/* mh_rnea_aba_f64 in fp32 (BASELINE.json configs[4] evaluates both per step): big AoS batches of wide matrices share the transposed
- * scratch copies of q and qd between the two algorithms; otherwise mh_rnea_f32 followed by mh_aba_f32.  Same results as those two. */
+/* mh_rnea_aba_f64 in fp32 (BASELINE.json configs[4] evaluates both per step): big batches of wide matrices go through ONE depth-first
+ * walk that carries the inverse dynamics through the forward dynamics' first pass (AoS callers: through shared transposed scratch
+ * copies of q and qd); otherwise mh_rnea_f32 followed by mh_aba_f32.  The results of those two, to fp32 rounding in the fused walk.
+ * The outputs must not overlap the inputs or each other (as for mh_rnea_aba_f64). */
 mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const float *qd, const float *qdd, const float *tau,
                           const double gravity[3], const float *f_ext, const mh_options *opts, float *tau_out, float *qdd_out);
 /* fp32 forms of the per-body outputs and of forward dynamics with acceleration-source joints (run-time-topology kernels) */

@@ -3265,6 +3265,18 @@ mh_status mh_aba_locked_f64(mh_model_t model, int64_t B, const double *q, const 
       return fail(MH_ERR_INVALID_ARGUMENT, "qdd_in is NULL but %d joint(s) are acceleration sources", model->n_locked);
    return launch<double>(ALGO_ABA, model, B, q, qd, tau, gravity, f_ext, opts, qdd_out, qdd_in, tau_out);
 }
+// The pair calls run their two algorithms side by side (or phase by phase in one workgroup): an output that overlaps an input of the OTHER
+// algorithm would be read half-written.  (mh_rnea_* then mh_aba_* is the call sequence for in-place use.)
+static bool pair_outputs_overlap(const void *q, const void *qd, const void *qdd, const void *tau, const void *tau_out, const void *qdd_out, size_t bq, size_t bv)
+{
+   auto overlap = [](const void *a, size_t na, const void *b, size_t nb) { return (const char *)a < (const char *)b + nb && (const char *)b < (const char *)a + na; };
+   const void *ins[4] = {q, qd, qdd, tau};
+   const size_t nin[4] = {bq, bv, bv, bv};
+   for (int i = 0; i < 4; i++)
+      if (overlap(tau_out, bv, ins[i], nin[i]) || overlap(qdd_out, bv, ins[i], nin[i]))
+         return true;
+   return overlap(tau_out, bv, qdd_out, bv);
+}
 mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const double *qd, const double *qdd, const double *tau,
                           const double gravity[3], const double *f_ext, const mh_options *opts_in, double *tau_out, double *qdd_out)
 {
@@ -3280,6 +3292,8 @@ mh_status mh_rnea_aba_f64(mh_model_t model, int64_t B, const double *q, const do
       return MH_OK;
    if (!q || !qd || !qdd || !tau || (!gravity && !opts.use_root_acceleration) || !tau_out || !qdd_out)
       return fail(MH_ERR_INVALID_ARGUMENT, "NULL state / output pointer");
+   if (pair_outputs_overlap(q, qd, qdd, tau, tau_out, qdd_out, (size_t)B * model->nq * sizeof(double), (size_t)B * model->nv * sizeof(double)))
+      return fail(MH_ERR_INVALID_ARGUMENT, "mh_rnea_aba_f64: tau_out / qdd_out must not overlap q, qd, qdd, tau or each other (the two algorithms run concurrently)");
    const long waves = (B + 63) / 64;
    const bool fusable = model->n_locked == 0 && model->spec.launch_fused && model->use_spec && model->use_fused && model->dense_maps && opts.layout == MH_LAYOUT_AOS
                         && opts.consider_coriolis && opts.consider_accelerations && 2 * waves <= (long)model->cu_count * model->fused_factor
@@ -3511,6 +3525,9 @@ mh_status mh_rnea_aba_f32(mh_model_t model, int64_t B, const float *q, const flo
       opts = *opts_in;
    else
       mh_options_default(&opts);
+   if (model && B > 0 && q && qd && qdd && tau && tau_out && qdd_out
+       && pair_outputs_overlap(q, qd, qdd, tau, tau_out, qdd_out, (size_t)B * model->nq * sizeof(float), (size_t)B * model->nv * sizeof(float)))
+      return fail(MH_ERR_INVALID_ARGUMENT, "mh_rnea_aba_f32: tau_out / qdd_out must not overlap q, qd, qdd, tau or each other (the two algorithms run concurrently)");
    const bool big = model && B >= 8192 && q && qd && qdd && tau && tau_out && qdd_out && !f_ext && model->use_dfs && model->n_locked == 0
                     && model->use_transpose < 0 && model->dfs_transpose < 0 && model->nq + model->nv >= 64 && opts.consider_coriolis
                     && opts.consider_accelerations;

@@ -382,3 +382,28 @@ def test_bias_split_on_every_registered_shape_and_under_graph_replay():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = [l for l in r.stdout.splitlines() if l.startswith("worst scaled error")]
     assert last and float(last[-1].split()[-1]) < 1e-9, r.stdout[-500:]
+
+
+def test_pair_call_refuses_outputs_that_overlap_its_inputs(torch_cuda):
+    """mh_rnea_aba_f64 / _f32 run their two algorithms concurrently (side by side on different workgroups, or phase by phase in one): an
+    output that overlaps an input of the other algorithm would be read half-written.  The call says so (MH_ERR_INVALID_ARGUMENT) instead
+    of computing something; separate buffers work, and the single calls remain the way to compute in place."""
+    torch = torch_cuda
+    from mecano_amd import _lib
+    from mecano_amd import random_tools as rt
+    from mecano_amd.engine import HipModel
+    sys_ = rt.nextHumanoid(np.random.default_rng(43))
+    hm = HipModel(sys_.toModelDesc())
+    for dt in (torch.float64, torch.float32):
+        q, qd, qdd, tau = (dev(torch, x, dt) for x in rt.nextState(np.random.default_rng(3), sys_, 256))
+        o1, o2 = torch.empty_like(qd), torch.empty_like(qd)
+        hm.bind_rnea_aba(q, qd, qdd, tau, o1, o2, G)()
+        assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
+        for bad in ((tau, o2), (o1, qdd), (o1, o1), (qd, o2)):
+            with pytest.raises(_lib.MecanoHipError) as e:
+                hm.bind_rnea_aba(q, qd, qdd, tau, bad[0], bad[1], G)()
+            assert "overlap" in str(e.value)
+        # in place, one after the other
+        t_ref = hm.rnea(q, qd, qdd, G)
+        assert torch.equal(t_ref, o1) or (t_ref - o1).abs().max().item() <= 1e-4
+
